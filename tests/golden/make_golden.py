@@ -1,0 +1,256 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by IMPORTING THE REFERENCE (evenrose/CMDIAD) in the build container.
+
+Run:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+Needs /root/reference (absent on the GPU box: only the .npz fixtures written next to this
+script travel).  Third-party packages the reference imports but this image lacks are
+replaced by inert stubs; the two CUDA-only ops the reference reaches through them
+(furthest_point_sample / KNN) are served by this repo's CPU oracle, so goldens that pass
+through them pin everything *after* those ops, not the ops themselves (oracle/README.md).
+
+Fixtures hold data only: seeded inputs (when small) and the reference's outputs.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("CMDIAD_REFERENCE", "/root/reference")
+sys.dont_write_bytecode = True
+sys.path.insert(0, REPO)
+
+from oracle import kernels as ok  # noqa: E402
+from oracle import nets as onets  # noqa: E402
+from cmdiad_amd.synth import synth_cloud  # noqa: E402
+
+
+# ----------------------------------------------------------------------------- stubs
+def _install_stubs():
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class DropPath(torch.nn.Module):  # eval-mode semantics: identity
+        def __init__(self, p=0.0):
+            super().__init__()
+
+        def forward(self, x):
+            return x
+
+    timm = mod("timm", create_model=lambda **kw: (_ for _ in ()).throw(RuntimeError("timm stub")))
+    mod("timm.models", layers=None)
+    mod("timm.models.layers", DropPath=DropPath)
+    timm.models = sys.modules["timm.models"]
+    timm.models.layers = sys.modules["timm.models.layers"]
+
+    class KNN:
+        def __init__(self, k, transpose_mode=True):
+            self.k = k
+
+        def __call__(self, ref, query):  # ref [B,N,3], query [B,G,3]
+            idx, _ = ok.knn_group(ref.numpy(), query.numpy(), self.k)
+            return None, torch.from_numpy(idx)
+
+    mod("knn_cuda", KNN=KNN)
+
+    def furthest_point_sample(xyz, n):
+        idx, _ = ok.fps(xyz.numpy(), n)
+        return torch.from_numpy(idx)
+
+    def gather_operation(feat, idx):  # feat [B,C,N], idx [B,G] -> [B,C,G]
+        return torch.gather(feat, 2, idx.long().unsqueeze(1).expand(-1, feat.shape[1], -1))
+
+    p2 = mod("pointnet2_ops")
+    p2.pointnet2_utils = mod("pointnet2_ops.pointnet2_utils", furthest_point_sample=furthest_point_sample,
+                             gather_operation=gather_operation)
+    mod("cupy", asarray=lambda x: x)
+    mod("cupyx")
+    mod("cupyx.scipy")
+    mod("cupyx.scipy.spatial", distance=None)
+    mod("tifffile")
+
+    # torchvision: only ToPILImage / ToTensor are reached (utils/utils.py:75-76)
+    from PIL import Image
+
+    class ToPILImage:
+        def __call__(self, pic):  # float tensor [1,H,W] -> 'L' image via mul(255).byte()
+            return Image.fromarray(pic.mul(255).byte().squeeze(0).numpy(), mode="L")
+
+    class ToTensor:
+        def __call__(self, img):
+            return torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).float().div(255).unsqueeze(0)
+
+    tv = mod("torchvision")
+    tv.transforms = mod("torchvision.transforms", ToPILImage=ToPILImage, ToTensor=ToTensor,
+                        v2=mod("torchvision.transforms.v2"))
+
+
+def _ns(**kw):
+    return types.SimpleNamespace(**kw)
+
+
+def main():
+    _install_stubs()
+    sys.path.insert(0, REF)
+    from models import models as rmodels
+    from models import pointnet2_utils as rp2
+    from models.hallucination_network import HallucinationCrossModalityNetwork
+    from feature_extractors import features as rfeat
+    from feature_extractors import multiple_features as rmf
+    from utils import utils as rutils
+    import utils.lr_sched as rlr
+
+    torch.manual_seed(0)
+    out = {}
+
+    # ---------------- G1: interpolating_points (pointnet2_utils.py:45-75)
+    g = torch.Generator().manual_seed(11)
+    pc, _ = rmf.organized_pc_to_unorganized_pc_no_zeros((None, synth_cloud(5, 0.06)))
+    xyz1 = pc[:, :, :2000].contiguous()
+    cidx, _ = ok.fps(xyz1.permute(0, 2, 1).numpy(), 64)
+    xyz2 = xyz1[:, :, torch.from_numpy(cidx[0]).long()]
+    feat = torch.randn(1, 16, 64, generator=g)
+    res = rp2.interpolating_points(xyz1, xyz2, feat)
+    np.savez_compressed(os.path.join(HERE, "g1_interp.npz"), xyz1=xyz1.numpy(), xyz2=xyz2.numpy(),
+                        feat=feat.numpy(), out=res.numpy())
+
+    # ---------------- G1b: organized_pc_to_unorganized_pc_no_zeros (multiple_features.py:10-25)
+    opc = synth_cloud(7, 0.4)
+    pc, nz = rmf.organized_pc_to_unorganized_pc_no_zeros((None, opc))
+    np.savez_compressed(os.path.join(HERE, "g1b_unorganize.npz"), seed=7, frac=0.4, n=pc.shape[2],
+                        nz_head=nz[:64], nz_tail=nz[-64:], nz_sum=np.int64(nz.sum()),
+                        pc_head=pc[0, :, :32].numpy())
+
+    # ---------------- G2: Point-MAE encoder / transformer / full PointTransformer (models.py:183-373)
+    sd = onets.synth_state_dict("pointmae", 21)
+    pt = rmodels.PointTransformer(group_size=32, num_group=64)
+    missing = pt.load_state_dict(sd, strict=True)
+    pc, _ = rmf.organized_pc_to_unorganized_pc_no_zeros((None, synth_cloud(9, 0.08)))
+    pc = pc[:, :, :3000].contiguous()
+    for mode in ("eval", "train"):
+        pt.eval() if mode == "eval" else pt.train()
+        with torch.no_grad():
+            feats, center, ori_idx, center_idx = pt(pc)
+            nb, _, _, _ = pt.group_divider(pc.transpose(-1, -2))
+            tok = pt.encoder(nb)
+        out[f"g2_{mode}"] = dict(feats=feats.numpy(), tokens=tok.numpy())
+    np.savez_compressed(os.path.join(HERE, "g2_pointmae.npz"), pc=pc.numpy(), center=center.numpy(),
+                        center_idx=center_idx.numpy(), ori_idx=ori_idx.numpy().astype(np.int32),
+                        feats_eval=out["g2_eval"]["feats"], tokens_eval=out["g2_eval"]["tokens"],
+                        feats_train=out["g2_train"]["feats"], tokens_train=out["g2_train"]["tokens"])
+
+    # ---------------- GV: ViT-B/8 block stack through the reference's in-tree Block (models.py:163-180)
+    from functools import partial
+    sdv = onets.synth_state_dict("vit", 31)
+    blocks = torch.nn.ModuleList([
+        rmodels.Block(dim=768, num_heads=12, mlp_ratio=4.0, qkv_bias=True,
+                      norm_layer=partial(torch.nn.LayerNorm, eps=1e-6)) for _ in range(12)])
+    blocks.load_state_dict({k[len("blocks."):]: v for k, v in sdv.items() if k.startswith("blocks.")})
+    blocks.eval()
+    g = torch.Generator().manual_seed(32)
+    x = torch.randn(1, 785, 768, generator=g)
+    with torch.no_grad():
+        y = x
+        for b in blocks:
+            y = b(y)
+    np.savez_compressed(os.path.join(HERE, "gv_vit_blocks.npz"), x_seed=32, y_sub=y[0, ::8, ::4].numpy(),
+                        y_mean=y.mean().item(), y_std=y.std().item())
+
+    # ---------------- G3: get_xyz_patch (56 and 28) / get_rgb_patch (features.py:160-184)
+    fake = _ns(xyz_size=224, average=torch.nn.AvgPool2d(3, stride=1),
+               resize28=torch.nn.AdaptiveAvgPool2d((28, 28)), resize56=torch.nn.AdaptiveAvgPool2d((56, 56)))
+    opc = synth_cloud(13, 0.5)
+    pc, nz = rmf.organized_pc_to_unorganized_pc_no_zeros((None, opc))
+    g = torch.Generator().manual_seed(14)
+    interp = torch.randn(1, 8, pc.shape[2], generator=g)
+    p56 = rfeat.Features.get_xyz_patch(fake, [torch.zeros(1, 8, 4)], interp, nz)
+    p28 = rfeat.Features.get_xyz_patch(fake, [torch.zeros(1, 8, 4)], interp, nz, get_2828=True)
+    rgbmap = torch.randn(1, 12, 28, 28, generator=g)
+    rp, rp2_ = rfeat.Features.get_rgb_patch(fake, [rgbmap])
+    np.savez_compressed(os.path.join(HERE, "g3_patch.npz"), cloud_seed=13, frac=0.5, interp_seed=14,
+                        n=pc.shape[2], p56=p56.numpy(), p28=p28.numpy(), rgbmap=rgbmap.numpy(),
+                        rgb_patch=rp.numpy(), rgb_patch2=rp2_.numpy())
+
+    # ---------------- G4: calculate_dist + compute_single_s_s_map (features.py:186-297)
+    class NoBlur:
+        def __call__(self, x):
+            return x[0]
+
+    g4 = {}
+    for tag, (Q, Nb, D, modal) in {"xyz_small": (3136, 2000, 64, "xyz"), "rgb_small": (784, 1500, 64, "rgb"),
+                                   "fusion_small": (3136, 1800, 64, "fusion"),
+                                   "xyz_fullD": (784, 1200, 768, "xyz")}.items():
+        g = torch.Generator().manual_seed({"xyz_small": 41, "rgb_small": 42, "fusion_small": 43, "xyz_fullD": 44}[tag])
+        bank = torch.randn(Nb, D, generator=g)
+        patch = bank[torch.randint(0, Nb, (Q,), generator=g)] + 0.3 * torch.randn(Q, D, generator=g)
+        patch[Q // 3] += 1.5  # a planted anomalous patch
+        fs = _ns(args=_ns(dist_method_s="l2"), n_reweight=3, gt_size=224, blur=NoBlur(),
+                 patch_xyz_lib=bank, patch_rgb_lib=bank, patch_fusion_lib=bank)
+        fs.calculate_dist = lambda a, b, fs=fs: rfeat.Features.calculate_dist(fs, a, b)
+        dist = fs.calculate_dist(patch, bank)
+        side = int(Q ** 0.5)
+        s, s_map = rfeat.Features.compute_single_s_s_map(fs, patch, dist, (side, side), modal=modal)
+        mv, mi = torch.min(dist, dim=1)
+        g4.update({f"{tag}_seed": {"xyz_small": 41, "rgb_small": 42, "fusion_small": 43, "xyz_fullD": 44}[tag],
+                   f"{tag}_shape": np.array([Q, Nb, D]), f"{tag}_min_val": mv.numpy(),
+                   f"{tag}_min_idx": mi.numpy().astype(np.int32), f"{tag}_s": s.numpy(),
+                   f"{tag}_s_map": s_map.numpy()[:, ::4, ::4]})
+    # blur (utils/utils.py:71-83) with the torchvision stub above + real PIL
+    g = torch.Generator().manual_seed(45)
+    smooth = torch.nn.functional.interpolate(torch.rand(1, 1, 56, 56, generator=g) * 3.0, size=(224, 224),
+                                             mode="bilinear")
+    blurred = rutils.KNNGaussianBlur(4)(smooth)
+    g4.update(blur_seed=45, blur_out=blurred.numpy()[:, ::2, ::2])
+    np.savez_compressed(os.path.join(HERE, "g4_score.npz"), **g4)
+
+    # ---------------- G5: hallucination net forward / losses / Adam steps
+    sdh = onets.synth_state_dict("halluc", 51)
+    args = _ns()
+    net = HallucinationCrossModalityNetwork(args, 768, 768, hidden_ratio=2.5, mlp_depth=1)
+    net.load_state_dict(sdh, strict=True)
+    g = torch.Generator().manual_seed(52)
+    samples = torch.randn(2, 64, 1536, generator=g)
+    xyz, rgb = samples[:, :, :768], samples[:, :, 768:]
+    g5 = {}
+    with torch.no_grad():
+        g5["gen_xyz2rgb"] = net.hallucination_generation(xyz_feature=xyz, out_type="rgb").numpy()
+        g5["gen_rgb2xyz"] = net.hallucination_generation(rgb_feature=rgb, out_type="xyz").numpy()
+        for dm in ("l2", "cos_dist", "smooth_l1"):
+            a, b = net(xyz, rgb, False, dm)
+            g5[f"loss_{dm}"] = np.array([a.item(), b.item()])
+    # three Adam steps as hallucination_network_pretrain.py:102-154 (lr 5e-4... warm-up via lr_sched.py)
+    opt = torch.optim.Adam(net.parameters(), lr=0.0005)
+    sargs = _ns(lr=0.0005, warmup_epochs=1, epochs=10)
+    steps_per_epoch = 4
+    losses = []
+    probes = ["xyz_mlp.mlp_module.0.fc1.weight", "rgb_mlp.mlp_module.0.fc3.bias", "xyz_norm.weight"]
+    net.train()
+    opt.zero_grad()
+    for it in range(3):
+        rlr.adjust_learning_rate(opt, it / steps_per_epoch + 0, sargs)
+        lx, lr_ = net(xyz, rgb, False, "l2")
+        loss = lx + lr_
+        losses.append([lx.item(), lr_.item()])
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+        if it in (0, 2):
+            for p in probes:
+                t = dict(net.named_parameters())[p].detach()
+                g5[f"step{it + 1}_{p}"] = (t[:8, :8] if t.dim() == 2 else t[:16]).numpy().copy()
+    g5["train_losses"] = np.array(losses)
+    np.savez_compressed(os.path.join(HERE, "g5_halluc.npz"), samples_seed=52, **g5)
+
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KB")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,145 @@
+"""CPU: the oracle (oracle/) against golden vectors produced by importing the reference
+(tests/golden/make_golden.py).  These pin the oracle before it is trusted as the checker
+for the HIP path."""
+import numpy as np
+import torch
+
+from cmdiad_amd.synth import synth_cloud
+from oracle import kernels as ok
+from oracle import nets, scoring
+
+
+def test_g1_interp3nn_c_and_torch(golden):
+    g = golden("g1_interp.npz")
+    xyz1, xyz2, feat, ref = g["xyz1"], g["xyz2"], g["feat"], g["out"]
+    out, idx3, w3 = ok.interp3nn(xyz1[0].T, xyz2[0].T, feat[0].T)
+    # -2ab+a^2+b^2 cancels catastrophically (|p|^2~0.25, d~1e-5 or ~0 for points that ARE centres):
+    # 1/(d+1e-8) then amplifies the last-bit differences between a sequential C dot product and
+    # torch's matmul, so the C restatement matches the reference statistically, not element-wise;
+    # the torch restatement below (same ops as the reference) matches it to 1e-5.
+    err = np.abs(out.T - ref[0])
+    assert np.mean(err) < 2e-3 and np.quantile(err, 0.995) < 2e-2 and np.mean(err > 5e-2) < 2e-3
+    t = scoring.interpolating_points(torch.from_numpy(xyz1), torch.from_numpy(xyz2), torch.from_numpy(feat))
+    np.testing.assert_allclose(t.numpy(), ref, rtol=1e-5, atol=1e-5)
+    assert np.all(np.abs(w3.sum(1) - 1) < 1e-5) and idx3.min() >= 0 and idx3.max() < 64
+
+
+def test_g1b_unorganize(golden):
+    g = golden("g1b_unorganize.npz")
+    pc, nz = scoring.unorganize_no_zeros(synth_cloud(int(g["seed"]), float(g["frac"])))
+    assert pc.shape[2] == int(g["n"]) and nz.sum() == g["nz_sum"]
+    np.testing.assert_array_equal(nz[:64], g["nz_head"])
+    np.testing.assert_array_equal(nz[-64:], g["nz_tail"])
+    np.testing.assert_array_equal(pc[0, :, :32].numpy(), g["pc_head"])
+
+
+def test_g2_pointmae_eval_and_train(golden):
+    g = golden("g2_pointmae.npz")
+    sd = nets.synth_state_dict("pointmae", 21)
+    pc = g["pc"]
+    xyz = np.ascontiguousarray(pc[0].T)[None]
+    cidx, cen = ok.fps(xyz, 64)
+    np.testing.assert_array_equal(cidx, g["center_idx"])
+    np.testing.assert_array_equal(cen, g["center"])
+    idx, nb = ok.knn_group(xyz, cen, 32)
+    np.testing.assert_array_equal(idx.astype(np.int32), g["ori_idx"])
+    for mode in ("eval", "train"):
+        with torch.no_grad():
+            tok = nets.pointmae_encoder(sd, torch.from_numpy(nb), batch_stats=(mode == "train"))
+            feats = nets.pointmae_transformer(sd, tok, torch.from_numpy(cen))
+        np.testing.assert_allclose(tok.numpy(), g[f"tokens_{mode}"], rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(feats.numpy(), g[f"feats_{mode}"], rtol=1e-3, atol=1e-3)
+
+
+def test_gv_vit_blocks(golden):
+    g = golden("gv_vit_blocks.npz")
+    sd = nets.synth_state_dict("vit", 31)
+    x = torch.randn(1, 785, 768, generator=torch.Generator().manual_seed(int(g["x_seed"])))
+    with torch.no_grad():
+        for i in range(12):
+            x = nets._block(x, sd, f"blocks.{i}", 12, 1e-6)
+    np.testing.assert_allclose(x[0, ::8, ::4].numpy(), g["y_sub"], rtol=1e-3, atol=1e-3)
+    assert abs(x.mean().item() - float(g["y_mean"])) < 1e-4
+
+
+def test_g3_patches(golden):
+    g = golden("g3_patch.npz")
+    pc, nz = scoring.unorganize_no_zeros(synth_cloud(int(g["cloud_seed"]), float(g["frac"])))
+    assert pc.shape[2] == int(g["n"])
+    interp = torch.randn(1, 8, pc.shape[2], generator=torch.Generator().manual_seed(int(g["interp_seed"])))
+    for P, key in ((56, "p56"), (28, "p28")):
+        t = scoring.get_xyz_patch(interp, nz, out=P)
+        np.testing.assert_allclose(t.numpy(), g[key], rtol=1e-5, atol=1e-6)
+        c = ok.xyz_patch(interp[0].T.numpy(), nz, 224, P)
+        np.testing.assert_allclose(c, g[key], rtol=1e-4, atol=1e-5)
+    rp, rp2 = scoring.get_rgb_patch(torch.from_numpy(g["rgbmap"]))
+    np.testing.assert_array_equal(rp.numpy(), g["rgb_patch"])
+    np.testing.assert_array_equal(rp2.numpy(), g["rgb_patch2"])
+    # the 28->56 "resize" is exact 2x nearest replication
+    m = g["rgbmap"][0]
+    np.testing.assert_array_equal(rp2.numpy().T.reshape(-1, 56, 56), np.repeat(np.repeat(m, 2, 1), 2, 2))
+
+
+def _g4_inputs(seed, Q, Nb, D):
+    g = torch.Generator().manual_seed(seed)
+    bank = torch.randn(Nb, D, generator=g)
+    patch = bank[torch.randint(0, Nb, (Q,), generator=g)] + 0.3 * torch.randn(Q, D, generator=g)
+    patch[Q // 3] += 1.5
+    return patch, bank
+
+
+def test_g4_scoring(golden):
+    g = golden("g4_score.npz")
+    for tag in ("xyz_small", "rgb_small", "fusion_small", "xyz_fullD"):
+        Q, Nb, D = (int(v) for v in g[f"{tag}_shape"])
+        patch, bank = _g4_inputs(int(g[f"{tag}_seed"]), Q, Nb, D)
+        side = int(Q ** 0.5)
+        r = scoring.single_s_s_map(patch, torch.cdist(patch, bank), bank, (side, side), blur=False)
+        np.testing.assert_allclose(r["min_val"].numpy(), g[f"{tag}_min_val"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_array_equal(r["min_idx"].numpy(), g[f"{tag}_min_idx"])
+        np.testing.assert_allclose(r["s"].numpy(), g[f"{tag}_s"], rtol=1e-5)
+        np.testing.assert_allclose(r["s_map"].numpy()[:, ::4, ::4], g[f"{tag}_s_map"], rtol=1e-5, atol=1e-6)
+        # C oracle: exact L2 (double accumulate) vs the reference's matmul-expansion cdist
+        mv, mi = ok.l2_min_argmin(patch[:200].numpy(), bank.numpy())
+        np.testing.assert_allclose(mv, g[f"{tag}_min_val"][:200], rtol=1e-4, atol=2e-3)
+        assert np.mean(mi == g[f"{tag}_min_idx"][:200]) > 0.99
+        up = ok.bilinear_up(r["min_val"].view(side, side).numpy(), 224)
+        np.testing.assert_allclose(up, r["s_map_pre"][0].numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_g4_blur(golden):
+    g = golden("g4_score.npz")
+    gen = torch.Generator().manual_seed(int(g["blur_seed"]))
+    smooth = torch.nn.functional.interpolate(torch.rand(1, 1, 56, 56, generator=gen) * 3.0, size=(224, 224),
+                                             mode="bilinear")
+    np.testing.assert_array_equal(scoring.knn_gaussian_blur(smooth).numpy()[:, ::2, ::2], g["blur_out"])
+
+
+def test_g5_hallucination(golden):
+    g = golden("g5_halluc.npz")
+    sd = {k: v.clone() for k, v in nets.synth_state_dict("halluc", 51).items()}
+    s = torch.randn(2, 64, 1536, generator=torch.Generator().manual_seed(int(g["samples_seed"])))
+    xyz, rgb = s[:, :, :768], s[:, :, 768:]
+    with torch.no_grad():
+        np.testing.assert_allclose(nets.halluc_generate(sd, xyz, "xyz2rgb").numpy(), g["gen_xyz2rgb"], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(nets.halluc_generate(sd, rgb, "rgb2xyz").numpy(), g["gen_rgb2xyz"], rtol=1e-4, atol=1e-5)
+        for dm in ("l2", "cos_dist", "smooth_l1"):
+            a, b = nets.halluc_losses(sd, xyz, rgb, dm)
+            np.testing.assert_allclose([a.item(), b.item()], g[f"loss_{dm}"], rtol=1e-5)
+    # three Adam steps with linear warm-up (hallucination_network_pretrain.py:102-154, lr_sched.py:4-17)
+    params = {k: v.requires_grad_(True) for k, v in sd.items()}
+    opt = torch.optim.Adam(list(params.values()), lr=5e-4)
+    for it in range(3):
+        lr = 5e-4 * (it / 4) / 1 if it / 4 < 1 else 5e-4
+        for pg in opt.param_groups:
+            pg["lr"] = lr
+        lx, lr_ = nets.halluc_losses(params, xyz, rgb, "l2")
+        np.testing.assert_allclose([lx.item(), lr_.item()], g["train_losses"][it], rtol=1e-4)
+        (lx + lr_).backward()
+        opt.step()
+        opt.zero_grad()
+        if it in (0, 2):
+            for p in ("xyz_mlp.mlp_module.0.fc1.weight", "rgb_mlp.mlp_module.0.fc3.bias", "xyz_norm.weight"):
+                t = params[p].detach()
+                got = (t[:8, :8] if t.dim() == 2 else t[:16]).numpy()
+                np.testing.assert_allclose(got, g[f"step{it + 1}_{p}"], rtol=1e-4, atol=1e-6)
