@@ -1,0 +1,96 @@
+"""ctypes binding of libcmdiad_hip.so (C ABI: include/cmdiad_hip.h).
+
+There is NO CPU fallback: if the shared object is missing or a call fails, this raises.
+`build()` compiles the library with hipcc for gfx950 (cross-compiles without a GPU).
+"""
+import ctypes
+import os
+import subprocess
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_size_t, c_uint32, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libcmdiad_hip.so")
+_lib = None
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+class GemmArgs(Structure):
+    _fields_ = [("A", c_void_p), ("lda", c_int), ("W", c_void_p), ("ldw", c_int),
+                ("M", c_int), ("N", c_int), ("K", c_int),
+                ("bias", c_void_p), ("group_bias", c_void_p), ("group_rows", c_int), ("act", c_int),
+                ("residual", c_void_p), ("ldr", c_int),
+                ("out_f32", c_void_p), ("ldo32", c_int), ("out_bf16", c_void_p), ("ldo16", c_int)]
+
+
+P, I, F, SZ, U32 = c_void_p, c_int, c_float, c_size_t, c_uint32
+# name -> argtypes (every entry point declared in include/cmdiad_hip.h; tests check the two agree)
+SIGNATURES = {
+    "cmdiad_fps": [P, P, I, I, I, P, P, P, SZ, P],
+    "cmdiad_knn_group": [P, P, P, I, I, I, I, P, P, P],
+    "cmdiad_unorganize": [P, I, I, I, P, P, P, P, P],
+    "cmdiad_interp3nn": [P, P, P, I, I, I, P, P, P],
+    "cmdiad_interp_gather": [P, P, P, P, I, I, I, I, P, P],
+    "cmdiad_xyz_patch_fused": [P, P, P, P, I, I, I, I, I, I, F, F, P, P, P],
+    "cmdiad_gemm_bf16": [POINTER(GemmArgs), P],
+    "cmdiad_gemm_qkv": [P, P, P, I, I, I, P, P, P, P],
+    "cmdiad_attention": [P, P, P, I, I, I, P, P],
+    "cmdiad_layernorm": [P, P, P, P, F, I, I, P, P, I, P],
+    "cmdiad_encoder_stage1": [P, P, P, P, I, I, P, P, P, P],
+    "cmdiad_gemm_groupmax": [P, P, P, I, I, I, I, P, P, P],
+    "cmdiad_l2_min_keys": [P, P, P, P, I, I, I, U32, P, P],
+    "cmdiad_l2_rescore": [P, P, P, I, I, I, U32, P, P, P],
+    "cmdiad_reweight_scan": [P, P, I, I, I, U32, P, P, SZ, P],
+    "cmdiad_normalize_cast": [P, SZ, I, F, F, P, P, P, P],
+    "cmdiad_im2col_patch8": [P, I, I, P, P],
+    "cmdiad_vit_assemble": [P, P, P, I, I, I, P, P],
+    "cmdiad_bilinear_up": [P, I, I, I, P, P],
+    "cmdiad_linear3": [P, P, SZ, I, I, P, P],
+    "cmdiad_cast_bf16": [P, SZ, P, P],
+    "cmdiad_transpose_bf16": [P, I, I, P, P],
+}
+SIZE_QUERIES = {
+    "cmdiad_fps_workspace_bytes": [I, I],
+    "cmdiad_reweight_workspace_bytes": [I, I],
+}
+
+
+def build(force=False, verbose=False):
+    """Compile cmdiad_amd/csrc into libcmdiad_hip.so with hipcc --offload-arch=gfx950."""
+    csrc = os.path.join(_HERE, "csrc")
+    cmd = ["make", "-C", csrc, "-j8"] + (["-B"] if force else [])
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout[-4000:], res.stderr[-4000:])
+    if res.returncode != 0:
+        raise NativeError("building libcmdiad_hip.so failed")
+    return SO_PATH
+
+
+def lib():
+    """Load the shared object (once).  Raises NativeError when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise NativeError(f"{SO_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              f"(or `make -C cmdiad_amd/csrc`). cmdiad_amd has no CPU fallback.")
+        L = ctypes.CDLL(SO_PATH)
+        for name, args in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.argtypes = args
+            fn.restype = c_int
+        for name, args in SIZE_QUERIES.items():
+            fn = getattr(L, name)
+            fn.argtypes = args
+            fn.restype = c_size_t
+        L.cmdiad_last_error.restype = c_char_p
+        L.cmdiad_abi_version.restype = c_int
+        _lib = L
+    return _lib
+
+
+def check(rc, name):
+    if rc != 0:
+        raise NativeError(f"{name} failed ({rc}): {lib().cmdiad_last_error().decode()}")

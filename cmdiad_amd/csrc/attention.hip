@@ -1,0 +1,169 @@
+// Fused softmax(q k^T) v for gfx950 (reference models/models.py:148-160 Attention.forward, and the
+// same algebra inside timm's ViT blocks reached at models/models.py:48), head_dim = 64, bf16 MFMA with
+// fp32 softmax statistics and accumulation.  The T x T score matrix never leaves the CU.
+//
+// Work decomposition: grid (ceil(T/128), H, B); 256 threads = 4 waves; a wave owns 32 queries and
+// walks the keys in tiles of 64.  Everything that belongs to ONE query lives on ONE lane:
+//   S^T tile (32 keys x 32 queries) = mfma_32x32x16(A = K rows from LDS, B = Q rows in registers)
+//       -> accumulator column = query (lane & 31), rows = keys spread over the 16 registers and the
+//          two lane halves, so the row max / row sum are in-lane reductions + one cross-half shuffle.
+//   O^T tile (32 d x 32 queries)  = mfma_32x32x16(A = V^T rows from LDS, B = P)
+//       -> P is taken STRAIGHT from the S^T accumulator (guide §3 "accumulator tile as the next
+//          MFMA's operand"): registers 8s..8s+7 converted to bf16 are the B fragment of k-step s, with
+//          the fixed k permutation k = 16s + 8(j>>2) + 4h + (j&3) matched on the V^T side by two
+//          8-byte LDS reads.  The online-softmax rescale of O^T is a per-lane scalar multiply.
+// Q is pre-scaled by head_dim^-0.5 and V arrives transposed ([B,H,64,Tp]) from cmdiad_gemm_qkv.
+// LDS tiles are padded (K rows 144 B, V^T rows 136 B) so the fragment reads are bank-conflict-free.
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kKeys = 64;          // keys per tile
+constexpr int kKStride = 144;      // bytes per K row in LDS  (64 bf16 + 16 pad)
+constexpr int kVStride = 136;      // bytes per V^T row in LDS (64 bf16 + 8 pad)
+constexpr float kLog2e = 1.4426950408889634f;
+
+__global__ __launch_bounds__(kThreads) void attention_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                             const bf16_t* __restrict__ vt, int H, int T, int Tp,
+                                                             bf16_t* __restrict__ out)
+{
+    __shared__ __attribute__((aligned(16))) char s_k[kKeys * kKStride];
+    __shared__ __attribute__((aligned(16))) char s_v[64 * kVStride];
+
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const size_t bh = (size_t)b * H + h;
+    const bf16_t* qb = q + bh * Tp * 64;
+    const bf16_t* kb = k + bh * Tp * 64;
+    const bf16_t* vb = vt + bh * 64 * Tp;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int C = H * 64;
+
+    // Q fragments (B operand): lane (query r, half hh) holds Q[q][16s + 8hh .. +7] for s = 0..3
+    bf16x8 qf[4];
+    {
+        const int qi = min(q0 + r, Tp - 1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qb + (size_t)qi * 64 + 16 * s + 8 * hh);
+    }
+
+    f32x16 o0 = {}, o1 = {};
+    float m_run = -__builtin_inff(), l_run = 0.0f;
+
+    const int nkt = (T + kKeys - 1) / kKeys;
+    uint4 rk[2], rv[2];
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 256 * i;           // 0..511
+            const int row = idx >> 3, ch = idx & 7;  // row: key (K) or d (V^T); ch: 16-byte chunk
+            rk[i] = *reinterpret_cast<const uint4*>(kb + (size_t)(kt * kKeys + row) * 64 + ch * 8);
+            rv[i] = *reinterpret_cast<const uint4*>(vb + (size_t)row * Tp + kt * kKeys + ch * 8);
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx >> 3, ch = idx & 7;
+            *reinterpret_cast<uint4*>(s_k + row * kKStride + ch * 16) = rk[i];
+            uint2* dv = reinterpret_cast<uint2*>(s_v + row * kVStride + ch * 16);  // 8-byte aligned rows
+            dv[0] = make_uint2(rv[i].x, rv[i].y);
+            dv[1] = make_uint2(rv[i].z, rv[i].w);
+        }
+    };
+
+    load_tile(0);
+    for (int kt = 0; kt < nkt; ++kt) {
+        store_tile();
+        __syncthreads();
+        if (kt + 1 < nkt) load_tile(kt + 1);
+
+        // ---- S^T = K . Q^T for the two 32-key sub-tiles
+        f32x16 s0 = {}, s1 = {};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const bf16x8 ka = *reinterpret_cast<const bf16x8*>(s_k + r * kKStride + 32 * s + 16 * hh);
+            const bf16x8 kb2 = *reinterpret_cast<const bf16x8*>(s_k + (32 + r) * kKStride + 32 * s + 16 * hh);
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[s], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb2, qf[s], s1, 0, 0, 0);
+        }
+        // ---- mask keys >= T, online softmax (per lane = per query)
+        const int kbase = kt * kKeys + 4 * hh;
+        float mloc = -__builtin_inff();
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int key = kbase + (e & 3) + 8 * (e >> 2);
+            s0[e] = key < T ? s0[e] * kLog2e : -__builtin_inff();
+            s1[e] = key + 32 < T ? s1[e] * kLog2e : -__builtin_inff();
+            mloc = fmaxf(mloc, fmaxf(s0[e], s1[e]));
+        }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        const float m_new = fmaxf(m_run, mloc);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // first tile: exp2(-inf) = 0
+        m_run = m_new;
+        float psum = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            s0[e] = __builtin_amdgcn_exp2f(s0[e] - m_new);
+            s1[e] = __builtin_amdgcn_exp2f(s1[e] - m_new);
+            psum += s0[e] + s1[e];
+        }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { o0[e] *= alpha; o1[e] *= alpha; }
+
+        // ---- O^T += V^T . P   (k-step = 16 keys; P fragment = 8 consecutive accumulator registers)
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                bf16x8 pf;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pf[j] = f2bf(sub == 0 ? s0[8 * s + j] : s1[8 * s + j]);
+                const int koff = (sub * 32 + 16 * s + 4 * hh) * 2;  // bytes into the key axis
+                union { uint2 u[2]; bf16x8 v; } a0, a1;
+                a0.u[0] = *reinterpret_cast<const uint2*>(s_v + r * kVStride + koff);
+                a0.u[1] = *reinterpret_cast<const uint2*>(s_v + r * kVStride + koff + 16);
+                a1.u[0] = *reinterpret_cast<const uint2*>(s_v + (32 + r) * kVStride + koff);
+                a1.u[1] = *reinterpret_cast<const uint2*>(s_v + (32 + r) * kVStride + koff + 16);
+                o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.v, pf, o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.v, pf, o1, 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    const int qi = q0 + r;
+    if (qi < T) {
+        bf16_t* dst = out + ((size_t)b * T + qi) * C + h * 64;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            bf16x4 a = {f2bf(o0[4 * g] * inv), f2bf(o0[4 * g + 1] * inv), f2bf(o0[4 * g + 2] * inv), f2bf(o0[4 * g + 3] * inv)};
+            bf16x4 c = {f2bf(o1[4 * g] * inv), f2bf(o1[4 * g + 1] * inv), f2bf(o1[4 * g + 2] * inv), f2bf(o1[4 * g + 3] * inv)};
+            *reinterpret_cast<bf16x4*>(dst + 8 * g + 4 * hh) = a;
+            *reinterpret_cast<bf16x4*>(dst + 32 + 8 * g + 4 * hh) = c;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int cmdiad_attention(const uint16_t* q, const uint16_t* k, const uint16_t* vt, int B, int H, int T,
+                                uint16_t* out, cmdiad_stream_t stream)
+{
+    CMDIAD_REQUIRE(q && k && vt && out, CMDIAD_ERR_ARG, "cmdiad_attention: null pointer");
+    CMDIAD_REQUIRE(B > 0 && H > 0 && T > 0, CMDIAD_ERR_ARG, "cmdiad_attention: bad sizes");
+    CMDIAD_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)vt) & 15) == 0 && ((uintptr_t)out & 7) == 0, CMDIAD_ERR_ARG,
+                   "cmdiad_attention: alignment");
+    const int Tp = (T + 63) / 64 * 64;
+    dim3 grid((T + 127) / 128, H, B);
+    hipLaunchKernelGGL(attention_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, (const bf16_t*)q, (const bf16_t*)k,
+                       (const bf16_t*)vt, H, T, Tp, (bf16_t*)out);
+    CMDIAD_CHECK_LAUNCH();
+    return CMDIAD_OK;
+}

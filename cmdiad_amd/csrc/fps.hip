@@ -1,0 +1,196 @@
+// Farthest point sampling + centre gather for gfx950.
+//
+// Replaces pointnet2_ops.furthest_point_sample + gather_operation as called from the
+// reference at models/models.py:76-77.  Semantics = oracle/cmdiad_oracle.c:orc_fps,
+// bit-for-bit: running min initialised to 1e10, points with |p|^2 <= 1e-3 skipped, distance
+// (dx*dx + dy*dy) + dz*dz with one rounding per operation (this file is compiled with
+// -ffp-contract=off), argmax ties -> lowest index.
+//
+// One 1024-thread workgroup (16 waves) per cloud: FPS is a chain of G-1 dependent argmax
+// rounds, so the design goal is the latency of ONE round.  In the fast path the cloud and
+// its running-min array live entirely in registers (point k -> thread k%1024, slot k/1024,
+// so the initial load is coalesced); a round is PPT x {3 sub, 3 mul, 2 add, min, cmp, 2 sel}
+// per lane, a 6-step wave64 shuffle reduction of a packed (value, ~index) key, one LDS
+// hand-off across the 16 waves (double-buffered, so ONE barrier per round) and a scalar
+// (SGPR) fetch of the winner's coordinates.
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 1024;         // fallback kernel
+constexpr int kWaves = kThreads / 64;
+constexpr int kMaxRegPoints = 512 * 56;  // largest cloud the register-resident path holds
+
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        unsigned long long o = shfl_xor_u64(v, m);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+// key: (fp32 bits of running-min, 0xFFFFFFFF - index): max over keys = largest value, lowest index.
+__device__ __forceinline__ unsigned long long fps_key(float v, int idx)
+{
+    return v < 0.0f ? 0ull : (((unsigned long long)__float_as_uint(v) << 32) | (0xFFFFFFFFu - (unsigned)idx));
+}
+
+template <int kThreads, int PPT>
+__global__ __launch_bounds__(kThreads) void fps_reg_kernel(const float* __restrict__ xyz,
+                                                           const int32_t* __restrict__ n_valid, int N, int G,
+                                                           int32_t* __restrict__ idx_out,
+                                                           float* __restrict__ center_out)
+{
+    constexpr int kWaves = kThreads / 64;
+    __shared__ unsigned long long s_key[2][kWaves];
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int n = n_valid ? n_valid[b] : N;
+    const float* p = xyz + (size_t)b * N * 3;
+    int32_t* out = idx_out + (size_t)b * G;
+    float* cen = center_out ? center_out + (size_t)b * G * 3 : nullptr;
+
+    float px[PPT], py[PPT], pz[PPT], t[PPT];
+#pragma unroll
+    for (int s = 0; s < PPT; ++s) {
+        const int k = s * kThreads + tid;
+        float x = 0.f, y = 0.f, z = 0.f;
+        if (k < n) { x = p[k * 3 + 0]; y = p[k * 3 + 1]; z = p[k * 3 + 2]; }
+        px[s] = x; py[s] = y; pz[s] = z;
+        const float mag = (x * x + y * y) + z * z;
+        // skipped / out-of-range points carry -inf: min() keeps it and "> best" never selects it
+        t[s] = (k < n && !(mag <= 1e-3f)) ? 1e10f : -__builtin_inff();
+    }
+
+    int old = 0;
+    if (tid == 0 && G > 0) {
+        out[0] = 0;
+        if (cen) { cen[0] = p[0]; cen[1] = p[1]; cen[2] = p[2]; }
+    }
+    for (int j = 1; j < G; ++j) {
+        const int so = __builtin_amdgcn_readfirstlane(old);
+        const float x1 = p[so * 3 + 0], y1 = p[so * 3 + 1], z1 = p[so * 3 + 2];
+        float best = -1.0f;
+        int bests = 0;  // winning SLOT (an inline constant per unrolled step: no index registers)
+#pragma unroll
+        for (int s = 0; s < PPT; ++s) {
+            const float dx = px[s] - x1, dy = py[s] - y1, dz = pz[s] - z1;
+            const float d = (dx * dx + dy * dy) + dz * dz;
+            const float d2 = fminf(d, t[s]);
+            t[s] = d2;
+            const bool gt = d2 > best;
+            best = gt ? d2 : best;
+            bests = gt ? s : bests;
+        }
+        const int besti = bests * kThreads + tid;
+        unsigned long long key = wave_max_u64(fps_key(best, besti));
+        const int buf = j & 1;
+        if ((tid & 63) == 0) s_key[buf][tid >> 6] = key;
+        __syncthreads();
+        unsigned long long m = s_key[buf][0];
+#pragma unroll
+        for (int w = 1; w < kWaves; ++w) {
+            const unsigned long long o = s_key[buf][w];
+            m = o > m ? o : m;
+        }
+        old = m == 0ull ? 0 : (int)(0xFFFFFFFFu - (unsigned)(m & 0xFFFFFFFFull));
+        if (tid == 0) {
+            out[j] = old;
+            if (cen) { cen[j * 3 + 0] = p[old * 3 + 0]; cen[j * 3 + 1] = p[old * 3 + 1]; cen[j * 3 + 2] = p[old * 3 + 2]; }
+        }
+    }
+}
+
+// Fallback for clouds that do not fit the register file of one CU (N > 24*1024): running min in
+// a caller-provided global workspace (L2-resident), coordinates re-read every round.
+__global__ __launch_bounds__(kThreads) void fps_mem_kernel(const float* __restrict__ xyz,
+                                                           const int32_t* __restrict__ n_valid, int N, int G,
+                                                           float* __restrict__ temp_ws,
+                                                           int32_t* __restrict__ idx_out,
+                                                           float* __restrict__ center_out)
+{
+    __shared__ unsigned long long s_key[2][kWaves];
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int n = n_valid ? n_valid[b] : N;
+    const float* p = xyz + (size_t)b * N * 3;
+    float* temp = temp_ws + (size_t)b * N;
+    int32_t* out = idx_out + (size_t)b * G;
+    float* cen = center_out ? center_out + (size_t)b * G * 3 : nullptr;
+
+    for (int k = tid; k < n; k += kThreads) {
+        const float x = p[k * 3], y = p[k * 3 + 1], z = p[k * 3 + 2];
+        const float mag = (x * x + y * y) + z * z;
+        temp[k] = !(mag <= 1e-3f) ? 1e10f : -__builtin_inff();
+    }
+    int old = 0;
+    if (tid == 0 && G > 0) {
+        out[0] = 0;
+        if (cen) { cen[0] = p[0]; cen[1] = p[1]; cen[2] = p[2]; }
+    }
+    for (int j = 1; j < G; ++j) {
+        const int so = __builtin_amdgcn_readfirstlane(old);
+        const float x1 = p[so * 3 + 0], y1 = p[so * 3 + 1], z1 = p[so * 3 + 2];
+        float best = -1.0f;
+        int besti = 0;
+        for (int k = tid; k < n; k += kThreads) {
+            const float dx = p[k * 3] - x1, dy = p[k * 3 + 1] - y1, dz = p[k * 3 + 2] - z1;
+            const float d = (dx * dx + dy * dy) + dz * dz;
+            const float d2 = fminf(d, temp[k]);
+            temp[k] = d2;
+            const bool gt = d2 > best;
+            best = gt ? d2 : best;
+            besti = gt ? k : besti;
+        }
+        unsigned long long key = wave_max_u64(fps_key(best, besti));
+        const int buf = j & 1;
+        if ((tid & 63) == 0) s_key[buf][tid >> 6] = key;
+        __syncthreads();
+        unsigned long long m = s_key[buf][0];
+#pragma unroll
+        for (int w = 1; w < kWaves; ++w) {
+            const unsigned long long o = s_key[buf][w];
+            m = o > m ? o : m;
+        }
+        old = m == 0ull ? 0 : (int)(0xFFFFFFFFu - (unsigned)(m & 0xFFFFFFFFull));
+        if (tid == 0) {
+            out[j] = old;
+            if (cen) { cen[j * 3 + 0] = p[old * 3 + 0]; cen[j * 3 + 1] = p[old * 3 + 1]; cen[j * 3 + 2] = p[old * 3 + 2]; }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" size_t cmdiad_fps_workspace_bytes(int B, int N)
+{
+    return N > kMaxRegPoints ? (size_t)B * (size_t)N * sizeof(float) : 0;
+}
+
+extern "C" int cmdiad_fps(const float* xyz, const int32_t* n_valid, int B, int N, int G, int32_t* idx_out,
+                          float* center_out, void* workspace, size_t workspace_bytes, cmdiad_stream_t stream)
+{
+    CMDIAD_REQUIRE(xyz && idx_out, CMDIAD_ERR_ARG, "cmdiad_fps: null pointer");
+    CMDIAD_REQUIRE(B >= 0 && N > 0 && G >= 0, CMDIAD_ERR_ARG, "cmdiad_fps: bad sizes B=%d N=%d G=%d", B, N, G);
+    if (B == 0 || G == 0) return CMDIAD_OK;
+    hipStream_t s = (hipStream_t)stream;
+#define FPS_LAUNCH(T, P) hipLaunchKernelGGL((fps_reg_kernel<T, P>), dim3(B), dim3(T), 0, s, xyz, n_valid, N, G, idx_out, center_out)
+    // 1024 threads (4 waves/SIMD, 128 VGPRs) hold 16 points per lane; larger clouds use 512 threads
+    // (2 waves/SIMD, 256 VGPRs): the register file of ONE CU bounds the resident cloud at ~28k points.
+    if (N <= 1024 * 4) FPS_LAUNCH(1024, 4);
+    else if (N <= 1024 * 8) FPS_LAUNCH(1024, 8);
+    else if (N <= 1024 * 16) FPS_LAUNCH(1024, 16);
+    else if (N <= 512 * 40) FPS_LAUNCH(512, 40);
+    else if (N <= 512 * 48) FPS_LAUNCH(512, 48);
+    else if (N <= 512 * 56) FPS_LAUNCH(512, 56);
+#undef FPS_LAUNCH
+    else {
+        CMDIAD_REQUIRE(workspace && workspace_bytes >= cmdiad_fps_workspace_bytes(B, N), CMDIAD_ERR_WORKSPACE,
+                       "cmdiad_fps: N=%d needs %zu workspace bytes", N, cmdiad_fps_workspace_bytes(B, N));
+        hipLaunchKernelGGL(fps_mem_kernel, dim3(B), dim3(kThreads), 0, s, xyz, n_valid, N, G, (float*)workspace, idx_out, center_out);
+    }
+    CMDIAD_CHECK_LAUNCH();
+    return CMDIAD_OK;
+}

@@ -1,0 +1,319 @@
+// GEMM entry points built on gemm_core.h: generic Linear with fused epilogue, QKV with head-split
+// stores, and the Point-MAE encoder stages (on-the-fly first conv, per-group max pooling).
+#include "gemm_core.h"
+
+namespace {
+
+using namespace gemm;
+
+// ------------------------------------------------------------------------------------------------
+// Generic:  out = act(A.W^T + bias + group_bias[row/group_rows]) + residual
+// ------------------------------------------------------------------------------------------------
+struct StdParams {
+    int M, N, K;
+    const float* bias;
+    const float* group_bias;
+    int group_rows;
+    int act;
+    const float* residual; int ldr;
+    float* out_f32; int ldo32;
+    bf16_t* out_bf16; int ldo16;
+};
+
+__global__ __launch_bounds__(kThreads, 2) void gemm_std_kernel(GlobalTile A, GlobalTile W, StdParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int ntn = (p.N + BN - 1) / BN;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int mt = wg / ntn, nt = wg % ntn;
+    const int m0 = mt * BM;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+
+    run<true>(A, W, m0, nt, 1, p.K / BK, lds, [&](Acc& acc, int ntile) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + wr * 64 + i * 16 + (lane & 15);
+            if (m >= p.M) continue;
+            const float* gb = p.group_bias ? p.group_bias + (size_t)(m / p.group_rows) * p.N : nullptr;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = ntile * BN + wc * 64 + j * 16 + (lane >> 4) * 4;
+                if (n >= p.N) continue;
+                f32x4 v = acc[i][j];
+                if (p.bias) { const float4 b = *reinterpret_cast<const float4*>(p.bias + n); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+                if (gb) { const float4 b = *reinterpret_cast<const float4*>(gb + n); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+                if (p.act == CMDIAD_ACT_GELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                } else if (p.act == CMDIAD_ACT_RELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
+                }
+                if (p.residual) {
+                    const float4 b = *reinterpret_cast<const float4*>(p.residual + (size_t)m * p.ldr + n);
+                    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+                }
+                if (p.out_f32) *reinterpret_cast<f32x4*>(p.out_f32 + (size_t)m * p.ldo32 + n) = v;
+                if (p.out_bf16) {
+                    bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+                    *reinterpret_cast<bf16x4*>(p.out_bf16 + (size_t)m * p.ldo16 + n) = o;
+                }
+            }
+        }
+    });
+}
+
+// ------------------------------------------------------------------------------------------------
+// QKV projection, head-split stores (head_dim 64).  Q and K tiles run swapped (4 consecutive d per
+// lane -> 8-byte stores into [B,H,Tp,64]); V tiles run un-swapped (4 consecutive tokens per lane)
+// and are stored transposed into [B,H,64,Tp] so the attention kernel reads keys contiguously.
+// ------------------------------------------------------------------------------------------------
+struct QkvParams {
+    int M, T, Tp, C, H;
+    const float* bias;
+    bf16_t *q, *k, *vt;
+};
+
+__global__ __launch_bounds__(kThreads, 2) void gemm_qkv_kernel(GlobalTile A, GlobalTile W, QkvParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int ntn = (3 * p.C) / BN;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int mt = wg / ntn, nt = wg % ntn;
+    const int m0 = mt * BM;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int which = (nt * BN) / p.C;  // 0 q, 1 k, 2 v : block-uniform because C % 128 == 0
+
+    if (which < 2) {
+        bf16_t* dst = which == 0 ? p.q : p.k;
+        const float scale = which == 0 ? 0.125f : 1.0f;  // head_dim^-0.5, exact in bf16
+        run<true>(A, W, m0, nt, 1, p.C / BK, lds, [&](Acc& acc, int ntile) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = m0 + wr * 64 + i * 16 + (lane & 15);
+                if (m >= p.M) continue;
+                const int b = m / p.T, t = m - b * p.T;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = ntile * BN + wc * 64 + j * 16 + (lane >> 4) * 4;
+                    const int c = n - which * p.C;
+                    const int h = c >> 6, d = c & 63;
+                    f32x4 v = acc[i][j];
+                    if (p.bias) { const float4 bb = *reinterpret_cast<const float4*>(p.bias + n); v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w; }
+                    bf16x4 o = {f2bf(v[0] * scale), f2bf(v[1] * scale), f2bf(v[2] * scale), f2bf(v[3] * scale)};
+                    *reinterpret_cast<bf16x4*>(dst + (((size_t)b * p.H + h) * p.Tp + t) * 64 + d) = o;
+                }
+            }
+        });
+    } else {
+        run<false>(A, W, m0, nt, 1, p.C / BK, lds, [&](Acc& acc, int ntile) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = ntile * BN + wc * 64 + j * 16 + (lane & 15);
+                const int c = n - 2 * p.C;
+                const int h = c >> 6, d = c & 63;
+                const float bb = p.bias ? p.bias[n] : 0.0f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int m = m0 + wr * 64 + i * 16 + (lane >> 4) * 4 + r;
+                        if (m >= p.M) continue;
+                        const int b = m / p.T, t = m - b * p.T;
+                        p.vt[(((size_t)b * p.H + h) * 64 + d) * p.Tp + t] = f2bf(acc[i][j][r] + bb);
+                    }
+            }
+        });
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Per-group max pooling epilogue shared by the two encoder stages.  The 128-row tile holds
+// 128/Mg whole groups.  Column max: in-lane over the row tiles, xor-shuffle over the 16 row lanes,
+// then a 4 x 128 LDS table (one row per 32-row block) combined by the first 128 threads.
+// ------------------------------------------------------------------------------------------------
+struct GroupMaxParams {
+    int M, N, K, Mg;
+    const float* bias;
+    bf16_t* full_bf16; int ldf;  // optional full activations [M,N]
+    float* max_f32;
+    bf16_t* max_bf16;
+};
+
+template <class ALoader>
+__device__ __forceinline__ void groupmax_body(const ALoader& A, const GlobalTile& W, const GroupMaxParams& p, char* lds,
+                                              float (*s_max)[BN])
+{
+    const int ntn = (p.N + BN - 1) / BN;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int mt = wg / ntn, nt = wg % ntn;
+    const int m0 = mt * BM;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+
+    run<true>(A, W, m0, nt, 1, p.K / BK, lds, [&](Acc& acc, int ntile) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int nl = wc * 64 + j * 16 + (lane >> 4) * 4;  // column within the tile
+            const int n = ntile * BN + nl;
+            float4 b = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias && n < p.N) b = *reinterpret_cast<const float4*>(p.bias + n);
+            f32x4 mx[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f32x4 v = acc[i][j];
+                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+                const int m = m0 + wr * 64 + i * 16 + (lane & 15);
+                if (p.full_bf16 && m < p.M && n < p.N) {
+                    bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+                    *reinterpret_cast<bf16x4*>(p.full_bf16 + (size_t)m * p.ldf + n) = o;
+                }
+                if ((i & 1) == 0) mx[i >> 1] = v;
+                else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) mx[i >> 1][r] = fmaxf(mx[i >> 1][r], v[r]);
+                }
+            }
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = mx[hb][r];
+                    v = fmaxf(v, __shfl_xor(v, 1, 64));
+                    v = fmaxf(v, __shfl_xor(v, 2, 64));
+                    v = fmaxf(v, __shfl_xor(v, 4, 64));
+                    v = fmaxf(v, __shfl_xor(v, 8, 64));
+                    if ((lane & 15) == 0) s_max[wr * 2 + hb][nl + r] = v;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < BN) {
+            const int n = ntile * BN + tid;
+            const int per = p.Mg / 32;  // 32-row blocks per group: 1, 2 or 4
+            for (int g = 0; g < 4 / per; ++g) {
+                float v = s_max[g * per][tid];
+                for (int q = 1; q < per; ++q) v = fmaxf(v, s_max[g * per + q][tid]);
+                const int grp = (m0 + g * p.Mg) / p.Mg;
+                if (n < p.N && m0 + g * p.Mg < p.M) {
+                    if (p.max_f32) p.max_f32[(size_t)grp * p.N + n] = v;
+                    if (p.max_bf16) p.max_bf16[(size_t)grp * p.N + n] = f2bf(v);
+                }
+            }
+        }
+    });
+}
+
+__global__ __launch_bounds__(kThreads, 2) void gemm_groupmax_kernel(GlobalTile A, GlobalTile W, GroupMaxParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    float(*s_max)[BN] = reinterpret_cast<float(*)[BN]>(lds + kLdsBytes);
+    groupmax_body(A, W, p, lds, s_max);
+}
+
+__global__ __launch_bounds__(kThreads, 2) void encoder_stage1_kernel(Conv1Tile A, GlobalTile W, GroupMaxParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    float(*s_max)[BN] = reinterpret_cast<float(*)[BN]>(lds + kLdsBytes);
+    groupmax_body(A, W, p, lds, s_max);
+}
+
+constexpr int kGroupMaxLds = kLdsBytes + 4 * BN * (int)sizeof(float);
+
+template <int TAG>
+int set_lds_tag(const void* kernel, int bytes)
+{
+    static bool done = false;  // one flag per TAG (= per kernel)
+    if (!done) {
+        if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
+            cmdiad_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d) failed", bytes);
+            return CMDIAD_ERR_LAUNCH;
+        }
+        done = true;
+    }
+    return CMDIAD_OK;
+}
+
+bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+}  // namespace
+
+extern "C" int cmdiad_gemm_bf16(const cmdiad_gemm_args* a, cmdiad_stream_t stream)
+{
+    CMDIAD_REQUIRE(a && a->A && a->W, CMDIAD_ERR_ARG, "cmdiad_gemm_bf16: null operand");
+    CMDIAD_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0 && a->K % 64 == 0 && a->N % 4 == 0, CMDIAD_ERR_ARG,
+                   "cmdiad_gemm_bf16: need K%%64==0 and N%%4==0 (M=%d N=%d K=%d)", a->M, a->N, a->K);
+    CMDIAD_REQUIRE(a->lda % 8 == 0 && a->ldw % 8 == 0 && aligned16(a->A) && aligned16(a->W), CMDIAD_ERR_ARG,
+                   "cmdiad_gemm_bf16: operands must be 16-byte aligned with ld%%8==0");
+    CMDIAD_REQUIRE(a->out_f32 || a->out_bf16, CMDIAD_ERR_ARG, "cmdiad_gemm_bf16: no output");
+    CMDIAD_REQUIRE((!a->out_f32 || (a->ldo32 % 4 == 0 && aligned16(a->out_f32))) &&
+                       (!a->out_bf16 || (a->ldo16 % 4 == 0 && ((uintptr_t)a->out_bf16 & 7) == 0)) &&
+                       (!a->residual || (a->ldr % 4 == 0 && aligned16(a->residual))) &&
+                       (!a->bias || aligned16(a->bias)) && (!a->group_bias || (aligned16(a->group_bias) && a->group_rows > 0)),
+                   CMDIAD_ERR_ARG, "cmdiad_gemm_bf16: epilogue operand alignment");
+    if (int rc = set_lds_tag<0>((const void*)gemm_std_kernel, kLdsBytes)) return rc;
+    GlobalTile A{(const bf16_t*)a->A, a->lda, a->M}, W{(const bf16_t*)a->W, a->ldw, a->N};
+    StdParams p{a->M, a->N, a->K, a->bias, a->group_bias, a->group_rows, a->act, a->residual, a->ldr,
+                a->out_f32, a->ldo32, (bf16_t*)a->out_bf16, a->ldo16};
+    const int grid = ((a->M + BM - 1) / BM) * ((a->N + BN - 1) / BN);
+    hipLaunchKernelGGL(gemm_std_kernel, dim3(grid), dim3(kThreads), kLdsBytes, (hipStream_t)stream, A, W, p);
+    CMDIAD_CHECK_LAUNCH();
+    return CMDIAD_OK;
+}
+
+extern "C" int cmdiad_gemm_qkv(const uint16_t* A, const uint16_t* W, const float* bias, int B, int T, int C,
+                               uint16_t* q_out, uint16_t* k_out, uint16_t* vt_out, cmdiad_stream_t stream)
+{
+    CMDIAD_REQUIRE(A && W && q_out && k_out && vt_out, CMDIAD_ERR_ARG, "cmdiad_gemm_qkv: null pointer");
+    CMDIAD_REQUIRE(B > 0 && T > 0 && C > 0 && C % 128 == 0, CMDIAD_ERR_ARG, "cmdiad_gemm_qkv: need C%%128==0 (C=%d)", C);
+    CMDIAD_REQUIRE(aligned16(A) && aligned16(W) && aligned16(q_out) && aligned16(k_out) && (!bias || aligned16(bias)),
+                   CMDIAD_ERR_ARG, "cmdiad_gemm_qkv: 16-byte alignment");
+    if (int rc = set_lds_tag<1>((const void*)gemm_qkv_kernel, kLdsBytes)) return rc;
+    const int M = B * T;
+    GlobalTile At{(const bf16_t*)A, C, M}, Wt{(const bf16_t*)W, C, 3 * C};
+    QkvParams p{M, T, (T + 63) / 64 * 64, C, C / 64, bias, (bf16_t*)q_out, (bf16_t*)k_out, (bf16_t*)vt_out};
+    const int grid = ((M + BM - 1) / BM) * (3 * C / BN);
+    hipLaunchKernelGGL(gemm_qkv_kernel, dim3(grid), dim3(kThreads), kLdsBytes, (hipStream_t)stream, At, Wt, p);
+    CMDIAD_CHECK_LAUNCH();
+    return CMDIAD_OK;
+}
+
+extern "C" int cmdiad_gemm_groupmax(const uint16_t* A, const uint16_t* W, const float* bias, int groups, int Mg,
+                                    int N, int K, float* out_f32, uint16_t* out_bf16, cmdiad_stream_t stream)
+{
+    CMDIAD_REQUIRE(A && W && (out_f32 || out_bf16), CMDIAD_ERR_ARG, "cmdiad_gemm_groupmax: null pointer");
+    CMDIAD_REQUIRE(groups > 0 && (Mg == 32 || Mg == 64 || Mg == 128) && N % 4 == 0 && K % 64 == 0, CMDIAD_ERR_ARG,
+                   "cmdiad_gemm_groupmax: Mg in {32,64,128}, N%%4==0, K%%64==0 (Mg=%d N=%d K=%d)", Mg, N, K);
+    CMDIAD_REQUIRE(aligned16(A) && aligned16(W) && (!bias || aligned16(bias)), CMDIAD_ERR_ARG,
+                   "cmdiad_gemm_groupmax: 16-byte alignment");
+    if (int rc = set_lds_tag<2>((const void*)gemm_groupmax_kernel, kGroupMaxLds)) return rc;
+    const int M = groups * Mg;
+    GlobalTile At{(const bf16_t*)A, K, M}, Wt{(const bf16_t*)W, K, N};
+    GroupMaxParams p{M, N, K, Mg, bias, nullptr, 0, out_f32, (bf16_t*)out_bf16};
+    const int grid = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    hipLaunchKernelGGL(gemm_groupmax_kernel, dim3(grid), dim3(kThreads), kGroupMaxLds, (hipStream_t)stream, At, Wt, p);
+    CMDIAD_CHECK_LAUNCH();
+    return CMDIAD_OK;
+}
+
+extern "C" int cmdiad_encoder_stage1(const float* neigh, const float* w1, const uint16_t* W2, const float* b2,
+                                     int groups, int Mg, uint16_t* h2_out, float* gmax_out,
+                                     uint16_t* gmax_bf16_out, cmdiad_stream_t stream)
+{
+    CMDIAD_REQUIRE(neigh && w1 && W2 && h2_out && gmax_out, CMDIAD_ERR_ARG, "cmdiad_encoder_stage1: null pointer");
+    CMDIAD_REQUIRE(groups > 0 && (Mg == 32 || Mg == 64 || Mg == 128), CMDIAD_ERR_ARG,
+                   "cmdiad_encoder_stage1: Mg in {32,64,128} (Mg=%d)", Mg);
+    CMDIAD_REQUIRE(aligned16(w1) && aligned16(W2) && (!b2 || aligned16(b2)) && ((uintptr_t)h2_out & 7) == 0,
+                   CMDIAD_ERR_ARG, "cmdiad_encoder_stage1: alignment");
+    if (int rc = set_lds_tag<3>((const void*)encoder_stage1_kernel, kGroupMaxLds)) return rc;
+    const int M = groups * Mg;
+    Conv1Tile At{neigh, (const float4*)w1, M};
+    GlobalTile Wt{(const bf16_t*)W2, 128, 256};
+    GroupMaxParams p{M, 256, 128, Mg, b2, (bf16_t*)h2_out, 256, gmax_out, (bf16_t*)gmax_bf16_out};
+    const int grid = ((M + BM - 1) / BM) * (256 / BN);
+    hipLaunchKernelGGL(encoder_stage1_kernel, dim3(grid), dim3(kThreads), kGroupMaxLds, (hipStream_t)stream, At, Wt, p);
+    CMDIAD_CHECK_LAUNCH();
+    return CMDIAD_OK;
+}

@@ -1,0 +1,288 @@
+// Point-cloud -> patch-grid kernels for gfx950:
+//   cmdiad_unorganize   reference feature_extractors/multiple_features.py:10-25
+//   cmdiad_interp3nn    reference models/pointnet2_utils.py:45-75 (selection + weights)
+//   cmdiad_interp_gather  ... :72 (weighted gather; only used to materialise the reference's
+//                         [1,D,N] tensor for callers that insist on it)
+//   cmdiad_xyz_patch_fused  reference features.py:169-184 fused with the gather above.
+//
+// The reference materialises interp [D,N] (154 MB), scatters it into a zero [D,224*224] map, then
+// runs AvgPool2d(3,1) and AdaptiveAvgPool2d.  All three steps are linear, so the patch feature is
+//   out[p][:] = sum_{pixels in p's footprint} c_y(Y) c_x(X) * sum_k w3[pt][k] * F[idx3[pt][k]][:]
+// with separable coefficients.  A footprint (<= 7x7 pixels x 3 neighbours) touches only a handful
+// of distinct group centres, so the kernel first folds the footprint into a short (centre, weight)
+// list in LDS (deterministic order: no float atomics) and then streams those few feature rows
+// from L2.  HBM traffic per image: F (3 MB) + idx3/w3 (0.6 MB) + output (9.6 MB) instead of
+// ~460 MB for the unfused chain.
+//
+// interp3nn is compiled with -ffp-contract=off and follows oracle/cmdiad_oracle.c:orc_interp3nn
+// operation by operation, so idx3 / w3 are bit-exact against the oracle.
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// a1: keep pixels whose x, y, z are all non-zero, in raster order.  One 1024-thread block per image;
+// thread t owns a contiguous run of pixels, block-wide exclusive scan of the run counts.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void unorganize_kernel(const float* __restrict__ pc, int HW, int Nmax,
+                                                          float* __restrict__ xyz, int32_t* __restrict__ nz,
+                                                          int32_t* __restrict__ pix2pt, int32_t* __restrict__ n_valid)
+{
+    __shared__ int s_scan[1024];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* px = pc + (size_t)b * 3 * HW;
+    const float* py = px + HW;
+    const float* pz = py + HW;
+    const int per = (HW + 1023) / 1024;
+    const int i0 = tid * per, i1 = min(i0 + per, HW);
+    int cnt = 0;
+    for (int i = i0; i < i1; ++i) cnt += (px[i] != 0.0f && py[i] != 0.0f && pz[i] != 0.0f) ? 1 : 0;
+    s_scan[tid] = cnt;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
+        const int v = tid >= off ? s_scan[tid - off] : 0;
+        __syncthreads();
+        s_scan[tid] += v;
+        __syncthreads();
+    }
+    int pos = s_scan[tid] - cnt;
+    if (tid == 1023 && n_valid) n_valid[b] = min(s_scan[1023], Nmax);
+    for (int i = i0; i < i1; ++i) {
+        const float x = px[i], y = py[i], z = pz[i];
+        const bool keep = x != 0.0f && y != 0.0f && z != 0.0f;
+        if (pix2pt) pix2pt[(size_t)b * HW + i] = (keep && pos < Nmax) ? pos : -1;
+        if (keep) {
+            if (pos < Nmax) {
+                float* o = xyz + ((size_t)b * Nmax + pos) * 3;
+                o[0] = x; o[1] = y; o[2] = z;
+                if (nz) nz[(size_t)b * Nmax + pos] = i;
+            }
+            ++pos;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// a7 (selection): 3 nearest centres per point, d = -2*dot + |a|^2 + |b|^2, weights 1/(d+1e-8).
+// Centres {x,y,z,|c|^2} staged in LDS; every lane scans them with broadcast ds_read_b128.
+// ---------------------------------------------------------------------------------------------
+constexpr int kMaxCentres = 4096;
+
+__global__ __launch_bounds__(256) void interp3nn_kernel(const float* __restrict__ xyz, const int32_t* __restrict__ n_valid,
+                                                        const float* __restrict__ center, int N, int S,
+                                                        int32_t* __restrict__ idx3, float* __restrict__ w3)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4* s_c = reinterpret_cast<float4*>(smem);
+    const int b = blockIdx.y;
+    const int n = n_valid ? n_valid[b] : N;
+    const float* cb = center + (size_t)b * S * 3;
+    for (int s = threadIdx.x; s < S; s += 256) {
+        const float x = cb[s * 3], y = cb[s * 3 + 1], z = cb[s * 3 + 2];
+        s_c[s] = make_float4(x, y, z, (x * x + y * y) + z * z);
+    }
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float* p = xyz + ((size_t)b * N + i) * 3;
+    const float x = p[0], y = p[1], z = p[2];
+    const float n1 = (x * x + y * y) + z * z;
+    float d0 = __builtin_inff(), d1 = __builtin_inff(), d2 = __builtin_inff();
+    int i0 = 0, i1 = 0, i2 = 0;
+    for (int s = 0; s < S; ++s) {
+        const float4 c = s_c[s];
+        const float dot = (x * c.x + y * c.y) + z * c.z;
+        float d = -2.0f * dot;
+        d = d + n1;
+        d = d + c.w;
+        if (d < d2) {  // s increases, so strict '<' keeps the lowest index among equal distances
+            if (d < d1) {
+                d2 = d1; i2 = i1;
+                if (d < d0) { d1 = d0; i1 = i0; d0 = d; i0 = s; }
+                else { d1 = d; i1 = s; }
+            } else { d2 = d; i2 = s; }
+        }
+    }
+    const float r0 = 1.0f / (d0 + 1e-8f);
+    const float r1 = S > 1 ? 1.0f / (d1 + 1e-8f) : 0.0f;
+    const float r2 = S > 2 ? 1.0f / (d2 + 1e-8f) : 0.0f;
+    const float norm = (r0 + r1) + r2;
+    const size_t o = ((size_t)b * N + i) * 3;
+    idx3[o] = i0; idx3[o + 1] = i1; idx3[o + 2] = i2;
+    w3[o] = r0 / norm; w3[o + 1] = r1 / norm; w3[o + 2] = r2 / norm;
+}
+
+// out[b][n][:] = (F[i0]*w0 + F[i1]*w1) + F[i2]*w2 ; one wave per point, 16-byte accesses.
+__global__ __launch_bounds__(256) void interp_gather_kernel(const float* __restrict__ feat, const int32_t* __restrict__ idx3,
+                                                            const float* __restrict__ w3,
+                                                            const int32_t* __restrict__ n_valid, int N, int S, int D,
+                                                            float* __restrict__ out)
+{
+    const int b = blockIdx.y;
+    const int n = n_valid ? n_valid[b] : N;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (i >= n) return;
+    const size_t o = ((size_t)b * N + i) * 3;
+    const float* f0 = feat + ((size_t)b * S + idx3[o]) * D;
+    const float* f1 = feat + ((size_t)b * S + idx3[o + 1]) * D;
+    const float* f2 = feat + ((size_t)b * S + idx3[o + 2]) * D;
+    const float w0 = w3[o], w1 = w3[o + 1], w2 = w3[o + 2];
+    float* dst = out + ((size_t)b * N + i) * D;
+    for (int c = lane * 4; c < D; c += 256) {
+        const float4 a = *reinterpret_cast<const float4*>(f0 + c);
+        const float4 bb = *reinterpret_cast<const float4*>(f1 + c);
+        const float4 cc = *reinterpret_cast<const float4*>(f2 + c);
+        float4 r;
+        r.x = (a.x * w0 + bb.x * w1) + cc.x * w2;
+        r.y = (a.y * w0 + bb.y * w1) + cc.y * w2;
+        r.z = (a.z * w0 + bb.z * w1) + cc.z * w2;
+        r.w = (a.w * w0 + bb.w * w1) + cc.w * w2;
+        *reinterpret_cast<float4*>(dst + c) = r;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// a7 (gather) + a9 fused: one 256-thread block per output patch.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void xyz_patch_fused_kernel(const float* __restrict__ feat, const int32_t* __restrict__ idx3,
+                                                              const float* __restrict__ w3,
+                                                              const int32_t* __restrict__ pix2pt, int N, int S, int D,
+                                                              int size, int P, float mean, float inv_std,
+                                                              float* __restrict__ out_f32, bf16_t* __restrict__ out_bf16)
+{
+    constexpr int kMaxEnt = 3 * 12 * 12;
+    __shared__ int s_g[kMaxEnt];
+    __shared__ float s_w[kMaxEnt];
+    __shared__ int s_lg[kMaxEnt];
+    __shared__ float s_lw[kMaxEnt];
+    __shared__ int s_cnt;
+
+    const int b = blockIdx.y;
+    const int py = blockIdx.x / P, px = blockIdx.x % P;
+    const int L = size - 2;
+    const int y0 = (py * L) / P, y1 = ((py + 1) * L + P - 1) / P;
+    const int x0 = (px * L) / P, x1 = ((px + 1) * L + P - 1) / P;
+    const int fh = y1 - y0 + 2, fw = x1 - x0 + 2;  // footprint in the size x size map
+    const int ne = fh * fw * 3;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_cnt = 0;
+
+    // entry e = (pixel, neighbour k): centre index and combined coefficient
+    for (int e = tid; e < ne; e += 256) {
+        const int k = e % 3, pix = e / 3;
+        const int fy = pix / fw, fx = pix % fw;
+        const int Y = y0 + fy, X = x0 + fx;
+        // number of 3-windows starting in [y0,y1) that cover row Y: starts y in [max(y0,Y-2), min(y1-1,Y)]
+        const int cy = min(y1 - 1, Y) - max(y0, Y - 2) + 1;
+        const int cx = min(x1 - 1, X) - max(x0, X - 2) + 1;
+        const float coef = ((float)cy / (3.0f * (float)(y1 - y0))) * ((float)cx / (3.0f * (float)(x1 - x0)));
+        const int pt = pix2pt[(size_t)b * size * size + (size_t)Y * size + X];
+        int g = -1;
+        float w = 0.0f;
+        if (pt >= 0) {
+            g = idx3[((size_t)b * N + pt) * 3 + k];
+            w = coef * w3[((size_t)b * N + pt) * 3 + k];
+        }
+        s_g[e] = g; s_w[e] = w;
+    }
+    __syncthreads();
+    // deterministic fold: the first entry of every distinct centre sums all its entries in index order
+    for (int e = tid; e < ne; e += 256) {
+        const int g = s_g[e];
+        if (g < 0) continue;
+        bool first = true;
+        for (int j = 0; j < e; ++j) if (s_g[j] == g) { first = false; break; }
+        if (!first) continue;
+        float acc = s_w[e];
+        for (int j = e + 1; j < ne; ++j) if (s_g[j] == g) acc += s_w[j];
+        const int slot = atomicAdd(&s_cnt, 1);
+        s_lg[slot] = g; s_lw[slot] = acc;
+    }
+    __syncthreads();
+    const int cnt = s_cnt;
+    // order the short list by centre index so the channel sums are run-to-run reproducible
+    if (tid == 0) {
+        for (int i = 1; i < cnt; ++i) {
+            const int g = s_lg[i]; const float w = s_lw[i];
+            int j = i - 1;
+            while (j >= 0 && s_lg[j] > g) { s_lg[j + 1] = s_lg[j]; s_lw[j + 1] = s_lw[j]; --j; }
+            s_lg[j + 1] = g; s_lw[j + 1] = w;
+        }
+    }
+    __syncthreads();
+
+    const size_t orow = ((size_t)b * P * P + blockIdx.x) * D;
+    for (int c = tid * 4; c < D; c += 1024) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < cnt; ++i) {
+            const float w = s_lw[i];
+            const float4 f = *reinterpret_cast<const float4*>(feat + ((size_t)b * S + s_lg[i]) * D + c);
+            acc.x += w * f.x; acc.y += w * f.y; acc.z += w * f.z; acc.w += w * f.w;
+        }
+        acc.x = (acc.x - mean) * inv_std; acc.y = (acc.y - mean) * inv_std;
+        acc.z = (acc.z - mean) * inv_std; acc.w = (acc.w - mean) * inv_std;
+        if (out_f32) *reinterpret_cast<float4*>(out_f32 + orow + c) = acc;
+        if (out_bf16) {
+            bf16x4 o = {f2bf(acc.x), f2bf(acc.y), f2bf(acc.z), f2bf(acc.w)};
+            *reinterpret_cast<bf16x4*>(out_bf16 + orow + c) = o;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int cmdiad_unorganize(const float* organized_pc, int B, int HW, int Nmax, float* xyz, int32_t* nz,
+                                 int32_t* pix2pt, int32_t* n_valid, cmdiad_stream_t stream)
+{
+    CMDIAD_REQUIRE(organized_pc && xyz && B > 0 && HW > 0 && Nmax > 0, CMDIAD_ERR_ARG, "cmdiad_unorganize: bad args");
+    hipLaunchKernelGGL(unorganize_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, organized_pc, HW, Nmax, xyz, nz,
+                       pix2pt, n_valid);
+    CMDIAD_CHECK_LAUNCH();
+    return CMDIAD_OK;
+}
+
+extern "C" int cmdiad_interp3nn(const float* xyz, const int32_t* n_valid, const float* center, int B, int N, int S,
+                                int32_t* idx3, float* w3, cmdiad_stream_t stream)
+{
+    CMDIAD_REQUIRE(xyz && center && idx3 && w3, CMDIAD_ERR_ARG, "cmdiad_interp3nn: null pointer");
+    CMDIAD_REQUIRE(B > 0 && N > 0 && S > 0 && S <= kMaxCentres, CMDIAD_ERR_ARG, "cmdiad_interp3nn: need 0<S<=%d (S=%d)",
+                   kMaxCentres, S);
+    dim3 grid((N + 255) / 256, B);
+    hipLaunchKernelGGL(interp3nn_kernel, grid, dim3(256), (size_t)S * sizeof(float4), (hipStream_t)stream, xyz, n_valid,
+                       center, N, S, idx3, w3);
+    CMDIAD_CHECK_LAUNCH();
+    return CMDIAD_OK;
+}
+
+extern "C" int cmdiad_interp_gather(const float* feat, const int32_t* idx3, const float* w3, const int32_t* n_valid,
+                                    int B, int N, int S, int D, float* out, cmdiad_stream_t stream)
+{
+    CMDIAD_REQUIRE(feat && idx3 && w3 && out, CMDIAD_ERR_ARG, "cmdiad_interp_gather: null pointer");
+    CMDIAD_REQUIRE(B > 0 && N > 0 && D % 4 == 0 && (((uintptr_t)feat | (uintptr_t)out) & 15) == 0, CMDIAD_ERR_ARG,
+                   "cmdiad_interp_gather: D%%4==0 and 16-byte alignment");
+    dim3 grid((N + 3) / 4, B);
+    hipLaunchKernelGGL(interp_gather_kernel, grid, dim3(256), 0, (hipStream_t)stream, feat, idx3, w3, n_valid, N, S, D, out);
+    CMDIAD_CHECK_LAUNCH();
+    return CMDIAD_OK;
+}
+
+extern "C" int cmdiad_xyz_patch_fused(const float* feat, const int32_t* idx3, const float* w3, const int32_t* pix2pt,
+                                      int B, int N, int S, int D, int size, int P, float mean, float inv_std,
+                                      float* patch_f32, uint16_t* patch_bf16, cmdiad_stream_t stream)
+{
+    CMDIAD_REQUIRE(feat && idx3 && w3 && pix2pt && (patch_f32 || patch_bf16), CMDIAD_ERR_ARG,
+                   "cmdiad_xyz_patch_fused: null pointer");
+    CMDIAD_REQUIRE(B > 0 && size > 2 && P > 0 && D % 4 == 0, CMDIAD_ERR_ARG, "cmdiad_xyz_patch_fused: bad sizes");
+    const int L = size - 2;
+    const int maxbin = (L + P - 1) / P + 1;  // adaptive bins are at most ceil(L/P)+1 wide
+    CMDIAD_REQUIRE(maxbin + 2 <= 12, CMDIAD_ERR_ARG, "cmdiad_xyz_patch_fused: footprint %d exceeds 12 (size=%d P=%d)",
+                   maxbin + 2, size, P);
+    CMDIAD_REQUIRE((((uintptr_t)feat | (uintptr_t)patch_f32) & 15) == 0 && ((uintptr_t)patch_bf16 & 7) == 0, CMDIAD_ERR_ARG,
+                   "cmdiad_xyz_patch_fused: alignment");
+    dim3 grid(P * P, B);
+    hipLaunchKernelGGL(xyz_patch_fused_kernel, grid, dim3(256), 0, (hipStream_t)stream, feat, idx3, w3, pix2pt, N, S, D,
+                       size, P, mean, inv_std, patch_f32, (bf16_t*)patch_bf16);
+    CMDIAD_CHECK_LAUNCH();
+    return CMDIAD_OK;
+}

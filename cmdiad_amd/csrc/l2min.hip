@@ -1,0 +1,282 @@
+// Patch-library nearest-neighbour scoring kernels (reference feature_extractors/features.py:186-190
+// calculate_dist = torch.cdist, :227 torch.min(dist, dim=1), :235-254 re-weighting scan).
+//
+// cmdiad_l2_min_keys: the Q x Nb x D distance contraction never leaves the chip.  Each block owns one
+// 128-query tile and a contiguous range of 128-row bank tiles; per bank tile the bf16 MFMA mainloop
+// (gemm_core.h, swapped orientation: a lane holds 4 bank rows for ONE query) produces q.b, the
+// epilogue forms d2 = |q|^2 + |b|^2 - 2 q.b and keeps a per-lane running (min, first index).  After
+// the last tile the four 16-lane groups and the two column waves are merged with packed 64-bit
+// keys (value bits << 32 | global row) and ONE atomicMin per query per block.  Blocks that share a
+// bank range get consecutive ids on one XCD, so a bank tile is fetched into that XCD's L2 once
+// per generation of resident blocks.
+#include "gemm_core.h"
+
+namespace {
+
+using namespace gemm;
+
+struct L2Params {
+    int Q, Nb, D;
+    const float* q_sqnorm;
+    const float* b_sqnorm;
+    unsigned row_offset;
+    unsigned long long* keys;
+    int nq_tiles, n_bank_tiles, splits;
+};
+
+__global__ __launch_bounds__(kThreads, 2) void l2_min_kernel(GlobalTile A, GlobalTile W, L2Params p)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = wg / p.nq_tiles, qt = wg % p.nq_tiles;  // same split -> same XCD neighbourhood
+    const int per = (p.n_bank_tiles + p.splits - 1) / p.splits;
+    const int nt0 = split * per;
+    const int ntc = min(per, p.n_bank_tiles - nt0);
+    if (ntc <= 0) return;
+    const int m0 = qt * BM;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+
+    float best[4], qn[4];
+    int besti[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        best[i] = __builtin_inff();
+        besti[i] = 0;
+        const int m = m0 + wr * 64 + i * 16 + (lane & 15);
+        qn[i] = m < p.Q ? p.q_sqnorm[m] : 0.0f;
+    }
+
+    run<true>(A, W, m0, nt0, ntc, p.D / BK, lds, [&](Acc& acc, int ntile) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = ntile * BN + wc * 64 + j * 16 + (lane >> 4) * 4;
+            float bn[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bn[r] = n + r < p.Nb ? p.b_sqnorm[n + r] : __builtin_inff();
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float d2 = (qn[i] + bn[r]) - 2.0f * acc[i][j][r];
+                    if (d2 < best[i]) { best[i] = d2; besti[i] = n + r; }  // n increases: first occurrence wins
+                }
+        }
+    });
+
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        unsigned long long key = pack_key(fmaxf(best[i], 0.0f), p.row_offset + (unsigned)besti[i]);
+        if (!(best[i] < __builtin_inff())) key = ~0ull;
+        unsigned long long o = shfl_xor_u64(key, 16);
+        key = o < key ? o : key;
+        o = shfl_xor_u64(key, 32);
+        key = o < key ? o : key;
+        const int m = m0 + wr * 64 + i * 16 + (lane & 15);
+        if (lane < 16 && m < p.Q) atomicMin(p.keys + m, key);
+    }
+}
+
+// Exact fp32 distance to the winning row: one wave per query.
+__global__ __launch_bounds__(256) void l2_rescore_kernel(const float* __restrict__ q, const float* __restrict__ bank,
+                                                         const unsigned long long* __restrict__ keys, int Q, int Nb,
+                                                         int D, unsigned row_offset, float* __restrict__ min_val,
+                                                         int64_t* __restrict__ min_idx)
+{
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= Q) return;
+    const unsigned gi = (unsigned)(keys[row] & 0xFFFFFFFFull);
+    if (gi < row_offset || gi >= row_offset + (unsigned)Nb) return;  // another shard owns the winner
+    const float* a = q + (size_t)row * D;
+    const float* b = bank + (size_t)(gi - row_offset) * D;
+    float s = 0.0f;
+    for (int c = lane * 4; c < D; c += 256) {
+        const float4 x = *reinterpret_cast<const float4*>(a + c);
+        const float4 y = *reinterpret_cast<const float4*>(b + c);
+        const float d0 = x.x - y.x, d1 = x.y - y.y, d2 = x.z - y.z, d3 = x.w - y.w;
+        s += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+    if (lane == 0) {
+        min_val[row] = sqrtf(s);
+        min_idx[row] = (int64_t)gi;
+    }
+}
+
+// Re-weighting scan: R probe rows against every bank row, exact fp32 ||a-b||^2, 3 smallest per probe.
+// One wave per bank row at a time (coalesced 16-byte loads of the row), probes re-read from L1/L2.
+// Per-wave top-3 in registers of lane 0 semantics (all lanes carry the same values after the
+// reduction), merged through LDS per block and then by atomic min-insertion into top3[R][3].
+
+__device__ __forceinline__ void top3_insert(unsigned long long (&t)[3], unsigned long long k)
+{
+    if (k < t[2]) {
+        if (k < t[1]) {
+            t[2] = t[1];
+            if (k < t[0]) { t[1] = t[0]; t[0] = k; }
+            else t[1] = k;
+        } else t[2] = k;
+    }
+}
+
+__global__ __launch_bounds__(256) void reweight_scan_kernel(const float* __restrict__ probes, const float* __restrict__ bank,
+                                                            int R, int Nb, int D, unsigned row_offset,
+                                                            unsigned long long* __restrict__ partial, int rows_per_block)
+{
+    __shared__ unsigned long long s_top[4][3];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(r0 + rows_per_block, Nb);
+    const int pr = blockIdx.y;  // probe handled by this block column
+    unsigned long long t[3] = {~0ull, ~0ull, ~0ull};
+    const float* a = probes + (size_t)pr * D;
+    for (int row = r0 + wave; row < r1; row += 4) {
+        const float* b = bank + (size_t)row * D;
+        float s = 0.0f;
+        for (int c = lane * 4; c < D; c += 256) {
+            const float4 x = *reinterpret_cast<const float4*>(a + c);
+            const float4 y = *reinterpret_cast<const float4*>(b + c);
+            const float d0 = x.x - y.x, d1 = x.y - y.y, d2 = x.z - y.z, d3 = x.w - y.w;
+            s += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+        top3_insert(t, pack_key(s, row_offset + (unsigned)row));
+    }
+    if (lane == 0) { s_top[wave][0] = t[0]; s_top[wave][1] = t[1]; s_top[wave][2] = t[2]; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long m[3] = {~0ull, ~0ull, ~0ull};
+        for (int w = 0; w < 4; ++w)
+            for (int k = 0; k < 3; ++k) top3_insert(m, s_top[w][k]);
+        unsigned long long* o = partial + ((size_t)pr * gridDim.x + blockIdx.x) * 3;
+        o[0] = m[0]; o[1] = m[1]; o[2] = m[2];
+    }
+}
+
+__global__ void reweight_merge_kernel(const unsigned long long* __restrict__ partial, int R, int nblocks,
+                                      unsigned long long* __restrict__ top3)
+{
+    const int pr = blockIdx.x;
+    if (threadIdx.x != 0 || pr >= R) return;
+    unsigned long long m[3] = {top3[pr * 3], top3[pr * 3 + 1], top3[pr * 3 + 2]};
+    const unsigned long long* src = partial + (size_t)pr * nblocks * 3;
+    for (int i = 0; i < nblocks * 3; ++i) top3_insert(m, src[i]);
+    top3[pr * 3] = m[0]; top3[pr * 3 + 1] = m[1]; top3[pr * 3 + 2] = m[2];
+}
+
+// (x - mean) * inv_std -> bf16 (+ optional f32 copy, + optional |row|^2 of the ROUNDED values).
+// One wave per row.
+__global__ __launch_bounds__(256) void normalize_cast_kernel(const float* __restrict__ x, size_t rows, int D, float mean,
+                                                             float inv_std, bf16_t* __restrict__ out_bf16,
+                                                             float* __restrict__ out_f32, float* __restrict__ sq)
+{
+    const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float s = 0.0f;
+    for (int c = lane * 4; c < D; c += 256) {
+        float4 v = *reinterpret_cast<const float4*>(x + row * D + c);
+        v.x = (v.x - mean) * inv_std; v.y = (v.y - mean) * inv_std;
+        v.z = (v.z - mean) * inv_std; v.w = (v.w - mean) * inv_std;
+        if (out_f32) *reinterpret_cast<float4*>(out_f32 + row * D + c) = v;
+        bf16x4 o = {f2bf(v.x), f2bf(v.y), f2bf(v.z), f2bf(v.w)};
+        if (out_bf16) *reinterpret_cast<bf16x4*>(out_bf16 + row * D + c) = o;
+        const float r0 = bf2f(o[0]), r1 = bf2f(o[1]), r2 = bf2f(o[2]), r3 = bf2f(o[3]);
+        s += r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3;
+    }
+    if (sq) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+        if (lane == 0) sq[row] = s;
+    }
+}
+
+bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+}  // namespace
+
+extern "C" int cmdiad_l2_min_keys(const uint16_t* q, const float* q_sqnorm, const uint16_t* bank,
+                                  const float* bank_sqnorm, int Q, int Nb, int D, uint32_t row_offset,
+                                  unsigned long long* keys, cmdiad_stream_t stream)
+{
+    CMDIAD_REQUIRE(q && q_sqnorm && bank && bank_sqnorm && keys, CMDIAD_ERR_ARG, "cmdiad_l2_min_keys: null pointer");
+    CMDIAD_REQUIRE(Q >= 0 && Nb >= 0 && D > 0 && D % 64 == 0, CMDIAD_ERR_ARG, "cmdiad_l2_min_keys: need D%%64==0 (D=%d)", D);
+    CMDIAD_REQUIRE(aligned16(q) && aligned16(bank), CMDIAD_ERR_ARG, "cmdiad_l2_min_keys: 16-byte alignment");
+    if (Q == 0 || Nb == 0) return CMDIAD_OK;
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)l2_min_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes) != hipSuccess) {
+            cmdiad_set_error("cmdiad_l2_min_keys: hipFuncSetAttribute failed");
+            return CMDIAD_ERR_LAUNCH;
+        }
+        attr = true;
+    }
+    const int nq = (Q + BM - 1) / BM, nbt = (Nb + BN - 1) / BN;
+    // enough blocks to fill 256 CUs x 2 several times over, but long bank ranges per block so the
+    // running min stays in registers and the per-block atomics stay negligible
+    int splits = (2048 + nq - 1) / nq;
+    splits = splits < 1 ? 1 : (splits > nbt ? nbt : splits);
+    if (splits > 8) splits = 8;
+    GlobalTile A{(const bf16_t*)q, D, Q}, W{(const bf16_t*)bank, D, Nb};
+    L2Params p{Q, Nb, D, q_sqnorm, bank_sqnorm, row_offset, keys, nq, nbt, splits};
+    hipLaunchKernelGGL(l2_min_kernel, dim3(nq * splits), dim3(kThreads), kLdsBytes, (hipStream_t)stream, A, W, p);
+    CMDIAD_CHECK_LAUNCH();
+    return CMDIAD_OK;
+}
+
+extern "C" int cmdiad_l2_rescore(const float* q, const float* bank, const unsigned long long* keys, int Q, int Nb,
+                                 int D, uint32_t row_offset, float* min_val, int64_t* min_idx, cmdiad_stream_t stream)
+{
+    CMDIAD_REQUIRE(q && bank && keys && min_val && min_idx, CMDIAD_ERR_ARG, "cmdiad_l2_rescore: null pointer");
+    CMDIAD_REQUIRE(D % 4 == 0 && aligned16(q) && aligned16(bank), CMDIAD_ERR_ARG, "cmdiad_l2_rescore: D%%4, alignment");
+    if (Q == 0) return CMDIAD_OK;
+    hipLaunchKernelGGL(l2_rescore_kernel, dim3((Q + 3) / 4), dim3(256), 0, (hipStream_t)stream, q, bank, keys, Q, Nb, D,
+                       row_offset, min_val, min_idx);
+    CMDIAD_CHECK_LAUNCH();
+    return CMDIAD_OK;
+}
+
+extern "C" size_t cmdiad_reweight_workspace_bytes(int R, int Nb)
+{
+    const int rows_per_block = 256;
+    const int nblocks = (Nb + rows_per_block - 1) / rows_per_block;
+    return (size_t)R * nblocks * 3 * sizeof(unsigned long long);
+}
+
+extern "C" int cmdiad_reweight_scan(const float* probes, const float* bank, int R, int Nb, int D, uint32_t row_offset,
+                                    unsigned long long* top3, void* workspace, size_t workspace_bytes,
+                                    cmdiad_stream_t stream)
+{
+    CMDIAD_REQUIRE(probes && bank && top3, CMDIAD_ERR_ARG, "cmdiad_reweight_scan: null pointer");
+    CMDIAD_REQUIRE(R > 0 && D % 4 == 0 && aligned16(probes) && aligned16(bank), CMDIAD_ERR_ARG,
+                   "cmdiad_reweight_scan: R>0, D%%4==0, 16-byte alignment");
+    if (Nb == 0) return CMDIAD_OK;
+    CMDIAD_REQUIRE(workspace && workspace_bytes >= cmdiad_reweight_workspace_bytes(R, Nb), CMDIAD_ERR_WORKSPACE,
+                   "cmdiad_reweight_scan: workspace too small");
+    const int rows_per_block = 256;
+    const int nblocks = (Nb + rows_per_block - 1) / rows_per_block;
+    hipLaunchKernelGGL(reweight_scan_kernel, dim3(nblocks, R), dim3(256), 0, (hipStream_t)stream, probes, bank, R, Nb, D,
+                       row_offset, (unsigned long long*)workspace, rows_per_block);
+    CMDIAD_CHECK_LAUNCH();
+    hipLaunchKernelGGL(reweight_merge_kernel, dim3(R), dim3(64), 0, (hipStream_t)stream,
+                       (const unsigned long long*)workspace, R, nblocks, top3);
+    CMDIAD_CHECK_LAUNCH();
+    return CMDIAD_OK;
+}
+
+extern "C" int cmdiad_normalize_cast(const float* x, size_t rows, int D, float mean, float inv_std, uint16_t* out_bf16,
+                                     float* out_f32, float* row_sqnorm, cmdiad_stream_t stream)
+{
+    CMDIAD_REQUIRE(x, CMDIAD_ERR_ARG, "cmdiad_normalize_cast: null input");
+    CMDIAD_REQUIRE(D % 4 == 0 && aligned16(x) && (!out_f32 || aligned16(out_f32)) &&
+                       (!out_bf16 || ((uintptr_t)out_bf16 & 7) == 0),
+                   CMDIAD_ERR_ARG, "cmdiad_normalize_cast: D%%4==0 and aligned buffers");
+    if (rows == 0) return CMDIAD_OK;
+    hipLaunchKernelGGL(normalize_cast_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, rows,
+                       D, mean, inv_std, (bf16_t*)out_bf16, out_f32, row_sqnorm);
+    CMDIAD_CHECK_LAUNCH();
+    return CMDIAD_OK;
+}

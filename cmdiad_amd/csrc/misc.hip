@@ -1,0 +1,251 @@
+// Bandwidth-bound helper kernels: LayerNorm (+ optional positional add), ViT patch im2col and token
+// assembly, bilinear up-sampling of the score map, casts.  One wave per row where a row reduction
+// is needed; 8/16-byte vector accesses everywhere (guide G13).
+#include "common.h"
+
+namespace {
+
+// y = LN(x (+ add)); optionally x <- x + add in place (Point-MAE: models/models.py:240 `block(x + pos)`).
+// C % 128 == 0, C <= 1024: a lane holds C/128 float2 pairs at columns 2*(lane + 64 e).
+template <int PAIRS>
+__global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, const float* __restrict__ add,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        float eps, int M, bf16_t* __restrict__ out_bf16,
+                                                        float* __restrict__ out_f32, int ldo32)
+{
+    constexpr int C = PAIRS * 128;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= M) return;
+    float2 v[PAIRS];
+    float s = 0.0f;
+#pragma unroll
+    for (int e = 0; e < PAIRS; ++e) {
+        const int c = 2 * (lane + 64 * e);
+        v[e] = *reinterpret_cast<const float2*>(x + (size_t)row * C + c);
+        if (add) {
+            const float2 a = *reinterpret_cast<const float2*>(add + (size_t)row * C + c);
+            v[e].x += a.x; v[e].y += a.y;
+            *reinterpret_cast<float2*>(x + (size_t)row * C + c) = v[e];
+        }
+        s += v[e].x + v[e].y;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+    const float mean = s / C;
+    float q = 0.0f;
+#pragma unroll
+    for (int e = 0; e < PAIRS; ++e) {
+        const float a = v[e].x - mean, b = v[e].y - mean;
+        q += a * a + b * b;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) q += __shfl_xor(q, m, 64);
+    const float rstd = rsqrtf(q / C + eps);
+#pragma unroll
+    for (int e = 0; e < PAIRS; ++e) {
+        const int c = 2 * (lane + 64 * e);
+        const float2 g = *reinterpret_cast<const float2*>(gamma + c);
+        const float2 bb = *reinterpret_cast<const float2*>(beta + c);
+        const float y0 = (v[e].x - mean) * rstd * g.x + bb.x;
+        const float y1 = (v[e].y - mean) * rstd * g.y + bb.y;
+        if (out_bf16) {
+            typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+            bf16x2 o = {f2bf(y0), f2bf(y1)};
+            *reinterpret_cast<bf16x2*>(out_bf16 + (size_t)row * C + c) = o;
+        }
+        if (out_f32) *reinterpret_cast<float2*>(out_f32 + (size_t)row * ldo32 + c) = make_float2(y0, y1);
+    }
+}
+
+// rgb [B,3,S,S] f32 -> patches [B*(S/8)^2, 192] bf16, k = c*64 + dy*8 + dx (conv weight [768,3,8,8] flattened).
+// One thread per (patch, c, dy): reads 8 contiguous floats, writes 8 contiguous bf16 (16 B).
+__global__ __launch_bounds__(256) void im2col_patch8_kernel(const float* __restrict__ rgb, int B, int S,
+                                                            bf16_t* __restrict__ patches)
+{
+    const int P = S / 8;
+    const size_t total = (size_t)B * P * P * 24;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int cd = (int)(i % 24);
+    const size_t pi = i / 24;
+    const int c = cd / 8, dy = cd % 8;
+    const int px = (int)(pi % P), py = (int)((pi / P) % P), b = (int)(pi / ((size_t)P * P));
+    const float* src = rgb + (((size_t)b * 3 + c) * S + (py * 8 + dy)) * S + px * 8;
+    const float4 a = *reinterpret_cast<const float4*>(src), d = *reinterpret_cast<const float4*>(src + 4);
+    bf16x8 o = {f2bf(a.x), f2bf(a.y), f2bf(a.z), f2bf(a.w), f2bf(d.x), f2bf(d.y), f2bf(d.z), f2bf(d.w)};
+    *reinterpret_cast<bf16x8*>(patches + pi * 192 + c * 64 + dy * 8) = o;
+}
+
+// tokens[b][0] = cls + pos[0]; tokens[b][1+i] = patch_out[b][i] + pos[1+i]
+__global__ __launch_bounds__(256) void vit_assemble_kernel(const float* __restrict__ patch_out, const float* __restrict__ cls,
+                                                           const float* __restrict__ pos, int B, int P, int C,
+                                                           float* __restrict__ tokens)
+{
+    const int c4 = C / 4;
+    const size_t total = (size_t)B * (P + 1) * c4;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % c4) * 4;
+    const size_t row = i / c4;
+    const int t = (int)(row % (P + 1));
+    const size_t b = row / (P + 1);
+    const float4 pe = *reinterpret_cast<const float4*>(pos + (size_t)t * C + c);
+    float4 v = t == 0 ? *reinterpret_cast<const float4*>(cls + c)
+                      : *reinterpret_cast<const float4*>(patch_out + (b * P + (t - 1)) * C + c);
+    v.x += pe.x; v.y += pe.y; v.z += pe.z; v.w += pe.w;
+    *reinterpret_cast<float4*>(tokens + row * C + c) = v;
+}
+
+// ATen upsample_bilinear2d, align_corners=False: src = max((dst + 0.5) * h/H - 0.5, 0).
+__global__ __launch_bounds__(256) void bilinear_up_kernel(const float* __restrict__ in, int B, int h, int H,
+                                                          float* __restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)B * H * H) return;
+    const int ox = (int)(i % H), oy = (int)((i / H) % H);
+    const size_t b = i / ((size_t)H * H);
+    const float scale = (float)h / (float)H;
+    float sy = scale * ((float)oy + 0.5f) - 0.5f; sy = sy < 0.f ? 0.f : sy;
+    float sx = scale * ((float)ox + 0.5f) - 0.5f; sx = sx < 0.f ? 0.f : sx;
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < h - 1 ? 1 : 0);
+    const float ly = sy - (float)y0, hy = 1.0f - ly, lx = sx - (float)x0, hx = 1.0f - lx;
+    const float* p = in + b * h * h;
+    out[i] = hy * (hx * p[y0 * h + x0] + lx * p[y0 * h + x1]) + ly * (hx * p[y1 * h + x0] + lx * p[y1 * h + x1]);
+}
+
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ x, size_t n4, bf16_t* __restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const float4 v = *reinterpret_cast<const float4*>(x + i * 4);
+    bf16x4 o = {f2bf(v.x), f2bf(v.y), f2bf(v.z), f2bf(v.w)};
+    *reinterpret_cast<bf16x4*>(out + i * 4) = o;
+}
+
+// out[c][r] = in[r][c] for bf16 matrices (training path: operands of the dW / dX GEMMs). 64x64 LDS tile.
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ in, int rows, int cols,
+                                                             bf16_t* __restrict__ out)
+{
+    __shared__ bf16_t tile[64][66];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        tile[r][c] = (r0 + r < rows && c0 + c < cols) ? in[(size_t)(r0 + r) * cols + c0 + c] : (bf16_t)0.0f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int c = i >> 6, r = i & 63;
+        if (c0 + c < cols && r0 + r < rows) out[(size_t)(c0 + c) * rows + r0 + r] = tile[r][c];
+    }
+}
+
+// out[m][n] = act(w[n].xyz . x[m] + w[n].w) for K = 3 inputs (Point-MAE pos_embed first layer,
+// models/models.py:268-272).  wb [N] float4 = {w_x, w_y, w_z, bias}.  One thread per 8 outputs.
+__global__ __launch_bounds__(256) void linear3_kernel(const float* __restrict__ x, const float4* __restrict__ wb, size_t M,
+                                                      int N, int act, bf16_t* __restrict__ out)
+{
+    const int n8 = N / 8;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M * n8) return;
+    const size_t m = i / n8;
+    const int n0 = (int)(i % n8) * 8;
+    const float a = x[m * 3], b = x[m * 3 + 1], c = x[m * 3 + 2];
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float4 w = wb[n0 + e];
+        float v = w.x * a + w.y * b + w.z * c + w.w;
+        v = act == CMDIAD_ACT_GELU ? gelu_erf(v) : (act == CMDIAD_ACT_RELU ? fmaxf(v, 0.0f) : v);
+        o[e] = f2bf(v);
+    }
+    *reinterpret_cast<bf16x8*>(out + m * N + n0) = o;
+}
+
+unsigned blocks_for(size_t n) { return (unsigned)((n + 255) / 256); }
+
+}  // namespace
+
+extern "C" int cmdiad_layernorm(float* x, const float* add, const float* gamma, const float* beta, float eps, int M,
+                                int C, uint16_t* out_bf16, float* out_f32, int ldo32, cmdiad_stream_t stream)
+{
+    CMDIAD_REQUIRE(x && gamma && beta && (out_bf16 || out_f32), CMDIAD_ERR_ARG, "cmdiad_layernorm: null pointer");
+    CMDIAD_REQUIRE(M >= 0 && C % 128 == 0 && C >= 128 && C <= 1024, CMDIAD_ERR_ARG,
+                   "cmdiad_layernorm: need C%%128==0, 128<=C<=1024 (C=%d)", C);
+    CMDIAD_REQUIRE((((uintptr_t)x | (uintptr_t)add | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)out_f32) & 7) == 0 &&
+                       ((uintptr_t)out_bf16 & 3) == 0 && (!out_f32 || ldo32 % 2 == 0),
+                   CMDIAD_ERR_ARG, "cmdiad_layernorm: alignment");
+    if (M == 0) return CMDIAD_OK;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((M + 3) / 4), block(256);
+#define LN_CASE(P) case P: hipLaunchKernelGGL(layernorm_kernel<P>, grid, block, 0, s, x, add, gamma, beta, eps, M, (bf16_t*)out_bf16, out_f32, ldo32); break;
+    switch (C / 128) {
+        LN_CASE(1) LN_CASE(2) LN_CASE(3) LN_CASE(4) LN_CASE(5) LN_CASE(6) LN_CASE(7) LN_CASE(8)
+    }
+#undef LN_CASE
+    CMDIAD_CHECK_LAUNCH();
+    return CMDIAD_OK;
+}
+
+extern "C" int cmdiad_im2col_patch8(const float* rgb, int B, int S, uint16_t* patches, cmdiad_stream_t stream)
+{
+    CMDIAD_REQUIRE(rgb && patches && B > 0 && S > 0 && S % 8 == 0, CMDIAD_ERR_ARG, "cmdiad_im2col_patch8: bad args");
+    CMDIAD_REQUIRE((((uintptr_t)rgb | (uintptr_t)patches) & 15) == 0, CMDIAD_ERR_ARG, "cmdiad_im2col_patch8: alignment");
+    const size_t total = (size_t)B * (S / 8) * (S / 8) * 24;
+    hipLaunchKernelGGL(im2col_patch8_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, rgb, B, S,
+                       (bf16_t*)patches);
+    CMDIAD_CHECK_LAUNCH();
+    return CMDIAD_OK;
+}
+
+extern "C" int cmdiad_vit_assemble(const float* patch_out, const float* cls, const float* pos, int B, int P, int C,
+                                   float* tokens, cmdiad_stream_t stream)
+{
+    CMDIAD_REQUIRE(patch_out && cls && pos && tokens && B > 0 && P > 0 && C % 4 == 0, CMDIAD_ERR_ARG,
+                   "cmdiad_vit_assemble: bad args");
+    const size_t total = (size_t)B * (P + 1) * (C / 4);
+    hipLaunchKernelGGL(vit_assemble_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, patch_out, cls, pos,
+                       B, P, C, tokens);
+    CMDIAD_CHECK_LAUNCH();
+    return CMDIAD_OK;
+}
+
+extern "C" int cmdiad_bilinear_up(const float* in, int B, int h, int H, float* out, cmdiad_stream_t stream)
+{
+    CMDIAD_REQUIRE(in && out && B > 0 && h > 0 && H > 0, CMDIAD_ERR_ARG, "cmdiad_bilinear_up: bad args");
+    hipLaunchKernelGGL(bilinear_up_kernel, dim3(blocks_for((size_t)B * H * H)), dim3(256), 0, (hipStream_t)stream, in, B, h,
+                       H, out);
+    CMDIAD_CHECK_LAUNCH();
+    return CMDIAD_OK;
+}
+
+extern "C" int cmdiad_linear3(const float* x, const float* wb, size_t M, int N, int act, uint16_t* out,
+                              cmdiad_stream_t stream)
+{
+    CMDIAD_REQUIRE(x && wb && out && N % 8 == 0, CMDIAD_ERR_ARG, "cmdiad_linear3: N%%8==0 required");
+    CMDIAD_REQUIRE((((uintptr_t)wb | (uintptr_t)out) & 15) == 0, CMDIAD_ERR_ARG, "cmdiad_linear3: alignment");
+    if (M == 0) return CMDIAD_OK;
+    hipLaunchKernelGGL(linear3_kernel, dim3(blocks_for(M * (N / 8))), dim3(256), 0, (hipStream_t)stream, x,
+                       (const float4*)wb, M, N, act, (bf16_t*)out);
+    CMDIAD_CHECK_LAUNCH();
+    return CMDIAD_OK;
+}
+
+extern "C" int cmdiad_cast_bf16(const float* x, size_t n, uint16_t* out, cmdiad_stream_t stream)
+{
+    CMDIAD_REQUIRE(x && out && n % 4 == 0, CMDIAD_ERR_ARG, "cmdiad_cast_bf16: n%%4==0 required");
+    if (n == 0) return CMDIAD_OK;
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(blocks_for(n / 4)), dim3(256), 0, (hipStream_t)stream, x, n / 4, (bf16_t*)out);
+    CMDIAD_CHECK_LAUNCH();
+    return CMDIAD_OK;
+}
+
+extern "C" int cmdiad_transpose_bf16(const uint16_t* in, int rows, int cols, uint16_t* out, cmdiad_stream_t stream)
+{
+    CMDIAD_REQUIRE(in && out && rows > 0 && cols > 0, CMDIAD_ERR_ARG, "cmdiad_transpose_bf16: bad args");
+    hipLaunchKernelGGL(transpose_bf16_kernel, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)in, rows, cols, (bf16_t*)out);
+    CMDIAD_CHECK_LAUNCH();
+    return CMDIAD_OK;
+}

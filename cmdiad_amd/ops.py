@@ -1,0 +1,268 @@
+"""Tensor-level entry points: torch tensors in (device memory + stream plumbing only),
+libcmdiad_hip.so kernels underneath.  Every op raises if the tensors are not on the GPU or the
+native library is missing -- there is no eager / CPU fallback here by design.
+"""
+import ctypes
+
+import torch
+
+from . import _native as nat
+
+ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
+U64_MAX = -1  # as int64 bit pattern
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _chk(t, dtype, name):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise nat.NativeError(f"{name}: tensor must live on the GPU (cmdiad_amd has no CPU path)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: tensor must be contiguous")
+
+
+def _call(name, *args):
+    nat.check(getattr(nat.lib(), name)(*args), name)
+
+
+# ------------------------------------------------------------------------------------ point cloud
+def fps(xyz, G, n_valid=None):
+    """xyz [B,N,3] f32 -> (idx [B,G] int32, centers [B,G,3] f32).  models/models.py:70-78."""
+    _chk(xyz, torch.float32, "fps.xyz"); _chk(n_valid, torch.int32, "fps.n_valid")
+    B, N, _ = xyz.shape
+    idx = torch.empty((B, G), dtype=torch.int32, device=xyz.device)
+    cen = torch.empty((B, G, 3), dtype=torch.float32, device=xyz.device)
+    wsb = nat.lib().cmdiad_fps_workspace_bytes(B, N)
+    ws = torch.empty(max(wsb, 4) // 4, dtype=torch.float32, device=xyz.device) if wsb else None
+    _call("cmdiad_fps", _p(xyz), _p(n_valid), B, N, G, _p(idx), _p(cen), _p(ws), wsb, _stream())
+    return idx, cen
+
+
+def knn_group(xyz, center, K, n_valid=None, want_idx=True):
+    """-> (idx [B,G,K] int64, neighborhood [B,G,K,3] f32).  models/models.py:88-113."""
+    _chk(xyz, torch.float32, "knn.xyz"); _chk(center, torch.float32, "knn.center")
+    B, N, _ = xyz.shape
+    G = center.shape[1]
+    idx = torch.empty((B, G, K), dtype=torch.int64, device=xyz.device) if want_idx else None
+    nb = torch.empty((B, G, K, 3), dtype=torch.float32, device=xyz.device)
+    _call("cmdiad_knn_group", _p(xyz), _p(n_valid), _p(center), B, N, G, K, _p(idx), _p(nb), _stream())
+    return idx, nb
+
+
+def unorganize(organized_pc, n_max=None):
+    """organized_pc [B,3,H,W] f32 -> (xyz [B,Nmax,3], nz [B,Nmax] i32, pix2pt [B,HW] i32, n_valid [B] i32).
+    multiple_features.py:10-25."""
+    _chk(organized_pc, torch.float32, "unorganize.pc")
+    B, _, H, W = organized_pc.shape
+    HW = H * W
+    n_max = n_max or HW
+    dev = organized_pc.device
+    xyz = torch.zeros((B, n_max, 3), dtype=torch.float32, device=dev)
+    nz = torch.zeros((B, n_max), dtype=torch.int32, device=dev)
+    pix2pt = torch.empty((B, HW), dtype=torch.int32, device=dev)
+    n_valid = torch.empty((B,), dtype=torch.int32, device=dev)
+    _call("cmdiad_unorganize", _p(organized_pc), B, HW, n_max, _p(xyz), _p(nz), _p(pix2pt), _p(n_valid), _stream())
+    return xyz, nz, pix2pt, n_valid
+
+
+def interp3nn(xyz, center, n_valid=None):
+    """-> (idx3 [B,N,3] i32, w3 [B,N,3] f32).  models/pointnet2_utils.py:45-71."""
+    _chk(xyz, torch.float32, "interp3nn.xyz"); _chk(center, torch.float32, "interp3nn.center")
+    B, N, _ = xyz.shape
+    idx3 = torch.zeros((B, N, 3), dtype=torch.int32, device=xyz.device)
+    w3 = torch.zeros((B, N, 3), dtype=torch.float32, device=xyz.device)
+    _call("cmdiad_interp3nn", _p(xyz), _p(n_valid), _p(center), B, N, center.shape[1], _p(idx3), _p(w3), _stream())
+    return idx3, w3
+
+
+def interp_gather(feat, idx3, w3, n_valid=None):
+    """feat [B,S,D] f32 -> [B,N,D] f32 (pointnet2_utils.py:72)."""
+    _chk(feat, torch.float32, "interp_gather.feat")
+    B, S, D = feat.shape
+    N = idx3.shape[1]
+    out = torch.zeros((B, N, D), dtype=torch.float32, device=feat.device)
+    _call("cmdiad_interp_gather", _p(feat), _p(idx3), _p(w3), _p(n_valid), B, N, S, D, _p(out), _stream())
+    return out
+
+
+def xyz_patch_fused(feat, idx3, w3, pix2pt, size=224, P=56, mean=0.0, inv_std=1.0, want_f32=True, want_bf16=False):
+    """features.py:169-184 fused with the interpolation gather.  -> (patch_f32 [B,P*P,D] | None, bf16 | None)."""
+    _chk(feat, torch.float32, "xyz_patch.feat")
+    B, S, D = feat.shape
+    N = idx3.shape[1]
+    o32 = torch.empty((B, P * P, D), dtype=torch.float32, device=feat.device) if want_f32 else None
+    o16 = torch.empty((B, P * P, D), dtype=torch.bfloat16, device=feat.device) if want_bf16 else None
+    _call("cmdiad_xyz_patch_fused", _p(feat), _p(idx3), _p(w3), _p(pix2pt), B, N, S, D, size, P, float(mean),
+          float(inv_std), _p(o32), _p(o16), _stream())
+    return o32, o16
+
+
+# ------------------------------------------------------------------------------------ dense blocks
+def gemm(A, W, bias=None, act=ACT_NONE, residual=None, group_bias=None, group_rows=1, out_f32=None, out_bf16=None,
+         want_f32=False, want_bf16=True):
+    """epilogue(A[M,K] . W[N,K]^T); A, W bf16.  Returns (out_f32 | None, out_bf16 | None)."""
+    _chk(A, torch.bfloat16, "gemm.A"); _chk(W, torch.bfloat16, "gemm.W")
+    M, K = A.shape
+    N = W.shape[0]
+    if out_f32 is None and want_f32:
+        out_f32 = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    if out_bf16 is None and want_bf16:
+        out_bf16 = torch.empty((M, N), dtype=torch.bfloat16, device=A.device)
+    a = nat.GemmArgs(_p(A), K, _p(W), K, M, N, K, _p(bias), _p(group_bias), group_rows, act,
+                     _p(residual), N, _p(out_f32), N, _p(out_bf16), N)
+    _call("cmdiad_gemm_bf16", ctypes.byref(a), _stream())
+    return out_f32, out_bf16
+
+
+def gemm_qkv(A, W, bias, B, T, q, k, vt):
+    """A [B*T,C] bf16 -> q,k [B,H,Tp,64], vt [B,H,64,Tp] (pre-allocated, zero-initialised padding)."""
+    _chk(A, torch.bfloat16, "qkv.A"); _chk(W, torch.bfloat16, "qkv.W")
+    C = A.shape[1]
+    _call("cmdiad_gemm_qkv", _p(A), _p(W), _p(bias), B, T, C, _p(q), _p(k), _p(vt), _stream())
+
+
+def attention(q, k, vt, B, H, T, out=None):
+    """-> out [B*T, H*64] bf16."""
+    if out is None:
+        out = torch.empty((B * T, H * 64), dtype=torch.bfloat16, device=q.device)
+    _call("cmdiad_attention", _p(q), _p(k), _p(vt), B, H, T, _p(out), _stream())
+    return out
+
+
+def layernorm(x, gamma, beta, eps, add=None, out_bf16=None, out_f32=None, want_bf16=True):
+    """x [M,C] f32 (updated in place to x+add when add is given) -> LN(x) as bf16 and/or f32."""
+    _chk(x, torch.float32, "ln.x"); _chk(add, torch.float32, "ln.add")
+    M, C = x.shape
+    if out_bf16 is None and want_bf16:
+        out_bf16 = torch.empty((M, C), dtype=torch.bfloat16, device=x.device)
+    ld = out_f32.stride(0) if out_f32 is not None else 0
+    _call("cmdiad_layernorm", _p(x), _p(add), _p(gamma), _p(beta), float(eps), M, C, _p(out_bf16), _p(out_f32), ld,
+          _stream())
+    return out_bf16
+
+
+def encoder_stage1(neigh, w1b1, W2, b2, groups, Mg):
+    """-> (h2 [groups*Mg,256] bf16, gmax [groups,256] f32, gmax_bf16)."""
+    dev = neigh.device
+    h2 = torch.empty((groups * Mg, 256), dtype=torch.bfloat16, device=dev)
+    g32 = torch.empty((groups, 256), dtype=torch.float32, device=dev)
+    g16 = torch.empty((groups, 256), dtype=torch.bfloat16, device=dev)
+    _call("cmdiad_encoder_stage1", _p(neigh), _p(w1b1), _p(W2), _p(b2), groups, Mg, _p(h2), _p(g32), _p(g16), _stream())
+    return h2, g32, g16
+
+
+def gemm_groupmax(A, W, bias, groups, Mg, want_bf16=False):
+    N, K = W.shape
+    o32 = torch.empty((groups, N), dtype=torch.float32, device=A.device)
+    o16 = torch.empty((groups, N), dtype=torch.bfloat16, device=A.device) if want_bf16 else None
+    _call("cmdiad_gemm_groupmax", _p(A), _p(W), _p(bias), groups, Mg, N, K, _p(o32), _p(o16), _stream())
+    return o32, o16
+
+
+# ------------------------------------------------------------------------------------ scoring
+def normalize_cast(x, mean=0.0, inv_std=1.0, want_f32=False, want_sq=True):
+    """x [rows,D] f32 -> (bf16 [rows,D], f32 normalised | None, row |.|^2 of the rounded rows | None)."""
+    _chk(x, torch.float32, "normalize_cast.x")
+    rows, D = x.shape
+    o16 = torch.empty((rows, D), dtype=torch.bfloat16, device=x.device)
+    o32 = torch.empty((rows, D), dtype=torch.float32, device=x.device) if want_f32 else None
+    sq = torch.empty((rows,), dtype=torch.float32, device=x.device) if want_sq else None
+    _call("cmdiad_normalize_cast", _p(x), rows, D, float(mean), float(inv_std), _p(o16), _p(o32), _p(sq), _stream())
+    return o16, o32, sq
+
+
+def new_keys(Q, device):
+    return torch.full((Q,), -1, dtype=torch.int64, device=device)  # 0xFFFF... = UINT64_MAX
+
+
+def l2_min_keys(q16, q_sq, bank16, bank_sq, keys, row_offset=0):
+    Q, D = q16.shape
+    _call("cmdiad_l2_min_keys", _p(q16), _p(q_sq), _p(bank16), _p(bank_sq), Q, bank16.shape[0], D, row_offset,
+          _p(keys), _stream())
+    return keys
+
+
+def l2_rescore(q32, bank32, keys, min_val=None, min_idx=None, row_offset=0):
+    Q, D = q32.shape
+    if min_val is None:
+        min_val = torch.zeros((Q,), dtype=torch.float32, device=q32.device)
+        min_idx = torch.zeros((Q,), dtype=torch.int64, device=q32.device)
+    _call("cmdiad_l2_rescore", _p(q32), _p(bank32), _p(keys), Q, bank32.shape[0], D, row_offset, _p(min_val),
+          _p(min_idx), _stream())
+    return min_val, min_idx
+
+
+def reweight_scan(probes, bank32, top3=None, row_offset=0):
+    """probes [R,D] f32 -> top3 [R,3] packed keys (int64 view of u64)."""
+    R, D = probes.shape
+    Nb = bank32.shape[0]
+    if top3 is None:
+        top3 = torch.full((R, 3), -1, dtype=torch.int64, device=probes.device)
+    wsb = nat.lib().cmdiad_reweight_workspace_bytes(R, Nb)
+    ws = torch.empty(max(wsb // 8, 1), dtype=torch.int64, device=probes.device)
+    _call("cmdiad_reweight_scan", _p(probes), _p(bank32), R, Nb, D, row_offset, _p(top3), _p(ws), wsb, _stream())
+    return top3
+
+
+def unpack_keys(keys):
+    """int64 view of packed u64 keys -> (value f32, index int64)."""
+    idx = keys & 0xFFFFFFFF
+    val = (keys >> 32).to(torch.int32).view(torch.float32) if keys.numel() else keys.float()
+    return val, idx
+
+
+# ------------------------------------------------------------------------------------ small ops
+def im2col_patch8(rgb):
+    _chk(rgb, torch.float32, "im2col.rgb")
+    B, _, S, _ = rgb.shape
+    out = torch.empty((B * (S // 8) ** 2, 192), dtype=torch.bfloat16, device=rgb.device)
+    _call("cmdiad_im2col_patch8", _p(rgb), B, S, _p(out), _stream())
+    return out
+
+
+def vit_assemble(patch_out, cls, pos, B, P, C):
+    tokens = torch.empty((B * (P + 1), C), dtype=torch.float32, device=patch_out.device)
+    _call("cmdiad_vit_assemble", _p(patch_out), _p(cls), _p(pos), B, P, C, _p(tokens), _stream())
+    return tokens
+
+
+def bilinear_up(x, H):
+    _chk(x, torch.float32, "bilinear.x")
+    B, h, _ = x.shape
+    out = torch.empty((B, H, H), dtype=torch.float32, device=x.device)
+    _call("cmdiad_bilinear_up", _p(x), B, h, H, _p(out), _stream())
+    return out
+
+
+def linear3(x, wb, act=ACT_NONE):
+    """x [M,3] f32, wb [N,4] f32 -> act(W x + b) as bf16 [M,N]."""
+    _chk(x, torch.float32, "linear3.x")
+    M, N = x.shape[0], wb.shape[0]
+    out = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
+    _call("cmdiad_linear3", _p(x), _p(wb), M, N, act, _p(out), _stream())
+    return out
+
+
+def cast_bf16(x):
+    _chk(x, torch.float32, "cast.x")
+    out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    _call("cmdiad_cast_bf16", _p(x), x.numel(), _p(out), _stream())
+    return out
+
+
+def transpose_bf16(x):
+    _chk(x, torch.bfloat16, "transpose.x")
+    r, c = x.shape
+    out = torch.empty((c, r), dtype=torch.bfloat16, device=x.device)
+    _call("cmdiad_transpose_bf16", _p(x), r, c, _p(out), _stream())
+    return out

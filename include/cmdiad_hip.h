@@ -1,0 +1,213 @@
+/*
+ * cmdiad_hip.h -- C ABI of libcmdiad_hip.so: the MI355X (gfx950) kernels behind CMDIAD's hot path.
+ *
+ * Conventions (all entry points):
+ *   - plain C: device pointers + sizes + a stream handle (hipStream_t passed as void*); no torch types.
+ *   - the caller owns every buffer (inputs, outputs, workspace); the library never allocates,
+ *     frees, retains a pointer past the call, or synchronises the device: all work is enqueued on
+ *     `stream` and is stream-ordered.  Workspace sizes come from the *_workspace_bytes() queries.
+ *   - return value: CMDIAD_OK (0) or a negative cmdiad_status; cmdiad_last_error() returns the
+ *     message of the calling thread's last failure.  Nothing throws across the ABI.
+ *   - one host thread per device, re-entrant across streams.
+ *   - bf16 tensors are passed as uint16_t* (raw bfloat16 bits), row-major unless stated.
+ *
+ * Each function cites the reference interface (evenrose/CMDIAD file:line) it replaces.
+ */
+#ifndef CMDIAD_HIP_H
+#define CMDIAD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* cmdiad_stream_t; /* hipStream_t */
+
+typedef enum {
+    CMDIAD_OK = 0,
+    CMDIAD_ERR_ARG = -1,       /* null pointer / bad size / unsupported shape */
+    CMDIAD_ERR_WORKSPACE = -2, /* workspace missing or too small */
+    CMDIAD_ERR_LAUNCH = -3     /* HIP reported a launch error */
+} cmdiad_status;
+
+const char* cmdiad_last_error(void);
+int cmdiad_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Point-cloud front end
+ * ------------------------------------------------------------------------------------------- */
+
+/* Farthest point sampling + centre gather.
+ * Replaces pointnet2_ops.furthest_point_sample(xyz[B,N,3] f32, npoint) -> int32[B,npoint] and
+ * pointnet2_ops.gather_operation as called at models/models.py:76-77 (fps()).
+ * xyz [B,N,3] f32; n_valid [B] int32 device array or NULL (= N points in every cloud; points at
+ * index >= n_valid[b] are padding); idx_out [B,G] int32; center_out [B,G,3] f32 or NULL.
+ * Bit-exact with oracle/cmdiad_oracle.c:orc_fps. */
+size_t cmdiad_fps_workspace_bytes(int B, int N);
+int cmdiad_fps(const float* xyz, const int32_t* n_valid, int B, int N, int G, int32_t* idx_out,
+               float* center_out, void* workspace, size_t workspace_bytes, cmdiad_stream_t stream);
+
+/* k-nearest-neighbour grouping: K nearest cloud points of every centre, ascending (d2, index),
+ * plus the gathered, centre-subtracted neighbourhood.
+ * Replaces knn_cuda.KNN(k, transpose_mode=True)(ref[B,N,3], query[B,G,3]) -> idx int64[B,G,k]
+ * (models/models.py:86,100) and the gather/subtract at models/models.py:105-112.
+ * idx_out [B,G,K] int64 (NULL allowed), neigh_out [B,G,K,3] f32 (NULL allowed).  K <= 128.
+ * Bit-exact with oracle/cmdiad_oracle.c:orc_knn_group. */
+int cmdiad_knn_group(const float* xyz, const int32_t* n_valid, const float* center, int B, int N, int G,
+                     int K, int64_t* idx_out, float* neigh_out, cmdiad_stream_t stream);
+
+/* 3-nearest-centre search + inverse-distance weights for every cloud point.
+ * Replaces the selection half of models/pointnet2_utils.py:45-75 (interpolating_points):
+ * d = -2*a.b + |a|^2 + |b|^2 (:19-22), three smallest (:66-67), w = 1/(d+1e-8) normalised (:69-71).
+ * xyz [B,N,3], center [B,S,3] -> idx3 [B,N,3] int32, w3 [B,N,3] f32.  S <= 4096. */
+int cmdiad_interp3nn(const float* xyz, const int32_t* n_valid, const float* center, int B, int N, int S,
+                     int32_t* idx3, float* w3, cmdiad_stream_t stream);
+
+/* Organised -> unorganised point cloud without zeros (feature_extractors/multiple_features.py:10-25):
+ * keeps, in raster order, the pixels whose x, y and z are all non-zero.
+ * organized_pc [B,3,HW] f32 -> xyz [B,Nmax,3] f32 (first n_valid[b] rows valid), nz [B,Nmax] int32 pixel
+ * indices (NULL allowed), pix2pt [B,HW] int32 = point index of a pixel or -1 (NULL allowed),
+ * n_valid [B] int32 (NULL allowed; counts are clamped to Nmax). */
+int cmdiad_unorganize(const float* organized_pc, int B, int HW, int Nmax, float* xyz, int32_t* nz,
+                      int32_t* pix2pt, int32_t* n_valid, cmdiad_stream_t stream);
+
+/* Weighted gather half of interpolating_points (pointnet2_utils.py:72):
+ *   out[b][n][:] = (F[i0]*w0 + F[i1]*w1) + F[i2]*w2,  feat [B,S,D] f32 (centre-major), out [B,N,D] f32.
+ * Only needed to materialise the reference's [1,D,N] `interpolated_feature_maps` for external callers;
+ * the product path uses cmdiad_xyz_patch_fused and never builds it. */
+int cmdiad_interp_gather(const float* feat, const int32_t* idx3, const float* w3, const int32_t* n_valid,
+                         int B, int N, int S, int D, float* out, cmdiad_stream_t stream);
+
+/* get_xyz_patch (feature_extractors/features.py:169-184) fused with the gather above: scatter into the
+ * size x size map at nonzero pixels, AvgPool2d(3, stride 1), AdaptiveAvgPool2d((P,P)), reshape to
+ * [P*P, D]; optionally the scalar normalisation (x - mean) * inv_std of multiple_features.py:976 and a
+ * bf16 copy for the distance GEMM.  pix2pt [B, size*size] from cmdiad_unorganize.
+ * patch_f32 [B,P*P,D] (NULL allowed), patch_bf16 [B,P*P,D] (NULL allowed). */
+int cmdiad_xyz_patch_fused(const float* feat, const int32_t* idx3, const float* w3, const int32_t* pix2pt,
+                           int B, int N, int S, int D, int size, int P, float mean, float inv_std,
+                           float* patch_f32, uint16_t* patch_bf16, cmdiad_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Transformer / MLP building blocks (ViT-B/8: timm VisionTransformer reached at
+ * models/models.py:41-52; Point-MAE: models/models.py:116-243; hallucination MLP:
+ * utils/utils.py:86-115)
+ * ------------------------------------------------------------------------------------------- */
+
+/* out[M,N] = epilogue(A[M,K] . W[N,K]^T): bf16 MFMA, fp32 accumulate.  K % 64 == 0.
+ * Epilogue, in order: + bias[N]; + group_bias[m / group_rows][N]; activation; + residual[M,N] (f32);
+ * stores to out_f32 and/or out_bf16 (either may be NULL; out_f32 may alias residual). */
+enum { CMDIAD_ACT_NONE = 0, CMDIAD_ACT_GELU = 1, CMDIAD_ACT_RELU = 2 };
+typedef struct {
+    const uint16_t* A; int lda;      /* [M,K] bf16 */
+    const uint16_t* W; int ldw;      /* [N,K] bf16 (nn.Linear weight layout) */
+    int M, N, K;
+    const float* bias;               /* [N] or NULL */
+    const float* group_bias;         /* [ceil(M/group_rows), N] or NULL */
+    int group_rows;
+    int act;
+    const float* residual; int ldr;  /* [M,N] f32 or NULL */
+    float* out_f32; int ldo32;
+    uint16_t* out_bf16; int ldo16;
+} cmdiad_gemm_args;
+int cmdiad_gemm_bf16(const cmdiad_gemm_args* args, cmdiad_stream_t stream);
+
+/* QKV projection with head-split stores for the attention kernel (models/models.py:150-151):
+ * A [B*T, C] bf16, W [3C, C], bias [3C] or NULL.  head_dim = 64, C = H*64.
+ * q_out, k_out [B,H,Tp,64] bf16 (q pre-multiplied by head_dim^-0.5, models.py:153),
+ * vt_out [B,H,64,Tp] bf16 (V transposed); Tp = T rounded up to 64; padding is never written. */
+int cmdiad_gemm_qkv(const uint16_t* A, const uint16_t* W, const float* bias, int B, int T, int C,
+                    uint16_t* q_out, uint16_t* k_out, uint16_t* vt_out, cmdiad_stream_t stream);
+
+/* softmax(q k^T) v per (image, head) (models/models.py:153-157), flash-style, bf16 MFMA.
+ * out [B*T, C] bf16 with heads concatenated along C (the `.transpose(1,2).reshape(B,N,C)` of :157). */
+int cmdiad_attention(const uint16_t* q, const uint16_t* k, const uint16_t* vt, int B, int H, int T,
+                     uint16_t* out, cmdiad_stream_t stream);
+
+/* y = LayerNorm(x (+ add)) * gamma + beta -> bf16; when `add` is given (Point-MAE re-adds the
+ * positional embedding in front of every block, models/models.py:240) x is updated in place to
+ * x + add first.  x [M,C] f32, add [M,C] f32 or NULL, C % 64 == 0, C <= 1024.
+ * out_bf16 [M, C] (NULL allowed); out_f32 (NULL allowed) with leading dimension ldo32. */
+int cmdiad_layernorm(float* x, const float* add, const float* gamma, const float* beta, float eps, int M,
+                     int C, uint16_t* out_bf16, float* out_f32, int ldo32, cmdiad_stream_t stream);
+
+/* Point-MAE Encoder (models/models.py:200-215), eval-mode BatchNorm folded into the convolutions:
+ *   h1 = relu(W1' x + b1')            3 -> 128   (computed on the fly while staging the GEMM tile)
+ *   h2 = W2 h1 + b2                   128 -> 256 ; g = max over the group's points
+ * neigh [groups*Mg, 3] f32; w1 [128,4] f32 = {w_x, w_y, w_z, b} per output channel (BN folded).
+ * Writes h2 [groups*Mg, 256] bf16, gmax [groups, 256] f32 and (optional) its bf16 copy.
+ * Mg (points per group) must be 128, 64 or 32. */
+int cmdiad_encoder_stage1(const float* neigh, const float* w1, const uint16_t* W2, const float* b2,
+                          int groups, int Mg, uint16_t* h2_out, float* gmax_out, uint16_t* gmax_bf16_out,
+                          cmdiad_stream_t stream);
+/* out[g][n] = max over the Mg rows of group g of (A . W^T + bias)[row][n]  (torch.max(...,dim=2),
+ * models/models.py:214).  A [groups*Mg, K] bf16, W [N,K] bf16, out [groups, N] f32 and/or bf16. */
+int cmdiad_gemm_groupmax(const uint16_t* A, const uint16_t* W, const float* bias, int groups, int Mg, int N,
+                         int K, float* out_f32, uint16_t* out_bf16, cmdiad_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Patch-library nearest-neighbour scoring
+ * ------------------------------------------------------------------------------------------- */
+
+/* Per-query nearest bank row under L2 (torch.cdist + torch.min(dim=1), features.py:190,227) without
+ * materialising the QxNb matrix: bf16 MFMA distance GEMM with a running (min, argmin) epilogue,
+ * d2 = |q|^2 + |b|^2 - 2 q.b.  keys[q] = min over rows of ((fp32 bits of max(d2,0)) << 32 | row_offset+row):
+ * integer order == (distance, index) order, so bank shards combine with an integer MIN (RCCL
+ * all-reduce over xGMI) and ties resolve to the lowest global row, as torch.min does.
+ * q [Q,D] bf16, q_sqnorm [Q] f32, bank [Nb,D] bf16, bank_sqnorm [Nb] f32 (squared norms of the
+ * bf16-rounded rows, from cmdiad_normalize_cast), keys [Q] u64: the caller initialises keys to
+ * UINT64_MAX; the kernel combines with atomic min.  D % 64 == 0. */
+int cmdiad_l2_min_keys(const uint16_t* q, const float* q_sqnorm, const uint16_t* bank, const float* bank_sqnorm,
+                       int Q, int Nb, int D, uint32_t row_offset, unsigned long long* keys,
+                       cmdiad_stream_t stream);
+
+/* Exact fp32 re-score of the winners: min_val[q] = || q_f32[q] - bank_f32[idx - row_offset] ||_2,
+ * min_idx[q] = idx (global row).  Queries whose winner lies outside [row_offset, row_offset+Nb) are
+ * left untouched (another shard owns them). */
+int cmdiad_l2_rescore(const float* q, const float* bank, const unsigned long long* keys, int Q, int Nb,
+                      int D, uint32_t row_offset, float* min_val, int64_t* min_idx, cmdiad_stream_t stream);
+
+/* Re-weighting scan (features.py:235-254): for each of R probe rows (m_star), exact fp32 squared L2
+ * distance to every bank row; the 3 smallest as packed keys (d2 bits << 32 | global row) are merged
+ * into top3 [R,3] u64, which the caller initialises to UINT64_MAX (shards call it in turn or
+ * all-gather their top3).  probes [R,D] f32, bank [Nb,D] f32. */
+size_t cmdiad_reweight_workspace_bytes(int R, int Nb);
+int cmdiad_reweight_scan(const float* probes, const float* bank, int R, int Nb, int D, uint32_t row_offset,
+                         unsigned long long* top3, void* workspace, size_t workspace_bytes,
+                         cmdiad_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Small fused element-wise / layout kernels
+ * ------------------------------------------------------------------------------------------- */
+
+/* out_bf16 = bf16((x - mean) * inv_std); optional out_f32 copy of the normalised values and
+ * optional per-row squared norm of the bf16-rounded row (a11 + the |b|^2 term of the distance GEMM). */
+int cmdiad_normalize_cast(const float* x, size_t rows, int D, float mean, float inv_std, uint16_t* out_bf16,
+                          float* out_f32, float* row_sqnorm, cmdiad_stream_t stream);
+
+/* ViT patch embedding as a GEMM operand: rgb [B,3,S,S] f32 -> patches [B*(S/8)^2, 192] bf16 with
+ * k = (c, dy, dx) matching conv weight [768,3,8,8] flattened (timm PatchEmbed, models/models.py:41). */
+int cmdiad_im2col_patch8(const float* rgb, int B, int S, uint16_t* patches, cmdiad_stream_t stream);
+
+/* tokens[b][0] = cls + pos[0]; tokens[b][1+i] = patch_out[b][i] + pos[1+i]  (timm _pos_embed,
+ * models/models.py:42).  patch_out [B*P, C] f32, tokens [B*(P+1), C] f32. */
+int cmdiad_vit_assemble(const float* patch_out, const float* cls, const float* pos, int B, int P, int C,
+                        float* tokens, cmdiad_stream_t stream);
+
+/* out[m][:] = act(W x[m] + b) for 3-d inputs: Point-MAE pos_embed first layer nn.Linear(3,128)+GELU
+ * (models/models.py:268-272).  x [M,3] f32, wb [N,4] f32 = {w_x,w_y,w_z,bias}, out [M,N] bf16, N % 8 == 0. */
+int cmdiad_linear3(const float* x, const float* wb, size_t M, int N, int act, uint16_t* out,
+                   cmdiad_stream_t stream);
+
+/* Bilinear up-sampling h x h -> H x H, align_corners=False (features.py:294). in [B,h,h], out [B,H,H]. */
+int cmdiad_bilinear_up(const float* in, int B, int h, int H, float* out, cmdiad_stream_t stream);
+
+/* Generic fp32 -> bf16 cast (n % 4 == 0) and bf16 2-D transpose out[c][r] = in[r][c]. */
+int cmdiad_cast_bf16(const float* x, size_t n, uint16_t* out, cmdiad_stream_t stream);
+int cmdiad_transpose_bf16(const uint16_t* in, int rows, int cols, uint16_t* out, cmdiad_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CMDIAD_HIP_H */

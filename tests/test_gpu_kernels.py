@@ -1,0 +1,301 @@
+"""GPU parity tests, kernel by kernel, through the C ABI (cmdiad_amd.ops -> libcmdiad_hip.so) against the
+CPU oracle (oracle/) on the same seeded inputs.  Integer/index outputs must be bit-exact; floating
+point outputs are compared with the tolerance written next to each assertion."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from cmdiad_amd import ops  # noqa: E402
+from cmdiad_amd.synth import synth_cloud, synth_cloud_fixed_n  # noqa: E402
+from oracle import kernels as ok  # noqa: E402
+from oracle import scoring  # noqa: E402
+
+DEV = "cuda"
+
+
+def _cloud(seed, frac):
+    pc, nz = scoring.unorganize_no_zeros(synth_cloud(seed, frac))
+    return np.ascontiguousarray(pc[0].T.numpy()), nz  # [N,3]
+
+
+def _bf(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+# ------------------------------------------------------------------------------------------ FPS / kNN
+@pytest.mark.parametrize("frac,G", [(0.06, 64), (0.2, 256), (0.45, 1024), (0.62, 128)])
+def test_fps_bit_exact(frac, G):
+    xyz, _ = _cloud(3, frac)  # N ~ 3k / 10k / 22.6k (register path, 512x48) / 31k (memory fallback)
+    idx_ref, cen_ref = ok.fps(xyz[None], G)
+    idx, cen = ops.fps(torch.from_numpy(xyz[None]).to(DEV), G)
+    np.testing.assert_array_equal(idx.cpu().numpy(), idx_ref)
+    np.testing.assert_array_equal(cen.cpu().numpy(), cen_ref)
+
+
+def test_fps_batched_ragged_and_skip_rule():
+    a, _ = _cloud(4, 0.1)
+    b, _ = _cloud(5, 0.07)
+    b[17] = 0.001  # |p|^2 <= 1e-3 -> skipped by the sampler (never selected), cmdiad_oracle.c:orc_fps
+    N = max(len(a), len(b))
+    xyz = np.zeros((2, N, 3), np.float32)
+    xyz[0, :len(a)] = a
+    xyz[1, :len(b)] = b
+    nv = torch.tensor([len(a), len(b)], dtype=torch.int32)
+    idx, _ = ops.fps(torch.from_numpy(xyz).to(DEV), 96, n_valid=nv.to(DEV))
+    np.testing.assert_array_equal(idx[0].cpu().numpy(), ok.fps(a[None], 96)[0][0])
+    ref_b = ok.fps(b[None], 96)[0][0]
+    np.testing.assert_array_equal(idx[1].cpu().numpy(), ref_b)
+    assert 17 not in ref_b
+
+
+def test_fps_duplicate_points_tie_rule():
+    xyz, _ = _cloud(6, 0.05)
+    xyz = np.concatenate([xyz, xyz[:500]], 0)  # exact duplicates -> exact distance ties -> lowest index wins
+    idx, _ = ops.fps(torch.from_numpy(xyz[None]).to(DEV), 200)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ok.fps(xyz[None], 200)[0])
+
+
+@pytest.mark.parametrize("frac,G,K", [(0.06, 64, 32), (0.3, 128, 128)])
+def test_knn_group_bit_exact(frac, G, K):
+    xyz, _ = _cloud(7, frac)
+    _, cen = ok.fps(xyz[None], G)
+    idx_ref, nb_ref = ok.knn_group(xyz[None], cen, K)
+    idx, nb = ops.knn_group(torch.from_numpy(xyz[None]).to(DEV), torch.from_numpy(cen).to(DEV), K)
+    np.testing.assert_array_equal(idx.cpu().numpy(), idx_ref)
+    np.testing.assert_array_equal(nb.cpu().numpy(), nb_ref)
+
+
+def test_knn_group_ties_and_ragged():
+    a, _ = _cloud(8, 0.08)
+    a = np.concatenate([a, a[:300]], 0)  # duplicates: ties at equal d2 resolved by index
+    b, _ = _cloud(9, 0.05)
+    N = max(len(a), len(b))
+    xyz = np.zeros((2, N, 3), np.float32)
+    xyz[0, :len(a)] = a
+    xyz[1, :len(b)] = b
+    nv = torch.tensor([len(a), len(b)], dtype=torch.int32, device=DEV)
+    cen = np.stack([ok.fps(a[None], 50)[1][0], ok.fps(b[None], 50)[1][0]])  # G=50: not a multiple of 4
+    idx, nb = ops.knn_group(torch.from_numpy(xyz).to(DEV), torch.from_numpy(cen).to(DEV), 64, n_valid=nv)
+    for i, cl in enumerate((a, b)):
+        ir, nr = ok.knn_group(cl[None], cen[i:i + 1], 64)
+        np.testing.assert_array_equal(idx[i].cpu().numpy(), ir[0])
+        np.testing.assert_array_equal(nb[i].cpu().numpy(), nr[0])
+
+
+# ------------------------------------------------------------------------------------------ unorganize / interp / pool
+def test_unorganize_matches_reference_semantics():
+    pcs = torch.cat([synth_cloud(11, 0.4), synth_cloud(12, 0.55), synth_cloud_fixed_n(13, 24576)], 0)
+    xyz, nz, pix2pt, nv = ops.unorganize(pcs.to(DEV))
+    for b in range(3):
+        pc, nzr = scoring.unorganize_no_zeros(pcs[b:b + 1])
+        n = pc.shape[2]
+        assert int(nv[b]) == n
+        np.testing.assert_array_equal(nz[b, :n].cpu().numpy(), nzr)
+        np.testing.assert_array_equal(xyz[b, :n].cpu().numpy(), pc[0].T.numpy())
+        p2p = pix2pt[b].cpu().numpy()
+        assert (p2p >= 0).sum() == n and np.array_equal(p2p[nzr], np.arange(n))
+    assert int(nv[2]) == 24576
+
+
+def test_interp3nn_indices_bit_exact_and_patch_fused():
+    organized = synth_cloud(14, 0.3)
+    pc, nzr = scoring.unorganize_no_zeros(organized)
+    xyz = np.ascontiguousarray(pc[0].T.numpy())
+    N, S, D = len(xyz), 256, 64
+    _, cen = ok.fps(xyz[None], S)
+    feat = torch.randn(S, D, generator=torch.Generator().manual_seed(15)).numpy()
+    out_ref, idx_ref, w_ref = ok.interp3nn(xyz, cen[0], feat)
+    dxyz, dnz, pix2pt, nv = ops.unorganize(organized.to(DEV))
+    idx3, w3 = ops.interp3nn(dxyz, torch.from_numpy(cen).to(DEV), n_valid=nv)
+    np.testing.assert_array_equal(idx3[0, :N].cpu().numpy(), idx_ref)
+    np.testing.assert_array_equal(w3[0, :N].cpu().numpy(), w_ref)  # same op order, IEEE division
+    dfeat = torch.from_numpy(feat[None]).to(DEV)
+    g = ops.interp_gather(dfeat, idx3, w3, n_valid=nv)
+    np.testing.assert_array_equal(g[0, :N].cpu().numpy(), out_ref)
+    for P in (56, 28):
+        ref = ok.xyz_patch(out_ref, nzr, 224, P)
+        p32, p16 = ops.xyz_patch_fused(dfeat, idx3, w3, pix2pt, 224, P, want_bf16=True)
+        # same linear map, different summation order: fp32 round-off only
+        np.testing.assert_allclose(p32[0].cpu().numpy(), ref, rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(p16[0].float().cpu().numpy(), ref, rtol=1e-2, atol=1e-3)
+    # fused normalisation (multiple_features.py:976)
+    p32n, _ = ops.xyz_patch_fused(dfeat, idx3, w3, pix2pt, 224, 56, mean=0.25, inv_std=1 / 1.7)
+    np.testing.assert_allclose(p32n[0].cpu().numpy(), (ok.xyz_patch(out_ref, nzr, 224, 56) - 0.25) / 1.7, rtol=2e-5, atol=2e-6)
+
+
+# ------------------------------------------------------------------------------------------ GEMM family
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 384, 192), (785, 768, 768), (1000, 1920, 768)])
+def test_gemm_epilogues(M, N, K):
+    g = torch.Generator().manual_seed(M + N + K)
+    A = _bf(torch.randn(M, K, generator=g))
+    W = _bf(torch.randn(N, K, generator=g) / K ** 0.5)
+    bias = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g)
+    gb = torch.randn((M + 31) // 32, N, generator=g)
+    ref = A.double() @ W.double().T
+    dA, dW = A.to(DEV).bfloat16(), W.to(DEV).bfloat16()
+    o32, o16 = ops.gemm(dA, dW, want_f32=True)
+    np.testing.assert_allclose(o32.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=1e-4)  # fp32 accumulate order
+    np.testing.assert_allclose(o16.float().cpu().numpy(), ref.numpy(), rtol=8e-3, atol=8e-3)  # bf16 rounding 2^-8
+    o32, _ = ops.gemm(dA, dW, bias=bias.to(DEV), act=ops.ACT_GELU, residual=res.to(DEV), want_f32=True, want_bf16=False)
+    want = torch.nn.functional.gelu(ref + bias.double()) + res.double()
+    np.testing.assert_allclose(o32.cpu().numpy(), want.numpy(), rtol=1e-4, atol=1e-4)
+    o32, _ = ops.gemm(dA, dW, bias=bias.to(DEV), act=ops.ACT_RELU, group_bias=gb.to(DEV), group_rows=32,
+                      want_f32=True, want_bf16=False)
+    want = torch.relu(ref + bias.double() + gb.double().repeat_interleave(32, 0)[:M])
+    np.testing.assert_allclose(o32.cpu().numpy(), want.numpy(), rtol=1e-4, atol=1e-4)
+    # in-place residual stream (out aliases residual), as the transformer blocks use it
+    x = res.clone().to(DEV)
+    ops.gemm(dA, dW, bias=bias.to(DEV), residual=x, out_f32=x, want_bf16=False)
+    np.testing.assert_allclose(x.cpu().numpy(), (ref + bias.double() + res.double()).numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_gemm_identity_asymmetric_layout():
+    # A = I against an asymmetric W catches any row/column swap in the accumulator mapping
+    K = 128
+    A = torch.eye(K)
+    W = torch.arange(K * K, dtype=torch.float32).reshape(K, K) % 251 - 125.0
+    o32, _ = ops.gemm(A.to(DEV).bfloat16(), W.to(DEV).bfloat16(), want_f32=True)
+    np.testing.assert_array_equal(o32.cpu().numpy(), W.T.numpy())
+
+
+@pytest.mark.parametrize("B,T,C", [(2, 785, 768), (1, 1024, 384), (3, 200, 128)])
+def test_qkv_and_attention(B, T, C):
+    H = C // 64
+    Tp = (T + 63) // 64 * 64
+    g = torch.Generator().manual_seed(B * T + C)
+    x = _bf(torch.randn(B * T, C, generator=g))
+    W = _bf(torch.randn(3 * C, C, generator=g) / C ** 0.5)
+    bias = 0.1 * torch.randn(3 * C, generator=g)
+    q = torch.zeros(B, H, Tp, 64, dtype=torch.bfloat16, device=DEV)
+    k = torch.zeros_like(q)
+    vt = torch.zeros(B, H, 64, Tp, dtype=torch.bfloat16, device=DEV)
+    ops.gemm_qkv(x.to(DEV).bfloat16(), W.to(DEV).bfloat16(), bias.to(DEV), B, T, q, k, vt)
+    qkv = (x.double() @ W.double().T + bias.double()).reshape(B, T, 3, H, 64).permute(2, 0, 3, 1, 4)
+    np.testing.assert_allclose(q[:, :, :T].float().cpu().numpy(), (qkv[0] * 0.125).numpy(), rtol=8e-3, atol=8e-3)
+    np.testing.assert_allclose(k[:, :, :T].float().cpu().numpy(), qkv[1].numpy(), rtol=8e-3, atol=8e-3)
+    np.testing.assert_allclose(vt[:, :, :, :T].float().cpu().numpy(), qkv[2].transpose(-1, -2).numpy(), rtol=8e-3, atol=8e-3)
+    assert float(q[:, :, T:].abs().max() if Tp > T else 0) == 0.0  # padding untouched
+    out = ops.attention(q, k, vt, B, H, T)
+    # reference from the SAME bf16-rounded q/k/v (isolates the attention kernel): fp64 softmax(q k^T) v
+    qd, kd, vd = q[:, :, :T].double().cpu(), k[:, :, :T].double().cpu(), vt[:, :, :, :T].double().cpu().transpose(-1, -2)
+    ref = (torch.softmax(qd @ kd.transpose(-1, -2), -1) @ vd).transpose(1, 2).reshape(B * T, C)
+    # P is rounded to bf16 before P.V and the output is bf16: |err| <~ 2^-8 * |v|_max-ish
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref.numpy(), rtol=2e-2, atol=2e-2)
+    assert float((out.float().cpu() - ref).abs().mean()) < 3e-3
+
+
+def test_attention_peaked_rows_exercise_rescale():
+    # one key per query dominates and sits in a LATE tile: the running max must jump (online-softmax rescale)
+    B, H, T = 1, 1, 300
+    Tp = 320
+    g = torch.Generator().manual_seed(5)
+    q = torch.zeros(B, H, Tp, 64)
+    k = torch.zeros(B, H, Tp, 64)
+    v = torch.zeros(B, H, Tp, 64)
+    q[0, 0, :T] = torch.randn(T, 64, generator=g)
+    k[0, 0, :T] = torch.randn(T, 64, generator=g)
+    v[0, 0, :T] = torch.randn(T, 64, generator=g)
+    k[0, 0, 280] = 4.0 * q[0, 0, 10]  # spike for query 10 in the last tile
+    q, k, v = _bf(q), _bf(k), _bf(v)
+    out = ops.attention(q.to(DEV).bfloat16(), k.to(DEV).bfloat16(), v.transpose(-1, -2).contiguous().to(DEV).bfloat16(), B, H, T)
+    ref = torch.softmax(q[0, 0, :T].double() @ k[0, 0, :T].double().T, -1) @ v[0, 0, :T].double()
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref.numpy(), rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("M,C", [(785, 768), (1024, 384), (5, 128)])
+def test_layernorm(M, C):
+    g = torch.Generator().manual_seed(M)
+    x = torch.randn(M, C, generator=g) * 3 + 1
+    add = torch.randn(M, C, generator=g)
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    dx = x.clone().to(DEV)
+    y = ops.layernorm(dx, gamma.to(DEV), beta.to(DEV), 1e-6)
+    ref = torch.nn.functional.layer_norm(x, (C,), gamma, beta, 1e-6)
+    np.testing.assert_allclose(y.float().cpu().numpy(), ref.numpy(), rtol=8e-3, atol=8e-3)
+    o32 = torch.empty(M, 2 * C, device=DEV)
+    ops.layernorm(dx, gamma.to(DEV), beta.to(DEV), 1e-5, add=add.to(DEV), out_f32=o32[:, C:], want_bf16=False)
+    np.testing.assert_allclose(dx.cpu().numpy(), (x + add).numpy(), rtol=0, atol=0)
+    ref = torch.nn.functional.layer_norm(x + add, (C,), gamma, beta, 1e-5)
+    np.testing.assert_allclose(o32[:, C:].cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("Mg", [32, 128])
+def test_pointmae_encoder_stages(Mg):
+    from oracle import nets
+    sd = nets.synth_state_dict("pointmae", 21)
+    groups = 24
+    g = torch.Generator().manual_seed(Mg)
+    nb = 0.02 * torch.randn(1, groups, Mg, 3, generator=g)
+    from cmdiad_amd.runtime import fold_pointmae_encoder
+    w = fold_pointmae_encoder(sd, "encoder.", DEV)
+    h2, g32, g16 = ops.encoder_stage1(nb.reshape(-1, 3).contiguous().to(DEV), w["w1b1"], w["W2"], w["b2"], groups, Mg)
+    _, gb = ops.gemm(g16, w["W3a"], bias=w["b3"], want_f32=True, want_bf16=False)
+    _, h3 = ops.gemm(h2, w["W3b"], act=ops.ACT_RELU, group_bias=gb, group_rows=Mg)
+    tok, _ = ops.gemm_groupmax(h3, w["W4"], w["b4"], groups, Mg)
+    with torch.no_grad():
+        ref = nets.pointmae_encoder(sd, nb)[0]
+    # three chained bf16 GEMMs against the fp32 oracle: relative error ~ 3 * 2^-8 of the token scale
+    scale = ref.abs().mean().item()
+    err = (tok.cpu() - ref).abs()
+    assert err.mean().item() < 0.01 * scale and err.max().item() < 0.08 * scale, (err.mean().item(), err.max().item(), scale)
+
+
+# ------------------------------------------------------------------------------------------ scoring
+@pytest.mark.parametrize("Q,Nb,D", [(784, 1500, 768), (3136, 5000, 128), (100, 77, 64)])
+def test_l2_min_and_rescore(Q, Nb, D):
+    g = torch.Generator().manual_seed(Q + Nb)
+    bank = torch.randn(Nb, D, generator=g)
+    q = bank[torch.randint(0, Nb, (Q,), generator=g)] + 0.3 * torch.randn(Q, D, generator=g)
+    b16, b32, bsq = ops.normalize_cast(bank.to(DEV), 0.1, 1 / 1.3, want_f32=True)
+    q16, q32, qsq = ops.normalize_cast(q.to(DEV), 0.1, 1 / 1.3, want_f32=True)
+    np.testing.assert_allclose(b32.cpu().numpy(), ((bank - 0.1) / 1.3).numpy(), rtol=1e-6, atol=1e-6)
+    keys = ops.l2_min_keys(q16, qsq, b16, bsq, ops.new_keys(Q, DEV))
+    mv, mi = ops.l2_rescore(q32, b32, keys)
+    ref_v, ref_i = ok.l2_min_argmin(q32.cpu().numpy(), b32.cpu().numpy())
+    same = mi.cpu().numpy() == ref_i
+    assert same.mean() > 0.995, same.mean()  # bf16 distance GEMM may flip near-ties only
+    np.testing.assert_allclose(mv.cpu().numpy()[same], ref_v[same], rtol=1e-5, atol=1e-5)  # exact fp32 re-score
+    np.testing.assert_allclose(mv.cpu().numpy(), ref_v, rtol=2e-3, atol=2e-3)  # a flipped tie is still a near-min
+    # sharded bank: two halves + integer min over packed keys == single pass
+    h = (Nb // 2 + 63) // 64 * 64 if Nb > 200 else Nb // 2
+    k2 = ops.new_keys(Q, DEV)
+    ops.l2_min_keys(q16, qsq, b16[:h].contiguous(), bsq[:h].contiguous(), k2, row_offset=0)
+    k3 = ops.new_keys(Q, DEV)
+    ops.l2_min_keys(q16, qsq, b16[h:].contiguous(), bsq[h:].contiguous(), k3, row_offset=h)
+    merged = torch.minimum(k2, k3)  # non-negative keys: signed min == unsigned min
+    assert torch.equal(merged, keys)
+
+
+def test_reweight_scan_top3():
+    g = torch.Generator().manual_seed(3)
+    bank = torch.randn(4000, 768, generator=g)
+    probes = bank[[5, 1234, 3999]].clone()
+    top3 = ops.reweight_scan(probes.to(DEV), bank.to(DEV))
+    val, idx = ops.unpack_keys(top3)
+    d = torch.cdist(probes.double(), bank.double())
+    rv, ri = torch.topk(d, 3, largest=False)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ri.numpy())
+    np.testing.assert_allclose(val.sqrt().cpu().numpy(), rv.numpy(), rtol=1e-5, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------ small ops
+def test_im2col_assemble_bilinear_transpose():
+    g = torch.Generator().manual_seed(9)
+    rgb = torch.randn(2, 3, 224, 224, generator=g)
+    pat = ops.im2col_patch8(rgb.to(DEV))
+    ref = torch.nn.functional.unfold(rgb, 8, stride=8).transpose(1, 2).reshape(-1, 192)
+    np.testing.assert_array_equal(pat.float().cpu().numpy(), _bf(ref).numpy())
+    po, cls, pos = torch.randn(2 * 784, 768, generator=g), torch.randn(768, generator=g), torch.randn(785, 768, generator=g)
+    tok = ops.vit_assemble(po.to(DEV), cls.to(DEV), pos.to(DEV), 2, 784, 768)
+    want = torch.cat([cls.expand(2, 1, 768), po.view(2, 784, 768)], 1) + pos
+    np.testing.assert_array_equal(tok.view(2, 785, 768).cpu().numpy(), want.numpy())
+    m = torch.rand(3, 56, 56, generator=g)
+    up = ops.bilinear_up(m.to(DEV), 224)
+    want = torch.nn.functional.interpolate(m[:, None], size=(224, 224), mode="bilinear")[:, 0]
+    np.testing.assert_allclose(up.cpu().numpy(), want.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(up[0].cpu().numpy(), ok.bilinear_up(m[0].numpy(), 224), rtol=1e-6, atol=1e-7)
+    t = torch.randn(130, 70, generator=g).bfloat16()
+    np.testing.assert_array_equal(ops.transpose_bf16(t.to(DEV)).float().cpu().numpy(), t.float().T.numpy())
