@@ -1,0 +1,219 @@
+"""Drop-in for the reference's ``models/models.py``: same class / function names, constructor
+arguments, state_dict keys and return values; the arithmetic runs in the gfx950 HIP kernels
+(cmdiad_amd.runtime) instead of timm / pointnet2_ops / knn_cuda.
+
+Reference anchors: Model models/models.py:9-67; fps :70-78; Group :81-113; Encoder :183-215;
+TransformerEncoder :218-243; PointTransformer :246-373.
+
+The nn.Module classes below only OWN parameters (so ``state_dict()`` / ``load_state_dict()`` /
+``.to()`` behave as in the reference and real checkpoints load by name).  Module construction order
+inside PointTransformer follows the reference, so a seeded default init reproduces the reference's
+seeded init tensor for tensor.  Forward passes pack the current parameters into bf16 GEMM
+operands once (re-packed automatically when a parameter is modified) and call the kernels.
+There is no CPU execution path: inputs must be CUDA tensors.
+"""
+import os
+import warnings
+
+import torch
+from torch import nn
+
+from .. import ops, runtime
+
+
+# ------------------------------------------------------------------------------------------------
+# parameter containers (timm-compatible names for the ViT, reference names for Point-MAE)
+# ------------------------------------------------------------------------------------------------
+class Mlp(nn.Module):
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.fc2 = nn.Linear(hidden_features, out_features)
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, num_heads=8, qkv_bias=False, qk_scale=None, attn_drop=0., proj_drop=0.):
+        super().__init__()
+        self.num_heads = num_heads
+        self.scale = qk_scale or (dim // num_heads) ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim)
+
+
+class Block(nn.Module):
+    def __init__(self, dim, num_heads, mlp_ratio=4., qkv_bias=False, qk_scale=None, drop=0., attn_drop=0.,
+                 drop_path=0., act_layer=nn.GELU, norm_layer=nn.LayerNorm):
+        super().__init__()
+        self.norm1 = norm_layer(dim)
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
+        self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale)
+
+
+class _PatchEmbed(nn.Module):
+    def __init__(self, dim, patch):
+        super().__init__()
+        self.proj = nn.Conv2d(3, dim, kernel_size=patch, stride=patch)
+
+
+class VisionTransformer(nn.Module):
+    """Parameter layout of timm's ``vit_base_patch8_224(_dino)`` (timm==0.9.12 [external])."""
+
+    def __init__(self, img_size=224, patch=8, dim=768, depth=12, num_heads=12):
+        super().__init__()
+        self.num_heads, self.depth = num_heads, depth
+        n = (img_size // patch) ** 2
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, dim))
+        self.pos_embed = nn.Parameter(torch.zeros(1, n + 1, dim))
+        self.patch_embed = _PatchEmbed(dim, patch)
+        self.blocks = nn.Sequential(*[Block(dim, num_heads, 4.0, qkv_bias=True) for _ in range(depth)])
+        self.norm = nn.LayerNorm(dim, eps=1e-6)
+        nn.init.trunc_normal_(self.pos_embed, std=0.02)
+        nn.init.normal_(self.cls_token, std=1e-6)
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.trunc_normal_(m.weight, std=0.02)
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+
+
+def _param_version(module):
+    return tuple((p.data_ptr(), p._version) for p in list(module.parameters()) + list(module.buffers()))
+
+
+class Model(torch.nn.Module):
+    def __init__(self, device, rgb_backbone_name='vit_base_patch8_224_dino', out_indices=None, checkpoint_path='',
+                 pool_last=False, xyz_backbone_name='Point_MAE', group_size=128, num_group=1024):
+        super().__init__()
+        self.device = device
+        self.rgb_backbone_name = rgb_backbone_name
+        if rgb_backbone_name not in ('vit_base_patch8_224_dino', 'vit_base_patch8_224', 'vit_base_patch8_224_in21k'):
+            raise NotImplementedError(f"cmdiad_amd implements the ViT-B/8 backbones only (got {rgb_backbone_name})")
+        self.rgb_backbone = VisionTransformer()
+        if checkpoint_path:
+            self.rgb_backbone.load_state_dict(torch.load(checkpoint_path, map_location='cpu'), strict=False)
+        else:
+            warnings.warn("no pretrained ViT weights offline: rgb_backbone keeps its seeded random init "
+                          "(load a timm state_dict with rgb_backbone.load_state_dict)")
+        if xyz_backbone_name != 'Point_MAE':
+            raise NotImplementedError("cmdiad_amd implements the Point_MAE xyz backbone only")
+        self.xyz_backbone = PointTransformer(group_size=group_size, num_group=num_group)
+        self.xyz_backbone.load_model_from_ckpt("checkpoints/pointmae_pretrain.pth")
+        self._vit_packed = None
+
+    def _vit(self):
+        ver = _param_version(self.rgb_backbone)
+        if self._vit_packed is None or self._vit_packed[0] != ver:
+            dev = next(self.rgb_backbone.parameters()).device
+            self._vit_packed = (ver, runtime.PackedViT(self.rgb_backbone.state_dict(), device=dev))
+        return self._vit_packed[1]
+
+    def forward_rgb_tokens(self, x):
+        """[B,3,224,224] -> final-LN tokens [B,785,768] (device-resident fast path)."""
+        return self._vit().forward_tokens(x.float().contiguous())
+
+    def forward_rgb_features(self, x):
+        tok = self.forward_rgb_tokens(x)
+        B, T, C = tok.shape
+        s = int((T - 1) ** 0.5)
+        return tok[:, 1:].permute(0, 2, 1).reshape(B, C, s, s)
+
+    def forward(self, rgb=None, xyz=None, out_type='rgb+xyz'):
+        if out_type == 'rgb+xyz':
+            rgb_features = self.forward_rgb_features(rgb)
+            xyz_features, center, ori_idx, center_idx = self.xyz_backbone(xyz)
+            return rgb_features, xyz_features, center, ori_idx, center_idx
+        elif out_type == 'rgb':
+            return self.forward_rgb_features(rgb)
+        elif out_type == 'xyz':
+            return self.xyz_backbone(xyz)
+
+
+def fps(data, number):
+    """data [B,N,3] -> (centres [B,number,3], idx [B,number] int32).  models/models.py:70-78."""
+    idx, centers = ops.fps(data.float().contiguous(), number)
+    return centers, idx
+
+
+class Group(torch.nn.Module):
+    def __init__(self, num_group, group_size):
+        super().__init__()
+        self.num_group = num_group
+        self.group_size = group_size
+
+    def forward(self, xyz, n_valid=None):
+        """xyz [B,N,3] -> (neighborhood [B,G,M,3], center [B,G,3], ori_idx [B,G,M] int64, center_idx [B,G])."""
+        xyz = xyz.float().contiguous()
+        center_idx, center = ops.fps(xyz, self.num_group, n_valid)
+        ori_idx, neighborhood = ops.knn_group(xyz, center, self.group_size, n_valid)
+        return neighborhood, center, ori_idx, center_idx
+
+
+class Encoder(torch.nn.Module):
+    def __init__(self, encoder_channel):
+        super().__init__()
+        self.encoder_channel = encoder_channel
+        self.first_conv = torch.nn.Sequential(nn.Conv1d(3, 128, 1), nn.BatchNorm1d(128), nn.ReLU(inplace=True),
+                                              nn.Conv1d(128, 256, 1))
+        self.second_conv = nn.Sequential(nn.Conv1d(512, 512, 1), nn.BatchNorm1d(512), nn.ReLU(inplace=True),
+                                         nn.Conv1d(512, self.encoder_channel, 1))
+
+
+class TransformerEncoder(nn.Module):
+    def __init__(self, embed_dim=768, depth=4, num_heads=12, mlp_ratio=4., qkv_bias=False, qk_scale=None,
+                 drop_rate=0., attn_drop_rate=0., drop_path_rate=0.):
+        super().__init__()
+        self.blocks = nn.ModuleList([
+            Block(dim=embed_dim, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale)
+            for _ in range(depth)])
+
+
+class PointTransformer(torch.nn.Module):
+    def __init__(self, group_size=128, num_group=1024, encoder_dims=384):
+        super().__init__()
+        if encoder_dims != 384:
+            raise NotImplementedError("cmdiad_amd implements Point_MAE (encoder_dims=384); Point_Bert is out of scope")
+        self.trans_dim, self.depth, self.drop_path_rate, self.num_heads = 384, 12, 0.1, 6
+        self.group_size, self.num_group = group_size, num_group
+        self.group_divider = Group(num_group=self.num_group, group_size=self.group_size)
+        self.encoder_dims = encoder_dims
+        self.encoder = Encoder(encoder_channel=self.encoder_dims)
+        self.pos_embed = nn.Sequential(nn.Linear(3, 128), nn.GELU(), nn.Linear(128, self.trans_dim))
+        self.blocks = TransformerEncoder(embed_dim=self.trans_dim, depth=self.depth, num_heads=self.num_heads)
+        self.norm = nn.LayerNorm(self.trans_dim)
+        self._packed = None
+
+    def load_model_from_ckpt(self, bert_ckpt_path):
+        if bert_ckpt_path is None:
+            return
+        if not os.path.exists(bert_ckpt_path):
+            warnings.warn(f"{bert_ckpt_path} not found: Point-MAE keeps its seeded random init")
+            return
+        ckpt = torch.load(bert_ckpt_path, map_location='cpu')
+        base = {k.replace("module.", ""): v for k, v in ckpt['base_model'].items()}
+        for k in list(base.keys()):  # models/models.py:289-295 key rewrite
+            if k.startswith('MAE_encoder'):
+                base[k[len('MAE_encoder.'):]] = base.pop(k)
+            elif k.startswith('base_model'):
+                base[k[len('base_model.'):]] = base.pop(k)
+        self.load_state_dict(base, strict=False)
+
+    def packed(self):
+        ver = _param_version(self)
+        if self._packed is None or self._packed[0] != ver:
+            dev = next(self.parameters()).device
+            self._packed = (ver, runtime.PackedPointMAE(self.state_dict(), device=dev, group_size=self.group_size,
+                                                        num_group=self.num_group))
+        return self._packed[1]
+
+    def forward_device(self, xyz_nc, n_valid=None):
+        """xyz_nc [B,N,3] contiguous -> (feats [B,G,768] centre-major, center, ori_idx, center_idx)."""
+        return self.packed().forward(xyz_nc, n_valid)
+
+    def forward(self, pts):
+        """pts [B,3,N] -> (x [B,768,G], center [B,G,3], ori_idx [B,G,M], center_idx [B,G]); models.py:352-373.
+        Eval-mode contract (BatchNorm running statistics, DropPath inactive): SURVEY F1 / DESIGN.md."""
+        feats, center, ori_idx, center_idx = self.forward_device(pts.float().transpose(-1, -2).contiguous())
+        return feats.transpose(1, 2), center, ori_idx, center_idx

@@ -232,7 +232,7 @@ def test_pointmae_encoder_stages(Mg):
     from cmdiad_amd.runtime import fold_pointmae_encoder
     w = fold_pointmae_encoder(sd, "encoder.", DEV)
     h2, g32, g16 = ops.encoder_stage1(nb.reshape(-1, 3).contiguous().to(DEV), w["w1b1"], w["W2"], w["b2"], groups, Mg)
-    _, gb = ops.gemm(g16, w["W3a"], bias=w["b3"], want_f32=True, want_bf16=False)
+    gb, _ = ops.gemm(g16, w["W3a"], bias=w["b3"], want_f32=True, want_bf16=False)
     _, h3 = ops.gemm(h2, w["W3b"], act=ops.ACT_RELU, group_bias=gb, group_rows=Mg)
     tok, _ = ops.gemm_groupmax(h3, w["W4"], w["b4"], groups, Mg)
     with torch.no_grad():
