@@ -6,8 +6,8 @@
 // LDS: two 32 KiB stages, each = A tile + W tile, [128 rows][64 bf16] with 128-byte rows whose 16-byte
 // chunks are XOR-swizzled by (row & 7): the ds_read_b128 fragment reads (16 rows x 4 k-chunks per
 // 16-lane service group) then touch 16 distinct 16-byte slots of the 256-byte bank row -> conflict-free.
-// Staging is register-based and split (guide T14): the global loads of step t+1 are issued before
-// the MFMAs of step t and written to the other LDS stage after them; ONE barrier per K-step.
+// Staging is LDS-DMA (global_load_lds_dwordx4): the loads of step t+1 are issued before the MFMAs of
+// step t straight into the other LDS stage; ONE barrier per K-step.
 // The (n-tile, k-tile) iteration space is flattened so a block that owns several N tiles (the
 // distance GEMM's running-min loop) keeps the pipeline full across tile boundaries.
 //
@@ -27,49 +27,57 @@ constexpr int kLdsBytes = 2 * kStageBytes;       // 64 KiB -> 2 blocks / CU
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * (BK * 2) + ((chunk ^ (row & 7)) << 4); }
 
-// Operand tile loaders: fill 4 x 16 B per thread (row = (tid>>3) + 32*i, chunk = tid&7).
+// Operand tile stagers.  stage(tile, row0, k0, tid) fills one [128][64] bf16 LDS tile.
+//
+// GlobalTile uses LDS-DMA (global_load_lds_dwordx4, guide §5): no staging VGPRs, no ds_write.  One
+// wave-instruction writes 1 KiB = 8 rows x 128 B at (wave-uniform base) + lane*16, i.e. lane l lands on
+// row l>>3, PHYSICAL chunk l&7; the XOR swizzle therefore goes on the per-lane SOURCE address
+// (logical chunk = (l&7) ^ (row&7), guide rule 21) and the same XOR is applied by the fragment reads.
+// Each of the 4 waves issues 4 such instructions per operand tile.  Completion is tracked by vmcnt;
+// the __syncthreads() that ends a K-step drains it (2-phase schedule of guide T3/T4 "minimum").
 struct GlobalTile {
     const bf16_t* base;
     int ld;    // elements
     int rows;  // rows beyond are clamped (their results are masked by the epilogue)
-    __device__ __forceinline__ void load(uint4 (&r)[4], int row0, int k0, int tid) const
+    __device__ __forceinline__ void stage(char* tile, int row0, int k0, int tid) const
     {
+        const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = min(row0 + (tid >> 3) + 32 * i, rows - 1);
-            r[i] = *reinterpret_cast<const uint4*>(base + (size_t)row * ld + k0 + (tid & 7) * 8);
+        for (int j = 0; j < 4; ++j) {
+            const int r = wave * 32 + j * 8 + (lane >> 3);           // row within the tile
+            const int row = min(row0 + r, rows - 1);
+            const int chunk = (lane & 7) ^ (r & 7);                   // logical chunk stored at physical l&7
+            const bf16_t* src = base + (size_t)row * ld + k0 + chunk * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(tile + (wave * 32 + j * 8) * (BK * 2)),
+                                             16, 0, 0);
         }
     }
 };
 
 // Point-MAE first conv (3 -> 128, BN folded, ReLU) evaluated while staging: models/models.py:188-190.
+// Computed values go through registers and ds_write_b128 (thread t: rows (t>>3) + 32 i, chunk t&7).
 struct Conv1Tile {
     const float* neigh;  // [rows,3]
     const float4* wb;    // [128] = {w_x, w_y, w_z, b} with BatchNorm folded in
     int rows;
-    __device__ __forceinline__ void load(uint4 (&r)[4], int row0, int k0, int tid) const
+    __device__ __forceinline__ void stage(char* tile, int row0, int k0, int tid) const
     {
         float4 w[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) w[e] = wb[k0 + (tid & 7) * 8 + e];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int row = min(row0 + (tid >> 3) + 32 * i, rows - 1);
+            const int r = (tid >> 3) + 32 * i;
+            const int row = min(row0 + r, rows - 1);
             const float x = neigh[(size_t)row * 3], y = neigh[(size_t)row * 3 + 1], z = neigh[(size_t)row * 3 + 2];
             bf16x8 h;
 #pragma unroll
             for (int e = 0; e < 8; ++e) h[e] = f2bf(fmaxf(w[e].x * x + w[e].y * y + w[e].z * z + w[e].w, 0.0f));
-            r[i] = __builtin_bit_cast(uint4, h);
+            *reinterpret_cast<bf16x8*>(tile + lds_off(r, tid & 7)) = h;
         }
     }
 };
-
-__device__ __forceinline__ void stage_store(char* tile, const uint4 (&r)[4], int tid)
-{
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-        *reinterpret_cast<uint4*>(tile + lds_off((tid >> 3) + 32 * i, tid & 7)) = r[i];
-}
 
 typedef f32x4 Acc[4][4];
 
@@ -110,11 +118,8 @@ __device__ __forceinline__ void run(const ALoader& A, const WLoader& W, int m0, 
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    uint4 ra[4], rw[4];
-    A.load(ra, m0, 0, tid);
-    W.load(rw, nt0 * BN, 0, tid);
-    stage_store(lds, ra, tid);
-    stage_store(lds + BM * BK * 2, rw, tid);
+    A.stage(lds, m0, 0, tid);
+    W.stage(lds + BM * BK * 2, nt0 * BN, 0, tid);
     __syncthreads();
 
     const int total = n_tiles * KT;
@@ -124,16 +129,11 @@ __device__ __forceinline__ void run(const ALoader& A, const WLoader& W, int m0, 
         char* nxt = lds + ((it + 1) & 1) * kStageBytes;
         int kt_n = kt + 1, nt_n = nt;
         if (kt_n == KT) { kt_n = 0; nt_n = nt + 1; }
-        const bool more = it + 1 < total;
-        if (more) {
-            A.load(ra, m0, kt_n * BK, tid);
-            W.load(rw, nt_n * BN, kt_n * BK, tid);
+        if (it + 1 < total) {  // every wave finished reading `nxt` before the barrier that ended step it-1
+            A.stage(nxt, m0, kt_n * BK, tid);
+            W.stage(nxt + BM * BK * 2, nt_n * BN, kt_n * BK, tid);
         }
         compute_stage<SWAP>(acc, cur, cur + BM * BK * 2, wr, wc, lane);
-        if (more) {
-            stage_store(nxt, ra, tid);
-            stage_store(nxt + BM * BK * 2, rw, tid);
-        }
         if (kt == KT - 1) {
             epi(acc, nt);
 #pragma unroll
@@ -141,7 +141,7 @@ __device__ __forceinline__ void run(const ALoader& A, const WLoader& W, int m0, 
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        __syncthreads();
+        __syncthreads();  // also drains the LDS-DMA of the next stage (vmcnt(0) before s_barrier)
         kt = kt_n; nt = nt_n;
     }
 }

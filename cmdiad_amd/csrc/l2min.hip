@@ -194,6 +194,80 @@ __global__ __launch_bounds__(256) void normalize_cast_kernel(const float* __rest
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Score head / tail (features.py:227-290), one block per image.
+//   head: s_idx = argmax(min_val) (first occurrence), s_star = max; gathers m_test = patch[s_idx] and
+//         m_star = bank[min_idx[s_idx]] into probe buffers for the re-weighting scan.
+//   tail: m_star_knn = || m_test - bank[nn[1:]] || for the 2nd and 3rd nearest rows of m_star,
+//         w = 1 - exp(s*/sqrt(D)) / sum(exp(m_star_knn/sqrt(D))), s = w * s*.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void score_head_kernel(const float* __restrict__ min_val, const int64_t* __restrict__ min_idx,
+                                                         const float* __restrict__ patch, const float* __restrict__ bank,
+                                                         int Q, int D, unsigned row_offset, int Nb,
+                                                         float* __restrict__ s_star, int32_t* __restrict__ s_idx,
+                                                         float* __restrict__ m_test, float* __restrict__ m_star)
+{
+    __shared__ unsigned long long s_key[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* mv = min_val + (size_t)b * Q;
+    // max value, lowest index: key = value bits << 32 | (0xFFFFFFFF - idx); distances are non-negative
+    unsigned long long best = 0ull;
+    for (int i = tid; i < Q; i += 256) {
+        const unsigned long long k = ((unsigned long long)__float_as_uint(fmaxf(mv[i], 0.0f)) << 32) | (0xFFFFFFFFu - (unsigned)i);
+        best = k > best ? k : best;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const unsigned long long o = shfl_xor_u64(best, m);
+        best = o > best ? o : best;
+    }
+    if ((tid & 63) == 0) s_key[tid >> 6] = best;
+    __syncthreads();
+    best = s_key[0];
+    for (int w = 1; w < 4; ++w) best = s_key[w] > best ? s_key[w] : best;
+    const int si = (int)(0xFFFFFFFFu - (unsigned)(best & 0xFFFFFFFFull));
+    if (tid == 0) { s_star[b] = mv[si]; s_idx[b] = si; }
+    const long long gi = min_idx[(size_t)b * Q + si] - (long long)row_offset;
+    const float* pt = patch + ((size_t)b * Q + si) * D;
+    for (int c = tid; c < D; c += 256) {
+        m_test[(size_t)b * D + c] = pt[c];
+        if (gi >= 0 && gi < Nb) m_star[(size_t)b * D + c] = bank[(size_t)gi * D + c];  // owner shard writes it
+    }
+}
+
+__global__ __launch_bounds__(256) void score_tail_kernel(const float* __restrict__ s_star, const float* __restrict__ m_test,
+                                                         const unsigned long long* __restrict__ top3,
+                                                         const float* __restrict__ bank, int D, unsigned row_offset, int Nb,
+                                                         float* __restrict__ knn_d /*[B,2]*/)
+{
+    __shared__ float s_part[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int k = 1; k < 3; ++k) {
+        const long long gi = (long long)(top3[b * 3 + k] & 0xFFFFFFFFull) - (long long)row_offset;
+        if (gi < 0 || gi >= Nb) continue;  // block-uniform: another shard owns this row
+        const float* row = bank + (size_t)gi * D;
+        float s = 0.0f;
+        for (int c = tid; c < D; c += 256) { const float d = m_test[(size_t)b * D + c] - row[c]; s += d * d; }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+        if ((tid & 63) == 0) s_part[tid >> 6] = s;
+        __syncthreads();
+        if (tid == 0) knn_d[b * 2 + (k - 1)] = sqrtf(s_part[0] + s_part[1] + s_part[2] + s_part[3]);
+        __syncthreads();
+    }
+}
+
+// s = (1 - exp(s*/sqrt(D)) / (exp(k0/sqrt(D)) + exp(k1/sqrt(D)))) * s*      features.py:285-290
+__global__ void score_final_kernel(const float* __restrict__ s_star, const float* __restrict__ knn_d, int B, int D,
+                                   float* __restrict__ s_out)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float rd = sqrtf((float)D);
+    const float w = 1.0f - expf(s_star[b] / rd) / (expf(knn_d[b * 2] / rd) + expf(knn_d[b * 2 + 1] / rd));
+    s_out[b] = w * s_star[b];
+}
+
 bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 }  // namespace
@@ -277,6 +351,41 @@ extern "C" int cmdiad_normalize_cast(const float* x, size_t rows, int D, float m
     if (rows == 0) return CMDIAD_OK;
     hipLaunchKernelGGL(normalize_cast_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, rows,
                        D, mean, inv_std, (bf16_t*)out_bf16, out_f32, row_sqnorm);
+    CMDIAD_CHECK_LAUNCH();
+    return CMDIAD_OK;
+}
+
+extern "C" int cmdiad_score_head(const float* min_val, const int64_t* min_idx, const float* patch, const float* bank,
+                                 int B, int Q, int D, int Nb, uint32_t row_offset, float* s_star, int32_t* s_idx,
+                                 float* m_test, float* m_star, cmdiad_stream_t stream)
+{
+    CMDIAD_REQUIRE(min_val && min_idx && patch && bank && s_star && s_idx && m_test && m_star, CMDIAD_ERR_ARG,
+                   "cmdiad_score_head: null pointer");
+    if (B == 0) return CMDIAD_OK;
+    hipLaunchKernelGGL(score_head_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, min_val, min_idx, patch, bank, Q, D,
+                       row_offset, Nb, s_star, s_idx, m_test, m_star);
+    CMDIAD_CHECK_LAUNCH();
+    return CMDIAD_OK;
+}
+
+extern "C" int cmdiad_score_tail(const float* s_star, const float* m_test, const unsigned long long* top3,
+                                 const float* bank, int B, int D, int Nb, uint32_t row_offset, float* knn_d,
+                                 cmdiad_stream_t stream)
+{
+    CMDIAD_REQUIRE(s_star && m_test && top3 && bank && knn_d, CMDIAD_ERR_ARG, "cmdiad_score_tail: null pointer");
+    if (B == 0) return CMDIAD_OK;
+    hipLaunchKernelGGL(score_tail_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, s_star, m_test, top3, bank, D,
+                       row_offset, Nb, knn_d);
+    CMDIAD_CHECK_LAUNCH();
+    return CMDIAD_OK;
+}
+
+extern "C" int cmdiad_score_final(const float* s_star, const float* knn_d, int B, int D, float* s_out,
+                                  cmdiad_stream_t stream)
+{
+    CMDIAD_REQUIRE(s_star && knn_d && s_out, CMDIAD_ERR_ARG, "cmdiad_score_final: null pointer");
+    if (B == 0) return CMDIAD_OK;
+    hipLaunchKernelGGL(score_final_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, s_star, knn_d, B, D, s_out);
     CMDIAD_CHECK_LAUNCH();
     return CMDIAD_OK;
 }

@@ -177,6 +177,21 @@ int cmdiad_reweight_scan(const float* probes, const float* bank, int R, int Nb, 
                          unsigned long long* top3, void* workspace, size_t workspace_bytes,
                          cmdiad_stream_t stream);
 
+/* compute_single_s_s_map head / tail (features.py:227-290), batched over B images.
+ * head: s_idx[b] = argmax_q min_val[b][q] (first occurrence), s_star[b] = the max; copies
+ *       m_test[b] = patch[b][s_idx] and m_star[b] = bank[min_idx[b][s_idx] - row_offset] (only when that
+ *       row lies in this shard) into [B,D] buffers (m_star feeds cmdiad_reweight_scan).
+ * tail: knn_d[b][k-1] = || m_test[b] - bank[top3[b][k]] || for k = 1, 2 (rows owned by this shard only).
+ * final: s[b] = (1 - exp(s_star / sqrt(D)) / sum_k exp(knn_d[b][k] / sqrt(D))) x s_star. */
+int cmdiad_score_head(const float* min_val, const int64_t* min_idx, const float* patch, const float* bank,
+                      int B, int Q, int D, int Nb, uint32_t row_offset, float* s_star, int32_t* s_idx,
+                      float* m_test, float* m_star, cmdiad_stream_t stream);
+int cmdiad_score_tail(const float* s_star, const float* m_test, const unsigned long long* top3,
+                      const float* bank, int B, int D, int Nb, uint32_t row_offset, float* knn_d,
+                      cmdiad_stream_t stream);
+int cmdiad_score_final(const float* s_star, const float* knn_d, int B, int D, float* s_out,
+                       cmdiad_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Small fused element-wise / layout kernels
  * ------------------------------------------------------------------------------------------- */
