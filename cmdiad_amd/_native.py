@@ -46,6 +46,7 @@ SIGNATURES = {
     "cmdiad_score_head": [P, P, P, P, I, I, I, I, U32, P, P, P, P, P],
     "cmdiad_score_tail": [P, P, P, P, I, I, I, U32, P, P],
     "cmdiad_score_final": [P, P, I, I, P, P],
+    "cmdiad_coreset_greedy": [P, I, I, I, I, P, P, SZ, P],
     "cmdiad_normalize_cast": [P, SZ, I, F, F, P, P, P, P],
     "cmdiad_im2col_patch8": [P, I, I, P, P],
     "cmdiad_vit_assemble": [P, P, P, I, I, I, P, P],
@@ -57,6 +58,7 @@ SIGNATURES = {
 SIZE_QUERIES = {
     "cmdiad_fps_workspace_bytes": [I, I],
     "cmdiad_reweight_workspace_bytes": [I, I],
+    "cmdiad_coreset_workspace_bytes": [I, I, I],
 }
 
 

@@ -1,0 +1,181 @@
+"""Batched, device-resident hot path: extract (a1-a10) -> normalise (a11) -> patch-library nearest
+neighbour + re-weighting (a12-a13) -> bilinear score map.  The drop-in classes in
+feature_extractors/ call this with B = 1 exactly where the reference calls its torch ops; bench.py
+calls it with B = 32.  Results per sample do not depend on B (tests/test_gpu_engine.py).
+
+Nothing here touches the CPU oracle; every stage is a HIP kernel from libcmdiad_hip.so.
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _native as nat
+from . import ops
+
+
+class Bank:
+    """One patch library resident in HBM.
+
+    * ``f32``  [Nb,D]  the reference's normalised library (exact re-score, re-weighting scan): replicated on
+      every GPU (<= 350 MB for the largest MVTec-3D class);
+    * ``bf16`` [rows,D] + ``sqnorm`` [rows]: the operand of the distance GEMM.  On a multi-GPU node this is the
+      rank's ROW SHARD of the search (``row_offset`` = first global row): every rank searches its
+      shard for the queries of ALL ranks and the per-shard minima are combined with one integer-MIN
+      all-reduce of packed (distance, global row) keys over RCCL/xGMI."""
+
+    def __init__(self, rows_f32, rank=0, world=1):
+        assert rows_f32.is_cuda and rows_f32.dtype == torch.float32
+        self.f32 = rows_f32.contiguous()
+        n = self.f32.shape[0]
+        lo, hi = shard_range(n, rank, world)
+        self.row_offset, self.rank, self.world = lo, rank, world
+        self.bf16, _, self.sqnorm = ops.normalize_cast(self.f32[lo:hi])
+
+    @property
+    def rows(self):
+        return self.f32.shape[0]
+
+
+def shard_range(n, rank, world):
+    """Contiguous row range of shard `rank`; 128-row aligned so shards start on a GEMM tile boundary."""
+    per = ((n + world - 1) // world + 127) // 128 * 128
+    return min(rank * per, n), min((rank + 1) * per, n)
+
+
+def merge_shard_keys(keys, group=None):
+    """Combine per-shard packed keys: key = (fp32 bits of d2 >= 0) << 32 | global row.  The keys are
+    non-negative as int64, so signed MIN == unsigned MIN == (smallest distance, lowest global row)."""
+    if group is not None:
+        import torch.distributed as td
+        td.all_reduce(keys, op=td.ReduceOp.MIN, group=group)
+    return keys
+
+
+def gather_queries(q16, qsq, group=None):
+    """All-gather the bf16 queries (+ their squared norms) of every rank: [Q,D] -> [W*Q,D]."""
+    if group is None:
+        return q16, qsq
+    import torch.distributed as td
+    world = td.get_world_size(group)
+    q_all = torch.empty((world * q16.shape[0], q16.shape[1]), dtype=q16.dtype, device=q16.device)
+    s_all = torch.empty((world * qsq.shape[0],), dtype=qsq.dtype, device=qsq.device)
+    td.all_gather_into_tensor(q_all.view(torch.int16), q16.view(torch.int16), group=group)
+    td.all_gather_into_tensor(s_all, qsq, group=group)
+    return q_all, s_all
+
+
+def _call(name, *args):
+    nat.check(getattr(nat.lib(), name)(*args), name)
+
+
+def score_patches(patch32, bank, dims, gt_size=224, group=None):
+    """features.py:225-294 for a batch.  patch32 [B,Q,D] f32 cuda, ALREADY normalised.
+    Returns dict(min_val [B,Q], min_idx [B,Q] int64, s_idx [B], s_star [B], s [B], s_map_pre [B,gt,gt], ...).
+
+    With `group` (torch.distributed over RCCL) the search is row-sharded: all-gather of the bf16 queries,
+    per-shard distance GEMM, ONE integer-MIN all-reduce of the packed keys; the exact fp32 re-score and
+    the re-weighting use the replicated fp32 library, so no further collectives are needed."""
+    B, Q, D = patch32.shape
+    dev = patch32.device
+    flat = patch32.reshape(B * Q, D)
+    q16, _, qsq = ops.normalize_cast(flat)
+    q_all, s_all = gather_queries(q16, qsq, group)
+    keys = ops.new_keys(q_all.shape[0], dev)
+    ops.l2_min_keys(q_all, s_all, bank.bf16, bank.sqnorm, keys, bank.row_offset)
+    keys = merge_shard_keys(keys, group)
+    if group is not None:
+        keys = keys[bank.rank * B * Q:(bank.rank + 1) * B * Q].contiguous()
+    return score_patches_from_keys(patch32, keys, bank, dims, gt_size)
+
+
+def score_patches_from_keys(patch32, keys, bank, dims, gt_size=224):
+    """Everything after the (merged) nearest-neighbour keys: exact re-score, s*, re-weighting, score map."""
+    B, Q, D = patch32.shape
+    dev = patch32.device
+    flat = patch32.reshape(B * Q, D)
+    min_val = torch.empty((B * Q,), dtype=torch.float32, device=dev)
+    min_idx = torch.empty((B * Q,), dtype=torch.int64, device=dev)
+    ops.l2_rescore(flat, bank.f32, keys, min_val, min_idx, 0)
+    s_star = torch.empty((B,), dtype=torch.float32, device=dev)
+    s_idx = torch.empty((B,), dtype=torch.int32, device=dev)
+    m_test = torch.empty((B, D), dtype=torch.float32, device=dev)
+    m_star = torch.empty((B, D), dtype=torch.float32, device=dev)
+    st = ops._stream()
+    _call("cmdiad_score_head", ops._p(min_val), ops._p(min_idx), ops._p(flat), ops._p(bank.f32), B, Q, D, bank.rows,
+          0, ops._p(s_star), ops._p(s_idx), ops._p(m_test), ops._p(m_star), st)
+    top3 = ops.reweight_scan(m_star, bank.f32)
+    knn_d = torch.empty((B, 2), dtype=torch.float32, device=dev)
+    _call("cmdiad_score_tail", ops._p(s_star), ops._p(m_test), ops._p(top3), ops._p(bank.f32), B, D, bank.rows, 0,
+          ops._p(knn_d), st)
+    s = torch.empty((B,), dtype=torch.float32, device=dev)
+    _call("cmdiad_score_final", ops._p(s_star), ops._p(knn_d), B, D, ops._p(s), st)
+    s_map = ops.bilinear_up(min_val.view(B, dims[0], dims[1]), gt_size)
+    return dict(min_val=min_val.view(B, Q), min_idx=min_idx.view(B, Q), s_idx=s_idx, s_star=s_star, s=s,
+                s_map_pre=s_map, top3=top3, knn_d=knn_d)
+
+
+class Extraction:
+    """Device-resident outputs of one extract() call (everything Features.__call__ returns, plus the
+    interpolation indices/weights that replace the reference's 154 MB interpolated tensor)."""
+    __slots__ = ("rgb_tokens", "xyz_feats", "center", "ori_idx", "center_idx", "idx3", "w3", "pix2pt", "n_valid",
+                 "xyz", "nz", "size")
+
+
+class Engine:
+    def __init__(self, vit, pointmae, size=224):
+        """vit: runtime.PackedViT (or a callable returning one); pointmae: runtime.PackedPointMAE."""
+        self._vit, self._pm, self.size = vit, pointmae, size
+
+    @property
+    def vit(self):
+        return self._vit() if callable(self._vit) else self._vit
+
+    @property
+    def pm(self):
+        return self._pm() if callable(self._pm) else self._pm
+
+    def extract(self, rgb, organized_pc=None, xyz=None, nz=None, want_rgb=True, want_xyz=True, n_max=None):
+        """rgb [B,3,S,S] f32 cuda; the cloud either organised ([B,3,S,S], zeros = background) or already
+        unorganised (xyz [B,N,3] + nz [B,N] int32 pixel indices, B == 1 or equal N)."""
+        ex = Extraction()
+        ex.size = self.size
+        ex.rgb_tokens = self.vit.forward_tokens(rgb) if want_rgb else None
+        if not want_xyz:
+            return ex
+        if organized_pc is not None:
+            ex.xyz, ex.nz, ex.pix2pt, ex.n_valid = ops.unorganize(organized_pc.contiguous(), n_max)
+        else:
+            B, N, _ = xyz.shape
+            ex.xyz, ex.nz, ex.n_valid = xyz.contiguous(), nz, None
+            ex.pix2pt = torch.full((B, self.size * self.size), -1, dtype=torch.int32, device=xyz.device)
+            ex.pix2pt.scatter_(1, nz.long(), torch.arange(N, dtype=torch.int32, device=xyz.device).expand(B, N))
+        ex.xyz_feats, ex.center, ex.ori_idx, ex.center_idx = self.pm.forward(ex.xyz, ex.n_valid)
+        ex.idx3, ex.w3 = ops.interp3nn(ex.xyz, ex.center, ex.n_valid)
+        return ex
+
+    def xyz_patch(self, ex, P=56, mean=0.0, inv_std=1.0, want_bf16=False):
+        """[B, P*P, 768] f32 (features.py:169-184), optionally normalised on the fly."""
+        return ops.xyz_patch_fused(ex.xyz_feats, ex.idx3, ex.w3, ex.pix2pt, ex.size, P, mean, inv_std,
+                                   want_f32=True, want_bf16=want_bf16)[0]
+
+    @staticmethod
+    def rgb_patch(ex):
+        """[B,784,768] view of the ViT tokens without cls (features.py:160-162)."""
+        return ex.rgb_tokens[:, 1:]
+
+    @staticmethod
+    def rgb_patch56(ex):
+        """features.py:165-166: AdaptiveAvgPool2d 28->56 == exact 2x nearest replication."""
+        p = ex.rgb_tokens[:, 1:]
+        B, T, C = p.shape
+        s = int(math.isqrt(T))
+        return p.reshape(B, s, 1, s, 1, C).expand(B, s, 2, s, 2, C).reshape(B, 4 * T, C)
+
+
+def normalize(x, mean, std):
+    """(x - mean) / std with the scalar library statistics (multiple_features.py:976-977) -> f32 copy."""
+    shape = x.shape
+    _, out, _ = ops.normalize_cast(x.reshape(-1, shape[-1]).contiguous(), float(mean), 1.0 / float(std), want_f32=True,
+                                   want_sq=False)
+    return out.view(shape)

@@ -1,0 +1,250 @@
+"""Drop-in for the reference's ``feature_extractors/features.py`` (class ``Features``, lines 21-425):
+same constructor, attributes and method names; extraction, patching and kNN scoring run in the HIP
+kernels through cmdiad_amd.engine.
+
+Differences a caller can observe (also listed in INTEGRATION.md):
+  * patch tensors returned by get_rgb_patch / get_xyz_patch and the memory banks live on the GPU
+    (the reference moves everything to the CPU, features.py:137-140, and then runs cdist there);
+  * ``interpolated_feature_maps`` is a lazy handle (``LazyInterpolated``): the 154 MB [1,768,N] tensor
+    is only materialised when ``.materialize()`` / ``.to()`` is called; get_xyz_patch consumes the handle;
+  * ``calculate_dist`` returns a ``DistHandle`` (the Q x N matrix is never built; ``.materialize()`` builds it);
+  * the feature extractor runs in eval mode, dist_method_s must be 'l2' (the reference's
+    l1 / cos branches are broken).
+"""
+import math
+
+import numpy as np
+import torch
+from sklearn import linear_model, random_projection
+from sklearn.metrics import roc_auc_score
+
+from .. import engine as eng
+from .. import ops
+from ..models.models import Model
+from ..utils.utils import KNNGaussianBlur, set_seeds
+
+
+class LazyInterpolated:
+    """Stands in for ``interpolating_points(...)`` of features.py:137: holds the 3-NN indices / weights and
+    the centre features on the device; ``materialize()`` produces the reference's [B, D, N] tensor."""
+
+    def __init__(self, extraction):
+        self.ex = extraction
+
+    @property
+    def shape(self):
+        B, G, D = self.ex.xyz_feats.shape
+        return torch.Size((B, D, self.ex.idx3.shape[1]))
+
+    def materialize(self):
+        return ops.interp_gather(self.ex.xyz_feats, self.ex.idx3, self.ex.w3, self.ex.n_valid).permute(0, 2, 1)
+
+    def to(self, *a, **k):
+        return self.materialize().to(*a, **k)
+
+
+class DistHandle:
+    """Stands in for the Q x N distance matrix of features.py:190 (never built on the product path)."""
+
+    def __init__(self, patch, lib):
+        self.patch, self.lib = patch, lib
+
+    @property
+    def shape(self):
+        return torch.Size((self.patch.shape[0], self.lib.shape[0]))
+
+    def materialize(self, chunk=4096):
+        """Exact fp32 matrix, built block-wise by the re-weighting scan's distance kernel (debug / API
+        compatibility only)."""
+        raise NotImplementedError("the Q x N distance matrix is not materialised by cmdiad_amd; use "
+                                  "compute_single_s_s_map(patch, dist_handle, ...) or engine.score_patches")
+
+
+class _NeedsFit(Exception):
+    pass
+
+
+class Features(torch.nn.Module):
+    def __init__(self, args, image_size=224, f_coreset=0.1, coreset_eps=0.9):
+        super().__init__()
+        from .. import _native
+        _native.lib()  # fail loudly at construction when libcmdiad_hip.so is missing
+        self.device = "cuda" if torch.cuda.is_available() else "cpu"
+        self.deep_feature_extractor = Model(
+            device=self.device, rgb_backbone_name=args.rgb_backbone_name, xyz_backbone_name=args.xyz_backbone_name,
+            group_size=args.group_size, num_group=args.num_group)
+        self.deep_feature_extractor.to(self.device)
+        self.deep_feature_extractor.eval()
+
+        self.args = args
+        self.class_name = None
+        self.rgb_size, self.xyz_size, self.gt_size = args.rgb_size, args.xyz_size, args.gt_size
+        self.f_coreset, self.coreset_eps, self.coreset_dtype = args.f_coreset, args.coreset_eps, args.coreset_dtype
+        self.blur = KNNGaussianBlur(4)
+        self.n_reweight = 3
+        set_seeds(0)
+        self.patch_xyz_lib, self.patch_rgb_lib, self.patch_fusion_lib = [], [], []
+        self.patch_lib, self.patch_share_lib, self.patch_non_share_lib = [], [], []
+        self.random_state = args.random_state
+        self.xyz_dim = self.rgb_dim = 0
+        self.xyz_mean = self.xyz_std = self.rgb_mean = self.rgb_std = self.fusion_mean = self.fusion_std = 0
+        self.share_mean = self.share_std = self.non_share_mean = self.non_share_std = 0
+        self.image_preds, self.image_labels, self.pixel_preds, self.pixel_labels = [], [], [], []
+        self.gts, self.predictions = [], []
+        self.image_rocauc = self.pixel_rocauc = self.au_pro = self.au_pro_001 = 0
+        self.ins_id = self.ins_id2 = self.ins_id3 = 0
+
+        if getattr(args, "use_hn", False):
+            from ..models.hallucination_network import HallucinationCrossModalityNetwork
+            self.fusion = HallucinationCrossModalityNetwork(args, 768, 768, hidden_ratio=2.5)
+            self.fusion.to(self.device)
+        for flag in ("use_hn_conv", "use_hn_from_rgb_mlp", "use_hn_from_rgb_conv", "use_hrnet", "use_uff"):
+            if getattr(args, flag, False):
+                raise NotImplementedError(f"--{flag}: the conv / FtoI / HRNet distillation heads are out of scope "
+                                          f"(SURVEY 2.1); cmdiad_amd implements the FtoF MLP head (--use_hn)")
+        if getattr(args, "fusion_module_path", "") != "":
+            ckpt = torch.load(args.fusion_module_path, map_location="cpu")["model"]
+            print("[Fusion Block]", self.fusion.load_state_dict(ckpt))
+            self.fusion.eval()
+
+        self.detect_fuser = linear_model.SGDOneClassSVM(random_state=42, nu=args.ocsvm_nu, max_iter=args.ocsvm_maxiter)
+        self.seg_fuser = linear_model.SGDOneClassSVM(random_state=42, nu=args.ocsvm_nu, max_iter=args.ocsvm_maxiter)
+        self.s_lib, self.s_map_lib = [], []
+        self.img_name = []
+        self.save_num = 0
+        self._engine = eng.Engine(self.deep_feature_extractor._vit, self.deep_feature_extractor.xyz_backbone.packed,
+                                  size=self.xyz_size)
+        self._banks = {}
+
+    # ------------------------------------------------------------------------------------ extraction
+    def __call__(self, rgb=None, xyz=None, out_type="rgb+xyz"):
+        """features.py:123-158.  rgb [B,3,S,S], xyz [B,3,N] (unorganised, zeros removed).  Returns the
+        reference's tuples; feature maps are copied to the CPU as the reference does, and each carries
+        the device-resident Extraction in ``._cmdiad`` so the patch getters avoid a round trip."""
+        want_rgb, want_xyz = "rgb" in out_type, "xyz" in out_type
+        dev = self.device
+        rgb_d = rgb.to(dev).float() if want_rgb else None
+        if want_xyz:
+            pts = xyz.to(dev).float().transpose(1, 2).contiguous()  # [B,N,3]
+            # pixel indices are only known to the caller (nonzero_indices); get_xyz_patch builds pix2pt from them
+            ex = eng.Extraction()
+            ex.size = self.xyz_size
+            with torch.no_grad():
+                ex.rgb_tokens = self._engine.vit.forward_tokens(rgb_d) if want_rgb else None
+                ex.xyz, ex.n_valid, ex.nz, ex.pix2pt = pts, None, None, None
+                ex.xyz_feats, ex.center, ex.ori_idx, ex.center_idx = self._engine.pm.forward(pts)
+                ex.idx3, ex.w3 = ops.interp3nn(pts, ex.center)
+        else:
+            with torch.no_grad():
+                ex = self._engine.extract(rgb_d, want_xyz=False)
+        out = []
+        if want_rgb:
+            B, T, C = ex.rgb_tokens.shape
+            s = int(math.isqrt(T - 1))
+            fmap = ex.rgb_tokens[:, 1:].permute(0, 2, 1).reshape(B, C, s, s).to("cpu")
+            fmap._cmdiad = ex
+            out.append([fmap])
+        if want_xyz:
+            xmap = ex.xyz_feats.transpose(1, 2).to("cpu")
+            xmap._cmdiad = ex
+            out += [[xmap], ex.center, ex.ori_idx, ex.center_idx, LazyInterpolated(ex)]
+        return out[0] if len(out) == 1 else tuple(out)
+
+    def get_rgb_patch(self, rgb_feature_maps):
+        """features.py:160-167 -> (rgb_patch [784,768], rgb_patch2 [3136,768]) on the GPU."""
+        ex = getattr(rgb_feature_maps[0], "_cmdiad", None)
+        if ex is not None and len(rgb_feature_maps) == 1:
+            return eng.Engine.rgb_patch(ex)[0], eng.Engine.rgb_patch56(ex)[0]
+        fm = torch.cat(rgb_feature_maps, 1).to(self.device)
+        p = fm.reshape(fm.shape[1], -1).T.contiguous()
+        s = int(math.isqrt(p.shape[0]))
+        p2 = p.reshape(s, 1, s, 1, -1).expand(s, 2, s, 2, -1).reshape(4 * s * s, -1)
+        return p, p2
+
+    def get_xyz_patch(self, xyz_feature_maps, interpolated_pc, nonzero_indices, get_2828=False):
+        """features.py:169-184 -> [3136,768] (or [784,768] with get_2828) on the GPU."""
+        if not isinstance(interpolated_pc, LazyInterpolated):
+            raise TypeError("get_xyz_patch expects the LazyInterpolated handle returned by Features.__call__")
+        ex = interpolated_pc.ex
+        if ex.pix2pt is None:
+            n = ex.xyz.shape[1]
+            nz = torch.as_tensor(np.asarray(nonzero_indices), device=ex.xyz.device).long().view(1, n)
+            ex.pix2pt = torch.full((1, self.xyz_size * self.xyz_size), -1, dtype=torch.int32, device=ex.xyz.device)
+            ex.pix2pt.scatter_(1, nz, torch.arange(n, dtype=torch.int32, device=ex.xyz.device).view(1, n))
+        return self._engine.xyz_patch(ex, P=28 if get_2828 else 56)[0]
+
+    # ------------------------------------------------------------------------------------ scoring
+    def calculate_dist(self, single_patch, patch_lib):
+        assert len(single_patch.shape) == 2 and len(patch_lib.shape) == 2
+        if self.args.dist_method_s != "l2":
+            raise NotImplementedError("only dist_method_s='l2' is implemented (the reference's l1/cos branches "
+                                      "pass CPU tensors to cupy and cannot run; SURVEY 2.2)")
+        return DistHandle(single_patch, patch_lib)
+
+    def _bank(self, lib):
+        """Device bank (bf16 copy + squared norms) cached per library tensor."""
+        key = (lib.data_ptr(), tuple(lib.shape), lib._version)
+        hit = self._banks.get(lib.data_ptr())
+        if hit is None or hit[0] != key:
+            hit = (key, eng.Bank(lib.to(self.device).float()))
+            self._banks[lib.data_ptr()] = hit
+        return hit[1]
+
+    def compute_single_s_s_map(self, patch, dist, feature_map_dims, modal='xyz'):
+        """features.py:225-297 -> (s scalar tensor, s_map [1,gt,gt]) on the CPU (the blur is host PIL)."""
+        lib = {"xyz": self.patch_xyz_lib, "rgb": self.patch_rgb_lib, "fusion": self.patch_fusion_lib,
+               "share": self.patch_share_lib, "non_share": self.patch_non_share_lib}[modal]
+        r = eng.score_patches(patch.to(self.device).float().unsqueeze(0).contiguous(), self._bank(lib),
+                              feature_map_dims, self.gt_size)
+        s_map = self.blur(r["s_map_pre"].unsqueeze(0))  # [1,1,H,W] -> [1,H,W], 8-bit PIL blur (utils.py:71-83)
+        return r["s"][0].cpu(), s_map
+
+    def add_sample_to_mem_bank(self, sample):
+        raise NotImplementedError
+
+    def predict(self, sample, mask, label, rgb_path):
+        raise NotImplementedError
+
+    def add_sample_to_late_fusion_mem_bank(self, sample):
+        raise NotImplementedError
+
+    def compute_s_s_map(self, *a, **k):
+        raise NotImplementedError
+
+    def run_coreset(self):
+        raise NotImplementedError
+
+    def calculate_metrics(self):
+        """features.py:302-324."""
+        from ..utils.au_pro_util import calculate_au_pro
+        self.image_preds = np.stack(self.image_preds)
+        self.image_labels = np.stack(self.image_labels)
+        self.pixel_preds = np.array(self.pixel_preds)
+        self.img_name = np.stack(self.img_name)
+        self.image_rocauc = roc_auc_score(self.image_labels, self.image_preds)
+        self.pixel_rocauc = roc_auc_score(self.pixel_labels, self.pixel_preds)
+        self.au_pro, _ = calculate_au_pro(self.gts, self.predictions)
+        self.au_pro_001, _ = calculate_au_pro(self.gts, self.predictions, 0.01)
+
+    def run_late_fusion(self):
+        """features.py:352-358 (host scikit-learn)."""
+        self.s_lib = torch.cat(self.s_lib, 0)
+        self.s_map_lib = torch.cat(self.s_map_lib, 0)
+        self.detect_fuser.fit(self.s_lib)
+        self.seg_fuser.fit(self.s_map_lib)
+
+    def get_coreset_idx_randomp(self, z_lib, n=1000, eps=0.90, coreset_dtype='FP16', force_cpu=False, lib=''):
+        """features.py:360-425: sparse random projection (host sklearn) + greedy k-centre selection.
+        The greedy loop is the HIP kernel cmdiad_coreset_* (SURVEY 8f row f1)."""
+        from .. import coreset
+        print(f"   Fitting random projections. Start dim = {z_lib.shape}.")
+        try:
+            transformer = random_projection.SparseRandomProjection(eps=eps, random_state=self.random_state)
+            z = torch.tensor(transformer.fit_transform(z_lib.detach().cpu().numpy()))
+            print(f"   DONE.                 Transformed dim = {z.shape}.")
+        except ValueError:
+            print("   Error: could not project vectors. Please increase `eps`.")
+            z = z_lib.detach().cpu()
+        if self.args.dist_method_coreset != "l2":
+            raise NotImplementedError("only dist_method_coreset='l2' is implemented")
+        return coreset.greedy_coreset(z.to(self.device), n, coreset_dtype).cpu()

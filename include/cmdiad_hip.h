@@ -192,6 +192,13 @@ int cmdiad_score_tail(const float* s_star, const float* m_test, const unsigned l
 int cmdiad_score_final(const float* s_star, const float* knn_d, int B, int D, float* s_out,
                        cmdiad_stream_t stream);
 
+/* Greedy k-centre coreset selection (features.py:372-425, get_coreset_idx_randomp after the random
+ * projection; coreset_dtype 'FP16', dist_method_coreset 'l2').  z32 [n,d] f32 projected library (d even),
+ * first_idx = 0 as the reference; idx_out [n_select] int64 in selection order. */
+size_t cmdiad_coreset_workspace_bytes(int n, int d, int n_select);
+int cmdiad_coreset_greedy(const float* z32, int n, int d, int n_select, int first_idx, int64_t* idx_out,
+                          void* workspace, size_t workspace_bytes, cmdiad_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Small fused element-wise / layout kernels
  * ------------------------------------------------------------------------------------------- */

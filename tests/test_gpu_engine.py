@@ -1,0 +1,169 @@
+"""GPU: the drop-in method classes and the batched engine end to end against the CPU oracle pipeline
+(oracle/pipeline.py) on a tiny synthetic class, plus batch-size invariance and the sharded-bank merge."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from cmdiad_amd import engine as eng  # noqa: E402
+from cmdiad_amd import ops  # noqa: E402
+from cmdiad_amd.synth import synth_cloud, synth_rgb  # noqa: E402
+from oracle import nets  # noqa: E402
+from oracle.pipeline import CpuDoubleRGBPoint, CpuExtractor  # noqa: E402
+
+DEV = "cuda"
+
+
+def make_args(**kw):
+    a = dict(rgb_backbone_name='vit_base_patch8_224_dino', xyz_backbone_name='Point_MAE', group_size=128, num_group=1024,
+             rgb_size=224, xyz_size=224, gt_size=224, f_coreset=1.0, coreset_eps=0.9, coreset_dtype='FP16',
+             random_state=None, dist_method_s='l2', dist_method_coreset='l2', main_modality='', use_hn=False,
+             fusion_module_path='', ocsvm_nu=0.5, ocsvm_maxiter=1000, xyz_s_lambda=1.0, xyz_smap_lambda=1.0,
+             rgb_s_lambda=0.1, rgb_smap_lambda=0.1, fusion_s_lambda=1.0, fusion_smap_lambda=1.0,
+             save_feature_for_fusion=False, save_seg_results=False, use_depth=False)
+    a.update(kw)
+    return types.SimpleNamespace(**a)
+
+
+def synth_sample(i, anomalous=False):
+    pc = synth_cloud(200 + i, 0.30 + 0.02 * (i % 3))
+    rgb = synth_rgb(i)
+    if anomalous:
+        pc[0, 2, 100:120, 100:120] -= 0.005 * (pc[0, 2, 100:120, 100:120] != 0)  # 5 mm dent
+        rgb[0, :, 100:120, 100:120] += 2.0
+    return rgb, pc
+
+
+@pytest.fixture(scope="module")
+def weights():
+    return nets.synth_state_dict("vit", 31), nets.synth_state_dict("pointmae", 21)
+
+
+@pytest.fixture(scope="module")
+def fitted(weights):
+    """CPU oracle fit + the drop-in's fit on the same 4 train samples."""
+    import warnings
+    from cmdiad_amd.feature_extractors.multiple_features import DoubleRGBPointFeatures
+    sd_vit, sd_pm = weights
+    train = [synth_sample(i) for i in range(4)]
+    cpu = CpuDoubleRGBPoint(CpuExtractor(sd_vit, sd_pm))
+    cpu_feats = cpu.fit(train)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = DoubleRGBPointFeatures(make_args())
+    m.deep_feature_extractor.rgb_backbone.load_state_dict(sd_vit)
+    m.deep_feature_extractor.xyz_backbone.load_state_dict(sd_pm)
+    for rgb, pc in train:
+        m.add_sample_to_mem_bank((rgb, pc, pc), class_name="synth")
+    m.run_coreset()
+    return cpu, cpu_feats, m, train
+
+
+def _rel(got, ref):
+    scale = ref.abs().mean().item()
+    err = (got - ref).abs()
+    return err.mean().item() / scale, err.max().item() / scale
+
+
+def test_fit_banks_and_statistics(fitted):
+    cpu, cpu_feats, m, _ = fitted
+    # F5 cross-wired scalar statistics
+    assert abs(float(m.xyz_mean) - float(cpu.xyz_mean)) < 5e-3 * abs(float(cpu.xyz_mean)) + 1e-4
+    assert abs(float(m.xyz_std) - float(cpu.xyz_std)) < 5e-3 * float(cpu.xyz_std)
+    assert float(m.rgb_mean) == float(m.xyz_mean) and float(m.rgb_std) == float(m.xyz_std)
+    assert m.patch_xyz_lib.shape == (4 * 3136, 768) and m.patch_rgb_lib.shape == (4 * 784, 768)
+    # patch features: bf16 networks vs fp32 oracle (tolerance model of tests/test_gpu_nets.py)
+    mr, xr = _rel(m.patch_rgb_lib.cpu(), cpu.rgb_lib)
+    assert mr < 0.02 and xr < 0.2, (mr, xr)
+    mx, xx = _rel(m.patch_xyz_lib.cpu(), cpu.xyz_lib)
+    assert mx < 0.02 and xx < 0.2, (mx, xx)
+
+
+def test_predict_scores_match_oracle(fitted):
+    cpu, _, m, _ = fitted
+    for i, anomalous in ((10, False), (11, True)):
+        rgb, pc = synth_sample(i, anomalous)
+        s_ref, map_ref, rx, rr = cpu.predict(rgb, pc)
+        s_got, map_got = m._s((rgb, pc, pc))
+        # image-level pre-OCSVM scores: w * s_star of each modality (2-3 % from the bf16 feature error)
+        np.testing.assert_allclose(s_got.numpy(), s_ref.numpy(), rtol=4e-2)
+        # 224x224 blurred maps (8-bit quantised): compare at 2 grey levels of the map maximum
+        for col in range(2):
+            a, b = map_got[:, col].numpy(), map_ref[:, col].numpy()
+            assert np.abs(a - b).max() <= 0.05 * np.abs(b).max(), (col, np.abs(a - b).max(), np.abs(b).max())
+            assert np.corrcoef(a, b)[0, 1] > 0.995
+
+
+def test_scoring_exact_features_isolated(fitted):
+    """Same (oracle) features fed to the GPU scorer: isolates a11-a13 from the network tolerance."""
+    cpu, cpu_feats, m, train = fitted
+    rp, xp = cpu_feats[1]
+    xyz_q = ((xp - cpu.xyz_mean) / cpu.xyz_std).to(DEV)
+    bank = eng.Bank(cpu.xyz_lib.to(DEV))
+    r = eng.score_patches(xyz_q.unsqueeze(0).contiguous(), bank, (56, 56))
+    from oracle import scoring
+    ref = scoring.single_s_s_map((xp - cpu.xyz_mean) / cpu.xyz_std, torch.cdist((xp - cpu.xyz_mean) / cpu.xyz_std, cpu.xyz_lib),
+                                 cpu.xyz_lib, (56, 56), blur=False)
+    # the query IS a bank row (train sample): distances ~0, so compare absolutely (cdist's own error ~1e-3)
+    np.testing.assert_allclose(r["min_val"][0].cpu().numpy(), ref["min_val"].numpy(), atol=5e-3)
+    assert (r["min_idx"][0].cpu() == ref["min_idx"]).float().mean() > 0.99
+    # an unseen query: every stage of compute_single_s_s_map
+    rgb, pc = synth_sample(12, True)
+    rq, xq = cpu.ex(rgb, pc)
+    xq = (xq - cpu.xyz_mean) / cpu.xyz_std
+    ref = scoring.single_s_s_map(xq, torch.cdist(xq, cpu.xyz_lib), cpu.xyz_lib, (56, 56), blur=False)
+    r = eng.score_patches(xq.to(DEV).unsqueeze(0).contiguous(), bank, (56, 56))
+    np.testing.assert_allclose(r["min_val"][0].cpu().numpy(), ref["min_val"].numpy(), rtol=1e-4, atol=1e-4)
+    assert (r["min_idx"][0].cpu() == ref["min_idx"]).float().mean() > 0.995
+    assert int(r["s_idx"][0]) == int(ref["s_idx"])
+    np.testing.assert_allclose(float(r["s_star"][0]), float(ref["s_star"]), rtol=1e-5)
+    _, nn_idx = ops.unpack_keys(r["top3"][0])
+    np.testing.assert_array_equal(nn_idx.cpu().numpy(), ref["nn_idx"].numpy())
+    np.testing.assert_allclose(r["knn_d"][0].cpu().numpy(), ref["m_star_knn"].numpy(), rtol=1e-5)
+    np.testing.assert_allclose(float(r["s"][0]), float(ref["s"]), rtol=1e-4)
+    np.testing.assert_allclose(r["s_map_pre"][0].cpu().numpy(), ref["s_map_pre"][0].numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_batch_invariance(weights):
+    """B = 3 (ragged clouds, padded) gives the per-sample B = 1 results."""
+    from cmdiad_amd import runtime
+    sd_vit, sd_pm = weights
+    e = eng.Engine(runtime.PackedViT(sd_vit, device=DEV), runtime.PackedPointMAE(sd_pm, device=DEV))
+    samples = [synth_sample(20 + i) for i in range(3)]
+    rgb = torch.cat([s[0] for s in samples]).to(DEV)
+    pcs = torch.cat([s[1] for s in samples]).to(DEV)
+    ex = e.extract(rgb, pcs)
+    xp = e.xyz_patch(ex)
+    rp = e.rgb_patch(ex)
+    for i in range(3):
+        ex1 = e.extract(rgb[i:i + 1], pcs[i:i + 1])
+        n = int(ex1.n_valid[0])
+        assert int(ex.n_valid[i]) == n
+        assert torch.equal(ex.center_idx[i], ex1.center_idx[0]) and torch.equal(ex.ori_idx[i], ex1.ori_idx[0])
+        assert torch.equal(ex.idx3[i, :n], ex1.idx3[0, :n])
+        torch.testing.assert_close(e.xyz_patch(ex1)[0], xp[i], rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(e.rgb_patch(ex1)[0], rp[i], rtol=1e-5, atol=1e-5)
+
+
+def test_greedy_coreset_matches_fp16_restatement():
+    """cmdiad_coreset_greedy vs a torch-CPU restatement of features.py:372-425 with the fp16 semantics
+    stated in coreset.hip (difference in fp16, fp32 accumulate, fp16 result, first max)."""
+    from cmdiad_amd import coreset
+    g = torch.Generator().manual_seed(7)
+    z = torch.randn(3000, 62, generator=g)
+    sel = coreset.greedy_coreset(z.to(DEV), 200).cpu()
+    zh = z.half()
+    min_d = torch.linalg.norm(z - z[0:1], dim=1).half()
+    ref = [0]
+    last = zh[0:1]
+    for _ in range(199):
+        d = torch.linalg.norm((zh - last).float(), dim=1).half()
+        min_d = torch.minimum(d, min_d)
+        mx = min_d.max()
+        i = int(torch.nonzero(min_d == mx)[0])
+        ref.append(i)
+        last = zh[i:i + 1]
+    np.testing.assert_array_equal(sel.numpy(), np.array(ref))
