@@ -22,7 +22,8 @@ class GemmArgs(Structure):
                 ("M", c_int), ("N", c_int), ("K", c_int),
                 ("bias", c_void_p), ("group_bias", c_void_p), ("group_rows", c_int), ("act", c_int),
                 ("residual", c_void_p), ("ldr", c_int),
-                ("out_f32", c_void_p), ("ldo32", c_int), ("out_bf16", c_void_p), ("ldo16", c_int)]
+                ("out_f32", c_void_p), ("ldo32", c_int), ("out_bf16", c_void_p), ("ldo16", c_int),
+                ("out_pre_bf16", c_void_p), ("dact_of", c_void_p), ("split_k", c_int)]
 
 
 P, I, F, SZ, U32 = c_void_p, c_int, c_float, c_size_t, c_uint32
@@ -37,7 +38,13 @@ SIGNATURES = {
     "cmdiad_gemm_bf16": [POINTER(GemmArgs), P],
     "cmdiad_gemm_qkv": [P, P, P, I, I, I, P, P, P, P],
     "cmdiad_attention": [P, P, P, I, I, I, P, P],
-    "cmdiad_layernorm": [P, P, P, P, F, I, I, P, P, I, P],
+    "cmdiad_layernorm": [P, P, P, P, F, I, I, P, P, I, P, P, P],
+    "cmdiad_loss_head": [P, P, I, I, I, F, P, P, P, P],
+    "cmdiad_reduce_slabs": [P, I, SZ, SZ, F, P, P],
+    "cmdiad_sum_vector": [P, SZ, F, P, P],
+    "cmdiad_colsum_bf16": [P, I, I, I, P, P],
+    "cmdiad_ln_param_grad": [P, P, P, P, I, I, I, P, P, P],
+    "cmdiad_adam_step": [P, P, P, P, SZ, F, F, F, F, I, F, P, P],
     "cmdiad_encoder_stage1": [P, P, P, P, I, I, P, P, P, P],
     "cmdiad_gemm_groupmax": [P, P, P, I, I, I, I, P, P, P],
     "cmdiad_l2_min_keys": [P, P, P, P, I, I, I, U32, P, P],

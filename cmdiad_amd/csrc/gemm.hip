@@ -18,7 +18,16 @@ struct StdParams {
     const float* residual; int ldr;
     float* out_f32; int ldo32;
     bf16_t* out_bf16; int ldo16;
+    bf16_t* out_pre_bf16;         // pre-activation copy (training keeps z for the GELU backward)
+    const bf16_t* dact_of;        // acc *= GELU'(dact_of[m][n]) first (backward through an activation)
+    int split_k;                  // > 1: block y handles K/split_k, writes slab y of out_f32 (no epilogue terms)
 };
+
+__device__ __forceinline__ float gelu_grad_f(float x)
+{
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    return cdf + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+}
 
 __global__ __launch_bounds__(kThreads, 2) void gemm_std_kernel(GlobalTile A, GlobalTile W, StdParams p)
 {
@@ -30,7 +39,13 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_std_kernel(GlobalTile A, Glo
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave >> 1, wc = wave & 1;
 
-    run<true>(A, W, m0, nt, 1, p.K / BK, lds, [&](Acc& acc, int ntile) {
+    const int kt_per = (p.K / BK + p.split_k - 1) / p.split_k;
+    const int kt_begin = blockIdx.y * kt_per;
+    const int kt_count = min(kt_per, p.K / BK - kt_begin);
+    float* out32 = p.out_f32 ? p.out_f32 + (size_t)blockIdx.y * p.M * p.ldo32 : nullptr;
+    if (kt_count <= 0) return;
+
+    run<true>(A, W, m0, nt, 1, kt_count, lds, [&](Acc& acc, int ntile) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int m = m0 + wr * 64 + i * 16 + (lane & 15);
@@ -41,8 +56,17 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_std_kernel(GlobalTile A, Glo
                 const int n = ntile * BN + wc * 64 + j * 16 + (lane >> 4) * 4;
                 if (n >= p.N) continue;
                 f32x4 v = acc[i][j];
+                if (p.dact_of) {
+                    const bf16x4 z = *reinterpret_cast<const bf16x4*>(p.dact_of + (size_t)m * p.N + n);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] *= gelu_grad_f(bf2f(z[r]));
+                }
                 if (p.bias) { const float4 b = *reinterpret_cast<const float4*>(p.bias + n); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
                 if (gb) { const float4 b = *reinterpret_cast<const float4*>(gb + n); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+                if (p.out_pre_bf16) {
+                    bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+                    *reinterpret_cast<bf16x4*>(p.out_pre_bf16 + (size_t)m * p.N + n) = o;
+                }
                 if (p.act == CMDIAD_ACT_GELU) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
@@ -54,14 +78,14 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_std_kernel(GlobalTile A, Glo
                     const float4 b = *reinterpret_cast<const float4*>(p.residual + (size_t)m * p.ldr + n);
                     v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
                 }
-                if (p.out_f32) *reinterpret_cast<f32x4*>(p.out_f32 + (size_t)m * p.ldo32 + n) = v;
+                if (out32) *reinterpret_cast<f32x4*>(out32 + (size_t)m * p.ldo32 + n) = v;
                 if (p.out_bf16) {
                     bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
                     *reinterpret_cast<bf16x4*>(p.out_bf16 + (size_t)m * p.ldo16 + n) = o;
                 }
             }
         }
-    });
+    }, kt_begin);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -255,10 +279,16 @@ extern "C" int cmdiad_gemm_bf16(const cmdiad_gemm_args* a, cmdiad_stream_t strea
                    CMDIAD_ERR_ARG, "cmdiad_gemm_bf16: epilogue operand alignment");
     if (int rc = set_lds_tag<0>((const void*)gemm_std_kernel, kLdsBytes)) return rc;
     GlobalTile A{(const bf16_t*)a->A, a->lda, a->M}, W{(const bf16_t*)a->W, a->ldw, a->N};
+    const int split = a->split_k > 1 ? a->split_k : 1;
+    CMDIAD_REQUIRE(split == 1 || (a->out_f32 && !a->out_bf16 && !a->bias && !a->group_bias && !a->residual &&
+                                  a->act == CMDIAD_ACT_NONE && !a->out_pre_bf16 && !a->dact_of),
+                   CMDIAD_ERR_ARG, "cmdiad_gemm_bf16: split_k > 1 writes raw f32 slabs only");
+    CMDIAD_REQUIRE((!a->out_pre_bf16 || ((uintptr_t)a->out_pre_bf16 & 7) == 0) && (!a->dact_of || ((uintptr_t)a->dact_of & 7) == 0),
+                   CMDIAD_ERR_ARG, "cmdiad_gemm_bf16: out_pre_bf16 / dact_of alignment");
     StdParams p{a->M, a->N, a->K, a->bias, a->group_bias, a->group_rows, a->act, a->residual, a->ldr,
-                a->out_f32, a->ldo32, (bf16_t*)a->out_bf16, a->ldo16};
+                a->out_f32, a->ldo32, (bf16_t*)a->out_bf16, a->ldo16, (bf16_t*)a->out_pre_bf16, (const bf16_t*)a->dact_of, split};
     const int grid = ((a->M + BM - 1) / BM) * ((a->N + BN - 1) / BN);
-    hipLaunchKernelGGL(gemm_std_kernel, dim3(grid), dim3(kThreads), kLdsBytes, (hipStream_t)stream, A, W, p);
+    hipLaunchKernelGGL(gemm_std_kernel, dim3(grid, split), dim3(kThreads), kLdsBytes, (hipStream_t)stream, A, W, p);
     CMDIAD_CHECK_LAUNCH();
     return CMDIAD_OK;
 }

@@ -108,7 +108,7 @@ __device__ __forceinline__ void compute_stage(Acc& acc, const char* ta, const ch
 // epi(acc, nt) is called once per finished N tile.  lds: kLdsBytes, 16-byte aligned.
 template <bool SWAP, class ALoader, class WLoader, class Epi>
 __device__ __forceinline__ void run(const ALoader& A, const WLoader& W, int m0, int nt0, int n_tiles, int KT,
-                                    char* lds, Epi&& epi)
+                                    char* lds, Epi&& epi, int kt_begin = 0)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -118,8 +118,8 @@ __device__ __forceinline__ void run(const ALoader& A, const WLoader& W, int m0, 
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    A.stage(lds, m0, 0, tid);
-    W.stage(lds + BM * BK * 2, nt0 * BN, 0, tid);
+    A.stage(lds, m0, kt_begin * BK, tid);
+    W.stage(lds + BM * BK * 2, nt0 * BN, kt_begin * BK, tid);
     __syncthreads();
 
     const int total = n_tiles * KT;
@@ -130,8 +130,8 @@ __device__ __forceinline__ void run(const ALoader& A, const WLoader& W, int m0, 
         int kt_n = kt + 1, nt_n = nt;
         if (kt_n == KT) { kt_n = 0; nt_n = nt + 1; }
         if (it + 1 < total) {  // every wave finished reading `nxt` before the barrier that ended step it-1
-            A.stage(nxt, m0, kt_n * BK, tid);
-            W.stage(nxt + BM * BK * 2, nt_n * BN, kt_n * BK, tid);
+            A.stage(nxt, m0, (kt_begin + kt_n) * BK, tid);
+            W.stage(nxt + BM * BK * 2, nt_n * BN, (kt_begin + kt_n) * BK, tid);
         }
         compute_stage<SWAP>(acc, cur, cur + BM * BK * 2, wr, wc, lane);
         if (kt == KT - 1) {

@@ -11,7 +11,8 @@ template <int PAIRS>
 __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, const float* __restrict__ add,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         float eps, int M, bf16_t* __restrict__ out_bf16,
-                                                        float* __restrict__ out_f32, int ldo32)
+                                                        float* __restrict__ out_f32, int ldo32,
+                                                        float* __restrict__ mean_out, float* __restrict__ rstd_out)
 {
     constexpr int C = PAIRS * 128;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -42,6 +43,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, c
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) q += __shfl_xor(q, m, 64);
     const float rstd = rsqrtf(q / C + eps);
+    if (mean_out && lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
 #pragma unroll
     for (int e = 0; e < PAIRS; ++e) {
         const int c = 2 * (lane + 64 * e);
@@ -168,9 +170,11 @@ unsigned blocks_for(size_t n) { return (unsigned)((n + 255) / 256); }
 }  // namespace
 
 extern "C" int cmdiad_layernorm(float* x, const float* add, const float* gamma, const float* beta, float eps, int M,
-                                int C, uint16_t* out_bf16, float* out_f32, int ldo32, cmdiad_stream_t stream)
+                                int C, uint16_t* out_bf16, float* out_f32, int ldo32, float* mean_out, float* rstd_out,
+                                cmdiad_stream_t stream)
 {
     CMDIAD_REQUIRE(x && gamma && beta && (out_bf16 || out_f32), CMDIAD_ERR_ARG, "cmdiad_layernorm: null pointer");
+    CMDIAD_REQUIRE((mean_out == nullptr) == (rstd_out == nullptr), CMDIAD_ERR_ARG, "cmdiad_layernorm: mean_out and rstd_out go together");
     CMDIAD_REQUIRE(M >= 0 && C % 128 == 0 && C >= 128 && C <= 1024, CMDIAD_ERR_ARG,
                    "cmdiad_layernorm: need C%%128==0, 128<=C<=1024 (C=%d)", C);
     CMDIAD_REQUIRE((((uintptr_t)x | (uintptr_t)add | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)out_f32) & 7) == 0 &&
@@ -179,7 +183,7 @@ extern "C" int cmdiad_layernorm(float* x, const float* add, const float* gamma, 
     if (M == 0) return CMDIAD_OK;
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((M + 3) / 4), block(256);
-#define LN_CASE(P) case P: hipLaunchKernelGGL(layernorm_kernel<P>, grid, block, 0, s, x, add, gamma, beta, eps, M, (bf16_t*)out_bf16, out_f32, ldo32); break;
+#define LN_CASE(P) case P: hipLaunchKernelGGL(layernorm_kernel<P>, grid, block, 0, s, x, add, gamma, beta, eps, M, (bf16_t*)out_bf16, out_f32, ldo32, mean_out, rstd_out); break;
     switch (C / 128) {
         LN_CASE(1) LN_CASE(2) LN_CASE(3) LN_CASE(4) LN_CASE(5) LN_CASE(6) LN_CASE(7) LN_CASE(8)
     }

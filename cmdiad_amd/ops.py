@@ -109,17 +109,17 @@ def xyz_patch_fused(feat, idx3, w3, pix2pt, size=224, P=56, mean=0.0, inv_std=1.
 
 # ------------------------------------------------------------------------------------ dense blocks
 def gemm(A, W, bias=None, act=ACT_NONE, residual=None, group_bias=None, group_rows=1, out_f32=None, out_bf16=None,
-         want_f32=False, want_bf16=True):
+         want_f32=False, want_bf16=True, out_pre_bf16=None, dact_of=None, split_k=1):
     """epilogue(A[M,K] . W[N,K]^T); A, W bf16.  Returns (out_f32 | None, out_bf16 | None)."""
     _chk(A, torch.bfloat16, "gemm.A"); _chk(W, torch.bfloat16, "gemm.W")
     M, K = A.shape
     N = W.shape[0]
     if out_f32 is None and want_f32:
-        out_f32 = torch.empty((M, N), dtype=torch.float32, device=A.device)
+        out_f32 = torch.empty((split_k, M, N) if split_k > 1 else (M, N), dtype=torch.float32, device=A.device)
     if out_bf16 is None and want_bf16:
         out_bf16 = torch.empty((M, N), dtype=torch.bfloat16, device=A.device)
     a = nat.GemmArgs(_p(A), K, _p(W), K, M, N, K, _p(bias), _p(group_bias), group_rows, act,
-                     _p(residual), N, _p(out_f32), N, _p(out_bf16), N)
+                     _p(residual), N, _p(out_f32), N, _p(out_bf16), N, _p(out_pre_bf16), _p(dact_of), split_k)
     _call("cmdiad_gemm_bf16", ctypes.byref(a), _stream())
     return out_f32, out_bf16
 
@@ -139,15 +139,16 @@ def attention(q, k, vt, B, H, T, out=None):
     return out
 
 
-def layernorm(x, gamma, beta, eps, add=None, out_bf16=None, out_f32=None, want_bf16=True):
+def layernorm(x, gamma, beta, eps, add=None, out_bf16=None, out_f32=None, want_bf16=True, stats=None):
     """x [M,C] f32 (updated in place to x+add when add is given) -> LN(x) as bf16 and/or f32."""
     _chk(x, torch.float32, "ln.x"); _chk(add, torch.float32, "ln.add")
     M, C = x.shape
     if out_bf16 is None and want_bf16:
         out_bf16 = torch.empty((M, C), dtype=torch.bfloat16, device=x.device)
     ld = out_f32.stride(0) if out_f32 is not None else 0
+    mean_o, rstd_o = stats if stats is not None else (None, None)
     _call("cmdiad_layernorm", _p(x), _p(add), _p(gamma), _p(beta), float(eps), M, C, _p(out_bf16), _p(out_f32), ld,
-          _stream())
+          _p(mean_o), _p(rstd_o), _stream())
     return out_bf16
 
 

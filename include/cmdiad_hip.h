@@ -110,6 +110,9 @@ typedef struct {
     const float* residual; int ldr;  /* [M,N] f32 or NULL */
     float* out_f32; int ldo32;
     uint16_t* out_bf16; int ldo16;
+    uint16_t* out_pre_bf16;          /* [M,N] bf16 copy BEFORE the activation (training keeps z), or NULL */
+    const uint16_t* dact_of;         /* [M,N] bf16 z: acc *= GELU'(z) before everything else, or NULL */
+    int split_k;                     /* > 1: K is split; slab s of out_f32 ([split_k][M][ldo32]) gets partial s */
 } cmdiad_gemm_args;
 int cmdiad_gemm_bf16(const cmdiad_gemm_args* args, cmdiad_stream_t stream);
 
@@ -130,7 +133,8 @@ int cmdiad_attention(const uint16_t* q, const uint16_t* k, const uint16_t* vt, i
  * x + add first.  x [M,C] f32, add [M,C] f32 or NULL, C % 64 == 0, C <= 1024.
  * out_bf16 [M, C] (NULL allowed); out_f32 (NULL allowed) with leading dimension ldo32. */
 int cmdiad_layernorm(float* x, const float* add, const float* gamma, const float* beta, float eps, int M,
-                     int C, uint16_t* out_bf16, float* out_f32, int ldo32, cmdiad_stream_t stream);
+                     int C, uint16_t* out_bf16, float* out_f32, int ldo32, float* mean_out, float* rstd_out,
+                     cmdiad_stream_t stream);
 
 /* Point-MAE Encoder (models/models.py:200-215), eval-mode BatchNorm folded into the convolutions:
  *   h1 = relu(W1' x + b1')            3 -> 128   (computed on the fly while staging the GEMM tile)
@@ -224,6 +228,28 @@ int cmdiad_linear3(const float* x, const float* wb, size_t M, int N, int act, ui
 
 /* Bilinear up-sampling h x h -> H x H, align_corners=False (features.py:294). in [B,h,h], out [B,H,H]. */
 int cmdiad_bilinear_up(const float* in, int B, int h, int H, float* out, cmdiad_stream_t stream);
+
+/* ---- training side of the FtoF distillation network (models/hallucination_network.py:47-69,
+ * hallucination_network_pretrain.py:102-159) ---- */
+
+/* Loss head: y = GELU(z3); mode 0 'l2' sum_rows ||y-t||_2, 1 'cos_dist' sum_rows (1 - cos(y,t)), 2 'smooth_l1'
+ * sum of elements (beta 1); row_loss [M] gets the per-row terms (reduce with cmdiad_sum_vector, scale 1/B);
+ * dz3 [M,D] bf16 (NULL allowed) = inv_b * dLoss/dz3 (through the output GELU); y_out [M,D] f32 optional. */
+int cmdiad_loss_head(const float* z3, const float* target, int M, int D, int mode, float inv_b,
+                     float* row_loss, uint16_t* dz3, float* y_out, cmdiad_stream_t stream);
+/* out[i] = scale * sum_s slabs[s*stride + i] in fixed order (split-K partials, column partials). n, stride % 4 == 0 */
+int cmdiad_reduce_slabs(const float* slabs, int S, size_t n, size_t stride, float scale, float* out,
+                        cmdiad_stream_t stream);
+int cmdiad_sum_vector(const float* x, size_t n, float scale, float* out, cmdiad_stream_t stream);
+/* partial[chunk][n] = sum over the chunk's rows of x[r][n]  (bias gradients). */
+int cmdiad_colsum_bf16(const uint16_t* x, int M, int N, int chunks, float* partial, cmdiad_stream_t stream);
+/* LayerNorm weight / bias gradient partials from dh [M,C], the LN input x and its saved row statistics. */
+int cmdiad_ln_param_grad(const float* dh, const float* x, const float* mean, const float* rstd, int M, int C,
+                         int chunks, float* partial_g, float* partial_b, cmdiad_stream_t stream);
+/* torch.optim.Adam update (no weight decay, amsgrad off; hallucination_network_pretrain.py:261) on g*grad_scale;
+ * optionally refreshes the bf16 GEMM operand copy of the parameter. */
+int cmdiad_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
+                     float eps, int step, float grad_scale, uint16_t* p_bf16, cmdiad_stream_t stream);
 
 /* Generic fp32 -> bf16 cast (n % 4 == 0) and bf16 2-D transpose out[c][r] = in[r][c]. */
 int cmdiad_cast_bf16(const float* x, size_t n, uint16_t* out, cmdiad_stream_t stream);

@@ -1,0 +1,107 @@
+"""GPU: training path of the FtoF distillation net (losses, gradients, Adam steps) against the reference's
+golden vectors (G5, produced by the reference's own module + torch.optim.Adam) and a torch fp32 reference."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from cmdiad_amd import train  # noqa: E402
+from cmdiad_amd.models.hallucination_network import HallucinationCrossModalityNetwork  # noqa: E402
+from cmdiad_amd.utils import lr_sched  # noqa: E402
+from oracle import nets  # noqa: E402
+
+DEV = "cuda"
+
+
+def _net():
+    net = HallucinationCrossModalityNetwork(None, 768, 768, hidden_ratio=2.5, mlp_depth=1)
+    net.load_state_dict(nets.synth_state_dict("halluc", 51), strict=True)
+    return net.to(DEV)
+
+
+def _samples(g):
+    s = torch.randn(2, 64, 1536, generator=torch.Generator().manual_seed(int(g["samples_seed"])))
+    return s[:, :, :768].contiguous(), s[:, :, 768:].contiguous()
+
+
+def test_state_dict_keys_match_reference_names():
+    keys = set(HallucinationCrossModalityNetwork(None, 768, 768).state_dict())
+    assert keys == set(nets.synth_state_dict("halluc", 51))
+    assert sum(p.numel() for p in HallucinationCrossModalityNetwork(None, 768, 768).parameters()) == 13283328
+
+
+def test_losses_match_golden(golden):
+    g = golden("g5_halluc.npz")
+    net = _net()
+    xyz, rgb = _samples(g)
+    with torch.no_grad():
+        for dm in ("l2", "cos_dist", "smooth_l1"):
+            a, b = net(xyz, rgb, False, dm)
+            # bf16 GEMM chain: outputs carry ~4e-3 absolute error, summed over 64 x 768 elements per sample
+            np.testing.assert_allclose([a.item(), b.item()], g[f"loss_{dm}"], rtol=1e-2)
+
+
+def test_gradients_match_torch_autograd():
+    sd = nets.synth_state_dict("halluc", 51)
+    s = torch.randn(2, 96, 1536, generator=torch.Generator().manual_seed(3))
+    xyz, rgb = s[:, :, :768].contiguous(), s[:, :, 768:].contiguous()
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    for dm in ("l2", "cos_dist", "smooth_l1"):
+        lx, lr = nets.halluc_losses(params, xyz, rgb, dm)
+        ref = torch.autograd.grad(lx + lr, list(params.values()))
+        net = _net()
+        ax, ar = net(xyz, rgb, False, dm)
+        (ax + ar).backward()
+        got = dict(net.named_parameters())
+        for (name, _), r in zip(params.items(), ref):
+            gq = got[name].grad.cpu()
+            # cosine similarity + norm ratio: gradients flow through three bf16 GEMMs each way
+            cos = torch.nn.functional.cosine_similarity(gq.flatten(), r.flatten(), dim=0).item()
+            ratio = (gq.norm() / r.norm()).item()
+            assert cos > 0.995 and abs(ratio - 1) < 0.02, (dm, name, cos, ratio)
+
+
+@pytest.mark.parametrize("opt_kind", ["torch", "fused"])
+def test_adam_steps_match_golden(golden, opt_kind):
+    """Three update steps exactly as hallucination_network_pretrain.py:102-154 drives them."""
+    import types
+    g = golden("g5_halluc.npz")
+    net = _net()
+    xyz, rgb = _samples(g)
+    opt = torch.optim.Adam(net.parameters(), lr=5e-4) if opt_kind == "torch" else train.FusedAdam(net.parameters(), lr=5e-4)
+    sargs = types.SimpleNamespace(lr=5e-4, warmup_epochs=1, epochs=10)
+    net.train()
+    opt.zero_grad()
+    for it in range(3):
+        lr_sched.adjust_learning_rate(opt, it / 4 + 0, sargs)
+        lx, lr_ = net(xyz, rgb, False, "l2")
+        np.testing.assert_allclose([lx.item(), lr_.item()], g["train_losses"][it], rtol=1e-2)
+        (lx + lr_).backward()
+        opt.step()
+        opt.zero_grad()
+        if it in (0, 2):
+            named = dict(net.named_parameters())
+            for pn in ("xyz_mlp.mlp_module.0.fc1.weight", "rgb_mlp.mlp_module.0.fc3.bias", "xyz_norm.weight"):
+                t = named[pn].detach().cpu()
+                got = (t[:8, :8] if t.dim() == 2 else t[:16]).numpy()
+                ref = g[f"step{it + 1}_{pn}"]
+                # Adam moves every weight by ~lr per step whatever the gradient scale: compare the UPDATE
+                init = nets.synth_state_dict("halluc", 51)[pn]
+                init = (init[:8, :8] if init.dim() == 2 else init[:16]).numpy()
+                du, dr = got - init, ref - init
+                if np.abs(dr).max() > 0:
+                    assert np.abs(du - dr).max() <= 0.35 * np.abs(dr).max() + 1e-7, (pn, it, du, dr)
+                    assert np.sign(du[np.abs(dr) > 0.5 * np.abs(dr).max()]).tolist() == np.sign(dr[np.abs(dr) > 0.5 * np.abs(dr).max()]).tolist()
+
+
+def test_config3_step_shape_runs():
+    """BASELINE configs[2] shape: batch 32 x 3136 tokens, one full step (forward, backward, Adam)."""
+    net = _net()
+    opt = train.FusedAdam(net.parameters(), lr=5e-4)
+    s = torch.randn(32, 3136, 1536, generator=torch.Generator().manual_seed(3407)).to(DEV)
+    lx, lr_ = net(s[:, :, :768], s[:, :, 768:], False, "l2")
+    (lx + lr_).backward()
+    opt.step()
+    torch.cuda.synchronize()
+    assert torch.isfinite(lx).item() and torch.isfinite(lr_).item()
