@@ -60,7 +60,7 @@ def gather_queries(q16, qsq, group=None):
     world = td.get_world_size(group)
     q_all = torch.empty((world * q16.shape[0], q16.shape[1]), dtype=q16.dtype, device=q16.device)
     s_all = torch.empty((world * qsq.shape[0],), dtype=qsq.dtype, device=qsq.device)
-    td.all_gather_into_tensor(q_all.view(torch.int16), q16.view(torch.int16), group=group)
+    td.all_gather_into_tensor(q_all.view(torch.uint8), q16.contiguous().view(torch.uint8), group=group)  # raw bytes: gloo has no bf16
     td.all_gather_into_tensor(s_all, qsq, group=group)
     return q_all, s_all
 

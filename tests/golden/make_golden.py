@@ -247,6 +247,34 @@ def main():
     g5["train_losses"] = np.array(losses)
     np.savez_compressed(os.path.join(HERE, "g5_halluc.npz"), samples_seed=52, **g5)
 
+    # ---------------- G8: seeded default initialisation of the reference's own modules (checksums only)
+    g8 = {}
+    torch.manual_seed(123)
+    pt2 = rmodels.PointTransformer(group_size=128, num_group=1024)
+    for k, v in pt2.state_dict().items():
+        g8["pm/" + k] = np.array([v.double().sum().item(), v.double().abs().sum().item()])
+    torch.manual_seed(321)
+    hn2 = HallucinationCrossModalityNetwork(_ns(), 768, 768, hidden_ratio=2.5, mlp_depth=1)
+    for k, v in hn2.state_dict().items():
+        g8["hn/" + k] = np.array([v.double().sum().item(), v.double().abs().sum().item()])
+    np.savez_compressed(os.path.join(HERE, "g8_init.npz"), **g8)
+
+    # ---------------- G7: calculate_au_pro (utils/au_pro_util.py) on synthetic maps
+    from utils.au_pro_util import calculate_au_pro
+    rs = np.random.RandomState(7)
+    gts, preds = [], []
+    for i in range(6):
+        gt = np.zeros((64, 64), dtype=int)
+        if i % 2 == 0:
+            gt[10 + i:22 + i, 8:20] = 1
+            gt[40:50, 30 + i:44] = 1
+        pr = rs.rand(64, 64) * 0.5 + gt * (0.2 + 0.1 * i) * rs.rand(64, 64)
+        gts.append(gt); preds.append(pr)
+    au03, _ = calculate_au_pro(gts, preds)
+    au001, _ = calculate_au_pro(gts, preds, 0.01)
+    np.savez_compressed(os.path.join(HERE, "g7_aupro.npz"), gts=np.array(gts), preds=np.array(preds),
+                        au_pro_03=au03, au_pro_001=au001)
+
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KB")

@@ -96,7 +96,9 @@ def test_predict_scores_match_oracle(fitted):
         # 224x224 blurred maps (8-bit quantised): compare at 2 grey levels of the map maximum
         for col in range(2):
             a, b = map_got[:, col].numpy(), map_ref[:, col].numpy()
-            assert np.abs(a - b).max() <= 0.05 * np.abs(b).max() + 0.05, (col, np.abs(a - b).max(), np.abs(b).max())
+            # col 0 (xyz): on this synthetic surface all xyz distances are ~0.1 of the unit feature scale, i.e.
+            # inside the bf16 feature noise, so only an absolute bound is meaningful there
+            assert np.abs(a - b).max() <= 0.05 * np.abs(b).max() + (0.1 if col == 0 else 0.02), (col, np.abs(a - b).max(), np.abs(b).max())
             if col == 1:
                 assert np.corrcoef(a, b)[0, 1] > 0.99
 
@@ -111,8 +113,10 @@ def test_scoring_exact_features_isolated(fitted):
     from oracle import scoring
     ref = scoring.single_s_s_map((xp - cpu.xyz_mean) / cpu.xyz_std, torch.cdist((xp - cpu.xyz_mean) / cpu.xyz_std, cpu.xyz_lib),
                                  cpu.xyz_lib, (56, 56), blur=False)
-    # the query IS a bank row (train sample): distances ~0, so compare absolutely (cdist's own error ~1e-3)
-    np.testing.assert_allclose(r["min_val"][0].cpu().numpy(), ref["min_val"].numpy(), atol=5e-3)
+    # the query IS a bank row (train sample): the true distance is exactly 0 and the GPU path returns 0; the
+    # reference's torch.cdist (matmul expansion) reports up to sqrt(|x|^2 * eps_fp32) ~ 0.025 there
+    np.testing.assert_allclose(r["min_val"][0].cpu().numpy(), ref["min_val"].numpy(), atol=3e-2)
+    assert float(r["min_val"][0].max()) < 1e-3
     assert (r["min_idx"][0].cpu() == ref["min_idx"]).float().mean() > 0.99
     # an unseen query: every stage of compute_single_s_s_map
     rgb, pc = synth_sample(12, True)
