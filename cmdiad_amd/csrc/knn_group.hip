@@ -13,6 +13,8 @@
 //     LDS atomic per wave (ballot + popcount), and when a buffer is half full it is pruned by an
 //     in-LDS bitonic sort that also refreshes tau.  Expected appends per centre ~ K ln(N/K), so
 //     steady-state cost is the streaming distance evaluation, not the selection.
+//   * chunks are visited in a coprime-strided order (see the kernel) so the threshold converges fast
+//     even though organised clouds arrive in raster order;
 //   * the final sort leaves the K winners in ascending order; the epilogue gathers p[idx] - c.
 #include "common.h"
 
@@ -69,7 +71,22 @@ __global__ __launch_bounds__(kThreads) void knn_group_kernel(const float* __rest
     if (tid < kCPB) { s_cnt[tid] = 0; s_tau[tid] = kInf; }
     __syncthreads();
 
-    for (int base = 0; base < n; base += kChunk) {
+    // Visit the 512-point chunks in a strided (coprime) order instead of raster order: the cloud comes
+    // from an organised scan, so a raster walk APPROACHES every centre monotonically and almost every
+    // point would beat the running threshold; a scattered walk makes tau representative after a few
+    // chunks (expected appends ~ K ln(chunks)).  The selected set and its order do not depend on it.
+    const int nchunks = (n + kChunk - 1) / kChunk;
+    int cstride = (int)(0.6180339887f * (float)nchunks) | 1;
+    for (;; cstride += 2) {
+        int a = cstride, bb = nchunks;
+        while (bb) { const int t = a % bb; a = bb; bb = t; }
+        if (a == 1) break;
+    }
+    int cidx = 0;
+    for (int step = 0; step < nchunks; ++step) {
+        const int base = cidx * kChunk;
+        cidx += cstride;
+        if (cidx >= nchunks) cidx %= nchunks;
         unsigned long long tau[kCPB];
 #pragma unroll
         for (int c = 0; c < kCPB; ++c) tau[c] = s_tau[c];

@@ -118,21 +118,27 @@ def test_scoring_exact_features_isolated(fitted):
     np.testing.assert_allclose(r["min_val"][0].cpu().numpy(), ref["min_val"].numpy(), atol=3e-2)
     assert float(r["min_val"][0].max()) < 1e-3
     assert (r["min_idx"][0].cpu() == ref["min_idx"]).float().mean() > 0.99
-    # an unseen query: every stage of compute_single_s_s_map
+    # an unseen query: every stage of compute_single_s_s_map.  The reference composes torch.cdist in fp32,
+    # whose matmul expansion has an absolute error floor of ~0.025 on these near-duplicate features, so the
+    # exact reference here is the same composition fed with a float64 distance matrix; the fp32-cdist
+    # composition is checked at that floor.
     rgb, pc = synth_sample(12, True)
     rq, xq = cpu.ex(rgb, pc)
     xq = (xq - cpu.xyz_mean) / cpu.xyz_std
-    ref = scoring.single_s_s_map(xq, torch.cdist(xq, cpu.xyz_lib), cpu.xyz_lib, (56, 56), blur=False)
+    exact = torch.cdist(xq.double(), cpu.xyz_lib.double()).float()
+    ref = scoring.single_s_s_map(xq, exact, cpu.xyz_lib, (56, 56), blur=False)
+    ref32 = scoring.single_s_s_map(xq, torch.cdist(xq, cpu.xyz_lib), cpu.xyz_lib, (56, 56), blur=False)
     r = eng.score_patches(xq.to(DEV).unsqueeze(0).contiguous(), bank, (56, 56))
-    np.testing.assert_allclose(r["min_val"][0].cpu().numpy(), ref["min_val"].numpy(), rtol=1e-4, atol=1e-4)
-    assert (r["min_idx"][0].cpu() == ref["min_idx"]).float().mean() > 0.995
+    np.testing.assert_allclose(r["min_val"][0].cpu().numpy(), ref["min_val"].numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(r["min_val"][0].cpu().numpy(), ref32["min_val"].numpy(), atol=3e-2)
+    assert (r["min_idx"][0].cpu() == ref["min_idx"]).float().mean() > 0.97  # bf16 search on near-duplicate rows
     assert int(r["s_idx"][0]) == int(ref["s_idx"])
     np.testing.assert_allclose(float(r["s_star"][0]), float(ref["s_star"]), rtol=1e-5)
     _, nn_idx = ops.unpack_keys(r["top3"][0])
     np.testing.assert_array_equal(nn_idx.cpu().numpy(), ref["nn_idx"].numpy())
     np.testing.assert_allclose(r["knn_d"][0].cpu().numpy(), ref["m_star_knn"].numpy(), rtol=1e-5)
     np.testing.assert_allclose(float(r["s"][0]), float(ref["s"]), rtol=1e-4)
-    np.testing.assert_allclose(r["s_map_pre"][0].cpu().numpy(), ref["s_map_pre"][0].numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(r["s_map_pre"][0].cpu().numpy(), ref["s_map_pre"][0].numpy(), rtol=1e-4, atol=1e-5)
 
 
 def test_batch_invariance(weights):
