@@ -83,36 +83,110 @@ class Timer:
         return sum(v) / max(len(v), 1)
 
 
-def gpu_step(st, group, timers):
-    """Everything up to the device-resident scores of one batch.  Returns pinned host tensors + an event."""
-    from cmdiad_amd import engine as eng
-    from cmdiad_amd import ops
-    e, s = st["engine"], st["stats"]
-    ex = e.extract(st["rgb"], st["pcs"], n_max=N_POINTS)
-    xyz_q = e.xyz_patch(ex, 56, s["xyz_mean"], 1.0 / s["xyz_std"])        # a9 + a11 fused
-    rgb_q = eng.normalize(e.rgb_patch(ex).contiguous(), s["rgb_mean"], s["rgb_std"])
-    out = {}
-    for name, q, bank, dims in (("xyz", xyz_q, st["bank_xyz"], (56, 56)), ("rgb", rgb_q, st["bank_rgb"], (28, 28))):
-        B, Q, D = q.shape
-        flat = q.reshape(B * Q, D)
-        q16, _, qsq = ops.normalize_cast(flat)
-        q_all, s_all = eng.gather_queries(q16, qsq, group)
-        keys = ops.new_keys(q_all.shape[0], q.device)
-        with timers[name]:
-            ops.l2_min_keys(q_all, s_all, bank.bf16, bank.sqnorm, keys, bank.row_offset)
-        keys = eng.merge_shard_keys(keys, group)
-        if group is not None:
-            keys = keys[bank.rank * B * Q:(bank.rank + 1) * B * Q].contiguous()
-        out[name] = eng.score_patches_from_keys(q, keys, bank, dims)
-    s_dev = torch.stack([out["xyz"]["s"], out["rgb"]["s"]], 1)                    # [B,2]
-    maps_dev = torch.stack([out["xyz"]["s_map_pre"], out["rgb"]["s_map_pre"]], 1)  # [B,2,224,224]
-    host_s = torch.empty(s_dev.shape, dtype=torch.float32, pin_memory=True)
-    host_m = torch.empty(maps_dev.shape, dtype=torch.float32, pin_memory=True)
-    host_s.copy_(s_dev, non_blocking=True)
-    host_m.copy_(maps_dev, non_blocking=True)
-    ev = torch.cuda.Event()
-    ev.record()
-    return host_s, host_m, ev
+class Pipeline:
+    """One step = stage1 (extract + queries; HIP graph) -> search (distance GEMMs, eager and bracketed by HIP
+    events so `roofline` is measured live; the collectives of the sharded mode live here) -> stage2 (re-score,
+    re-weighting, score maps; HIP graph) -> async D2H into a ring of pinned buffers.
+
+    The two graphs remove the Python/ctypes launch path of ~300 small launches per step from the critical
+    path (guide G9: the C ABI never synchronises or allocates, so capture is legal); set CMDIAD_GRAPH=0 to run
+    everything eagerly."""
+
+    def __init__(self, st, group, timers, use_graph=True, ring=3):
+        self.st, self.group, self.timers = st, group, timers
+        self.side = torch.cuda.Stream()
+        self.ring = [(torch.empty((BATCH, 2), dtype=torch.float32, pin_memory=True),
+                      torch.empty((BATCH, 2, 224, 224), dtype=torch.float32, pin_memory=True)) for _ in range(ring)]
+        self.slot = 0
+        self.g1 = self.g2 = None
+        self.use_graph = use_graph
+        self.static = {}
+
+    # ---- stage 1: everything up to the bf16 queries of both modalities
+    def stage1(self):
+        from cmdiad_amd import engine as eng
+        from cmdiad_amd import ops
+        st = self.st
+        e, s = st["engine"], st["stats"]
+        ex = e.extract(st["rgb"], st["pcs"], n_max=N_POINTS, side_stream=self.side)
+        xyz_q = e.xyz_patch(ex, 56, s["xyz_mean"], 1.0 / s["xyz_std"])        # a9 + a11 fused
+        rgb_q = eng.normalize(e.rgb_patch(ex).contiguous(), s["rgb_mean"], s["rgb_std"])
+        out = {}
+        for name, q in (("xyz", xyz_q), ("rgb", rgb_q)):
+            B, Q, D = q.shape
+            q16, _, qsq = ops.normalize_cast(q.reshape(B * Q, D))
+            out[name] = (q, q16, qsq)
+        return out
+
+    # ---- search: eager (HIP events around the distance GEMM; RCCL collectives when sharded)
+    def search(self, qs):
+        from cmdiad_amd import engine as eng
+        from cmdiad_amd import ops
+        keys = {}
+        for name, bank in (("xyz", self.st["bank_xyz"]), ("rgb", self.st["bank_rgb"])):
+            q, q16, qsq = qs[name]
+            B, Q, D = q.shape
+            q_all, s_all = eng.gather_queries(q16, qsq, self.group)
+            k = self.static.get("keys_" + name)
+            if k is None or k.shape[0] != q_all.shape[0]:
+                k = self.static["keys_" + name] = torch.empty((q_all.shape[0],), dtype=torch.int64, device=q.device)
+            k.fill_(-1)
+            with self.timers[name]:
+                ops.l2_min_keys(q_all, s_all, bank.bf16, bank.sqnorm, k, bank.row_offset)
+            k = eng.merge_shard_keys(k, self.group)
+            keys[name] = k[bank.rank * B * Q:(bank.rank + 1) * B * Q] if self.group is not None else k
+        return keys
+
+    # ---- stage 2: exact re-score, re-weighting, bilinear maps
+    def stage2(self, qs, keys):
+        from cmdiad_amd import engine as eng
+        st = self.st
+        rx = eng.score_patches_from_keys(qs["xyz"][0], keys["xyz"].contiguous(), st["bank_xyz"], (56, 56))
+        rr = eng.score_patches_from_keys(qs["rgb"][0], keys["rgb"].contiguous(), st["bank_rgb"], (28, 28))
+        return torch.stack([rx["s"], rr["s"]], 1), torch.stack([rx["s_map_pre"], rr["s_map_pre"]], 1)
+
+    def _capture(self):
+        qs = self.stage1()  # one eager pass first: module loading / attribute setting must not happen in capture
+        self.stage2(qs, self.search(qs))
+        torch.cuda.synchronize()
+        try:
+            self.g1 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g1):
+                self.static["qs"] = self.stage1()
+            self.g1.replay()
+            keys = self.search(self.static["qs"])
+            self.static["k"] = {n: k.contiguous() for n, k in keys.items()}
+            self.g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g2):
+                self.static["out"] = self.stage2(self.static["qs"], self.static["k"])
+            torch.cuda.synchronize()
+        except Exception as exc:  # capture is an optimisation, never a requirement
+            print(f"[bench] HIP graph capture unavailable ({type(exc).__name__}: {exc}); running eagerly", file=sys.stderr)
+            self.g1 = self.g2 = None
+            self.use_graph = False
+            torch.cuda.synchronize()
+
+    def step(self):
+        if self.use_graph and self.g1 is None:
+            self._capture()
+        if self.use_graph:
+            self.g1.replay()
+            keys = self.search(self.static["qs"])
+            for n, k in keys.items():
+                if k.data_ptr() != self.static["k"][n].data_ptr():
+                    self.static["k"][n].copy_(k)
+            self.g2.replay()
+            s_dev, maps_dev = self.static["out"]
+        else:
+            qs = self.stage1()
+            s_dev, maps_dev = self.stage2(qs, self.search(qs))
+        host_s, host_m = self.ring[self.slot]
+        self.slot = (self.slot + 1) % len(self.ring)
+        host_s.copy_(s_dev, non_blocking=True)
+        host_m.copy_(maps_dev, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return host_s, host_m, ev
 
 
 def host_post(host_s, host_m, ev, st, lambdas=(1.0, 1.0, 0.1, 0.1)):
@@ -121,7 +195,8 @@ def host_post(host_s, host_m, ev, st, lambdas=(1.0, 1.0, 0.1, 0.1)):
     ev.synchronize()
     blur = ImageFilter.GaussianBlur(radius=4)
     B = host_s.shape[0]
-    maps = host_m.numpy()
+    maps = host_m.numpy().copy()   # leave the pinned ring slot free for a later step
+    host_s = host_s.clone()
     fused = np.empty((B, 224 * 224, 2), np.float64)
     for b in range(B):
         for c, lam in ((0, lambdas[1]), (1, lambdas[3])):
@@ -187,11 +262,14 @@ def main():
     timers = {"xyz": Timer(), "rgb": Timer()}
     pool = ThreadPoolExecutor(max_workers=8)
     g = group if sharded else None
+    pipe = Pipeline(st, g, timers, use_graph=os.environ.get("CMDIAD_GRAPH", "1") != "0")
 
     def run(n):
         futs = []
         for _ in range(n):
-            host_s, host_m, ev = gpu_step(st, g, timers)
+            if len(futs) >= 2:
+                futs[-2].result()  # at most two steps of host post-processing in flight (pinned ring of 3)
+            host_s, host_m, ev = pipe.step()
             futs.append(pool.submit(host_post, host_s, host_m, ev, st))
         return [f.result() for f in futs]
 
@@ -229,6 +307,7 @@ def main():
                                    "24576-point clouds (1024 groups x 128), batch 32/GPU, bagel-sized banks "
                                    "(xyz 76518x768, rgb 19129x768)",
                        "batch_per_gpu": BATCH, "bank": "row-sharded search + RCCL min-reduce" if sharded else "single",
+                       "hip_graphs": bool(pipe.use_graph),
                        "weights": "seeded random init (no checkpoints offline)"},
             "roofline": {"kernel": "l2_min_kernel (xyz library distance GEMM + running min/argmin)", "bound": "mfma",
                          "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",

@@ -115,6 +115,14 @@ def score_patches_from_keys(patch32, keys, bank, dims, gt_size=224):
                 s_map_pre=s_map, top3=top3, knn_d=knn_d)
 
 
+class _Null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
 class Extraction:
     """Device-resident outputs of one extract() call (everything Features.__call__ returns, plus the
     interpolation indices/weights that replace the reference's 154 MB interpolated tensor)."""
@@ -135,23 +143,38 @@ class Engine:
     def pm(self):
         return self._pm() if callable(self._pm) else self._pm
 
-    def extract(self, rgb, organized_pc=None, xyz=None, nz=None, want_rgb=True, want_xyz=True, n_max=None):
+    def extract(self, rgb, organized_pc=None, xyz=None, nz=None, want_rgb=True, want_xyz=True, n_max=None,
+                side_stream=None):
         """rgb [B,3,S,S] f32 cuda; the cloud either organised ([B,3,S,S], zeros = background) or already
-        unorganised (xyz [B,N,3] + nz [B,N] int32 pixel indices, B == 1 or equal N)."""
+        unorganised (xyz [B,N,3] + nz [B,N] int32 pixel indices, B == 1 or equal N).
+        With `side_stream` the point-cloud branch (unorganise, FPS, kNN-group, Point-MAE, 3-NN) runs on that
+        HIP stream concurrently with the ViT on the current stream: FPS is a latency-bound chain on B
+        workgroups (B of 256 CUs), the ViT GEMMs fill the rest of the chip."""
         ex = Extraction()
         ex.size = self.size
-        ex.rgb_tokens = self.vit.forward_tokens(rgb) if want_rgb else None
         if not want_xyz:
+            ex.rgb_tokens = self.vit.forward_tokens(rgb) if want_rgb else None
             return ex
-        if organized_pc is not None:
-            ex.xyz, ex.nz, ex.pix2pt, ex.n_valid = ops.unorganize(organized_pc.contiguous(), n_max)
-        else:
-            B, N, _ = xyz.shape
-            ex.xyz, ex.nz, ex.n_valid = xyz.contiguous(), nz, None
-            ex.pix2pt = torch.full((B, self.size * self.size), -1, dtype=torch.int32, device=xyz.device)
-            ex.pix2pt.scatter_(1, nz.long(), torch.arange(N, dtype=torch.int32, device=xyz.device).expand(B, N))
-        ex.xyz_feats, ex.center, ex.ori_idx, ex.center_idx = self.pm.forward(ex.xyz, ex.n_valid)
-        ex.idx3, ex.w3 = ops.interp3nn(ex.xyz, ex.center, ex.n_valid)
+        cur = torch.cuda.current_stream()
+        ctx = torch.cuda.stream(side_stream) if side_stream is not None else _Null()
+        if side_stream is not None:
+            side_stream.wait_stream(cur)
+        with ctx:
+            if organized_pc is not None:
+                ex.xyz, ex.nz, ex.pix2pt, ex.n_valid = ops.unorganize(organized_pc.contiguous(), n_max)
+            else:
+                B, N, _ = xyz.shape
+                ex.xyz, ex.nz, ex.n_valid = xyz.contiguous(), nz, None
+                ex.pix2pt = torch.full((B, self.size * self.size), -1, dtype=torch.int32, device=xyz.device)
+                ex.pix2pt.scatter_(1, nz.long(), torch.arange(N, dtype=torch.int32, device=xyz.device).expand(B, N))
+            ex.xyz_feats, ex.center, ex.ori_idx, ex.center_idx = self.pm.forward(ex.xyz, ex.n_valid)
+            ex.idx3, ex.w3 = ops.interp3nn(ex.xyz, ex.center, ex.n_valid)
+        ex.rgb_tokens = self.vit.forward_tokens(rgb) if want_rgb else None
+        if side_stream is not None:
+            cur.wait_stream(side_stream)
+            for t in (ex.xyz, ex.nz, ex.pix2pt, ex.n_valid, ex.xyz_feats, ex.center, ex.ori_idx, ex.center_idx, ex.idx3, ex.w3):
+                if t is not None:
+                    t.record_stream(cur)  # allocated on the side stream, consumed on the current one
         return ex
 
     def xyz_patch(self, ex, P=56, mean=0.0, inv_std=1.0, want_bf16=False):
