@@ -47,14 +47,14 @@ SIGNATURES = {
     "cmdiad_adam_step": [P, P, P, P, SZ, F, F, F, F, I, F, P, P],
     "cmdiad_encoder_stage1": [P, P, P, P, I, I, P, P, P, P],
     "cmdiad_gemm_groupmax": [P, P, P, I, I, I, I, P, P, P],
-    "cmdiad_l2_min_keys": [P, P, P, P, I, I, I, U32, P, P],
+    "cmdiad_l2_min_keys": [P, P, P, P, I, I, I, U32, P, I, P],
     "cmdiad_l2_rescore": [P, P, P, I, I, I, U32, P, P, P],
     "cmdiad_reweight_scan": [P, P, I, I, I, U32, P, P, SZ, P],
     "cmdiad_score_head": [P, P, P, P, I, I, I, I, U32, P, P, P, P, P],
     "cmdiad_score_tail": [P, P, P, P, I, I, I, U32, P, P],
     "cmdiad_score_final": [P, P, I, I, P, P],
     "cmdiad_coreset_greedy": [P, I, I, I, I, P, P, SZ, P],
-    "cmdiad_normalize_cast": [P, SZ, I, F, F, P, P, P, P],
+    "cmdiad_normalize_cast": [P, SZ, I, F, F, P, P, P, I, P],
     "cmdiad_im2col_patch8": [P, I, I, P, P],
     "cmdiad_vit_assemble": [P, P, P, I, I, I, P, P],
     "cmdiad_bilinear_up": [P, I, I, I, P, P],

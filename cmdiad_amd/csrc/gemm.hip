@@ -1,5 +1,7 @@
 // GEMM entry points built on gemm_core.h: generic Linear with fused epilogue, QKV with head-split
 // stores, and the Point-MAE encoder stages (on-the-fly first conv, per-group max pooling).
+#include <stdlib.h>
+
 #include "gemm_core.h"
 
 namespace {
@@ -29,13 +31,14 @@ __device__ __forceinline__ float gelu_grad_f(float x)
     return cdf + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
 }
 
-__global__ __launch_bounds__(kThreads, 2) void gemm_std_kernel(GlobalTile A, GlobalTile W, StdParams p)
+template <class S>
+__global__ __launch_bounds__(S::THREADS, S::WAVES_PER_SIMD) void gemm_std_kernel(GlobalTile A, GlobalTile W, StdParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int ntn = (p.N + BN - 1) / BN;
     const int wg = xcd_remap(blockIdx.x, gridDim.x);
     const int mt = wg / ntn, nt = wg % ntn;
-    const int m0 = mt * BM;
+    const int m0 = mt * S::BM;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave >> 1, wc = wave & 1;
 
@@ -45,7 +48,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_std_kernel(GlobalTile A, Glo
     float* out32 = p.out_f32 ? p.out_f32 + (size_t)blockIdx.y * p.M * p.ldo32 : nullptr;
     if (kt_count <= 0) return;
 
-    run<true>(A, W, m0, nt, 1, kt_count, lds, [&](Acc& acc, int ntile) {
+    run<S, true>(A, W, m0, nt, 1, kt_count, lds, [&](Acc& acc, int ntile) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int m = m0 + wr * 64 + i * 16 + (lane & 15);
@@ -99,13 +102,14 @@ struct QkvParams {
     bf16_t *q, *k, *vt;
 };
 
-__global__ __launch_bounds__(kThreads, 2) void gemm_qkv_kernel(GlobalTile A, GlobalTile W, QkvParams p)
+template <class S>
+__global__ __launch_bounds__(S::THREADS, S::WAVES_PER_SIMD) void gemm_qkv_kernel(GlobalTile A, GlobalTile W, QkvParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int ntn = (3 * p.C) / BN;
     const int wg = xcd_remap(blockIdx.x, gridDim.x);
     const int mt = wg / ntn, nt = wg % ntn;
-    const int m0 = mt * BM;
+    const int m0 = mt * S::BM;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int which = (nt * BN) / p.C;  // 0 q, 1 k, 2 v : block-uniform because C % 128 == 0
@@ -113,7 +117,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_qkv_kernel(GlobalTile A, Glo
     if (which < 2) {
         bf16_t* dst = which == 0 ? p.q : p.k;
         const float scale = which == 0 ? 0.125f : 1.0f;  // head_dim^-0.5, exact in bf16
-        run<true>(A, W, m0, nt, 1, p.C / BK, lds, [&](Acc& acc, int ntile) {
+        run<S, true>(A, W, m0, nt, 1, p.C / BK, lds, [&](Acc& acc, int ntile) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int m = m0 + wr * 64 + i * 16 + (lane & 15);
@@ -132,7 +136,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_qkv_kernel(GlobalTile A, Glo
             }
         });
     } else {
-        run<false>(A, W, m0, nt, 1, p.C / BK, lds, [&](Acc& acc, int ntile) {
+        run<S, false>(A, W, m0, nt, 1, p.C / BK, lds, [&](Acc& acc, int ntile) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int n = ntile * BN + wc * 64 + j * 16 + (lane & 15);
@@ -166,18 +170,18 @@ struct GroupMaxParams {
     bf16_t* max_bf16;
 };
 
-template <class ALoader>
+template <class S, class ALoader>
 __device__ __forceinline__ void groupmax_body(const ALoader& A, const GlobalTile& W, const GroupMaxParams& p, char* lds,
                                               float (*s_max)[BN])
 {
     const int ntn = (p.N + BN - 1) / BN;
     const int wg = xcd_remap(blockIdx.x, gridDim.x);
     const int mt = wg / ntn, nt = wg % ntn;
-    const int m0 = mt * BM;
+    const int m0 = mt * S::BM;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
 
-    run<true>(A, W, m0, nt, 1, p.K / BK, lds, [&](Acc& acc, int ntile) {
+    run<S, true>(A, W, m0, nt, 1, p.K / BK, lds, [&](Acc& acc, int ntile) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int nl = wc * 64 + j * 16 + (lane >> 4) * 4;  // column within the tile
@@ -217,7 +221,7 @@ __device__ __forceinline__ void groupmax_body(const ALoader& A, const GlobalTile
         if (tid < BN) {
             const int n = ntile * BN + tid;
             const int per = p.Mg / 32;  // 32-row blocks per group: 1, 2 or 4
-            for (int g = 0; g < 4 / per; ++g) {
+            for (int g = 0; g < (S::BM / 32) / per; ++g) {
                 float v = s_max[g * per][tid];
                 for (int q = 1; q < per; ++q) v = fmaxf(v, s_max[g * per + q][tid]);
                 const int grp = (m0 + g * p.Mg) / p.Mg;
@@ -230,21 +234,23 @@ __device__ __forceinline__ void groupmax_body(const ALoader& A, const GlobalTile
     });
 }
 
-__global__ __launch_bounds__(kThreads, 2) void gemm_groupmax_kernel(GlobalTile A, GlobalTile W, GroupMaxParams p)
+template <class S>
+__global__ __launch_bounds__(S::THREADS, S::WAVES_PER_SIMD) void gemm_groupmax_kernel(GlobalTile A, GlobalTile W, GroupMaxParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    float(*s_max)[BN] = reinterpret_cast<float(*)[BN]>(lds + kLdsBytes);
-    groupmax_body(A, W, p, lds, s_max);
+    float(*s_max)[BN] = reinterpret_cast<float(*)[BN]>(lds + S::LDS_BYTES);
+    groupmax_body<S>(A, W, p, lds, s_max);
 }
 
-__global__ __launch_bounds__(kThreads, 2) void encoder_stage1_kernel(Conv1Tile A, GlobalTile W, GroupMaxParams p)
+template <class S>
+__global__ __launch_bounds__(S::THREADS, S::WAVES_PER_SIMD) void encoder_stage1_kernel(Conv1Tile A, GlobalTile W, GroupMaxParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    float(*s_max)[BN] = reinterpret_cast<float(*)[BN]>(lds + kLdsBytes);
-    groupmax_body(A, W, p, lds, s_max);
+    float(*s_max)[BN] = reinterpret_cast<float(*)[BN]>(lds + S::LDS_BYTES);
+    groupmax_body<S>(A, W, p, lds, s_max);
 }
 
-constexpr int kGroupMaxLds = kLdsBytes + 4 * BN * (int)sizeof(float);
+template <class S> constexpr int group_max_lds() { return S::LDS_BYTES + (S::BM / 32) * BN * (int)sizeof(float); }
 
 template <int TAG>
 int set_lds_tag(const void* kernel, int bytes)
@@ -262,6 +268,15 @@ int set_lds_tag(const void* kernel, int bytes)
 
 bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
+// 256-row tiles (1 block of 8 waves per CU, 3-stage prefetch) once there are enough of them to fill the chip
+bool use_big_tile(int M, int other_tiles)
+{
+    static const int force = getenv("CMDIAD_GEMM_TILE") ? atoi(getenv("CMDIAD_GEMM_TILE")) : 0;
+    if (force == 128) return false;
+    if (force == 256) return true;
+    return (long)((M + 255) / 256) * other_tiles >= 224;
+}
+
 }  // namespace
 
 extern "C" int cmdiad_gemm_bf16(const cmdiad_gemm_args* a, cmdiad_stream_t stream)
@@ -277,7 +292,7 @@ extern "C" int cmdiad_gemm_bf16(const cmdiad_gemm_args* a, cmdiad_stream_t strea
                        (!a->residual || (a->ldr % 4 == 0 && aligned16(a->residual))) &&
                        (!a->bias || aligned16(a->bias)) && (!a->group_bias || (aligned16(a->group_bias) && a->group_rows > 0)),
                    CMDIAD_ERR_ARG, "cmdiad_gemm_bf16: epilogue operand alignment");
-    if (int rc = set_lds_tag<0>((const void*)gemm_std_kernel, kLdsBytes)) return rc;
+
     GlobalTile A{(const bf16_t*)a->A, a->lda, a->M}, W{(const bf16_t*)a->W, a->ldw, a->N};
     const int split = a->split_k > 1 ? a->split_k : 1;
     CMDIAD_REQUIRE(split == 1 || (a->out_f32 && !a->out_bf16 && !a->bias && !a->group_bias && !a->residual &&
@@ -287,8 +302,16 @@ extern "C" int cmdiad_gemm_bf16(const cmdiad_gemm_args* a, cmdiad_stream_t strea
                    CMDIAD_ERR_ARG, "cmdiad_gemm_bf16: out_pre_bf16 / dact_of alignment");
     StdParams p{a->M, a->N, a->K, a->bias, a->group_bias, a->group_rows, a->act, a->residual, a->ldr,
                 a->out_f32, a->ldo32, (bf16_t*)a->out_bf16, a->ldo16, (bf16_t*)a->out_pre_bf16, (const bf16_t*)a->dact_of, split};
-    const int grid = ((a->M + BM - 1) / BM) * ((a->N + BN - 1) / BN);
-    hipLaunchKernelGGL(gemm_std_kernel, dim3(grid, split), dim3(kThreads), kLdsBytes, (hipStream_t)stream, A, W, p);
+    const int ntn = (a->N + BN - 1) / BN;
+    if (use_big_tile(a->M, ntn * split)) {
+        if (int rc = set_lds_tag<10>((const void*)gemm_std_kernel<S256>, S256::LDS_BYTES)) return rc;
+        hipLaunchKernelGGL(gemm_std_kernel<S256>, dim3(((a->M + 255) / 256) * ntn, split), dim3(S256::THREADS), S256::LDS_BYTES,
+                           (hipStream_t)stream, A, W, p);
+    } else {
+        if (int rc = set_lds_tag<0>((const void*)gemm_std_kernel<S128>, S128::LDS_BYTES)) return rc;
+        hipLaunchKernelGGL(gemm_std_kernel<S128>, dim3(((a->M + 127) / 128) * ntn, split), dim3(S128::THREADS), S128::LDS_BYTES,
+                           (hipStream_t)stream, A, W, p);
+    }
     CMDIAD_CHECK_LAUNCH();
     return CMDIAD_OK;
 }
@@ -300,12 +323,19 @@ extern "C" int cmdiad_gemm_qkv(const uint16_t* A, const uint16_t* W, const float
     CMDIAD_REQUIRE(B > 0 && T > 0 && C > 0 && C % 128 == 0, CMDIAD_ERR_ARG, "cmdiad_gemm_qkv: need C%%128==0 (C=%d)", C);
     CMDIAD_REQUIRE(aligned16(A) && aligned16(W) && aligned16(q_out) && aligned16(k_out) && (!bias || aligned16(bias)),
                    CMDIAD_ERR_ARG, "cmdiad_gemm_qkv: 16-byte alignment");
-    if (int rc = set_lds_tag<1>((const void*)gemm_qkv_kernel, kLdsBytes)) return rc;
+
     const int M = B * T;
     GlobalTile At{(const bf16_t*)A, C, M}, Wt{(const bf16_t*)W, C, 3 * C};
     QkvParams p{M, T, (T + 63) / 64 * 64, C, C / 64, bias, (bf16_t*)q_out, (bf16_t*)k_out, (bf16_t*)vt_out};
-    const int grid = ((M + BM - 1) / BM) * (3 * C / BN);
-    hipLaunchKernelGGL(gemm_qkv_kernel, dim3(grid), dim3(kThreads), kLdsBytes, (hipStream_t)stream, At, Wt, p);
+    if (use_big_tile(M, 3 * C / BN)) {
+        if (int rc = set_lds_tag<11>((const void*)gemm_qkv_kernel<S256>, S256::LDS_BYTES)) return rc;
+        hipLaunchKernelGGL(gemm_qkv_kernel<S256>, dim3(((M + 255) / 256) * (3 * C / BN)), dim3(S256::THREADS), S256::LDS_BYTES,
+                           (hipStream_t)stream, At, Wt, p);
+    } else {
+        if (int rc = set_lds_tag<1>((const void*)gemm_qkv_kernel<S128>, S128::LDS_BYTES)) return rc;
+        hipLaunchKernelGGL(gemm_qkv_kernel<S128>, dim3(((M + 127) / 128) * (3 * C / BN)), dim3(S128::THREADS), S128::LDS_BYTES,
+                           (hipStream_t)stream, At, Wt, p);
+    }
     CMDIAD_CHECK_LAUNCH();
     return CMDIAD_OK;
 }
@@ -318,12 +348,20 @@ extern "C" int cmdiad_gemm_groupmax(const uint16_t* A, const uint16_t* W, const 
                    "cmdiad_gemm_groupmax: Mg in {32,64,128}, N%%4==0, K%%64==0 (Mg=%d N=%d K=%d)", Mg, N, K);
     CMDIAD_REQUIRE(aligned16(A) && aligned16(W) && (!bias || aligned16(bias)), CMDIAD_ERR_ARG,
                    "cmdiad_gemm_groupmax: 16-byte alignment");
-    if (int rc = set_lds_tag<2>((const void*)gemm_groupmax_kernel, kGroupMaxLds)) return rc;
+
     const int M = groups * Mg;
     GlobalTile At{(const bf16_t*)A, K, M}, Wt{(const bf16_t*)W, K, N};
     GroupMaxParams p{M, N, K, Mg, bias, nullptr, 0, out_f32, (bf16_t*)out_bf16};
-    const int grid = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-    hipLaunchKernelGGL(gemm_groupmax_kernel, dim3(grid), dim3(kThreads), kGroupMaxLds, (hipStream_t)stream, At, Wt, p);
+    const int ntn = (N + BN - 1) / BN;
+    if (use_big_tile(M, ntn)) {
+        if (int rc = set_lds_tag<12>((const void*)gemm_groupmax_kernel<S256>, group_max_lds<S256>())) return rc;
+        hipLaunchKernelGGL(gemm_groupmax_kernel<S256>, dim3(((M + 255) / 256) * ntn), dim3(S256::THREADS), group_max_lds<S256>(),
+                           (hipStream_t)stream, At, Wt, p);
+    } else {
+        if (int rc = set_lds_tag<2>((const void*)gemm_groupmax_kernel<S128>, group_max_lds<S128>())) return rc;
+        hipLaunchKernelGGL(gemm_groupmax_kernel<S128>, dim3(((M + 127) / 128) * ntn), dim3(S128::THREADS), group_max_lds<S128>(),
+                           (hipStream_t)stream, At, Wt, p);
+    }
     CMDIAD_CHECK_LAUNCH();
     return CMDIAD_OK;
 }
@@ -337,13 +375,20 @@ extern "C" int cmdiad_encoder_stage1(const float* neigh, const float* w1, const 
                    "cmdiad_encoder_stage1: Mg in {32,64,128} (Mg=%d)", Mg);
     CMDIAD_REQUIRE(aligned16(w1) && aligned16(W2) && (!b2 || aligned16(b2)) && ((uintptr_t)h2_out & 7) == 0,
                    CMDIAD_ERR_ARG, "cmdiad_encoder_stage1: alignment");
-    if (int rc = set_lds_tag<3>((const void*)encoder_stage1_kernel, kGroupMaxLds)) return rc;
+
     const int M = groups * Mg;
     Conv1Tile At{neigh, (const float4*)w1, M};
     GlobalTile Wt{(const bf16_t*)W2, 128, 256};
     GroupMaxParams p{M, 256, 128, Mg, b2, (bf16_t*)h2_out, 256, gmax_out, (bf16_t*)gmax_bf16_out};
-    const int grid = ((M + BM - 1) / BM) * (256 / BN);
-    hipLaunchKernelGGL(encoder_stage1_kernel, dim3(grid), dim3(kThreads), kGroupMaxLds, (hipStream_t)stream, At, Wt, p);
+    if (use_big_tile(M, 256 / BN)) {
+        if (int rc = set_lds_tag<13>((const void*)encoder_stage1_kernel<S256>, group_max_lds<S256>())) return rc;
+        hipLaunchKernelGGL(encoder_stage1_kernel<S256>, dim3(((M + 255) / 256) * (256 / BN)), dim3(S256::THREADS),
+                           group_max_lds<S256>(), (hipStream_t)stream, At, Wt, p);
+    } else {
+        if (int rc = set_lds_tag<3>((const void*)encoder_stage1_kernel<S128>, group_max_lds<S128>())) return rc;
+        hipLaunchKernelGGL(encoder_stage1_kernel<S128>, dim3(((M + 127) / 128) * (256 / BN)), dim3(S128::THREADS),
+                           group_max_lds<S128>(), (hipStream_t)stream, At, Wt, p);
+    }
     CMDIAD_CHECK_LAUNCH();
     return CMDIAD_OK;
 }

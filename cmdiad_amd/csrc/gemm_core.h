@@ -1,74 +1,92 @@
 // bf16 MFMA GEMM core for gfx950: C[M,N] = A[M,K] . W[N,K]^T ("NT": both operands K-contiguous,
 // the layout of nn.Linear weights, of token matrices and of the query / bank matrices).
 //
-// Tile 128 x 128 x 64, 256 threads = 4 waves in a 2 x 2 grid, each wave owns a 64 x 64 output as
-// 4 x 4 tiles of v_mfma_f32_16x16x32_bf16 (16 f32x4 accumulators = 64 VGPRs).
-// LDS: two 32 KiB stages, each = A tile + W tile, [128 rows][64 bf16] with 128-byte rows whose 16-byte
-// chunks are XOR-swizzled by (row & 7): the ds_read_b128 fragment reads (16 rows x 4 k-chunks per
-// 16-lane service group) then touch 16 distinct 16-byte slots of the 256-byte bank row -> conflict-free.
-// Staging is LDS-DMA (global_load_lds_dwordx4): the loads of step t+1 are issued before the MFMAs of
-// step t straight into the other LDS stage; ONE barrier per K-step.
-// The (n-tile, k-tile) iteration space is flattened so a block that owns several N tiles (the
-// distance GEMM's running-min loop) keeps the pipeline full across tile boundaries.
+// Shape<BM, STAGES>: block tile BM x 128 x 64 with BM/32 waves (4 waves at BM=128, 8 at BM=256) in a
+// (BM/64) x 2 grid; every wave owns a 64 x 64 output as 4 x 4 tiles of v_mfma_f32_16x16x32_bf16
+// (16 f32x4 accumulators = 64 VGPRs).
+//   Shape<128,2>:  64 KiB LDS, 2 blocks/CU  -- small grids (keeps all 256 CUs busy on few tiles)
+//   Shape<256,3>: 144 KiB LDS, 1 block/CU, 8 waves -- large grids: the A panel is reused over twice the
+//                 rows and the LDS-DMA prefetch runs TWO K-steps ahead.
+// LDS stage = A tile + W tile, [rows][64 bf16] with 128-byte rows whose 16-byte chunks are XOR-swizzled by
+// (row & 7): the ds_read_b128 fragment reads (16 rows x 4 k-chunks per 16-lane service group) touch 16
+// distinct 16-byte slots of the 256-byte bank row -> conflict-free.
+// Staging is LDS-DMA (global_load_lds_dwordx4, no staging VGPRs): step t issues the loads of step
+// t+STAGES-1, computes on stage t, then waits with a COUNTED s_waitcnt vmcnt -- only the loads of step
+// t+1 must have landed, the younger ones stay in flight across the raw s_barrier (guide T3/T4;
+// __syncthreads() would drain them with vmcnt(0)).  ONE barrier per K-step.
+// The (n-tile, k-tile) iteration space is flattened so a block that owns several N tiles (the distance
+// GEMM's running-min loop) keeps the pipeline full across tile boundaries.
 //
-// Orientation: with SWAP = true the weight fragment is fed as the MFMA "A" operand, so the
-// accumulator tile is C^T: every lane then holds 4 CONSECUTIVE n for one m, which makes the
-// row-major epilogue stores 16-byte (f32) / 8-byte (bf16) vectors and lets a per-query running
-// min live in one lane.  SWAP = false gives 4 consecutive m per lane (used for transposed stores).
+// Orientation: with SWAP = true the weight fragment is fed as the MFMA "A" operand, so the accumulator
+// tile is C^T: every lane then holds 4 CONSECUTIVE n for one m, which makes the row-major epilogue
+// stores 16-byte (f32) / 8-byte (bf16) vectors and lets a per-query running min live in one lane.
+// SWAP = false gives 4 consecutive m per lane (used for transposed stores).
 #pragma once
 #include "common.h"
 
 namespace gemm {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int kThreads = 256;
-constexpr int kStageBytes = (BM + BN) * BK * 2;  // 32 KiB
-constexpr int kLdsBytes = 2 * kStageBytes;       // 64 KiB -> 2 blocks / CU
+constexpr int BN = 128, BK = 64;
+
+template <int BM_, int STAGES_>
+struct Shape {
+    static_assert(STAGES_ == 2 || STAGES_ == 3, "2 or 3 LDS stages");
+    static constexpr int BM = BM_, STAGES = STAGES_;
+    static constexpr int WAVES = BM_ / 32, THREADS = WAVES * 64;
+    static constexpr int STAGE_BYTES = (BM_ + BN) * BK * 2;
+    static constexpr int LDS_BYTES = STAGES_ * STAGE_BYTES;
+    static constexpr int GL = BM_ / WAVES / 8 + BN / WAVES / 8;  // LDS-DMA instructions per wave per K-step
+    static constexpr int WAVES_PER_SIMD = (160 * 1024 / LDS_BYTES >= 2 ? 2 : 1) * WAVES / 4;
+};
+typedef Shape<128, 2> S128;
+typedef Shape<256, 3> S256;
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * (BK * 2) + ((chunk ^ (row & 7)) << 4); }
 
-// Operand tile stagers.  stage(tile, row0, k0, tid) fills one [128][64] bf16 LDS tile.
+// Operand tile stagers.  stage<ROWS, WAVES>(tile, row0, k0, tid) fills one [ROWS][64] bf16 LDS tile.
 //
-// GlobalTile uses LDS-DMA (global_load_lds_dwordx4, guide §5): no staging VGPRs, no ds_write.  One
-// wave-instruction writes 1 KiB = 8 rows x 128 B at (wave-uniform base) + lane*16, i.e. lane l lands on
-// row l>>3, PHYSICAL chunk l&7; the XOR swizzle therefore goes on the per-lane SOURCE address
-// (logical chunk = (l&7) ^ (row&7), guide rule 21) and the same XOR is applied by the fragment reads.
-// Each of the 4 waves issues 4 such instructions per operand tile.  Completion is tracked by vmcnt;
-// the __syncthreads() that ends a K-step drains it (2-phase schedule of guide T3/T4 "minimum").
+// GlobalTile uses LDS-DMA: one wave-instruction writes 1 KiB = 8 rows x 128 B at (wave-uniform base) +
+// lane*16, i.e. lane l lands on row l>>3, PHYSICAL chunk l&7; the XOR swizzle therefore goes on the
+// per-lane SOURCE address (logical chunk = (l&7) ^ (row&7), guide rule 21) and the same XOR is applied
+// by the fragment reads.
 struct GlobalTile {
     const bf16_t* base;
     int ld;    // elements
     int rows;  // rows beyond are clamped (their results are masked by the epilogue)
+    template <int ROWS, int WAVES>
     __device__ __forceinline__ void stage(char* tile, int row0, int k0, int tid) const
     {
         const int lane = tid & 63, wave = tid >> 6;
+        constexpr int PER_WAVE = ROWS / WAVES;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int r = wave * 32 + j * 8 + (lane >> 3);           // row within the tile
+        for (int j = 0; j < PER_WAVE / 8; ++j) {
+            const int r = wave * PER_WAVE + j * 8 + (lane >> 3);      // row within the tile
             const int row = min(row0 + r, rows - 1);
             const int chunk = (lane & 7) ^ (r & 7);                   // logical chunk stored at physical l&7
             const bf16_t* src = base + (size_t)row * ld + k0 + chunk * 8;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(tile + (wave * 32 + j * 8) * (BK * 2)),
+                                             (__attribute__((address_space(3))) void*)(tile + (wave * PER_WAVE + j * 8) * (BK * 2)),
                                              16, 0, 0);
         }
     }
 };
 
 // Point-MAE first conv (3 -> 128, BN folded, ReLU) evaluated while staging: models/models.py:188-190.
-// Computed values go through registers and ds_write_b128 (thread t: rows (t>>3) + 32 i, chunk t&7).
+// Computed values go through registers and ds_write_b128 (thread t: rows (t>>3) + (THREADS/8) i, chunk t&7).
 struct Conv1Tile {
     const float* neigh;  // [rows,3]
     const float4* wb;    // [128] = {w_x, w_y, w_z, b} with BatchNorm folded in
     int rows;
+    template <int ROWS, int WAVES>
     __device__ __forceinline__ void stage(char* tile, int row0, int k0, int tid) const
     {
+        constexpr int STEP = WAVES * 8;  // rows covered per pass
         float4 w[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) w[e] = wb[k0 + (tid & 7) * 8 + e];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = (tid >> 3) + 32 * i;
+        for (int i = 0; i < ROWS / STEP; ++i) {
+            const int r = (tid >> 3) + STEP * i;
             const int row = min(row0 + r, rows - 1);
             const float x = neigh[(size_t)row * 3], y = neigh[(size_t)row * 3 + 1], z = neigh[(size_t)row * 3 + 2];
             bf16x8 h;
@@ -81,9 +99,34 @@ struct Conv1Tile {
 
 typedef f32x4 Acc[4][4];
 
-template <bool SWAP>
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+
+// F16 = true: the staged 16-bit operands are IEEE half (same MFMA rate, 3 more mantissa bits: used by the
+// distance GEMM, whose operands are normalised features); false: bfloat16 (networks).
+template <bool SWAP, bool F16 = false>
 __device__ __forceinline__ void compute_stage(Acc& acc, const char* ta, const char* tw, int wr, int wc, int lane)
 {
+    if constexpr (F16) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            f16x8 af[4], wf[4];
+            const int chunk = kk * 4 + (lane >> 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                af[i] = *reinterpret_cast<const f16x8*>(ta + lds_off(wr * 64 + i * 16 + (lane & 15), chunk));
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                wf[j] = *reinterpret_cast<const f16x8*>(tw + lds_off(wc * 64 + j * 16 + (lane & 15), chunk));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = SWAP ? mfma16(wf[j], af[i], acc[i][j]) : mfma16(af[i], wf[j], acc[i][j]);
+        }
+        return;
+    }
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
         bf16x8 af[4], wf[4];
@@ -104,12 +147,28 @@ __device__ __forceinline__ void compute_stage(Acc& acc, const char* ta, const ch
     }
 }
 
-// Runs n_tiles consecutive 128-wide N tiles (starting at tile index nt0) against the block's M tile.
-// epi(acc, nt) is called once per finished N tile.  lds: kLdsBytes, 16-byte aligned.
-template <bool SWAP, class ALoader, class WLoader, class Epi>
+template <int N>
+__device__ __forceinline__ void wait_vmcnt()
+{
+    static_assert(N == 0 || N == 6 || N == 8, "add the immediate");
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+}
+
+__device__ __forceinline__ void block_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's ds_writes (Conv1Tile) are in LDS
+    __builtin_amdgcn_s_barrier();
+}
+
+// Runs n_tiles consecutive 128-wide N tiles (starting at tile index nt0) against the block's M tile, over
+// K-steps [kt_begin, kt_begin + KT).  epi(acc, nt) is called once per finished N tile.
+template <class S, bool SWAP, bool F16 = false, class ALoader, class WLoader, class Epi>
 __device__ __forceinline__ void run(const ALoader& A, const WLoader& W, int m0, int nt0, int n_tiles, int KT,
                                     char* lds, Epi&& epi, int kt_begin = 0)
 {
+    constexpr int BM = S::BM, ST = S::STAGES, AHEAD = ST - 1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     Acc acc;
@@ -118,22 +177,27 @@ __device__ __forceinline__ void run(const ALoader& A, const WLoader& W, int m0, 
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    A.stage(lds, m0, kt_begin * BK, tid);
-    W.stage(lds + BM * BK * 2, nt0 * BN, kt_begin * BK, tid);
-    __syncthreads();
-
     const int total = n_tiles * KT;
-    int kt = 0, nt = nt0;
+    int kt_s = 0, nt_s = nt0;  // coordinates of the next K-step to STAGE
+    auto stage_next = [&](int slot) {
+        char* buf = lds + slot * S::STAGE_BYTES;
+        A.template stage<BM, S::WAVES>(buf, m0, (kt_begin + kt_s) * BK, tid);
+        W.template stage<BN, S::WAVES>(buf + BM * BK * 2, nt_s * BN, (kt_begin + kt_s) * BK, tid);
+        if (++kt_s == KT) { kt_s = 0; ++nt_s; }
+    };
+    stage_next(0);
+    if (AHEAD == 2 && total >= 2) {
+        stage_next(1);
+        wait_vmcnt<S::GL>();  // step 0 landed, step 1 may still be in flight
+    } else wait_vmcnt<0>();
+    block_barrier();
+
+    int kt = 0, nt = nt0, slot = 0, slot_s = AHEAD % ST;
     for (int it = 0; it < total; ++it) {
-        char* cur = lds + (it & 1) * kStageBytes;
-        char* nxt = lds + ((it + 1) & 1) * kStageBytes;
-        int kt_n = kt + 1, nt_n = nt;
-        if (kt_n == KT) { kt_n = 0; nt_n = nt + 1; }
-        if (it + 1 < total) {  // every wave finished reading `nxt` before the barrier that ended step it-1
-            A.stage(nxt, m0, (kt_begin + kt_n) * BK, tid);
-            W.stage(nxt + BM * BK * 2, nt_n * BN, (kt_begin + kt_n) * BK, tid);
-        }
-        compute_stage<SWAP>(acc, cur, cur + BM * BK * 2, wr, wc, lane);
+        const char* cur = lds + slot * S::STAGE_BYTES;
+        const bool more = it + AHEAD < total;
+        if (more) stage_next(slot_s);  // that stage was last read in step it-1, which every wave has left
+        compute_stage<SWAP, F16>(acc, cur, cur + BM * BK * 2, wr, wc, lane);
         if (kt == KT - 1) {
             epi(acc, nt);
 #pragma unroll
@@ -141,8 +205,13 @@ __device__ __forceinline__ void run(const ALoader& A, const WLoader& W, int m0, 
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        __syncthreads();  // also drains the LDS-DMA of the next stage (vmcnt(0) before s_barrier)
-        kt = kt_n; nt = nt_n;
+        // step it+1 must be in LDS before anyone reads it; with 3 stages the loads issued in THIS step
+        // (step it+2) may stay in flight across the barrier
+        if (AHEAD == 2 && more) wait_vmcnt<S::GL>(); else wait_vmcnt<0>();
+        block_barrier();
+        if (++kt == KT) { kt = 0; ++nt; }
+        slot = slot + 1 == ST ? 0 : slot + 1;
+        slot_s = slot_s + 1 == ST ? 0 : slot_s + 1;
     }
 }
 

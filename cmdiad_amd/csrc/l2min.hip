@@ -9,6 +9,8 @@
 // keys (value bits << 32 | global row) and ONE atomicMin per query per block.  Blocks that share a
 // bank range get consecutive ids on one XCD, so a bank tile is fetched into that XCD's L2 once
 // per generation of resident blocks.
+#include <stdlib.h>
+
 #include "gemm_core.h"
 
 namespace {
@@ -24,7 +26,8 @@ struct L2Params {
     int nq_tiles, n_bank_tiles, splits;
 };
 
-__global__ __launch_bounds__(kThreads, 2) void l2_min_kernel(GlobalTile A, GlobalTile W, L2Params p)
+template <class S, bool F16>
+__global__ __launch_bounds__(S::THREADS, S::WAVES_PER_SIMD) void l2_min_kernel(GlobalTile A, GlobalTile W, L2Params p)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int wg = xcd_remap(blockIdx.x, gridDim.x);
@@ -33,7 +36,7 @@ __global__ __launch_bounds__(kThreads, 2) void l2_min_kernel(GlobalTile A, Globa
     const int nt0 = split * per;
     const int ntc = min(per, p.n_bank_tiles - nt0);
     if (ntc <= 0) return;
-    const int m0 = qt * BM;
+    const int m0 = qt * S::BM;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave >> 1, wc = wave & 1;
 
@@ -47,7 +50,7 @@ __global__ __launch_bounds__(kThreads, 2) void l2_min_kernel(GlobalTile A, Globa
         qn[i] = m < p.Q ? p.q_sqnorm[m] : 0.0f;
     }
 
-    run<true>(A, W, m0, nt0, ntc, p.D / BK, lds, [&](Acc& acc, int ntile) {
+    run<S, true, F16>(A, W, m0, nt0, ntc, p.D / BK, lds, [&](Acc& acc, int ntile) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int n = ntile * BN + wc * 64 + j * 16 + (lane >> 4) * 4;
@@ -169,8 +172,9 @@ __global__ void reweight_merge_kernel(const unsigned long long* __restrict__ par
 
 // (x - mean) * inv_std -> bf16 (+ optional f32 copy, + optional |row|^2 of the ROUNDED values).
 // One wave per row.
+template <bool F16>
 __global__ __launch_bounds__(256) void normalize_cast_kernel(const float* __restrict__ x, size_t rows, int D, float mean,
-                                                             float inv_std, bf16_t* __restrict__ out_bf16,
+                                                             float inv_std, uint16_t* __restrict__ out16,
                                                              float* __restrict__ out_f32, float* __restrict__ sq)
 {
     const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -182,9 +186,19 @@ __global__ __launch_bounds__(256) void normalize_cast_kernel(const float* __rest
         v.x = (v.x - mean) * inv_std; v.y = (v.y - mean) * inv_std;
         v.z = (v.z - mean) * inv_std; v.w = (v.w - mean) * inv_std;
         if (out_f32) *reinterpret_cast<float4*>(out_f32 + row * D + c) = v;
-        bf16x4 o = {f2bf(v.x), f2bf(v.y), f2bf(v.z), f2bf(v.w)};
-        if (out_bf16) *reinterpret_cast<bf16x4*>(out_bf16 + row * D + c) = o;
-        const float r0 = bf2f(o[0]), r1 = bf2f(o[1]), r2 = bf2f(o[2]), r3 = bf2f(o[3]);
+        float r0, r1, r2, r3;
+        if constexpr (F16) {
+            typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+            const float lim = 65504.0f;  // saturate instead of overflowing to inf
+            f16x4 o = {(_Float16)fminf(fmaxf(v.x, -lim), lim), (_Float16)fminf(fmaxf(v.y, -lim), lim),
+                       (_Float16)fminf(fmaxf(v.z, -lim), lim), (_Float16)fminf(fmaxf(v.w, -lim), lim)};
+            if (out16) *reinterpret_cast<f16x4*>(out16 + row * D + c) = o;
+            r0 = (float)o[0]; r1 = (float)o[1]; r2 = (float)o[2]; r3 = (float)o[3];
+        } else {
+            bf16x4 o = {f2bf(v.x), f2bf(v.y), f2bf(v.z), f2bf(v.w)};
+            if (out16) *reinterpret_cast<bf16x4*>(out16 + row * D + c) = o;
+            r0 = bf2f(o[0]); r1 = bf2f(o[1]); r2 = bf2f(o[2]); r3 = bf2f(o[3]);
+        }
         s += r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3;
     }
     if (sq) {
@@ -272,31 +286,48 @@ bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 }  // namespace
 
-extern "C" int cmdiad_l2_min_keys(const uint16_t* q, const float* q_sqnorm, const uint16_t* bank,
-                                  const float* bank_sqnorm, int Q, int Nb, int D, uint32_t row_offset,
-                                  unsigned long long* keys, cmdiad_stream_t stream)
+template <class S, bool F16>
+int launch_l2(const uint16_t* q, const float* q_sqnorm, const uint16_t* bank, const float* bank_sqnorm, int Q, int Nb,
+              int D, uint32_t row_offset, unsigned long long* keys, hipStream_t stream)
 {
-    CMDIAD_REQUIRE(q && q_sqnorm && bank && bank_sqnorm && keys, CMDIAD_ERR_ARG, "cmdiad_l2_min_keys: null pointer");
-    CMDIAD_REQUIRE(Q >= 0 && Nb >= 0 && D > 0 && D % 64 == 0, CMDIAD_ERR_ARG, "cmdiad_l2_min_keys: need D%%64==0 (D=%d)", D);
-    CMDIAD_REQUIRE(aligned16(q) && aligned16(bank), CMDIAD_ERR_ARG, "cmdiad_l2_min_keys: 16-byte alignment");
-    if (Q == 0 || Nb == 0) return CMDIAD_OK;
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)l2_min_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)l2_min_kernel<S, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, S::LDS_BYTES) != hipSuccess) {
             cmdiad_set_error("cmdiad_l2_min_keys: hipFuncSetAttribute failed");
             return CMDIAD_ERR_LAUNCH;
         }
         attr = true;
     }
-    const int nq = (Q + BM - 1) / BM, nbt = (Nb + BN - 1) / BN;
-    // enough blocks to fill 256 CUs x 2 several times over, but long bank ranges per block so the
-    // running min stays in registers and the per-block atomics stay negligible
-    int splits = (2048 + nq - 1) / nq;
+    const int nq = (Q + S::BM - 1) / S::BM, nbt = (Nb + BN - 1) / BN;
+    // enough blocks to fill the chip a few times over, but long bank ranges per block so the running
+    // min stays in registers and the per-block atomics stay negligible
+    int splits = (1024 * (S::BM == 256 ? 1 : 2) + nq - 1) / nq;
     splits = splits < 1 ? 1 : (splits > nbt ? nbt : splits);
     if (splits > 8) splits = 8;
     GlobalTile A{(const bf16_t*)q, D, Q}, W{(const bf16_t*)bank, D, Nb};
     L2Params p{Q, Nb, D, q_sqnorm, bank_sqnorm, row_offset, keys, nq, nbt, splits};
-    hipLaunchKernelGGL(l2_min_kernel, dim3(nq * splits), dim3(kThreads), kLdsBytes, (hipStream_t)stream, A, W, p);
+    hipLaunchKernelGGL((l2_min_kernel<S, F16>), dim3(nq * splits), dim3(S::THREADS), S::LDS_BYTES, stream, A, W, p);
+    return CMDIAD_OK;
+}
+
+extern "C" int cmdiad_l2_min_keys(const uint16_t* q, const float* q_sqnorm, const uint16_t* bank,
+                                  const float* bank_sqnorm, int Q, int Nb, int D, uint32_t row_offset,
+                                  unsigned long long* keys, int dtype, cmdiad_stream_t stream)
+{
+    CMDIAD_REQUIRE(q && q_sqnorm && bank && bank_sqnorm && keys, CMDIAD_ERR_ARG, "cmdiad_l2_min_keys: null pointer");
+    CMDIAD_REQUIRE(Q >= 0 && Nb >= 0 && D > 0 && D % 64 == 0, CMDIAD_ERR_ARG, "cmdiad_l2_min_keys: need D%%64==0 (D=%d)", D);
+    CMDIAD_REQUIRE(aligned16(q) && aligned16(bank), CMDIAD_ERR_ARG, "cmdiad_l2_min_keys: 16-byte alignment");
+    CMDIAD_REQUIRE(dtype == CMDIAD_DT_BF16 || dtype == CMDIAD_DT_F16, CMDIAD_ERR_ARG, "cmdiad_l2_min_keys: dtype");
+    if (Q == 0 || Nb == 0) return CMDIAD_OK;
+    static const int force = getenv("CMDIAD_GEMM_TILE") ? atoi(getenv("CMDIAD_GEMM_TILE")) : 0;
+    const bool big = force == 256 || (force != 128 && Q >= 256 * 64);
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    if (big) rc = dtype == CMDIAD_DT_F16 ? launch_l2<S256, true>(q, q_sqnorm, bank, bank_sqnorm, Q, Nb, D, row_offset, keys, s)
+                                         : launch_l2<S256, false>(q, q_sqnorm, bank, bank_sqnorm, Q, Nb, D, row_offset, keys, s);
+    else rc = dtype == CMDIAD_DT_F16 ? launch_l2<S128, true>(q, q_sqnorm, bank, bank_sqnorm, Q, Nb, D, row_offset, keys, s)
+                                     : launch_l2<S128, false>(q, q_sqnorm, bank, bank_sqnorm, Q, Nb, D, row_offset, keys, s);
+    if (rc) return rc;
     CMDIAD_CHECK_LAUNCH();
     return CMDIAD_OK;
 }
@@ -342,15 +373,19 @@ extern "C" int cmdiad_reweight_scan(const float* probes, const float* bank, int 
 }
 
 extern "C" int cmdiad_normalize_cast(const float* x, size_t rows, int D, float mean, float inv_std, uint16_t* out_bf16,
-                                     float* out_f32, float* row_sqnorm, cmdiad_stream_t stream)
+                                     float* out_f32, float* row_sqnorm, int out_dtype, cmdiad_stream_t stream)
 {
     CMDIAD_REQUIRE(x, CMDIAD_ERR_ARG, "cmdiad_normalize_cast: null input");
     CMDIAD_REQUIRE(D % 4 == 0 && aligned16(x) && (!out_f32 || aligned16(out_f32)) &&
                        (!out_bf16 || ((uintptr_t)out_bf16 & 7) == 0),
                    CMDIAD_ERR_ARG, "cmdiad_normalize_cast: D%%4==0 and aligned buffers");
     if (rows == 0) return CMDIAD_OK;
-    hipLaunchKernelGGL(normalize_cast_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, rows,
-                       D, mean, inv_std, (bf16_t*)out_bf16, out_f32, row_sqnorm);
+    if (out_dtype == CMDIAD_DT_F16)
+        hipLaunchKernelGGL(normalize_cast_kernel<true>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x,
+                           rows, D, mean, inv_std, out_bf16, out_f32, row_sqnorm);
+    else
+        hipLaunchKernelGGL(normalize_cast_kernel<false>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x,
+                           rows, D, mean, inv_std, out_bf16, out_f32, row_sqnorm);
     CMDIAD_CHECK_LAUNCH();
     return CMDIAD_OK;
 }

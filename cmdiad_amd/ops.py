@@ -171,14 +171,20 @@ def gemm_groupmax(A, W, bias, groups, Mg, want_bf16=False):
 
 
 # ------------------------------------------------------------------------------------ scoring
-def normalize_cast(x, mean=0.0, inv_std=1.0, want_f32=False, want_sq=True):
-    """x [rows,D] f32 -> (bf16 [rows,D], f32 normalised | None, row |.|^2 of the rounded rows | None)."""
+SEARCH_DTYPE = torch.float16  # 16-bit operand type of the patch-library distance GEMM (fp16: 3 more mantissa bits)
+
+
+def normalize_cast(x, mean=0.0, inv_std=1.0, want_f32=False, want_sq=True, dtype=None):
+    """x [rows,D] f32 -> (16-bit [rows,D] (fp16 by default, or bf16), f32 normalised | None,
+    row |.|^2 of the ROUNDED rows | None)."""
     _chk(x, torch.float32, "normalize_cast.x")
     rows, D = x.shape
-    o16 = torch.empty((rows, D), dtype=torch.bfloat16, device=x.device)
+    dtype = dtype or SEARCH_DTYPE
+    o16 = torch.empty((rows, D), dtype=dtype, device=x.device)
     o32 = torch.empty((rows, D), dtype=torch.float32, device=x.device) if want_f32 else None
     sq = torch.empty((rows,), dtype=torch.float32, device=x.device) if want_sq else None
-    _call("cmdiad_normalize_cast", _p(x), rows, D, float(mean), float(inv_std), _p(o16), _p(o32), _p(sq), _stream())
+    _call("cmdiad_normalize_cast", _p(x), rows, D, float(mean), float(inv_std), _p(o16), _p(o32), _p(sq),
+          1 if dtype == torch.float16 else 0, _stream())
     return o16, o32, sq
 
 
@@ -188,8 +194,10 @@ def new_keys(Q, device):
 
 def l2_min_keys(q16, q_sq, bank16, bank_sq, keys, row_offset=0):
     Q, D = q16.shape
+    if q16.dtype != bank16.dtype:
+        raise TypeError("l2_min_keys: queries and bank must share the 16-bit dtype")
     _call("cmdiad_l2_min_keys", _p(q16), _p(q_sq), _p(bank16), _p(bank_sq), Q, bank16.shape[0], D, row_offset,
-          _p(keys), _stream())
+          _p(keys), 1 if q16.dtype == torch.float16 else 0, _stream())
     return keys
 
 

@@ -162,8 +162,9 @@ int cmdiad_gemm_groupmax(const uint16_t* A, const uint16_t* W, const float* bias
  * q [Q,D] bf16, q_sqnorm [Q] f32, bank [Nb,D] bf16, bank_sqnorm [Nb] f32 (squared norms of the
  * bf16-rounded rows, from cmdiad_normalize_cast), keys [Q] u64: the caller initialises keys to
  * UINT64_MAX; the kernel combines with atomic min.  D % 64 == 0. */
+enum { CMDIAD_DT_BF16 = 0, CMDIAD_DT_F16 = 1 };   /* 16-bit operand type of the distance GEMM */
 int cmdiad_l2_min_keys(const uint16_t* q, const float* q_sqnorm, const uint16_t* bank, const float* bank_sqnorm,
-                       int Q, int Nb, int D, uint32_t row_offset, unsigned long long* keys,
+                       int Q, int Nb, int D, uint32_t row_offset, unsigned long long* keys, int dtype,
                        cmdiad_stream_t stream);
 
 /* Exact fp32 re-score of the winners: min_val[q] = || q_f32[q] - bank_f32[idx - row_offset] ||_2,
@@ -207,10 +208,10 @@ int cmdiad_coreset_greedy(const float* z32, int n, int d, int n_select, int firs
  * Small fused element-wise / layout kernels
  * ------------------------------------------------------------------------------------------- */
 
-/* out_bf16 = bf16((x - mean) * inv_std); optional out_f32 copy of the normalised values and
+/* out_bf16 = bf16 or (out_dtype = CMDIAD_DT_F16) saturating fp16 of ((x - mean) * inv_std); optional out_f32 copy of the normalised values and
  * optional per-row squared norm of the bf16-rounded row (a11 + the |b|^2 term of the distance GEMM). */
 int cmdiad_normalize_cast(const float* x, size_t rows, int D, float mean, float inv_std, uint16_t* out_bf16,
-                          float* out_f32, float* row_sqnorm, cmdiad_stream_t stream);
+                          float* out_f32, float* row_sqnorm, int out_dtype, cmdiad_stream_t stream);
 
 /* ViT patch embedding as a GEMM operand: rgb [B,3,S,S] f32 -> patches [B*(S/8)^2, 192] bf16 with
  * k = (c, dy, dx) matching conv weight [768,3,8,8] flattened (timm PatchEmbed, models/models.py:41). */
