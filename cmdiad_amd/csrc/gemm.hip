@@ -31,32 +31,45 @@ __device__ __forceinline__ float gelu_grad_f(float x)
     return cdf + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
 }
 
+// block -> (m tile, n tile) with the XCD remap; lane/wave coordinates shared by every epilogue
+template <class S>
+struct Coord {
+    int m0, nt, lane, wr, wc;
+    __device__ __forceinline__ Coord(int n_tiles_n)
+    {
+        const int wg = xcd_remap(blockIdx.x, gridDim.x);
+        m0 = (wg / n_tiles_n) * S::BM;
+        nt = wg % n_tiles_n;
+        lane = threadIdx.x & 63;
+        const int wave = threadIdx.x >> 6;
+        wr = wave / S::WN;
+        wc = wave % S::WN;
+    }
+    // swapped orientation: lane holds row m(i), columns n(j) .. n(j)+3
+    __device__ __forceinline__ int m(int i) const { return m0 + wr * (S::MI * 16) + i * 16 + (lane & 15); }
+    __device__ __forceinline__ int n(int ntile, int j) const { return ntile * S::BN + wc * 64 + j * 16 + (lane >> 4) * 4; }
+};
+
 template <class S>
 __global__ __launch_bounds__(S::THREADS, S::WAVES_PER_SIMD) void gemm_std_kernel(GlobalTile A, GlobalTile W, StdParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int ntn = (p.N + BN - 1) / BN;
-    const int wg = xcd_remap(blockIdx.x, gridDim.x);
-    const int mt = wg / ntn, nt = wg % ntn;
-    const int m0 = mt * S::BM;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
-
+    const Coord<S> c((p.N + S::BN - 1) / S::BN);
     const int kt_per = (p.K / BK + p.split_k - 1) / p.split_k;
     const int kt_begin = blockIdx.y * kt_per;
     const int kt_count = min(kt_per, p.K / BK - kt_begin);
     float* out32 = p.out_f32 ? p.out_f32 + (size_t)blockIdx.y * p.M * p.ldo32 : nullptr;
     if (kt_count <= 0) return;
 
-    run<S, true>(A, W, m0, nt, 1, kt_count, lds, [&](Acc& acc, int ntile) {
+    run<S, true>(A, W, c.m0, c.nt, 1, kt_count, lds, [&](auto& acc, int ntile) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = m0 + wr * 64 + i * 16 + (lane & 15);
+        for (int i = 0; i < S::MI; ++i) {
+            const int m = c.m(i);
             if (m >= p.M) continue;
             const float* gb = p.group_bias ? p.group_bias + (size_t)(m / p.group_rows) * p.N : nullptr;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int n = ntile * BN + wc * 64 + j * 16 + (lane >> 4) * 4;
+                const int n = c.n(ntile, j);
                 if (n >= p.N) continue;
                 f32x4 v = acc[i][j];
                 if (p.dact_of) {
@@ -106,28 +119,23 @@ template <class S>
 __global__ __launch_bounds__(S::THREADS, S::WAVES_PER_SIMD) void gemm_qkv_kernel(GlobalTile A, GlobalTile W, QkvParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int ntn = (3 * p.C) / BN;
-    const int wg = xcd_remap(blockIdx.x, gridDim.x);
-    const int mt = wg / ntn, nt = wg % ntn;
-    const int m0 = mt * S::BM;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
-    const int which = (nt * BN) / p.C;  // 0 q, 1 k, 2 v : block-uniform because C % 128 == 0
+    const Coord<S> c((3 * p.C) / S::BN);
+    const int which = (c.nt * S::BN) / p.C;  // 0 q, 1 k, 2 v : block-uniform because C % BN == 0
 
     if (which < 2) {
         bf16_t* dst = which == 0 ? p.q : p.k;
         const float scale = which == 0 ? 0.125f : 1.0f;  // head_dim^-0.5, exact in bf16
-        run<S, true>(A, W, m0, nt, 1, p.C / BK, lds, [&](Acc& acc, int ntile) {
+        run<S, true>(A, W, c.m0, c.nt, 1, p.C / BK, lds, [&](auto& acc, int ntile) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int m = m0 + wr * 64 + i * 16 + (lane & 15);
+            for (int i = 0; i < S::MI; ++i) {
+                const int m = c.m(i);
                 if (m >= p.M) continue;
                 const int b = m / p.T, t = m - b * p.T;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int n = ntile * BN + wc * 64 + j * 16 + (lane >> 4) * 4;
-                    const int c = n - which * p.C;
-                    const int h = c >> 6, d = c & 63;
+                    const int n = c.n(ntile, j);
+                    const int cc = n - which * p.C;
+                    const int h = cc >> 6, d = cc & 63;
                     f32x4 v = acc[i][j];
                     if (p.bias) { const float4 bb = *reinterpret_cast<const float4*>(p.bias + n); v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w; }
                     bf16x4 o = {f2bf(v[0] * scale), f2bf(v[1] * scale), f2bf(v[2] * scale), f2bf(v[3] * scale)};
@@ -136,18 +144,18 @@ __global__ __launch_bounds__(S::THREADS, S::WAVES_PER_SIMD) void gemm_qkv_kernel
             }
         });
     } else {
-        run<S, false>(A, W, m0, nt, 1, p.C / BK, lds, [&](Acc& acc, int ntile) {
+        run<S, false>(A, W, c.m0, c.nt, 1, p.C / BK, lds, [&](auto& acc, int ntile) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int n = ntile * BN + wc * 64 + j * 16 + (lane & 15);
-                const int c = n - 2 * p.C;
-                const int h = c >> 6, d = c & 63;
+                const int n = ntile * S::BN + c.wc * 64 + j * 16 + (c.lane & 15);
+                const int cc = n - 2 * p.C;
+                const int h = cc >> 6, d = cc & 63;
                 const float bb = p.bias ? p.bias[n] : 0.0f;
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < S::MI; ++i)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int m = m0 + wr * 64 + i * 16 + (lane >> 4) * 4 + r;
+                        const int m = c.m0 + c.wr * (S::MI * 16) + i * 16 + (c.lane >> 4) * 4 + r;
                         if (m >= p.M) continue;
                         const int b = m / p.T, t = m - b * p.T;
                         p.vt[(((size_t)b * p.H + h) * 64 + d) * p.Tp + t] = f2bf(acc[i][j][r] + bb);
@@ -158,9 +166,9 @@ __global__ __launch_bounds__(S::THREADS, S::WAVES_PER_SIMD) void gemm_qkv_kernel
 }
 
 // ------------------------------------------------------------------------------------------------
-// Per-group max pooling epilogue shared by the two encoder stages.  The 128-row tile holds
-// 128/Mg whole groups.  Column max: in-lane over the row tiles, xor-shuffle over the 16 row lanes,
-// then a 4 x 128 LDS table (one row per 32-row block) combined by the first 128 threads.
+// Per-group max pooling epilogue shared by the two encoder stages.  The BM-row tile holds BM/Mg whole
+// groups.  Column max: in-lane over pairs of row tiles (32 rows), xor-shuffle over the 16 row lanes,
+// then a [BM/32][BN] LDS table (one row per 32-row block) combined by the first BN threads.
 // ------------------------------------------------------------------------------------------------
 struct GroupMaxParams {
     int M, N, K, Mg;
@@ -171,29 +179,25 @@ struct GroupMaxParams {
 };
 
 template <class S, class ALoader>
-__device__ __forceinline__ void groupmax_body(const ALoader& A, const GlobalTile& W, const GroupMaxParams& p, char* lds,
-                                              float (*s_max)[BN])
+__device__ __forceinline__ void groupmax_body(const ALoader& A, const GlobalTile& W, const GroupMaxParams& p, char* lds)
 {
-    const int ntn = (p.N + BN - 1) / BN;
-    const int wg = xcd_remap(blockIdx.x, gridDim.x);
-    const int mt = wg / ntn, nt = wg % ntn;
-    const int m0 = mt * S::BM;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
+    float(*s_max)[S::BN] = reinterpret_cast<float(*)[S::BN]>(lds + S::LDS_BYTES);
+    const Coord<S> c((p.N + S::BN - 1) / S::BN);
+    const int tid = threadIdx.x;
 
-    run<S, true>(A, W, m0, nt, 1, p.K / BK, lds, [&](Acc& acc, int ntile) {
+    run<S, true>(A, W, c.m0, c.nt, 1, p.K / BK, lds, [&](auto& acc, int ntile) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int nl = wc * 64 + j * 16 + (lane >> 4) * 4;  // column within the tile
-            const int n = ntile * BN + nl;
+            const int nl = c.wc * 64 + j * 16 + (c.lane >> 4) * 4;  // column within the tile
+            const int n = ntile * S::BN + nl;
             float4 b = {0.f, 0.f, 0.f, 0.f};
             if (p.bias && n < p.N) b = *reinterpret_cast<const float4*>(p.bias + n);
-            f32x4 mx[2];
+            f32x4 mx[S::MI / 2];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < S::MI; ++i) {
                 f32x4 v = acc[i][j];
                 v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-                const int m = m0 + wr * 64 + i * 16 + (lane & 15);
+                const int m = c.m(i);
                 if (p.full_bf16 && m < p.M && n < p.N) {
                     bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
                     *reinterpret_cast<bf16x4*>(p.full_bf16 + (size_t)m * p.ldf + n) = o;
@@ -205,7 +209,7 @@ __device__ __forceinline__ void groupmax_body(const ALoader& A, const GlobalTile
                 }
             }
 #pragma unroll
-            for (int hb = 0; hb < 2; ++hb) {
+            for (int hb = 0; hb < S::MI / 2; ++hb) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float v = mx[hb][r];
@@ -213,19 +217,19 @@ __device__ __forceinline__ void groupmax_body(const ALoader& A, const GlobalTile
                     v = fmaxf(v, __shfl_xor(v, 2, 64));
                     v = fmaxf(v, __shfl_xor(v, 4, 64));
                     v = fmaxf(v, __shfl_xor(v, 8, 64));
-                    if ((lane & 15) == 0) s_max[wr * 2 + hb][nl + r] = v;
+                    if ((c.lane & 15) == 0) s_max[c.wr * (S::MI / 2) + hb][nl + r] = v;
                 }
             }
         }
         __syncthreads();
-        if (tid < BN) {
-            const int n = ntile * BN + tid;
+        if (tid < S::BN) {
+            const int n = ntile * S::BN + tid;
             const int per = p.Mg / 32;  // 32-row blocks per group: 1, 2 or 4
             for (int g = 0; g < (S::BM / 32) / per; ++g) {
                 float v = s_max[g * per][tid];
                 for (int q = 1; q < per; ++q) v = fmaxf(v, s_max[g * per + q][tid]);
-                const int grp = (m0 + g * p.Mg) / p.Mg;
-                if (n < p.N && m0 + g * p.Mg < p.M) {
+                const int grp = (c.m0 + g * p.Mg) / p.Mg;
+                if (n < p.N && c.m0 + g * p.Mg < p.M) {
                     if (p.max_f32) p.max_f32[(size_t)grp * p.N + n] = v;
                     if (p.max_bf16) p.max_bf16[(size_t)grp * p.N + n] = f2bf(v);
                 }
@@ -238,44 +242,49 @@ template <class S>
 __global__ __launch_bounds__(S::THREADS, S::WAVES_PER_SIMD) void gemm_groupmax_kernel(GlobalTile A, GlobalTile W, GroupMaxParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    float(*s_max)[BN] = reinterpret_cast<float(*)[BN]>(lds + S::LDS_BYTES);
-    groupmax_body<S>(A, W, p, lds, s_max);
+    groupmax_body<S>(A, W, p, lds);
 }
 
 template <class S>
 __global__ __launch_bounds__(S::THREADS, S::WAVES_PER_SIMD) void encoder_stage1_kernel(Conv1Tile A, GlobalTile W, GroupMaxParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    float(*s_max)[BN] = reinterpret_cast<float(*)[BN]>(lds + S::LDS_BYTES);
-    groupmax_body<S>(A, W, p, lds, s_max);
+    groupmax_body<S>(A, W, p, lds);
 }
 
-template <class S> constexpr int group_max_lds() { return S::LDS_BYTES + (S::BM / 32) * BN * (int)sizeof(float); }
+template <class S> constexpr int group_max_lds() { return S::LDS_BYTES + (S::BM / 32) * S::BN * (int)sizeof(float); }
 
-template <int TAG>
-int set_lds_tag(const void* kernel, int bytes)
+bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+// Tile choice.  0 = S128 (128x128, 2 blocks/CU), 1 = S256 (256x128, 3 stages), 2 = S2x2 (256x256).
+// Large tiles only once there are enough of them to fill the 256 CUs; CMDIAD_GEMM_TILE forces one (A/B runs).
+int pick_tile(long M, long N, int split)
 {
-    static bool done = false;  // one flag per TAG (= per kernel)
+    static const int force = getenv("CMDIAD_GEMM_TILE") ? atoi(getenv("CMDIAD_GEMM_TILE")) : -1;
+    if (force >= 0) return force;
+    const long t22 = ((M + 255) / 256) * ((N + 255) / 256) * split;
+    if (t22 >= 224 && N % 256 == 0) return 2;
+    return 0;
+}
+
+// one launcher per kernel instantiation: sets the dynamic-LDS attribute once
+template <class S, class Kern, class... Args>
+int launch(Kern kernel, dim3 grid, int lds, hipStream_t s, Args... args)
+{
+    static bool done = false;
     if (!done) {
-        if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
-            cmdiad_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d) failed", bytes);
+        if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+            cmdiad_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d) failed", lds);
             return CMDIAD_ERR_LAUNCH;
         }
         done = true;
     }
+    hipLaunchKernelGGL(kernel, grid, dim3(S::THREADS), lds, s, args...);
     return CMDIAD_OK;
 }
 
-bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
-
-// 256-row tiles (1 block of 8 waves per CU, 3-stage prefetch) once there are enough of them to fill the chip
-bool use_big_tile(int M, int other_tiles)
-{
-    static const int force = getenv("CMDIAD_GEMM_TILE") ? atoi(getenv("CMDIAD_GEMM_TILE")) : 0;
-    if (force == 128) return false;
-    if (force == 256) return true;
-    return (long)((M + 255) / 256) * other_tiles >= 224;
-}
+template <class S>
+dim3 grid_for(long M, long N, int y = 1) { return dim3((unsigned)(((M + S::BM - 1) / S::BM) * ((N + S::BN - 1) / S::BN)), y); }
 
 }  // namespace
 
@@ -292,26 +301,23 @@ extern "C" int cmdiad_gemm_bf16(const cmdiad_gemm_args* a, cmdiad_stream_t strea
                        (!a->residual || (a->ldr % 4 == 0 && aligned16(a->residual))) &&
                        (!a->bias || aligned16(a->bias)) && (!a->group_bias || (aligned16(a->group_bias) && a->group_rows > 0)),
                    CMDIAD_ERR_ARG, "cmdiad_gemm_bf16: epilogue operand alignment");
-
-    GlobalTile A{(const bf16_t*)a->A, a->lda, a->M}, W{(const bf16_t*)a->W, a->ldw, a->N};
     const int split = a->split_k > 1 ? a->split_k : 1;
     CMDIAD_REQUIRE(split == 1 || (a->out_f32 && !a->out_bf16 && !a->bias && !a->group_bias && !a->residual &&
                                   a->act == CMDIAD_ACT_NONE && !a->out_pre_bf16 && !a->dact_of),
                    CMDIAD_ERR_ARG, "cmdiad_gemm_bf16: split_k > 1 writes raw f32 slabs only");
     CMDIAD_REQUIRE((!a->out_pre_bf16 || ((uintptr_t)a->out_pre_bf16 & 7) == 0) && (!a->dact_of || ((uintptr_t)a->dact_of & 7) == 0),
                    CMDIAD_ERR_ARG, "cmdiad_gemm_bf16: out_pre_bf16 / dact_of alignment");
+    GlobalTile A{(const bf16_t*)a->A, a->lda, a->M}, W{(const bf16_t*)a->W, a->ldw, a->N};
     StdParams p{a->M, a->N, a->K, a->bias, a->group_bias, a->group_rows, a->act, a->residual, a->ldr,
                 a->out_f32, a->ldo32, (bf16_t*)a->out_bf16, a->ldo16, (bf16_t*)a->out_pre_bf16, (const bf16_t*)a->dact_of, split};
-    const int ntn = (a->N + BN - 1) / BN;
-    if (use_big_tile(a->M, ntn * split)) {
-        if (int rc = set_lds_tag<10>((const void*)gemm_std_kernel<S256>, S256::LDS_BYTES)) return rc;
-        hipLaunchKernelGGL(gemm_std_kernel<S256>, dim3(((a->M + 255) / 256) * ntn, split), dim3(S256::THREADS), S256::LDS_BYTES,
-                           (hipStream_t)stream, A, W, p);
-    } else {
-        if (int rc = set_lds_tag<0>((const void*)gemm_std_kernel<S128>, S128::LDS_BYTES)) return rc;
-        hipLaunchKernelGGL(gemm_std_kernel<S128>, dim3(((a->M + 127) / 128) * ntn, split), dim3(S128::THREADS), S128::LDS_BYTES,
-                           (hipStream_t)stream, A, W, p);
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    switch (pick_tile(a->M, a->N, split)) {
+        case 2: rc = launch<S2x2>(gemm_std_kernel<S2x2>, grid_for<S2x2>(a->M, a->N, split), S2x2::LDS_BYTES, s, A, W, p); break;
+        case 1: rc = launch<S256>(gemm_std_kernel<S256>, grid_for<S256>(a->M, a->N, split), S256::LDS_BYTES, s, A, W, p); break;
+        default: rc = launch<S128>(gemm_std_kernel<S128>, grid_for<S128>(a->M, a->N, split), S128::LDS_BYTES, s, A, W, p);
     }
+    if (rc) return rc;
     CMDIAD_CHECK_LAUNCH();
     return CMDIAD_OK;
 }
@@ -323,19 +329,19 @@ extern "C" int cmdiad_gemm_qkv(const uint16_t* A, const uint16_t* W, const float
     CMDIAD_REQUIRE(B > 0 && T > 0 && C > 0 && C % 128 == 0, CMDIAD_ERR_ARG, "cmdiad_gemm_qkv: need C%%128==0 (C=%d)", C);
     CMDIAD_REQUIRE(aligned16(A) && aligned16(W) && aligned16(q_out) && aligned16(k_out) && (!bias || aligned16(bias)),
                    CMDIAD_ERR_ARG, "cmdiad_gemm_qkv: 16-byte alignment");
-
     const int M = B * T;
     GlobalTile At{(const bf16_t*)A, C, M}, Wt{(const bf16_t*)W, C, 3 * C};
     QkvParams p{M, T, (T + 63) / 64 * 64, C, C / 64, bias, (bf16_t*)q_out, (bf16_t*)k_out, (bf16_t*)vt_out};
-    if (use_big_tile(M, 3 * C / BN)) {
-        if (int rc = set_lds_tag<11>((const void*)gemm_qkv_kernel<S256>, S256::LDS_BYTES)) return rc;
-        hipLaunchKernelGGL(gemm_qkv_kernel<S256>, dim3(((M + 255) / 256) * (3 * C / BN)), dim3(S256::THREADS), S256::LDS_BYTES,
-                           (hipStream_t)stream, At, Wt, p);
-    } else {
-        if (int rc = set_lds_tag<1>((const void*)gemm_qkv_kernel<S128>, S128::LDS_BYTES)) return rc;
-        hipLaunchKernelGGL(gemm_qkv_kernel<S128>, dim3(((M + 127) / 128) * (3 * C / BN)), dim3(S128::THREADS), S128::LDS_BYTES,
-                           (hipStream_t)stream, At, Wt, p);
+    hipStream_t s = (hipStream_t)stream;
+    int tile = pick_tile(M, 3 * C, 1);
+    if (tile == 2 && C % 256 != 0) tile = 0;  // a 256-wide N tile must not straddle the q|k|v boundary
+    int rc;
+    switch (tile) {
+        case 2: rc = launch<S2x2>(gemm_qkv_kernel<S2x2>, grid_for<S2x2>(M, 3 * C), S2x2::LDS_BYTES, s, At, Wt, p); break;
+        case 1: rc = launch<S256>(gemm_qkv_kernel<S256>, grid_for<S256>(M, 3 * C), S256::LDS_BYTES, s, At, Wt, p); break;
+        default: rc = launch<S128>(gemm_qkv_kernel<S128>, grid_for<S128>(M, 3 * C), S128::LDS_BYTES, s, At, Wt, p);
     }
+    if (rc) return rc;
     CMDIAD_CHECK_LAUNCH();
     return CMDIAD_OK;
 }
@@ -348,20 +354,17 @@ extern "C" int cmdiad_gemm_groupmax(const uint16_t* A, const uint16_t* W, const 
                    "cmdiad_gemm_groupmax: Mg in {32,64,128}, N%%4==0, K%%64==0 (Mg=%d N=%d K=%d)", Mg, N, K);
     CMDIAD_REQUIRE(aligned16(A) && aligned16(W) && (!bias || aligned16(bias)), CMDIAD_ERR_ARG,
                    "cmdiad_gemm_groupmax: 16-byte alignment");
-
     const int M = groups * Mg;
     GlobalTile At{(const bf16_t*)A, K, M}, Wt{(const bf16_t*)W, K, N};
     GroupMaxParams p{M, N, K, Mg, bias, nullptr, 0, out_f32, (bf16_t*)out_bf16};
-    const int ntn = (N + BN - 1) / BN;
-    if (use_big_tile(M, ntn)) {
-        if (int rc = set_lds_tag<12>((const void*)gemm_groupmax_kernel<S256>, group_max_lds<S256>())) return rc;
-        hipLaunchKernelGGL(gemm_groupmax_kernel<S256>, dim3(((M + 255) / 256) * ntn), dim3(S256::THREADS), group_max_lds<S256>(),
-                           (hipStream_t)stream, At, Wt, p);
-    } else {
-        if (int rc = set_lds_tag<2>((const void*)gemm_groupmax_kernel<S128>, group_max_lds<S128>())) return rc;
-        hipLaunchKernelGGL(gemm_groupmax_kernel<S128>, dim3(((M + 127) / 128) * ntn), dim3(S128::THREADS), group_max_lds<S128>(),
-                           (hipStream_t)stream, At, Wt, p);
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    switch (pick_tile(M, N, 1)) {
+        case 2: rc = launch<S2x2>(gemm_groupmax_kernel<S2x2>, grid_for<S2x2>(M, N), group_max_lds<S2x2>(), s, At, Wt, p); break;
+        case 1: rc = launch<S256>(gemm_groupmax_kernel<S256>, grid_for<S256>(M, N), group_max_lds<S256>(), s, At, Wt, p); break;
+        default: rc = launch<S128>(gemm_groupmax_kernel<S128>, grid_for<S128>(M, N), group_max_lds<S128>(), s, At, Wt, p);
     }
+    if (rc) return rc;
     CMDIAD_CHECK_LAUNCH();
     return CMDIAD_OK;
 }
@@ -375,20 +378,18 @@ extern "C" int cmdiad_encoder_stage1(const float* neigh, const float* w1, const 
                    "cmdiad_encoder_stage1: Mg in {32,64,128} (Mg=%d)", Mg);
     CMDIAD_REQUIRE(aligned16(w1) && aligned16(W2) && (!b2 || aligned16(b2)) && ((uintptr_t)h2_out & 7) == 0,
                    CMDIAD_ERR_ARG, "cmdiad_encoder_stage1: alignment");
-
     const int M = groups * Mg;
     Conv1Tile At{neigh, (const float4*)w1, M};
     GlobalTile Wt{(const bf16_t*)W2, 128, 256};
     GroupMaxParams p{M, 256, 128, Mg, b2, (bf16_t*)h2_out, 256, gmax_out, (bf16_t*)gmax_bf16_out};
-    if (use_big_tile(M, 256 / BN)) {
-        if (int rc = set_lds_tag<13>((const void*)encoder_stage1_kernel<S256>, group_max_lds<S256>())) return rc;
-        hipLaunchKernelGGL(encoder_stage1_kernel<S256>, dim3(((M + 255) / 256) * (256 / BN)), dim3(S256::THREADS),
-                           group_max_lds<S256>(), (hipStream_t)stream, At, Wt, p);
-    } else {
-        if (int rc = set_lds_tag<3>((const void*)encoder_stage1_kernel<S128>, group_max_lds<S128>())) return rc;
-        hipLaunchKernelGGL(encoder_stage1_kernel<S128>, dim3(((M + 127) / 128) * (256 / BN)), dim3(S128::THREADS),
-                           group_max_lds<S128>(), (hipStream_t)stream, At, Wt, p);
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    switch (pick_tile(M, 256, 1)) {
+        case 2: rc = launch<S2x2>(encoder_stage1_kernel<S2x2>, grid_for<S2x2>(M, 256), group_max_lds<S2x2>(), s, At, Wt, p); break;
+        case 1: rc = launch<S256>(encoder_stage1_kernel<S256>, grid_for<S256>(M, 256), group_max_lds<S256>(), s, At, Wt, p); break;
+        default: rc = launch<S128>(encoder_stage1_kernel<S128>, grid_for<S128>(M, 256), group_max_lds<S128>(), s, At, Wt, p);
     }
+    if (rc) return rc;
     CMDIAD_CHECK_LAUNCH();
     return CMDIAD_OK;
 }

@@ -22,24 +22,29 @@
 // stores 16-byte (f32) / 8-byte (bf16) vectors and lets a per-query running min live in one lane.
 // SWAP = false gives 4 consecutive m per lane (used for transposed stores).
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 
 namespace gemm {
 
-constexpr int BN = 128, BK = 64;
+constexpr int BK = 64;
 
-template <int BM_, int STAGES_>
+// Shape<BM, BN, WAVES, STAGES>: waves in a (WAVES/WN) x WN grid with WN = BN/64; a wave owns (MI*16) x 64 outputs.
+template <int BM_, int BN_, int WAVES_, int STAGES_>
 struct Shape {
     static_assert(STAGES_ == 2 || STAGES_ == 3, "2 or 3 LDS stages");
-    static constexpr int BM = BM_, STAGES = STAGES_;
-    static constexpr int WAVES = BM_ / 32, THREADS = WAVES * 64;
-    static constexpr int STAGE_BYTES = (BM_ + BN) * BK * 2;
+    static constexpr int BM = BM_, BN = BN_, WAVES = WAVES_, STAGES = STAGES_, THREADS = WAVES_ * 64;
+    static constexpr int WN = BN_ / 64, WM = WAVES_ / WN, MI = BM_ / WM / 16;
+    static constexpr int STAGE_BYTES = (BM_ + BN_) * BK * 2;
     static constexpr int LDS_BYTES = STAGES_ * STAGE_BYTES;
-    static constexpr int GL = BM_ / WAVES / 8 + BN / WAVES / 8;  // LDS-DMA instructions per wave per K-step
-    static constexpr int WAVES_PER_SIMD = (160 * 1024 / LDS_BYTES >= 2 ? 2 : 1) * WAVES / 4;
+    static constexpr int GL = BM_ / WAVES_ / 8 + BN_ / WAVES_ / 8;  // LDS-DMA instructions per wave per K-step
+    static constexpr int WAVES_PER_SIMD = (160 * 1024 / LDS_BYTES >= 2 ? 2 : 1) * WAVES_ / 4;
+    static_assert(WM * WN == WAVES_ && MI * 16 * WM == BM_ && (MI == 4 || MI == 8), "wave grid");
 };
-typedef Shape<128, 2> S128;
-typedef Shape<256, 3> S256;
+typedef Shape<128, 128, 4, 2> S128;   //  64 KiB LDS, 2 blocks/CU: small grids
+typedef Shape<256, 128, 8, 3> S256;   // 144 KiB, 1 block/CU, 3-stage counted-vmcnt pipeline
+typedef Shape<256, 256, 8, 2> S2x2;   // 128 KiB, 1 block/CU: half the L2->LDS bytes per FLOP of S128
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * (BK * 2) + ((chunk ^ (row & 7)) << 4); }
 
@@ -97,7 +102,6 @@ struct Conv1Tile {
     }
 };
 
-typedef f32x4 Acc[4][4];
 
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 
@@ -106,44 +110,24 @@ __device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) { return __bu
 
 // F16 = true: the staged 16-bit operands are IEEE half (same MFMA rate, 3 more mantissa bits: used by the
 // distance GEMM, whose operands are normalised features); false: bfloat16 (networks).
-template <bool SWAP, bool F16 = false>
-__device__ __forceinline__ void compute_stage(Acc& acc, const char* ta, const char* tw, int wr, int wc, int lane)
+template <class S, bool SWAP, bool F16, class AccT>
+__device__ __forceinline__ void compute_stage(AccT& acc, const char* ta, const char* tw, int wr, int wc, int lane)
 {
-    if constexpr (F16) {
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            f16x8 af[4], wf[4];
-            const int chunk = kk * 4 + (lane >> 4);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                af[i] = *reinterpret_cast<const f16x8*>(ta + lds_off(wr * 64 + i * 16 + (lane & 15), chunk));
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                wf[j] = *reinterpret_cast<const f16x8*>(tw + lds_off(wc * 64 + j * 16 + (lane & 15), chunk));
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = SWAP ? mfma16(wf[j], af[i], acc[i][j]) : mfma16(af[i], wf[j], acc[i][j]);
-        }
-        return;
-    }
+    using frag = typename std::conditional<F16, f16x8, bf16x8>::type;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-        bf16x8 af[4], wf[4];
+        frag af[S::MI], wf[4];
         const int chunk = kk * 4 + (lane >> 4);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            af[i] = *reinterpret_cast<const bf16x8*>(ta + lds_off(wr * 64 + i * 16 + (lane & 15), chunk));
+        for (int i = 0; i < S::MI; ++i)
+            af[i] = *reinterpret_cast<const frag*>(ta + lds_off(wr * (S::MI * 16) + i * 16 + (lane & 15), chunk));
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            wf[j] = *reinterpret_cast<const bf16x8*>(tw + lds_off(wc * 64 + j * 16 + (lane & 15), chunk));
+            wf[j] = *reinterpret_cast<const frag*>(tw + lds_off(wc * 64 + j * 16 + (lane & 15), chunk));
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < S::MI; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (SWAP) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
-                else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], wf[j], acc[i][j], 0, 0, 0);
-            }
+            for (int j = 0; j < 4; ++j) acc[i][j] = SWAP ? mfma16(wf[j], af[i], acc[i][j]) : mfma16(af[i], wf[j], acc[i][j]);
     }
 }
 
@@ -162,7 +146,7 @@ __device__ __forceinline__ void block_barrier()
     __builtin_amdgcn_s_barrier();
 }
 
-// Runs n_tiles consecutive 128-wide N tiles (starting at tile index nt0) against the block's M tile, over
+// Runs n_tiles consecutive BN-wide N tiles (starting at tile index nt0) against the block's M tile, over
 // K-steps [kt_begin, kt_begin + KT).  epi(acc, nt) is called once per finished N tile.
 template <class S, bool SWAP, bool F16 = false, class ALoader, class WLoader, class Epi>
 __device__ __forceinline__ void run(const ALoader& A, const WLoader& W, int m0, int nt0, int n_tiles, int KT,
@@ -170,10 +154,11 @@ __device__ __forceinline__ void run(const ALoader& A, const WLoader& W, int m0, 
 {
     constexpr int BM = S::BM, ST = S::STAGES, AHEAD = ST - 1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
-    Acc acc;
+    constexpr int BN = S::BN;
+    const int wr = wave / S::WN, wc = wave % S::WN;
+    f32x4 acc[S::MI][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < S::MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -197,11 +182,11 @@ __device__ __forceinline__ void run(const ALoader& A, const WLoader& W, int m0, 
         const char* cur = lds + slot * S::STAGE_BYTES;
         const bool more = it + AHEAD < total;
         if (more) stage_next(slot_s);  // that stage was last read in step it-1, which every wave has left
-        compute_stage<SWAP, F16>(acc, cur, cur + BM * BK * 2, wr, wc, lane);
+        compute_stage<S, SWAP, F16>(acc, cur, cur + BM * BK * 2, wr, wc, lane);
         if (kt == KT - 1) {
             epi(acc, nt);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < S::MI; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         }

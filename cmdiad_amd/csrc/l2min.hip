@@ -30,6 +30,7 @@ template <class S, bool F16>
 __global__ __launch_bounds__(S::THREADS, S::WAVES_PER_SIMD) void l2_min_kernel(GlobalTile A, GlobalTile W, L2Params p)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr int MI = S::MI;
     const int wg = xcd_remap(blockIdx.x, gridDim.x);
     const int split = wg / p.nq_tiles, qt = wg % p.nq_tiles;  // same split -> same XCD neighbourhood
     const int per = (p.n_bank_tiles + p.splits - 1) / p.splits;
@@ -38,27 +39,27 @@ __global__ __launch_bounds__(S::THREADS, S::WAVES_PER_SIMD) void l2_min_kernel(G
     if (ntc <= 0) return;
     const int m0 = qt * S::BM;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave / S::WN, wc = wave % S::WN;
 
-    float best[4], qn[4];
-    int besti[4];
+    float best[MI], qn[MI];
+    int besti[MI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < MI; ++i) {
         best[i] = __builtin_inff();
         besti[i] = 0;
-        const int m = m0 + wr * 64 + i * 16 + (lane & 15);
+        const int m = m0 + wr * (MI * 16) + i * 16 + (lane & 15);
         qn[i] = m < p.Q ? p.q_sqnorm[m] : 0.0f;
     }
 
-    run<S, true, F16>(A, W, m0, nt0, ntc, p.D / BK, lds, [&](Acc& acc, int ntile) {
+    run<S, true, F16>(A, W, m0, nt0, ntc, p.D / BK, lds, [&](auto& acc, int ntile) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int n = ntile * BN + wc * 64 + j * 16 + (lane >> 4) * 4;
+            const int n = ntile * S::BN + wc * 64 + j * 16 + (lane >> 4) * 4;
             float bn[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) bn[r] = n + r < p.Nb ? p.b_sqnorm[n + r] : __builtin_inff();
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float d2 = (qn[i] + bn[r]) - 2.0f * acc[i][j][r];
@@ -68,14 +69,14 @@ __global__ __launch_bounds__(S::THREADS, S::WAVES_PER_SIMD) void l2_min_kernel(G
     });
 
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < MI; ++i) {
         unsigned long long key = pack_key(fmaxf(best[i], 0.0f), p.row_offset + (unsigned)besti[i]);
         if (!(best[i] < __builtin_inff())) key = ~0ull;
         unsigned long long o = shfl_xor_u64(key, 16);
         key = o < key ? o : key;
         o = shfl_xor_u64(key, 32);
         key = o < key ? o : key;
-        const int m = m0 + wr * 64 + i * 16 + (lane & 15);
+        const int m = m0 + wr * (MI * 16) + i * 16 + (lane & 15);
         if (lane < 16 && m < p.Q) atomicMin(p.keys + m, key);
     }
 }
@@ -124,37 +125,65 @@ __device__ __forceinline__ void top3_insert(unsigned long long (&t)[3], unsigned
     }
 }
 
-__global__ __launch_bounds__(256) void reweight_scan_kernel(const float* __restrict__ probes, const float* __restrict__ bank,
-                                                            int R, int Nb, int D, unsigned row_offset,
-                                                            unsigned long long* __restrict__ partial, int rows_per_block)
+// All R probes are evaluated against a bank row while it sits in registers, so the library is streamed
+// ONCE (Nb*D*4 bytes) whatever R is.  Block = 8 waves; probes live in LDS (R*D*4 <= 96 KiB for R = 32,
+// D = 768); each wave walks rows r0+wave, r0+wave+8, ...; per (row, probe) a 64-lane butterfly reduction
+// gives every lane the squared distance; lane p keeps probe p's current 3rd-best key as the insertion
+// threshold (R <= 64), the per-wave top-3 lists live in LDS and are touched only on an insertion.
+constexpr int kScanWaves = 8;
+constexpr int kMaxProbes = 64;
+
+template <int D4>  // D4 = float4 chunks per lane = D / 256
+__global__ __launch_bounds__(kScanWaves * 64) void reweight_scan_kernel(const float* __restrict__ probes,
+                                                                        const float* __restrict__ bank, int R, int Nb,
+                                                                        unsigned row_offset,
+                                                                        unsigned long long* __restrict__ partial,
+                                                                        int rows_per_block)
 {
-    __shared__ unsigned long long s_top[4][3];
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int D = D4 * 256;
+    float* s_probe = reinterpret_cast<float*>(smem);                                            // [R][D]
+    unsigned long long* s_top = reinterpret_cast<unsigned long long*>(smem + (size_t)R * D * 4);  // [waves][R][3]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int i = threadIdx.x * 4; i < R * D; i += kScanWaves * 64 * 4)
+        *reinterpret_cast<float4*>(s_probe + i) = *reinterpret_cast<const float4*>(probes + i);
+    for (int i = threadIdx.x; i < kScanWaves * R * 3; i += kScanWaves * 64) s_top[i] = ~0ull;
+    __syncthreads();
+    unsigned long long thr = ~0ull;  // lane p: 3rd-best key of probe p in THIS wave
+    unsigned long long* my_top = s_top + (size_t)wave * R * 3;
     const int r0 = blockIdx.x * rows_per_block;
     const int r1 = min(r0 + rows_per_block, Nb);
-    const int pr = blockIdx.y;  // probe handled by this block column
-    unsigned long long t[3] = {~0ull, ~0ull, ~0ull};
-    const float* a = probes + (size_t)pr * D;
-    for (int row = r0 + wave; row < r1; row += 4) {
-        const float* b = bank + (size_t)row * D;
-        float s = 0.0f;
-        for (int c = lane * 4; c < D; c += 256) {
-            const float4 x = *reinterpret_cast<const float4*>(a + c);
-            const float4 y = *reinterpret_cast<const float4*>(b + c);
-            const float d0 = x.x - y.x, d1 = x.y - y.y, d2 = x.z - y.z, d3 = x.w - y.w;
-            s += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
-        }
+    for (int row = r0 + wave; row < r1; row += kScanWaves) {
+        float4 b[D4];
 #pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
-        top3_insert(t, pack_key(s, row_offset + (unsigned)row));
+        for (int c = 0; c < D4; ++c) b[c] = *reinterpret_cast<const float4*>(bank + (size_t)row * D + c * 256 + lane * 4);
+        for (int p = 0; p < R; ++p) {
+            const float* a = s_probe + p * D;
+            float s = 0.0f;
+#pragma unroll
+            for (int c = 0; c < D4; ++c) {
+                const float4 x = *reinterpret_cast<const float4*>(a + c * 256 + lane * 4);
+                const float d0 = x.x - b[c].x, d1 = x.y - b[c].y, d2 = x.z - b[c].z, d3 = x.w - b[c].w;
+                s += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+            }
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+            const unsigned long long key = pack_key(s, row_offset + (unsigned)row);
+            const unsigned long long tp = ((unsigned long long)__shfl((unsigned)(thr >> 32), p, 64) << 32) | __shfl((unsigned)thr, p, 64);
+            if (key < tp) {  // wave-uniform: rare after the first rows
+                unsigned long long t3[3] = {my_top[p * 3], my_top[p * 3 + 1], my_top[p * 3 + 2]};
+                top3_insert(t3, key);
+                if (lane == 0) { my_top[p * 3] = t3[0]; my_top[p * 3 + 1] = t3[1]; my_top[p * 3 + 2] = t3[2]; }
+                if (lane == p) thr = t3[2];
+            }
+        }
     }
-    if (lane == 0) { s_top[wave][0] = t[0]; s_top[wave][1] = t[1]; s_top[wave][2] = t[2]; }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    for (int p = threadIdx.x; p < R; p += kScanWaves * 64) {
         unsigned long long m[3] = {~0ull, ~0ull, ~0ull};
-        for (int w = 0; w < 4; ++w)
-            for (int k = 0; k < 3; ++k) top3_insert(m, s_top[w][k]);
-        unsigned long long* o = partial + ((size_t)pr * gridDim.x + blockIdx.x) * 3;
+        for (int w = 0; w < kScanWaves; ++w)
+            for (int k = 0; k < 3; ++k) top3_insert(m, s_top[((size_t)w * R + p) * 3 + k]);
+        unsigned long long* o = partial + ((size_t)p * gridDim.x + blockIdx.x) * 3;
         o[0] = m[0]; o[1] = m[1]; o[2] = m[2];
     }
 }
@@ -298,10 +327,10 @@ int launch_l2(const uint16_t* q, const float* q_sqnorm, const uint16_t* bank, co
         }
         attr = true;
     }
-    const int nq = (Q + S::BM - 1) / S::BM, nbt = (Nb + BN - 1) / BN;
+    const int nq = (Q + S::BM - 1) / S::BM, nbt = (Nb + S::BN - 1) / S::BN;
     // enough blocks to fill the chip a few times over, but long bank ranges per block so the running
     // min stays in registers and the per-block atomics stay negligible
-    int splits = (1024 * (S::BM == 256 ? 1 : 2) + nq - 1) / nq;
+    int splits = (1024 * (S::BM == 256 ? 1 : 2) + nq - 1) / nq;  // ~4 (2) resident generations of blocks
     splits = splits < 1 ? 1 : (splits > nbt ? nbt : splits);
     if (splits > 8) splits = 8;
     GlobalTile A{(const bf16_t*)q, D, Q}, W{(const bf16_t*)bank, D, Nb};
@@ -319,14 +348,16 @@ extern "C" int cmdiad_l2_min_keys(const uint16_t* q, const float* q_sqnorm, cons
     CMDIAD_REQUIRE(aligned16(q) && aligned16(bank), CMDIAD_ERR_ARG, "cmdiad_l2_min_keys: 16-byte alignment");
     CMDIAD_REQUIRE(dtype == CMDIAD_DT_BF16 || dtype == CMDIAD_DT_F16, CMDIAD_ERR_ARG, "cmdiad_l2_min_keys: dtype");
     if (Q == 0 || Nb == 0) return CMDIAD_OK;
-    static const int force = getenv("CMDIAD_GEMM_TILE") ? atoi(getenv("CMDIAD_GEMM_TILE")) : 0;
-    const bool big = force == 256 || (force != 128 && Q >= 256 * 64);
+    static const int force = getenv("CMDIAD_GEMM_TILE") ? atoi(getenv("CMDIAD_GEMM_TILE")) : -1;
+    const int tile = force >= 0 ? force : (Q >= 256 * 64 ? 2 : 0);  // 0 S128, 1 S256 (256x128x3), 2 S2x2 (256x256)
     hipStream_t s = (hipStream_t)stream;
+    const bool h = dtype == CMDIAD_DT_F16;
     int rc;
-    if (big) rc = dtype == CMDIAD_DT_F16 ? launch_l2<S256, true>(q, q_sqnorm, bank, bank_sqnorm, Q, Nb, D, row_offset, keys, s)
-                                         : launch_l2<S256, false>(q, q_sqnorm, bank, bank_sqnorm, Q, Nb, D, row_offset, keys, s);
-    else rc = dtype == CMDIAD_DT_F16 ? launch_l2<S128, true>(q, q_sqnorm, bank, bank_sqnorm, Q, Nb, D, row_offset, keys, s)
-                                     : launch_l2<S128, false>(q, q_sqnorm, bank, bank_sqnorm, Q, Nb, D, row_offset, keys, s);
+#define L2_ARGS q, q_sqnorm, bank, bank_sqnorm, Q, Nb, D, row_offset, keys, s
+    if (tile == 2) rc = h ? launch_l2<S2x2, true>(L2_ARGS) : launch_l2<S2x2, false>(L2_ARGS);
+    else if (tile == 1) rc = h ? launch_l2<S256, true>(L2_ARGS) : launch_l2<S256, false>(L2_ARGS);
+    else rc = h ? launch_l2<S128, true>(L2_ARGS) : launch_l2<S128, false>(L2_ARGS);
+#undef L2_ARGS
     if (rc) return rc;
     CMDIAD_CHECK_LAUNCH();
     return CMDIAD_OK;
@@ -344,11 +375,30 @@ extern "C" int cmdiad_l2_rescore(const float* q, const float* bank, const unsign
     return CMDIAD_OK;
 }
 
+constexpr int kScanRowsPerBlock = 152;  // ~2 blocks of work per CU for the bagel-sized xyz library
+
 extern "C" size_t cmdiad_reweight_workspace_bytes(int R, int Nb)
 {
-    const int rows_per_block = 256;
-    const int nblocks = (Nb + rows_per_block - 1) / rows_per_block;
+    const int nblocks = (Nb + kScanRowsPerBlock - 1) / kScanRowsPerBlock;
     return (size_t)R * nblocks * 3 * sizeof(unsigned long long);
+}
+
+template <int D4>
+int launch_scan(const float* probes, const float* bank, int R, int Nb, uint32_t row_offset, unsigned long long* ws,
+                int nblocks, hipStream_t s)
+{
+    const size_t lds = (size_t)R * D4 * 256 * 4 + (size_t)kScanWaves * R * 3 * 8;
+    static size_t attr = 0;
+    if (lds > attr) {
+        if (hipFuncSetAttribute((const void*)reweight_scan_kernel<D4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            cmdiad_set_error("cmdiad_reweight_scan: %zu bytes of LDS exceed the device limit (R too large for D)", lds);
+            return CMDIAD_ERR_ARG;
+        }
+        attr = lds;
+    }
+    hipLaunchKernelGGL(reweight_scan_kernel<D4>, dim3(nblocks), dim3(kScanWaves * 64), lds, s, probes, bank, R, Nb, row_offset, ws,
+                       kScanRowsPerBlock);
+    return CMDIAD_OK;
 }
 
 extern "C" int cmdiad_reweight_scan(const float* probes, const float* bank, int R, int Nb, int D, uint32_t row_offset,
@@ -356,18 +406,26 @@ extern "C" int cmdiad_reweight_scan(const float* probes, const float* bank, int 
                                     cmdiad_stream_t stream)
 {
     CMDIAD_REQUIRE(probes && bank && top3, CMDIAD_ERR_ARG, "cmdiad_reweight_scan: null pointer");
-    CMDIAD_REQUIRE(R > 0 && D % 4 == 0 && aligned16(probes) && aligned16(bank), CMDIAD_ERR_ARG,
-                   "cmdiad_reweight_scan: R>0, D%%4==0, 16-byte alignment");
+    CMDIAD_REQUIRE(R > 0 && R <= kMaxProbes && D % 256 == 0 && D <= 1024 && aligned16(probes) && aligned16(bank), CMDIAD_ERR_ARG,
+                   "cmdiad_reweight_scan: 0<R<=64, D%%256==0, D<=1024, 16-byte alignment (R=%d D=%d)", R, D);
+    CMDIAD_REQUIRE((size_t)R * D * 4 + (size_t)kScanWaves * R * 24 <= 160 * 1024, CMDIAD_ERR_ARG,
+                   "cmdiad_reweight_scan: R*D too large for LDS; split the probes (R=%d D=%d)", R, D);
     if (Nb == 0) return CMDIAD_OK;
     CMDIAD_REQUIRE(workspace && workspace_bytes >= cmdiad_reweight_workspace_bytes(R, Nb), CMDIAD_ERR_WORKSPACE,
                    "cmdiad_reweight_scan: workspace too small");
-    const int rows_per_block = 256;
-    const int nblocks = (Nb + rows_per_block - 1) / rows_per_block;
-    hipLaunchKernelGGL(reweight_scan_kernel, dim3(nblocks, R), dim3(256), 0, (hipStream_t)stream, probes, bank, R, Nb, D,
-                       row_offset, (unsigned long long*)workspace, rows_per_block);
+    const int nblocks = (Nb + kScanRowsPerBlock - 1) / kScanRowsPerBlock;
+    hipStream_t s = (hipStream_t)stream;
+    unsigned long long* ws = (unsigned long long*)workspace;
+    int rc;
+    switch (D / 256) {
+        case 1: rc = launch_scan<1>(probes, bank, R, Nb, row_offset, ws, nblocks, s); break;
+        case 2: rc = launch_scan<2>(probes, bank, R, Nb, row_offset, ws, nblocks, s); break;
+        case 3: rc = launch_scan<3>(probes, bank, R, Nb, row_offset, ws, nblocks, s); break;
+        default: rc = launch_scan<4>(probes, bank, R, Nb, row_offset, ws, nblocks, s); break;
+    }
+    if (rc) return rc;
     CMDIAD_CHECK_LAUNCH();
-    hipLaunchKernelGGL(reweight_merge_kernel, dim3(R), dim3(64), 0, (hipStream_t)stream,
-                       (const unsigned long long*)workspace, R, nblocks, top3);
+    hipLaunchKernelGGL(reweight_merge_kernel, dim3(R), dim3(64), 0, s, (const unsigned long long*)workspace, R, nblocks, top3);
     CMDIAD_CHECK_LAUNCH();
     return CMDIAD_OK;
 }

@@ -212,14 +212,17 @@ def l2_rescore(q32, bank32, keys, min_val=None, min_idx=None, row_offset=0):
 
 
 def reweight_scan(probes, bank32, top3=None, row_offset=0):
-    """probes [R,D] f32 -> top3 [R,3] packed keys (int64 view of u64)."""
+    """probes [R,D] f32 -> top3 [R,3] packed keys (int64 view of u64).  One pass over the bank per 32 probes."""
     R, D = probes.shape
     Nb = bank32.shape[0]
     if top3 is None:
         top3 = torch.full((R, 3), -1, dtype=torch.int64, device=probes.device)
-    wsb = nat.lib().cmdiad_reweight_workspace_bytes(R, Nb)
-    ws = torch.empty(max(wsb // 8, 1), dtype=torch.int64, device=probes.device)
-    _call("cmdiad_reweight_scan", _p(probes), _p(bank32), R, Nb, D, row_offset, _p(top3), _p(ws), wsb, _stream())
+    for lo in range(0, R, 32):
+        r = min(32, R - lo)
+        wsb = nat.lib().cmdiad_reweight_workspace_bytes(r, Nb)
+        ws = torch.empty(max(wsb // 8, 1), dtype=torch.int64, device=probes.device)
+        _call("cmdiad_reweight_scan", _p(probes[lo:lo + r]), _p(bank32), r, Nb, D, row_offset, _p(top3[lo:lo + r]), _p(ws),
+              wsb, _stream())
     return top3
 
 

@@ -47,6 +47,24 @@ def main():
         out = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
         ms = timeit(lambda: ops.gemm(A, W, out_bf16=out))
         line(f"gemm vit {nm} {M}x{N}x{K}", ms, 2.0 * M * N * K)
+    if os.environ.get("MB_ONLY") == "gemm":
+        for (Qi, Nb, nm) in [(3136, 76518, "xyz")]:
+            Q = B * Qi
+            bank = torch.randn(Nb, 768, generator=g).to(DEV)
+            qq = torch.randn(Q, 768, generator=g).to(DEV)
+            b16, b32, bsq = ops.normalize_cast(bank, want_f32=True)
+            q16, q32, qsq = ops.normalize_cast(qq, want_f32=True)
+            keys = ops.new_keys(Q, DEV)
+            ms = timeit(lambda: ops.l2_min_keys(q16, qsq, b16, bsq, keys), iters=3, warm=1)
+            line(f"l2_min_keys {nm} Q={Q} Nb={Nb}", ms, 2.0 * Q * Nb * 768)
+        M2 = B * 1024 * 128
+        for (N, K, nm) in [(512, 256, "enc h3"), (384, 512, "enc out")]:
+            A = torch.randn(M2, K, generator=g).to(DEV).bfloat16()
+            W = torch.randn(N, K, generator=g).to(DEV).bfloat16()
+            out = torch.empty(M2, N, device=DEV, dtype=torch.bfloat16)
+            ms = timeit(lambda: ops.gemm(A, W, out_bf16=out), iters=3, warm=1)
+            line(f"gemm {nm} {M2}x{N}x{K}", ms, 2.0 * M2 * N * K)
+        return
     # ---- attention
     for (T, H, nm) in [(785, 12, "vit"), (1024, 6, "pmae")]:
         Tp = (T + 63) // 64 * 64
