@@ -262,9 +262,8 @@ int pick_tile(long M, long N, int split)
 {
     static const int force = getenv("CMDIAD_GEMM_TILE") ? atoi(getenv("CMDIAD_GEMM_TILE")) : -1;
     if (force >= 0) return force;
-    const long t22 = ((M + 255) / 256) * ((N + 255) / 256) * split;
-    if (t22 >= 224 && N % 256 == 0) return 2;
-    return 0;
+    (void)M; (void)N; (void)split;
+    return 0;  // measured on MI355X (profiles/r1_tile_sweep.md): S128 wins every network GEMM shape; S2x2 only the distance GEMM
 }
 
 // one launcher per kernel instantiation: sets the dynamic-LDS attribute once

@@ -23,7 +23,7 @@ struct L2Params {
     const float* b_sqnorm;
     unsigned row_offset;
     unsigned long long* keys;
-    int nq_tiles, n_bank_tiles, splits;
+    int nq_tiles, n_bank_tiles, splits, qgroup;
 };
 
 template <class S, bool F16>
@@ -32,7 +32,15 @@ __global__ __launch_bounds__(S::THREADS, S::WAVES_PER_SIMD) void l2_min_kernel(G
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int MI = S::MI;
     const int wg = xcd_remap(blockIdx.x, gridDim.x);
-    const int split = wg / p.nq_tiles, qt = wg % p.nq_tiles;  // same split -> same XCD neighbourhood
+    // L2-aware 2-D arrangement: consecutive workgroup ids (= co-resident blocks of one XCD after the remap)
+    // form groups of `qgroup` query tiles x `splits` bank ranges.  Per XCD the L2 then holds a handful of query
+    // tiles (re-read every bank tile) while each streamed bank tile is shared by `qgroup` blocks -- with one
+    // bank range per XCD the 32+ different query tiles (12 MB) thrash the 4 MB L2 and every K-step is fed
+    // from the Infinity Cache instead.
+    const int gsz = p.qgroup * p.splits;
+    const int within = wg % gsz;
+    const int split = within / p.qgroup, qt = (wg / gsz) * p.qgroup + within % p.qgroup;
+    if (qt >= p.nq_tiles) return;
     const int per = (p.n_bank_tiles + p.splits - 1) / p.splits;
     const int nt0 = split * per;
     const int ntc = min(per, p.n_bank_tiles - nt0);
@@ -157,24 +165,35 @@ __global__ __launch_bounds__(kScanWaves * 64) void reweight_scan_kernel(const fl
         float4 b[D4];
 #pragma unroll
         for (int c = 0; c < D4; ++c) b[c] = *reinterpret_cast<const float4*>(bank + (size_t)row * D + c * 256 + lane * 4);
-        for (int p = 0; p < R; ++p) {
-            const float* a = s_probe + p * D;
-            float s = 0.0f;
+        for (int p0 = 0; p0 < R; p0 += 4) {  // 4 probes per pass: four independent reduction chains hide the shuffle latency
+            float s[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int c = 0; c < D4; ++c) {
-                const float4 x = *reinterpret_cast<const float4*>(a + c * 256 + lane * 4);
-                const float d0 = x.x - b[c].x, d1 = x.y - b[c].y, d2 = x.z - b[c].z, d3 = x.w - b[c].w;
-                s += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+            for (int u = 0; u < 4; ++u) {
+                const float* a = s_probe + min(p0 + u, R - 1) * D;
+#pragma unroll
+                for (int c = 0; c < D4; ++c) {
+                    const float4 x = *reinterpret_cast<const float4*>(a + c * 256 + lane * 4);
+                    const float d0 = x.x - b[c].x, d1 = x.y - b[c].y, d2 = x.z - b[c].z, d3 = x.w - b[c].w;
+                    s[u] += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+                }
             }
 #pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
-            const unsigned long long key = pack_key(s, row_offset + (unsigned)row);
-            const unsigned long long tp = ((unsigned long long)__shfl((unsigned)(thr >> 32), p, 64) << 32) | __shfl((unsigned)thr, p, 64);
-            if (key < tp) {  // wave-uniform: rare after the first rows
-                unsigned long long t3[3] = {my_top[p * 3], my_top[p * 3 + 1], my_top[p * 3 + 2]};
-                top3_insert(t3, key);
-                if (lane == 0) { my_top[p * 3] = t3[0]; my_top[p * 3 + 1] = t3[1]; my_top[p * 3 + 2] = t3[2]; }
-                if (lane == p) thr = t3[2];
+            for (int m = 32; m >= 1; m >>= 1) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) s[u] += __shfl_xor(s[u], m, 64);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int p = p0 + u;
+                if (p >= R) break;
+                const unsigned long long key = pack_key(s[u], row_offset + (unsigned)row);
+                const unsigned long long tp = ((unsigned long long)__shfl((unsigned)(thr >> 32), p, 64) << 32) | __shfl((unsigned)thr, p, 64);
+                if (key < tp) {  // wave-uniform: rare after the first rows
+                    unsigned long long t3[3] = {my_top[p * 3], my_top[p * 3 + 1], my_top[p * 3 + 2]};
+                    top3_insert(t3, key);
+                    if (lane == 0) { my_top[p * 3] = t3[0]; my_top[p * 3 + 1] = t3[1]; my_top[p * 3 + 2] = t3[2]; }
+                    if (lane == p) thr = t3[2];
+                }
             }
         }
     }
@@ -330,12 +349,16 @@ int launch_l2(const uint16_t* q, const float* q_sqnorm, const uint16_t* bank, co
     const int nq = (Q + S::BM - 1) / S::BM, nbt = (Nb + S::BN - 1) / S::BN;
     // enough blocks to fill the chip a few times over, but long bank ranges per block so the running
     // min stays in registers and the per-block atomics stay negligible
-    int splits = (1024 * (S::BM == 256 ? 1 : 2) + nq - 1) / nq;  // ~4 (2) resident generations of blocks
-    splits = splits < 1 ? 1 : (splits > nbt ? nbt : splits);
-    if (splits > 8) splits = 8;
+    static const int env_splits = getenv("CMDIAD_L2_SPLITS") ? atoi(getenv("CMDIAD_L2_SPLITS")) : 0;
+    static const int env_qgroup = getenv("CMDIAD_L2_QGROUP") ? atoi(getenv("CMDIAD_L2_QGROUP")) : 0;
+    int splits = env_splits > 0 ? env_splits : 8;
+    splits = splits > nbt ? nbt : splits;
+    int qgroup = env_qgroup > 0 ? env_qgroup : 4;
+    qgroup = qgroup > nq ? nq : qgroup;
     GlobalTile A{(const bf16_t*)q, D, Q}, W{(const bf16_t*)bank, D, Nb};
-    L2Params p{Q, Nb, D, q_sqnorm, bank_sqnorm, row_offset, keys, nq, nbt, splits};
-    hipLaunchKernelGGL((l2_min_kernel<S, F16>), dim3(nq * splits), dim3(S::THREADS), S::LDS_BYTES, stream, A, W, p);
+    L2Params p{Q, Nb, D, q_sqnorm, bank_sqnorm, row_offset, keys, nq, nbt, splits, qgroup};
+    const int ngroups = (nq + qgroup - 1) / qgroup;
+    hipLaunchKernelGGL((l2_min_kernel<S, F16>), dim3(ngroups * qgroup * splits), dim3(S::THREADS), S::LDS_BYTES, stream, A, W, p);
     return CMDIAD_OK;
 }
 
@@ -375,10 +398,17 @@ extern "C" int cmdiad_l2_rescore(const float* q, const float* bank, const unsign
     return CMDIAD_OK;
 }
 
-constexpr int kScanRowsPerBlock = 152;  // ~2 blocks of work per CU for the bagel-sized xyz library
+// rows per block: ~3 blocks of work per CU whatever the library size (each block re-loads the probes into LDS)
+static int scan_rows_per_block(int Nb)
+{
+    int r = (Nb + 767) / 768;
+    r = (r + 7) / 8 * 8;
+    return r < 16 ? 16 : r;
+}
 
 extern "C" size_t cmdiad_reweight_workspace_bytes(int R, int Nb)
 {
+    const int kScanRowsPerBlock = scan_rows_per_block(Nb);
     const int nblocks = (Nb + kScanRowsPerBlock - 1) / kScanRowsPerBlock;
     return (size_t)R * nblocks * 3 * sizeof(unsigned long long);
 }
@@ -387,6 +417,7 @@ template <int D4>
 int launch_scan(const float* probes, const float* bank, int R, int Nb, uint32_t row_offset, unsigned long long* ws,
                 int nblocks, hipStream_t s)
 {
+    const int kScanRowsPerBlock = scan_rows_per_block(Nb);
     const size_t lds = (size_t)R * D4 * 256 * 4 + (size_t)kScanWaves * R * 3 * 8;
     static size_t attr = 0;
     if (lds > attr) {
@@ -413,7 +444,7 @@ extern "C" int cmdiad_reweight_scan(const float* probes, const float* bank, int 
     if (Nb == 0) return CMDIAD_OK;
     CMDIAD_REQUIRE(workspace && workspace_bytes >= cmdiad_reweight_workspace_bytes(R, Nb), CMDIAD_ERR_WORKSPACE,
                    "cmdiad_reweight_scan: workspace too small");
-    const int nblocks = (Nb + kScanRowsPerBlock - 1) / kScanRowsPerBlock;
+    const int nblocks = (Nb + scan_rows_per_block(Nb) - 1) / scan_rows_per_block(Nb);
     hipStream_t s = (hipStream_t)stream;
     unsigned long long* ws = (unsigned long long*)workspace;
     int rc;
