@@ -257,11 +257,14 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     group = None
-    if world > 1:
+    force_dist = os.environ.get("CMDIAD_FORCE_DIST", "0") == "1"  # exercise the RCCL path on a single GPU
+    if world > 1 or force_dist:
         import torch.distributed as td
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29571", RANK="0", WORLD_SIZE="1")
         td.init_process_group("nccl", device_id=dev)
         group = td.group.WORLD
-    sharded = world > 1 and os.environ.get("CMDIAD_BANK", "sharded") == "sharded"
+    sharded = (world > 1 or force_dist) and os.environ.get("CMDIAD_BANK", "sharded") == "sharded"
 
     st = build_state(dev, rank if sharded else 0, world if sharded else 1)
     timers = {"xyz": Timer(), "rgb": Timer()}
@@ -285,17 +288,17 @@ def main():
     run(args.warmup)
     for t in timers.values():
         t.pairs.clear()
-    if world > 1:
+    if group is not None:
         td.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     res = run(args.steps)
     torch.cuda.synchronize()
-    if world > 1:
+    if group is not None:
         td.barrier()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
+    if group is not None:
         td.all_reduce(tmax, op=td.ReduceOp.MAX)
     dt = float(tmax.item())
     assert all(np.isfinite(r[0]).all() and np.isfinite(r[1]).all() for r in res)
@@ -330,7 +333,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.cpu_images)
         print(json.dumps(out), flush=True)
     pool.shutdown()
-    if world > 1:
+    waiter.shutdown()
+    if group is not None:
         td.destroy_process_group()
 
 

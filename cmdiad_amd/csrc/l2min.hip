@@ -372,7 +372,8 @@ extern "C" int cmdiad_l2_min_keys(const uint16_t* q, const float* q_sqnorm, cons
     CMDIAD_REQUIRE(dtype == CMDIAD_DT_BF16 || dtype == CMDIAD_DT_F16, CMDIAD_ERR_ARG, "cmdiad_l2_min_keys: dtype");
     if (Q == 0 || Nb == 0) return CMDIAD_OK;
     static const int force = getenv("CMDIAD_GEMM_TILE") ? atoi(getenv("CMDIAD_GEMM_TILE")) : -1;
-    const int tile = force >= 0 ? force : (Q >= 256 * 64 ? 2 : 0);  // 0 S128, 1 S256 (256x128x3), 2 S2x2 (256x256)
+    // 0 S128, 1 S256 (256x128x3), 2 S2x2 (256x256): measured 892 / 826 / 942 TFLOP/s on the bagel xyz library
+    const int tile = force >= 0 ? force : (Q >= 256 * 64 ? 2 : 0);
     hipStream_t s = (hipStream_t)stream;
     const bool h = dtype == CMDIAD_DT_F16;
     int rc;

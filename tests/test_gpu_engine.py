@@ -183,3 +183,81 @@ def test_greedy_coreset_matches_fp16_restatement():
         ref.append(i)
         last = zh[i:i + 1]
     np.testing.assert_array_equal(sel.numpy(), np.array(ref))
+
+
+def test_full_protocol_double_rgb_point_vs_oracle(fitted):
+    """cmdiad_runner.py:44-92 end to end for DINO+Point_MAE: late-fusion bank, OCSVM fit, predict, metrics --
+    the drop-in against the CPU oracle driven through the same protocol (same scikit-learn on both sides)."""
+    from sklearn import linear_model
+    cpu, cpu_feats, m, train = fitted
+    # ---- GPU drop-in: pass 2 + late fusion
+    for rgb, pc in train:
+        m.add_sample_to_late_fusion_mem_bank((rgb, pc, pc))
+    m.run_late_fusion()
+    # ---- CPU oracle: the same (multiple_features.py:897-927, features.py:352-358)
+    s_lib, s_map_lib = [], []
+    for rp, xp in cpu_feats:
+        s, s_map, _, _ = cpu.score(rp, xp)
+        s_lib.append(s)
+        s_map_lib.append(s_map)
+    det = linear_model.SGDOneClassSVM(random_state=42, nu=0.5, max_iter=1000).fit(torch.cat(s_lib, 0))
+    seg = linear_model.SGDOneClassSVM(random_state=42, nu=0.5, max_iter=1000).fit(torch.cat(s_map_lib, 0))
+    tests = [(30, False), (31, True), (32, False), (33, True)]
+    ref_img, ref_pix = [], []
+    for i, anomalous in tests:
+        rgb, pc = synth_sample(i, anomalous)
+        mask = torch.zeros(1, 1, 224, 224)
+        if anomalous:
+            mask[..., 100:120, 100:120] = 1
+        m.predict((rgb, pc, pc), mask, np.array([int(anomalous)]), [f"synth/{i}.png"])
+        s, s_map, _, _ = cpu.predict(rgb, pc)
+        ref_img.append(det.score_samples(s))
+        ref_pix.append(seg.score_samples(s_map))
+    m.calculate_metrics()
+    got_img = np.concatenate(m.image_preds).ravel()
+    ref_img = np.concatenate(ref_img).ravel()
+    assert np.isfinite([m.image_rocauc, m.pixel_rocauc, m.au_pro, m.au_pro_001]).all()
+    # the planted RGB anomaly (+2 sigma patch) dominates the image score on both sides: same ranking
+    assert list(np.argsort(got_img)) == list(np.argsort(ref_img)), (got_img, ref_img)
+    from sklearn.metrics import roc_auc_score
+    labels = np.array([int(a) for _, a in tests])
+    assert roc_auc_score(labels, got_img) == roc_auc_score(labels, ref_img)
+    ref_pix_auc = roc_auc_score(np.array(m.pixel_labels).astype(int), np.concatenate(ref_pix))
+    assert abs(m.pixel_rocauc - ref_pix_auc) < 0.03, (m.pixel_rocauc, ref_pix_auc)
+
+
+def test_other_method_classes_run_the_protocol(weights):
+    """RGBFeatures, PointFeatures (with the greedy coreset, f_coreset = 0.5) and the FtoF hallucination class
+    run fit + late fusion + predict + metrics on the GPU path and produce finite, well-formed results."""
+    import warnings
+    from cmdiad_amd.feature_extractors import multiple_features as mf
+    sd_vit, sd_pm = weights
+    train = [synth_sample(40 + i) for i in range(3)]
+    tests = [(50, False), (51, True)]
+    for cls, kw in ((mf.RGBFeatures, {}), (mf.PointFeatures, dict(f_coreset=0.5, random_state=0)),
+                    (mf.RGBorXYZWithOneHallucination, dict(use_hn=True, main_modality='xyz'))):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m = cls(make_args(**kw))
+        m.deep_feature_extractor.rgb_backbone.load_state_dict(sd_vit)
+        m.deep_feature_extractor.xyz_backbone.load_state_dict(sd_pm)
+        if kw.get("use_hn"):
+            m.fusion.load_state_dict(nets.synth_state_dict("halluc", 51))
+        for rgb, pc in train:
+            m.add_sample_to_mem_bank((rgb, pc, pc), class_name="synth")
+        m.run_coreset()
+        if cls is mf.PointFeatures:
+            assert m.patch_xyz_lib.shape == (int(0.5 * 3 * 3136), 768)
+            assert len(set(m.coreset_idx.tolist())) == m.coreset_idx.numel()  # greedy selection never repeats a row
+        for rgb, pc in train:
+            m.add_sample_to_late_fusion_mem_bank((rgb, pc, pc))
+        m.run_late_fusion()
+        for i, anomalous in tests:
+            rgb, pc = synth_sample(i, anomalous)
+            mask = torch.zeros(1, 1, 224, 224)
+            if anomalous:
+                mask[..., 100:120, 100:120] = 1
+            m.predict((rgb, pc, pc), mask, np.array([int(anomalous)]), [f"synth/{i}.png"])
+        m.calculate_metrics()
+        assert np.isfinite([m.image_rocauc, m.pixel_rocauc, m.au_pro]).all(), cls.__name__
+        assert m.predictions[0].shape == (224, 224)
