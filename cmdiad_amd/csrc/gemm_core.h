@@ -114,20 +114,47 @@ template <class S, bool SWAP, bool F16, class AccT>
 __device__ __forceinline__ void compute_stage(AccT& acc, const char* ta, const char* tw, int wr, int wc, int lane)
 {
     using frag = typename std::conditional<F16, f16x8, bf16x8>::type;
+    if constexpr (S::MI == 4) {
+        // all fragment reads of the K-step are issued up front (both 32-deep halves, 64 VGPRs): the second
+        // half's LDS latency hides behind the first half's MFMAs instead of being exposed a second time
+        frag af[2][4], wf[2][4];
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-        frag af[S::MI], wf[4];
-        const int chunk = kk * 4 + (lane >> 4);
+        for (int kk = 0; kk < 2; ++kk) {
+            const int chunk = kk * 4 + (lane >> 4);
 #pragma unroll
-        for (int i = 0; i < S::MI; ++i)
-            af[i] = *reinterpret_cast<const frag*>(ta + lds_off(wr * (S::MI * 16) + i * 16 + (lane & 15), chunk));
+            for (int i = 0; i < 4; ++i)
+                af[kk][i] = *reinterpret_cast<const frag*>(ta + lds_off(wr * 64 + i * 16 + (lane & 15), chunk));
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            wf[j] = *reinterpret_cast<const frag*>(tw + lds_off(wc * 64 + j * 16 + (lane & 15), chunk));
+            for (int j = 0; j < 4; ++j)
+                wf[kk][j] = *reinterpret_cast<const frag*>(tw + lds_off(wc * 64 + j * 16 + (lane & 15), chunk));
+        }
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int i = 0; i < S::MI; ++i)
+        for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = SWAP ? mfma16(wf[j], af[i], acc[i][j]) : mfma16(af[i], wf[j], acc[i][j]);
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = SWAP ? mfma16(wf[kk][j], af[kk][i], acc[i][j]) : mfma16(af[kk][i], wf[kk][j], acc[i][j]);
+        __builtin_amdgcn_s_setprio(0);
+    } else {  // 128 x 64 per wave: 128 accumulator VGPRs leave room for one half's fragments at a time
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            frag af[S::MI], wf[4];
+            const int chunk = kk * 4 + (lane >> 4);
+#pragma unroll
+            for (int i = 0; i < S::MI; ++i)
+                af[i] = *reinterpret_cast<const frag*>(ta + lds_off(wr * (S::MI * 16) + i * 16 + (lane & 15), chunk));
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                wf[j] = *reinterpret_cast<const frag*>(tw + lds_off(wc * 64 + j * 16 + (lane & 15), chunk));
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < S::MI; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = SWAP ? mfma16(wf[j], af[i], acc[i][j]) : mfma16(af[i], wf[j], acc[i][j]);
+            __builtin_amdgcn_s_setprio(0);
+        }
     }
 }
 
