@@ -55,40 +55,35 @@ __device__ __forceinline__ int lds_off(int row, int chunk) { return row * (BK * 
 // per-lane SOURCE address (logical chunk = (l&7) ^ (row&7), guide rule 21) and the same XOR is applied
 // by the fragment reads.
 struct GlobalTile {
-    static constexpr bool kDma = true;
     const bf16_t* base;
     int ld;    // elements
     int rows;  // rows beyond are clamped (their results are masked by the epilogue)
-    // one LDS-DMA wave-instruction: piece j (0 .. ROWS/WAVES/8 - 1) of this wave's share of the tile
     template <int ROWS, int WAVES>
-    __device__ __forceinline__ void piece(char* tile, int row0, int k0, int lane, int wave, int j) const
+    __device__ __forceinline__ void stage(char* tile, int row0, int k0, int tid) const
     {
+        const int lane = tid & 63, wave = tid >> 6;
         constexpr int PER_WAVE = ROWS / WAVES;
-        const int r = wave * PER_WAVE + j * 8 + (lane >> 3);      // row within the tile
-        const int row = min(row0 + r, rows - 1);
-        const int chunk = (lane & 7) ^ (r & 7);                   // logical chunk stored at physical l&7
-        const bf16_t* src = base + (size_t)row * ld + k0 + chunk * 8;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(tile + (wave * PER_WAVE + j * 8) * (BK * 2)),
-                                         16, 0, 0);
-    }
-    template <int ROWS, int WAVES>
-    __device__ __forceinline__ void stage(char* tile, int row0, int k0, int tid, int wave) const
-    {
 #pragma unroll
-        for (int j = 0; j < ROWS / WAVES / 8; ++j) piece<ROWS, WAVES>(tile, row0, k0, tid & 63, wave, j);
+        for (int j = 0; j < PER_WAVE / 8; ++j) {
+            const int r = wave * PER_WAVE + j * 8 + (lane >> 3);      // row within the tile
+            const int row = min(row0 + r, rows - 1);
+            const int chunk = (lane & 7) ^ (r & 7);                   // logical chunk stored at physical l&7
+            const bf16_t* src = base + (size_t)row * ld + k0 + chunk * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(tile + (wave * PER_WAVE + j * 8) * (BK * 2)),
+                                             16, 0, 0);
+        }
     }
 };
 
 // Point-MAE first conv (3 -> 128, BN folded, ReLU) evaluated while staging: models/models.py:188-190.
 // Computed values go through registers and ds_write_b128 (thread t: rows (t>>3) + (THREADS/8) i, chunk t&7).
 struct Conv1Tile {
-    static constexpr bool kDma = false;
     const float* neigh;  // [rows,3]
     const float4* wb;    // [128] = {w_x, w_y, w_z, b} with BatchNorm folded in
     int rows;
     template <int ROWS, int WAVES>
-    __device__ __forceinline__ void stage(char* tile, int row0, int k0, int tid, int /*wave*/) const
+    __device__ __forceinline__ void stage(char* tile, int row0, int k0, int tid) const
     {
         constexpr int STEP = WAVES * 8;  // rows covered per pass
         float4 w[8];
@@ -115,34 +110,13 @@ __device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) { return __bu
 
 // F16 = true: the staged 16-bit operands are IEEE half (same MFMA rate, 3 more mantissa bits: used by the
 // distance GEMM, whose operands are normalised features); false: bfloat16 (networks).
-// One K-step of MFMAs with the LDS-DMA pieces of a later K-step interleaved between the MFMA groups
-// (issue(p) launches piece p, 0 <= p < NP): an LDS-DMA costs ~100 issue cycles (M0 setup, address math);
-// issued in a burst at the top of the step they stall the wave for as long as its MFMAs take, spread
-// between MFMA groups they hide under the matrix pipe (guide: "the per-phase interleave is the lever").
-template <class S, bool SWAP, bool F16, int NP, class AccT, class Issue>
-__device__ __forceinline__ void compute_stage(AccT& acc, const char* ta, const char* tw, int wr, int wc, int lane,
-                                              Issue&& issue)
+template <class S, bool SWAP, bool F16, class AccT>
+__device__ __forceinline__ void compute_stage(AccT& acc, const char* ta, const char* tw, int wr, int wc, int lane)
 {
     using frag = typename std::conditional<F16, f16x8, bf16x8>::type;
-    constexpr int MI = S::MI;
-    constexpr int GROUPS = 8;                       // MFMA groups per K-step
-    constexpr int PER = (2 * MI * 4) / GROUPS;      // MFMAs per group: 4 (MI=4) or 8 (MI=8)
-    auto mfma_range = [&](const frag (&af)[MI], const frag (&wf)[4], int g0, int g1) {
-#pragma unroll
-        for (int g = g0; g < g1; ++g) {
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int t = 0; t < PER; ++t) {
-                const int idx = (g - g0) * PER + t, i = idx / 4, j = idx % 4;
-                acc[i][j] = SWAP ? mfma16(wf[j], af[i], acc[i][j]) : mfma16(af[i], wf[j], acc[i][j]);
-            }
-            __builtin_amdgcn_s_setprio(0);
-            if (g < NP) issue(g);
-        }
-    };
-    if constexpr (MI == 4) {
-        // all fragment reads of the K-step up front (both 32-deep halves, 64 VGPRs): the second half's LDS
-        // latency hides behind the first half's MFMAs instead of being exposed a second time
+    if constexpr (S::MI == 4) {
+        // all fragment reads of the K-step are issued up front (both 32-deep halves, 64 VGPRs): the second
+        // half's LDS latency hides behind the first half's MFMAs instead of being exposed a second time
         frag af[2][4], wf[2][4];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -154,24 +128,34 @@ __device__ __forceinline__ void compute_stage(AccT& acc, const char* ta, const c
             for (int j = 0; j < 4; ++j)
                 wf[kk][j] = *reinterpret_cast<const frag*>(tw + lds_off(wc * 64 + j * 16 + (lane & 15), chunk));
         }
-        mfma_range(af[0], wf[0], 0, 4);
-        mfma_range(af[1], wf[1], 4, 8);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = SWAP ? mfma16(wf[kk][j], af[kk][i], acc[i][j]) : mfma16(af[kk][i], wf[kk][j], acc[i][j]);
+        __builtin_amdgcn_s_setprio(0);
     } else {  // 128 x 64 per wave: 128 accumulator VGPRs leave room for one half's fragments at a time
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            frag af[MI], wf[4];
+            frag af[S::MI], wf[4];
             const int chunk = kk * 4 + (lane >> 4);
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
-                af[i] = *reinterpret_cast<const frag*>(ta + lds_off(wr * (MI * 16) + i * 16 + (lane & 15), chunk));
+            for (int i = 0; i < S::MI; ++i)
+                af[i] = *reinterpret_cast<const frag*>(ta + lds_off(wr * (S::MI * 16) + i * 16 + (lane & 15), chunk));
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 wf[j] = *reinterpret_cast<const frag*>(tw + lds_off(wc * 64 + j * 16 + (lane & 15), chunk));
-            mfma_range(af, wf, kk * 4, kk * 4 + 4);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < S::MI; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = SWAP ? mfma16(wf[j], af[i], acc[i][j]) : mfma16(af[i], wf[j], acc[i][j]);
+            __builtin_amdgcn_s_setprio(0);
         }
     }
-#pragma unroll
-    for (int p = GROUPS; p < NP; ++p) issue(p);  // (NP <= 8 for every Shape; kept for safety)
 }
 
 template <int N>
@@ -196,8 +180,9 @@ __device__ __forceinline__ void run(const ALoader& A, const WLoader& W, int m0, 
                                     char* lds, Epi&& epi, int kt_begin = 0)
 {
     constexpr int BM = S::BM, ST = S::STAGES, AHEAD = ST - 1;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: LDS-DMA bases stay in SGPRs
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // (tried and measured slower on MI355X, profiles/r1_notes.md: spreading the LDS-DMA pieces between MFMA
+    //  groups -- 735 -> 650 TFLOP/s on the ViT qkv shape -- and a 3-stage counted-vmcnt pipeline at 256x128)
     constexpr int BN = S::BN;
     const int wr = wave / S::WN, wc = wave % S::WN;
     f32x4 acc[S::MI][4];
@@ -208,19 +193,16 @@ __device__ __forceinline__ void run(const ALoader& A, const WLoader& W, int m0, 
 
     const int total = n_tiles * KT;
     int kt_s = 0, nt_s = nt0;  // coordinates of the next K-step to STAGE
-    constexpr int PA = ALoader::kDma ? BM / S::WAVES / 8 : 0;   // LDS-DMA pieces per wave: A, W
-    constexpr int PW = BN / S::WAVES / 8;
-    auto stage_whole = [&](int slot) {
+    auto stage_next = [&](int slot) {
         char* buf = lds + slot * S::STAGE_BYTES;
-        A.template stage<BM, S::WAVES>(buf, m0, (kt_begin + kt_s) * BK, tid, wave);
-        W.template stage<BN, S::WAVES>(buf + BM * BK * 2, nt_s * BN, (kt_begin + kt_s) * BK, tid, wave);
+        A.template stage<BM, S::WAVES>(buf, m0, (kt_begin + kt_s) * BK, tid);
+        W.template stage<BN, S::WAVES>(buf + BM * BK * 2, nt_s * BN, (kt_begin + kt_s) * BK, tid);
         if (++kt_s == KT) { kt_s = 0; ++nt_s; }
     };
-    stage_whole(0);
+    stage_next(0);
     if (AHEAD == 2 && total >= 2) {
-        stage_whole(1);
-        if constexpr (ALoader::kDma) wait_vmcnt<S::GL>();  // step 0 landed, step 1 may still be in flight
-        else wait_vmcnt<0>();                              // (register-staged A: its plain loads share vmcnt)
+        stage_next(1);
+        wait_vmcnt<S::GL>();  // step 0 landed, step 1 may still be in flight
     } else wait_vmcnt<0>();
     block_barrier();
 
@@ -228,20 +210,8 @@ __device__ __forceinline__ void run(const ALoader& A, const WLoader& W, int m0, 
     for (int it = 0; it < total; ++it) {
         const char* cur = lds + slot * S::STAGE_BYTES;
         const bool more = it + AHEAD < total;
-        // the stage being refilled was last read in step it-1, which every wave has left
-        char* nbuf = lds + slot_s * S::STAGE_BYTES;
-        const int k0_s = (kt_begin + kt_s) * BK, n0_s = nt_s * BN;
-        if constexpr (!ALoader::kDma) {
-            if (more) A.template stage<BM, S::WAVES>(nbuf, m0, k0_s, tid, wave);
-        }
-        compute_stage<S, SWAP, F16, PA + PW>(acc, cur, cur + BM * BK * 2, wr, wc, lane, [&](int p) {
-            if (!more) return;
-            if constexpr (ALoader::kDma) {
-                if (p < PA) { A.template piece<BM, S::WAVES>(nbuf, m0, k0_s, lane, wave, p); return; }
-            }
-            W.template piece<BN, S::WAVES>(nbuf + BM * BK * 2, n0_s, k0_s, lane, wave, p - PA);
-        });
-        if (more && ++kt_s == KT) { kt_s = 0; ++nt_s; }
+        if (more) stage_next(slot_s);  // that stage was last read in step it-1, which every wave has left
+        compute_stage<S, SWAP, F16>(acc, cur, cur + BM * BK * 2, wr, wc, lane);
         if (kt == KT - 1) {
             epi(acc, nt);
 #pragma unroll
@@ -251,7 +221,7 @@ __device__ __forceinline__ void run(const ALoader& A, const WLoader& W, int m0, 
         }
         // step it+1 must be in LDS before anyone reads it; with 3 stages the loads issued in THIS step
         // (step it+2) may stay in flight across the barrier
-        if (AHEAD == 2 && more && ALoader::kDma) wait_vmcnt<S::GL>(); else wait_vmcnt<0>();
+        if (AHEAD == 2 && more) wait_vmcnt<S::GL>(); else wait_vmcnt<0>();
         block_barrier();
         if (++kt == KT) { kt = 0; ++nt; }
         slot = slot + 1 == ST ? 0 : slot + 1;

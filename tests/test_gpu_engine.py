@@ -29,7 +29,7 @@ def make_args(**kw):
 
 
 def synth_sample(i, anomalous=False):
-    pc = synth_cloud(200 + i, 0.30 + 0.02 * (i % 3))
+    pc = synth_cloud(200 + i, 0.30 + 0.02 * (i % 3), texture=0.004)
     rgb = synth_rgb(i)
     if anomalous:
         pc[0, 2, 100:120, 100:120] -= 0.005 * (pc[0, 2, 100:120, 100:120] != 0)  # 5 mm dent
@@ -222,7 +222,9 @@ def test_full_protocol_double_rgb_point_vs_oracle(fitted):
     ref_img = np.concatenate(ref_img).ravel()
     assert np.isfinite([m.image_rocauc, m.pixel_rocauc, m.au_pro, m.au_pro_001]).all()
     # the planted RGB anomaly (+2 sigma patch) dominates the image score on both sides: same ranking
-    np.testing.assert_allclose(got_img, ref_img, rtol=5e-2, atol=5e-2 * np.abs(ref_img).max())
+    assert list(np.argsort(got_img)) == list(np.argsort(ref_img)), (got_img, ref_img)
+    spread = float(ref_img.max() - ref_img.min())
+    assert np.abs(got_img - ref_img).max() <= 0.35 * spread + 1e-6, (got_img, ref_img)
     from sklearn.metrics import roc_auc_score
     labels = np.array([int(a) for _, a in tests])
     assert np.isfinite(roc_auc_score(labels, got_img))
