@@ -12,7 +12,7 @@
 //          MFMA's operand"): registers 8s..8s+7 converted to bf16 are the B fragment of k-step s, with
 //          the fixed k permutation k = 16s + 8(j>>2) + 4h + (j&3) matched on the V^T side by two
 //          8-byte LDS reads.  The online-softmax rescale of O^T is a per-lane scalar multiply.
-// Q is pre-scaled by head_dim^-0.5 and V arrives transposed ([B,H,64,Tp]) from cmdiad_gemm_qkv.
+// Q is pre-scaled by head_dim^-0.5 * log2(e) and V arrives transposed ([B,H,64,Tp]) from cmdiad_gemm_qkv.
 // LDS tiles are padded (K rows 144 B, V^T rows 136 B) so the fragment reads are bank-conflict-free.
 #include "common.h"
 
@@ -22,14 +22,15 @@ constexpr int kThreads = 256;
 constexpr int kKeys = 64;          // keys per tile
 constexpr int kKStride = 144;      // bytes per K row in LDS  (64 bf16 + 16 pad)
 constexpr int kVStride = 136;      // bytes per V^T row in LDS (64 bf16 + 8 pad)
-constexpr float kLog2e = 1.4426950408889634f;
 
+// q is pre-multiplied by head_dim^-0.5 * log2(e) (cmdiad_gemm_qkv), so softmax is exp2 of the raw dot product.
 __global__ __launch_bounds__(kThreads) void attention_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                              const bf16_t* __restrict__ vt, int H, int T, int Tp,
                                                              bf16_t* __restrict__ out)
 {
-    __shared__ __attribute__((aligned(16))) char s_k[kKeys * kKStride];
-    __shared__ __attribute__((aligned(16))) char s_v[64 * kVStride];
+    // two LDS stages: the next tile is written while the current one is being read -> ONE barrier per tile
+    __shared__ __attribute__((aligned(16))) char s_k[2][kKeys * kKStride];
+    __shared__ __attribute__((aligned(16))) char s_v[2][64 * kVStride];
 
     const int b = blockIdx.z, h = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -63,57 +64,68 @@ __global__ __launch_bounds__(kThreads) void attention_kernel(const bf16_t* __res
             rv[i] = *reinterpret_cast<const uint4*>(vb + (size_t)row * Tp + kt * kKeys + ch * 8);
         }
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int idx = tid + 256 * i;
             const int row = idx >> 3, ch = idx & 7;
-            *reinterpret_cast<uint4*>(s_k + row * kKStride + ch * 16) = rk[i];
-            uint2* dv = reinterpret_cast<uint2*>(s_v + row * kVStride + ch * 16);  // 8-byte aligned rows
+            *reinterpret_cast<uint4*>(s_k[buf] + row * kKStride + ch * 16) = rk[i];
+            uint2* dv = reinterpret_cast<uint2*>(s_v[buf] + row * kVStride + ch * 16);  // 8-byte aligned rows
             dv[0] = make_uint2(rv[i].x, rv[i].y);
             dv[1] = make_uint2(rv[i].z, rv[i].w);
         }
     };
 
     load_tile(0);
+    store_tile(0);
+    __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
-        store_tile();
-        __syncthreads();
-        if (kt + 1 < nkt) load_tile(kt + 1);
+        const char* sk = s_k[kt & 1];
+        const char* sv = s_v[kt & 1];
+        const bool more = kt + 1 < nkt;
+        if (more) load_tile(kt + 1);  // global loads stay in flight under the MFMAs below
 
         // ---- S^T = K . Q^T for the two 32-key sub-tiles
         f32x16 s0 = {}, s1 = {};
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const bf16x8 ka = *reinterpret_cast<const bf16x8*>(s_k + r * kKStride + 32 * s + 16 * hh);
-            const bf16x8 kb2 = *reinterpret_cast<const bf16x8*>(s_k + (32 + r) * kKStride + 32 * s + 16 * hh);
+            const bf16x8 ka = *reinterpret_cast<const bf16x8*>(sk + r * kKStride + 32 * s + 16 * hh);
+            const bf16x8 kb2 = *reinterpret_cast<const bf16x8*>(sk + (32 + r) * kKStride + 32 * s + 16 * hh);
             s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[s], s0, 0, 0, 0);
             s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb2, qf[s], s1, 0, 0, 0);
         }
-        // ---- mask keys >= T, online softmax (per lane = per query)
-        const int kbase = kt * kKeys + 4 * hh;
-        float mloc = -__builtin_inff();
+        // ---- keys >= T only exist in the last tile
+        if (kt == nkt - 1 && (T & (kKeys - 1))) {
+            const int kbase = kt * kKeys + 4 * hh;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int key = kbase + (e & 3) + 8 * (e >> 2);
-            s0[e] = key < T ? s0[e] * kLog2e : -__builtin_inff();
-            s1[e] = key + 32 < T ? s1[e] * kLog2e : -__builtin_inff();
-            mloc = fmaxf(mloc, fmaxf(s0[e], s1[e]));
+            for (int e = 0; e < 16; ++e) {
+                const int key = kbase + (e & 3) + 8 * (e >> 2);
+                s0[e] = key < T ? s0[e] : -__builtin_inff();
+                s1[e] = key + 32 < T ? s1[e] : -__builtin_inff();
+            }
         }
+        // ---- online softmax, per lane = per query; the accumulators are rescaled only when some query's
+        //      running maximum actually grew (wave-uniform branch; exact, no threshold)
+        float mloc = fmaxf(s0[0], s1[0]);
+#pragma unroll
+        for (int e = 1; e < 16; ++e) mloc = fmaxf(mloc, fmaxf(s0[e], s1[e]));
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-        const float m_new = fmaxf(m_run, mloc);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // first tile: exp2(-inf) = 0
-        m_run = m_new;
+        if (!__all(mloc <= m_run)) {
+            const float m_new = fmaxf(m_run, mloc);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // first tile: exp2(-inf) = 0
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { o0[e] *= alpha; o1[e] *= alpha; }
+        }
         float psum = 0.0f;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            s0[e] = __builtin_amdgcn_exp2f(s0[e] - m_new);
-            s1[e] = __builtin_amdgcn_exp2f(s1[e] - m_new);
+            s0[e] = __builtin_amdgcn_exp2f(s0[e] - m_run);
+            s1[e] = __builtin_amdgcn_exp2f(s1[e] - m_run);
             psum += s0[e] + s1[e];
         }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) { o0[e] *= alpha; o1[e] *= alpha; }
+        l_run += psum;
 
         // ---- O^T += V^T . P   (k-step = 16 keys; P fragment = 8 consecutive accumulator registers)
 #pragma unroll
@@ -125,14 +137,15 @@ __global__ __launch_bounds__(kThreads) void attention_kernel(const bf16_t* __res
                 for (int j = 0; j < 8; ++j) pf[j] = f2bf(sub == 0 ? s0[8 * s + j] : s1[8 * s + j]);
                 const int koff = (sub * 32 + 16 * s + 4 * hh) * 2;  // bytes into the key axis
                 union { uint2 u[2]; bf16x8 v; } a0, a1;
-                a0.u[0] = *reinterpret_cast<const uint2*>(s_v + r * kVStride + koff);
-                a0.u[1] = *reinterpret_cast<const uint2*>(s_v + r * kVStride + koff + 16);
-                a1.u[0] = *reinterpret_cast<const uint2*>(s_v + (32 + r) * kVStride + koff);
-                a1.u[1] = *reinterpret_cast<const uint2*>(s_v + (32 + r) * kVStride + koff + 16);
+                a0.u[0] = *reinterpret_cast<const uint2*>(sv + r * kVStride + koff);
+                a0.u[1] = *reinterpret_cast<const uint2*>(sv + r * kVStride + koff + 16);
+                a1.u[0] = *reinterpret_cast<const uint2*>(sv + (32 + r) * kVStride + koff);
+                a1.u[1] = *reinterpret_cast<const uint2*>(sv + (32 + r) * kVStride + koff + 16);
                 o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.v, pf, o0, 0, 0, 0);
                 o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.v, pf, o1, 0, 0, 0);
             }
         }
+        if (more) store_tile((kt + 1) & 1);  // that stage was last read in iteration kt-1
         __syncthreads();
     }
 

@@ -124,7 +124,8 @@ __global__ __launch_bounds__(S::THREADS, S::WAVES_PER_SIMD) void gemm_qkv_kernel
 
     if (which < 2) {
         bf16_t* dst = which == 0 ? p.q : p.k;
-        const float scale = which == 0 ? 0.125f : 1.0f;  // head_dim^-0.5, exact in bf16
+        // q carries head_dim^-0.5 (models.py:153) AND log2(e), so the attention kernel's softmax is a bare exp2
+        const float scale = which == 0 ? 0.125f * 1.4426950408889634f : 1.0f;
         run<S, true>(A, W, c.m0, c.nt, 1, p.C / BK, lds, [&](auto& acc, int ntile) {
 #pragma unroll
             for (int i = 0; i < S::MI; ++i) {

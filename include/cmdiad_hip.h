@@ -118,12 +118,13 @@ int cmdiad_gemm_bf16(const cmdiad_gemm_args* args, cmdiad_stream_t stream);
 
 /* QKV projection with head-split stores for the attention kernel (models/models.py:150-151):
  * A [B*T, C] bf16, W [3C, C], bias [3C] or NULL.  head_dim = 64, C = H*64.
- * q_out, k_out [B,H,Tp,64] bf16 (q pre-multiplied by head_dim^-0.5, models.py:153),
+ * q_out, k_out [B,H,Tp,64] bf16 (q pre-multiplied by head_dim^-0.5 (models.py:153) times log2(e)),
  * vt_out [B,H,64,Tp] bf16 (V transposed); Tp = T rounded up to 64; padding is never written. */
 int cmdiad_gemm_qkv(const uint16_t* A, const uint16_t* W, const float* bias, int B, int T, int C,
                     uint16_t* q_out, uint16_t* k_out, uint16_t* vt_out, cmdiad_stream_t stream);
 
-/* softmax(q k^T) v per (image, head) (models/models.py:153-157), flash-style, bf16 MFMA.
+/* softmax(q k^T) v per (image, head) (models/models.py:153-157), flash-style, bf16 MFMA; q as written by
+ * cmdiad_gemm_qkv (pre-scaled by head_dim^-0.5 * log2(e): the kernel evaluates exp2 of the raw q.k).
  * out [B*T, C] bf16 with heads concatenated along C (the `.transpose(1,2).reshape(B,N,C)` of :157). */
 int cmdiad_attention(const uint16_t* q, const uint16_t* k, const uint16_t* vt, int B, int H, int T,
                      uint16_t* out, cmdiad_stream_t stream);

@@ -174,14 +174,15 @@ def test_qkv_and_attention(B, T, C):
     vt = torch.zeros(B, H, 64, Tp, dtype=torch.bfloat16, device=DEV)
     ops.gemm_qkv(x.to(DEV).bfloat16(), W.to(DEV).bfloat16(), bias.to(DEV), B, T, q, k, vt)
     qkv = (x.double() @ W.double().T + bias.double()).reshape(B, T, 3, H, 64).permute(2, 0, 3, 1, 4)
-    np.testing.assert_allclose(q[:, :, :T].float().cpu().numpy(), (qkv[0] * 0.125).numpy(), rtol=8e-3, atol=8e-3)
+    LOG2E = 1.4426950408889634
+    np.testing.assert_allclose(q[:, :, :T].float().cpu().numpy(), (qkv[0] * 0.125 * LOG2E).numpy(), rtol=8e-3, atol=8e-3)
     np.testing.assert_allclose(k[:, :, :T].float().cpu().numpy(), qkv[1].numpy(), rtol=8e-3, atol=8e-3)
     np.testing.assert_allclose(vt[:, :, :, :T].float().cpu().numpy(), qkv[2].transpose(-1, -2).numpy(), rtol=8e-3, atol=8e-3)
     assert float(q[:, :, T:].abs().max() if Tp > T else 0) == 0.0  # padding untouched
     out = ops.attention(q, k, vt, B, H, T)
     # reference from the SAME bf16-rounded q/k/v (isolates the attention kernel): fp64 softmax(q k^T) v
     qd, kd, vd = q[:, :, :T].double().cpu(), k[:, :, :T].double().cpu(), vt[:, :, :, :T].double().cpu().transpose(-1, -2)
-    ref = (torch.softmax(qd @ kd.transpose(-1, -2), -1) @ vd).transpose(1, 2).reshape(B * T, C)
+    ref = (torch.softmax(qd @ kd.transpose(-1, -2) / LOG2E, -1) @ vd).transpose(1, 2).reshape(B * T, C)
     # P is rounded to bf16 before P.V and the output is bf16: |err| <~ 2^-8 * |v|_max-ish
     np.testing.assert_allclose(out.float().cpu().numpy(), ref.numpy(), rtol=2e-2, atol=2e-2)
     assert float((out.float().cpu() - ref).abs().mean()) < 3e-3
@@ -201,7 +202,8 @@ def test_attention_peaked_rows_exercise_rescale():
     k[0, 0, 280] = 4.0 * q[0, 0, 10]  # spike for query 10 in the last tile
     q, k, v = _bf(q), _bf(k), _bf(v)
     out = ops.attention(q.to(DEV).bfloat16(), k.to(DEV).bfloat16(), v.transpose(-1, -2).contiguous().to(DEV).bfloat16(), B, H, T)
-    ref = torch.softmax(q[0, 0, :T].double() @ k[0, 0, :T].double().T, -1) @ v[0, 0, :T].double()
+    # the kernel's contract: q carries log2(e), i.e. it computes softmax_2(q.k) = softmax(q.k * ln 2)
+    ref = torch.softmax(q[0, 0, :T].double() @ k[0, 0, :T].double().T * np.log(2.0), -1) @ v[0, 0, :T].double()
     np.testing.assert_allclose(out.float().cpu().numpy(), ref.numpy(), rtol=2e-2, atol=2e-2)
 
 
