@@ -9,7 +9,7 @@ import subprocess
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_size_t, c_uint32, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libcmdiad_hip.so")
+SO_PATH = os.environ.get("CMDIAD_HIP_LIB") or os.path.join(_HERE, "libcmdiad_hip.so")  # override: A/B runs of two builds
 _lib = None
 
 

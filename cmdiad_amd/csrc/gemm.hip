@@ -2,6 +2,9 @@
 // stores, and the Point-MAE encoder stages (on-the-fly first conv, per-group max pooling).
 #include <stdlib.h>
 
+#include <mutex>
+#include <set>
+
 #include "gemm_core.h"
 
 namespace {
@@ -23,6 +26,7 @@ struct StdParams {
     bf16_t* out_pre_bf16;         // pre-activation copy (training keeps z for the GELU backward)
     const bf16_t* dact_of;        // acc *= GELU'(dact_of[m][n]) first (backward through an activation)
     int split_k;                  // > 1: block y handles K/split_k, writes slab y of out_f32 (no epilogue terms)
+    int panel;                    // N tiles walked by one block (see panel_tiles)
 };
 
 __device__ __forceinline__ float gelu_grad_f(float x)
@@ -34,12 +38,16 @@ __device__ __forceinline__ float gelu_grad_f(float x)
 // block -> (m tile, n tile) with the XCD remap; lane/wave coordinates shared by every epilogue
 template <class S>
 struct Coord {
-    int m0, nt, lane, wr, wc;
-    __device__ __forceinline__ Coord(int n_tiles_n)
+    int m0, nt, count, lane, wr, wc;
+    // panel > 1: the block owns `panel` consecutive N tiles of its M panel and runs them as ONE flattened
+    // pipeline (A comes from HBM once, from L2 afterwards; the fill/drain latency is paid once per panel).
+    __device__ __forceinline__ Coord(int n_tiles_n, int panel = 1)
     {
         const int wg = xcd_remap(blockIdx.x, gridDim.x);
-        m0 = (wg / n_tiles_n) * S::BM;
-        nt = wg % n_tiles_n;
+        const int groups = (n_tiles_n + panel - 1) / panel;
+        m0 = (wg / groups) * S::BM;
+        nt = (wg % groups) * panel;
+        count = min(panel, n_tiles_n - nt);
         lane = threadIdx.x & 63;
         const int wave = threadIdx.x >> 6;
         wr = wave / S::WN;
@@ -50,54 +58,65 @@ struct Coord {
     __device__ __forceinline__ int n(int ntile, int j) const { return ntile * S::BN + wc * 64 + j * 16 + (lane >> 4) * 4; }
 };
 
-template <class S>
+// The epilogue is specialised at compile time.  With every optional term as a run-time branch the 16 unrolled
+// (row tile, column tile) bodies carried 64 inlined erff/expf expansions -- ~40 KB of code that even the skipped
+// branches had to fetch through the instruction cache (measured: the plain 4.2M x 512 x 256 product spent as long
+// in that epilogue as in its MFMA loop).  ACT = CMDIAD_ACT_*; EXTRAS = the training-only terms (dact_of, out_pre).
+template <class S, int ACT, bool EXTRAS>
 __global__ __launch_bounds__(S::THREADS, S::WAVES_PER_SIMD) void gemm_std_kernel(GlobalTile A, GlobalTile W, StdParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    const Coord<S> c((p.N + S::BN - 1) / S::BN);
+    const Coord<S> c((p.N + S::BN - 1) / S::BN, p.panel);
     const int kt_per = (p.K / BK + p.split_k - 1) / p.split_k;
     const int kt_begin = blockIdx.y * kt_per;
     const int kt_count = min(kt_per, p.K / BK - kt_begin);
     float* out32 = p.out_f32 ? p.out_f32 + (size_t)blockIdx.y * p.M * p.ldo32 : nullptr;
     if (kt_count <= 0) return;
 
-    run<S, true>(A, W, c.m0, c.nt, 1, kt_count, lds, [&](auto& acc, int ntile) {
+    run<S, true>(A, W, c.m0, c.nt, c.count, kt_count, lds, [&](auto& acc, int ntile, char*) {
+        // (do NOT hoist the bias loads above the row loop: the compiler then speculates them into the K loop and
+        //  guards the fragment reads with s_waitcnt vmcnt(0), which also waits for the LDS-DMA of the next stage --
+        //  15 % slower on every shape; tools/isa_lint.py checks the main loops for that pattern)
 #pragma unroll
         for (int i = 0; i < S::MI; ++i) {
             const int m = c.m(i);
             if (m >= p.M) continue;
             const float* gb = p.group_bias ? p.group_bias + (size_t)(m / p.group_rows) * p.N : nullptr;
+            const float* res = p.residual ? p.residual + (size_t)m * p.ldr : nullptr;
+            float* o32 = out32 ? out32 + (size_t)m * p.ldo32 : nullptr;
+            bf16_t* o16 = p.out_bf16 ? p.out_bf16 + (size_t)m * p.ldo16 : nullptr;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int n = c.n(ntile, j);
                 if (n >= p.N) continue;
                 f32x4 v = acc[i][j];
-                if (p.dact_of) {
-                    const bf16x4 z = *reinterpret_cast<const bf16x4*>(p.dact_of + (size_t)m * p.N + n);
+                if constexpr (EXTRAS) {
+                    if (p.dact_of) {
+                        const bf16x4 z = *reinterpret_cast<const bf16x4*>(p.dact_of + (size_t)m * p.N + n);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] *= gelu_grad_f(bf2f(z[r]));
+                        for (int r = 0; r < 4; ++r) v[r] *= gelu_grad_f(bf2f(z[r]));
+                    }
                 }
                 if (p.bias) { const float4 b = *reinterpret_cast<const float4*>(p.bias + n); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
                 if (gb) { const float4 b = *reinterpret_cast<const float4*>(gb + n); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
-                if (p.out_pre_bf16) {
-                    bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-                    *reinterpret_cast<bf16x4*>(p.out_pre_bf16 + (size_t)m * p.N + n) = o;
+                if constexpr (EXTRAS) {
+                    if (p.out_pre_bf16) {
+                        bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+                        *reinterpret_cast<bf16x4*>(p.out_pre_bf16 + (size_t)m * p.N + n) = o;
+                    }
                 }
-                if (p.act == CMDIAD_ACT_GELU) {
+                if constexpr (ACT == CMDIAD_ACT_GELU) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
-                } else if (p.act == CMDIAD_ACT_RELU) {
+                } else if constexpr (ACT == CMDIAD_ACT_RELU) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
                 }
-                if (p.residual) {
-                    const float4 b = *reinterpret_cast<const float4*>(p.residual + (size_t)m * p.ldr + n);
-                    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-                }
-                if (out32) *reinterpret_cast<f32x4*>(out32 + (size_t)m * p.ldo32 + n) = v;
-                if (p.out_bf16) {
+                if (res) { const float4 b = *reinterpret_cast<const float4*>(res + n); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+                if (o32) *reinterpret_cast<f32x4*>(o32 + n) = v;
+                if (o16) {
                     bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-                    *reinterpret_cast<bf16x4*>(p.out_bf16 + (size_t)m * p.ldo16 + n) = o;
+                    *reinterpret_cast<bf16x4*>(o16 + n) = o;
                 }
             }
         }
@@ -126,7 +145,7 @@ __global__ __launch_bounds__(S::THREADS, S::WAVES_PER_SIMD) void gemm_qkv_kernel
         bf16_t* dst = which == 0 ? p.q : p.k;
         // q carries head_dim^-0.5 (models.py:153) AND log2(e), so the attention kernel's softmax is a bare exp2
         const float scale = which == 0 ? 0.125f * 1.4426950408889634f : 1.0f;
-        run<S, true>(A, W, c.m0, c.nt, 1, p.C / BK, lds, [&](auto& acc, int ntile) {
+        run<S, true>(A, W, c.m0, c.nt, 1, p.C / BK, lds, [&](auto& acc, int ntile, char*) {
 #pragma unroll
             for (int i = 0; i < S::MI; ++i) {
                 const int m = c.m(i);
@@ -145,7 +164,7 @@ __global__ __launch_bounds__(S::THREADS, S::WAVES_PER_SIMD) void gemm_qkv_kernel
             }
         });
     } else {
-        run<S, false>(A, W, c.m0, c.nt, 1, p.C / BK, lds, [&](auto& acc, int ntile) {
+        run<S, false>(A, W, c.m0, c.nt, 1, p.C / BK, lds, [&](auto& acc, int ntile, char*) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int n = ntile * S::BN + c.wc * 64 + j * 16 + (c.lane & 15);
@@ -172,7 +191,7 @@ __global__ __launch_bounds__(S::THREADS, S::WAVES_PER_SIMD) void gemm_qkv_kernel
 // then a [BM/32][BN] LDS table (one row per 32-row block) combined by the first BN threads.
 // ------------------------------------------------------------------------------------------------
 struct GroupMaxParams {
-    int M, N, K, Mg;
+    int M, N, K, Mg, panel;
     const float* bias;
     bf16_t* full_bf16; int ldf;  // optional full activations [M,N]
     float* max_f32;
@@ -183,10 +202,10 @@ template <class S, class ALoader>
 __device__ __forceinline__ void groupmax_body(const ALoader& A, const GlobalTile& W, const GroupMaxParams& p, char* lds)
 {
     float(*s_max)[S::BN] = reinterpret_cast<float(*)[S::BN]>(lds + S::LDS_BYTES);
-    const Coord<S> c((p.N + S::BN - 1) / S::BN);
+    const Coord<S> c((p.N + S::BN - 1) / S::BN, p.panel);
     const int tid = threadIdx.x;
 
-    run<S, true>(A, W, c.m0, c.nt, 1, p.K / BK, lds, [&](auto& acc, int ntile) {
+    run<S, true>(A, W, c.m0, c.nt, c.count, p.K / BK, lds, [&](auto& acc, int ntile, char*) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int nl = c.wc * 64 + j * 16 + (c.lane >> 4) * 4;  // column within the tile
@@ -271,20 +290,42 @@ int pick_tile(long M, long N, int split)
 template <class S, class Kern, class... Args>
 int launch(Kern kernel, dim3 grid, int lds, hipStream_t s, Args... args)
 {
-    static bool done = false;
+    // several kernels share one signature (the epilogue variants): remember the attribute per function, not per type
+    static std::mutex mu;
+    static std::set<const void*> configured;
+    std::lock_guard<std::mutex> lock(mu);
+    bool done = configured.count((const void*)kernel) != 0;
     if (!done) {
         if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
             cmdiad_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d) failed", lds);
             return CMDIAD_ERR_LAUNCH;
         }
-        done = true;
+        configured.insert((const void*)kernel);
     }
     hipLaunchKernelGGL(kernel, grid, dim3(S::THREADS), lds, s, args...);
     return CMDIAD_OK;
 }
 
+// N tiles per block.  Short-K, tall-M products (the Point-MAE encoder: M = 4.2 M rows, K <= 512) are bound by the
+// HBM latency of each block's few K-steps, not by bandwidth or MFMA rate; walking the whole N panel in one block
+// pays that latency once and re-reads A from L2.  CMDIAD_GEMM_PANEL_MIN = smallest M-tile count that switches
+// it on (default 2048; 1 in the parity tests so small shapes cover the path; a huge value disables it).
 template <class S>
-dim3 grid_for(long M, long N, int y = 1) { return dim3((unsigned)(((M + S::BM - 1) / S::BM) * ((N + S::BN - 1) / S::BN)), y); }
+int panel_tiles(long M, long N, long K, int split)
+{
+    const char* e = getenv("CMDIAD_GEMM_PANEL_MIN");
+    const long min_mt = e ? atol(e) : 2048;
+    const long mt = (M + S::BM - 1) / S::BM, ntl = (N + S::BN - 1) / S::BN;
+    if (split > 1 || ntl == 1 || K > 512 || mt < min_mt) return 1;
+    return (int)(ntl < 8 ? ntl : 8);
+}
+
+template <class S>
+dim3 grid_for(long M, long N, int y = 1, int panel = 1)
+{
+    const long ntl = (N + S::BN - 1) / S::BN;
+    return dim3((unsigned)(((M + S::BM - 1) / S::BM) * ((ntl + panel - 1) / panel)), y);
+}
 
 }  // namespace
 
@@ -305,18 +346,28 @@ extern "C" int cmdiad_gemm_bf16(const cmdiad_gemm_args* a, cmdiad_stream_t strea
     CMDIAD_REQUIRE(split == 1 || (a->out_f32 && !a->out_bf16 && !a->bias && !a->group_bias && !a->residual &&
                                   a->act == CMDIAD_ACT_NONE && !a->out_pre_bf16 && !a->dact_of),
                    CMDIAD_ERR_ARG, "cmdiad_gemm_bf16: split_k > 1 writes raw f32 slabs only");
+    CMDIAD_REQUIRE(pick_tile(a->M, a->N, split) == 0 || (a->act == CMDIAD_ACT_NONE && !a->out_pre_bf16 && !a->dact_of), CMDIAD_ERR_ARG,
+                   "cmdiad_gemm_bf16: CMDIAD_GEMM_TILE shapes carry the plain epilogue only");
     CMDIAD_REQUIRE((!a->out_pre_bf16 || ((uintptr_t)a->out_pre_bf16 & 7) == 0) && (!a->dact_of || ((uintptr_t)a->dact_of & 7) == 0),
                    CMDIAD_ERR_ARG, "cmdiad_gemm_bf16: out_pre_bf16 / dact_of alignment");
     GlobalTile A{(const bf16_t*)a->A, a->lda, a->M}, W{(const bf16_t*)a->W, a->ldw, a->N};
     StdParams p{a->M, a->N, a->K, a->bias, a->group_bias, a->group_rows, a->act, a->residual, a->ldr,
-                a->out_f32, a->ldo32, (bf16_t*)a->out_bf16, a->ldo16, (bf16_t*)a->out_pre_bf16, (const bf16_t*)a->dact_of, split};
+                a->out_f32, a->ldo32, (bf16_t*)a->out_bf16, a->ldo16, (bf16_t*)a->out_pre_bf16, (const bf16_t*)a->dact_of, split, 1};
     hipStream_t s = (hipStream_t)stream;
+    const bool extras = a->out_pre_bf16 || a->dact_of;
+    const int tile = pick_tile(a->M, a->N, split);
     int rc;
-    switch (pick_tile(a->M, a->N, split)) {
-        case 2: rc = launch<S2x2>(gemm_std_kernel<S2x2>, grid_for<S2x2>(a->M, a->N, split), S2x2::LDS_BYTES, s, A, W, p); break;
-        case 1: rc = launch<S256>(gemm_std_kernel<S256>, grid_for<S256>(a->M, a->N, split), S256::LDS_BYTES, s, A, W, p); break;
-        default: rc = launch<S128>(gemm_std_kernel<S128>, grid_for<S128>(a->M, a->N, split), S128::LDS_BYTES, s, A, W, p);
+#define CMDIAD_STD(SH, ACT, EX) launch<SH>(gemm_std_kernel<SH, ACT, EX>, grid_for<SH>(a->M, a->N, split, p.panel), SH::LDS_BYTES, s, A, W, p)
+    if (tile == 2) rc = CMDIAD_STD(S2x2, CMDIAD_ACT_NONE, false);   // A/B shapes (CMDIAD_GEMM_TILE): plain epilogue only
+    else if (tile == 1) rc = CMDIAD_STD(S256, CMDIAD_ACT_NONE, false);
+    else {
+        p.panel = panel_tiles<S128>(a->M, a->N, a->K, split);
+        if (extras) rc = a->act == CMDIAD_ACT_GELU ? CMDIAD_STD(S128, CMDIAD_ACT_GELU, true)
+                       : a->act == CMDIAD_ACT_RELU ? CMDIAD_STD(S128, CMDIAD_ACT_RELU, true) : CMDIAD_STD(S128, CMDIAD_ACT_NONE, true);
+        else rc = a->act == CMDIAD_ACT_GELU ? CMDIAD_STD(S128, CMDIAD_ACT_GELU, false)
+                : a->act == CMDIAD_ACT_RELU ? CMDIAD_STD(S128, CMDIAD_ACT_RELU, false) : CMDIAD_STD(S128, CMDIAD_ACT_NONE, false);
     }
+#undef CMDIAD_STD
     if (rc) return rc;
     CMDIAD_CHECK_LAUNCH();
     return CMDIAD_OK;
@@ -356,13 +407,15 @@ extern "C" int cmdiad_gemm_groupmax(const uint16_t* A, const uint16_t* W, const 
                    "cmdiad_gemm_groupmax: 16-byte alignment");
     const int M = groups * Mg;
     GlobalTile At{(const bf16_t*)A, K, M}, Wt{(const bf16_t*)W, K, N};
-    GroupMaxParams p{M, N, K, Mg, bias, nullptr, 0, out_f32, (bf16_t*)out_bf16};
+    GroupMaxParams p{M, N, K, Mg, 1, bias, nullptr, 0, out_f32, (bf16_t*)out_bf16};
     hipStream_t s = (hipStream_t)stream;
     int rc;
     switch (pick_tile(M, N, 1)) {
         case 2: rc = launch<S2x2>(gemm_groupmax_kernel<S2x2>, grid_for<S2x2>(M, N), group_max_lds<S2x2>(), s, At, Wt, p); break;
         case 1: rc = launch<S256>(gemm_groupmax_kernel<S256>, grid_for<S256>(M, N), group_max_lds<S256>(), s, At, Wt, p); break;
-        default: rc = launch<S128>(gemm_groupmax_kernel<S128>, grid_for<S128>(M, N), group_max_lds<S128>(), s, At, Wt, p);
+        default:
+            p.panel = panel_tiles<S128>(M, N, K, 1);
+            rc = launch<S128>(gemm_groupmax_kernel<S128>, grid_for<S128>(M, N, 1, p.panel), group_max_lds<S128>(), s, At, Wt, p);
     }
     if (rc) return rc;
     CMDIAD_CHECK_LAUNCH();
@@ -381,13 +434,15 @@ extern "C" int cmdiad_encoder_stage1(const float* neigh, const float* w1, const 
     const int M = groups * Mg;
     Conv1Tile At{neigh, (const float4*)w1, M};
     GlobalTile Wt{(const bf16_t*)W2, 128, 256};
-    GroupMaxParams p{M, 256, 128, Mg, b2, (bf16_t*)h2_out, 256, gmax_out, (bf16_t*)gmax_bf16_out};
+    GroupMaxParams p{M, 256, 128, Mg, 1, b2, (bf16_t*)h2_out, 256, gmax_out, (bf16_t*)gmax_bf16_out};
     hipStream_t s = (hipStream_t)stream;
     int rc;
     switch (pick_tile(M, 256, 1)) {
         case 2: rc = launch<S2x2>(encoder_stage1_kernel<S2x2>, grid_for<S2x2>(M, 256), group_max_lds<S2x2>(), s, At, Wt, p); break;
         case 1: rc = launch<S256>(encoder_stage1_kernel<S256>, grid_for<S256>(M, 256), group_max_lds<S256>(), s, At, Wt, p); break;
-        default: rc = launch<S128>(encoder_stage1_kernel<S128>, grid_for<S128>(M, 256), group_max_lds<S128>(), s, At, Wt, p);
+        default:
+            p.panel = panel_tiles<S128>(M, 256, 128, 1);
+            rc = launch<S128>(encoder_stage1_kernel<S128>, grid_for<S128>(M, 256, 1, p.panel), group_max_lds<S128>(), s, At, Wt, p);
     }
     if (rc) return rc;
     CMDIAD_CHECK_LAUNCH();

@@ -174,7 +174,7 @@ __device__ __forceinline__ void block_barrier()
 }
 
 // Runs n_tiles consecutive BN-wide N tiles (starting at tile index nt0) against the block's M tile, over
-// K-steps [kt_begin, kt_begin + KT).  epi(acc, nt) is called once per finished N tile.
+// K-steps [kt_begin, kt_begin + KT).  epi(acc, nt, scratch) is called once per finished N tile.
 template <class S, bool SWAP, bool F16 = false, class ALoader, class WLoader, class Epi>
 __device__ __forceinline__ void run(const ALoader& A, const WLoader& W, int m0, int nt0, int n_tiles, int KT,
                                     char* lds, Epi&& epi, int kt_begin = 0)
@@ -213,7 +213,9 @@ __device__ __forceinline__ void run(const ALoader& A, const WLoader& W, int m0, 
         if (more) stage_next(slot_s);  // that stage was last read in step it-1, which every wave has left
         compute_stage<S, SWAP, F16>(acc, cur, cur + BM * BK * 2, wr, wc, lane);
         if (kt == KT - 1) {
-            epi(acc, nt);
+            epi(acc, nt, n_tiles == 1 ? lds + slot_s * S::STAGE_BYTES : nullptr);  // scratch: a stage nobody reads or fills (single-tile runs only)
+            // (an LDS-staged 16-byte coalesced bf16 store through that scratch measured SLOWER than the direct
+            //  8-byte stores: 3.32 vs 3.06 ms on the 4.2M x 512 x 256 product, profiles/r1_notes.md)
 #pragma unroll
             for (int i = 0; i < S::MI; ++i)
 #pragma unroll

@@ -59,7 +59,7 @@ __global__ __launch_bounds__(S::THREADS, S::WAVES_PER_SIMD) void l2_min_kernel(G
         qn[i] = m < p.Q ? p.q_sqnorm[m] : 0.0f;
     }
 
-    run<S, true, F16>(A, W, m0, nt0, ntc, p.D / BK, lds, [&](auto& acc, int ntile) {
+    run<S, true, F16>(A, W, m0, nt0, ntc, p.D / BK, lds, [&](auto& acc, int ntile, char*) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int n = ntile * S::BN + wc * 64 + j * 16 + (lane >> 4) * 4;

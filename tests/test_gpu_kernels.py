@@ -126,8 +126,11 @@ def test_interp3nn_indices_bit_exact_and_patch_fused():
 
 
 # ------------------------------------------------------------------------------------------ GEMM family
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 384, 192), (785, 768, 768), (1000, 1920, 768)])
-def test_gemm_epilogues(M, N, K):
+@pytest.mark.parametrize("M,N,K,panel_min", [(128, 128, 64, None), (300, 384, 192, None), (785, 768, 768, None),
+                                              (1000, 1920, 768, None), (300, 384, 192, "1"), (1000, 1156, 512, "1")])
+def test_gemm_epilogues(M, N, K, panel_min, monkeypatch):
+    if panel_min:  # panel mode: one block walks up to 8 N tiles (K <= 512 products)
+        monkeypatch.setenv("CMDIAD_GEMM_PANEL_MIN", panel_min)
     g = torch.Generator().manual_seed(M + N + K)
     A = _bf(torch.randn(M, K, generator=g))
     W = _bf(torch.randn(N, K, generator=g) / K ** 0.5)
@@ -224,9 +227,11 @@ def test_layernorm(M, C):
     np.testing.assert_allclose(o32[:, C:].cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("Mg", [32, 128])
-def test_pointmae_encoder_stages(Mg):
+@pytest.mark.parametrize("Mg,panel_min", [(32, None), (128, None), (128, "1"), (32, "1")])
+def test_pointmae_encoder_stages(Mg, panel_min, monkeypatch):
     from oracle import nets
+    if panel_min:  # one block walks every N tile of its M panel (the production path at M = 4.2 M rows)
+        monkeypatch.setenv("CMDIAD_GEMM_PANEL_MIN", panel_min)
     sd = nets.synth_state_dict("pointmae", 21)
     groups = 24
     g = torch.Generator().manual_seed(Mg)
