@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void interp_gather_kernel(const float* __restr
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void xyz_patch_fused_kernel(const float* __restrict__ feat, const int32_t* __restrict__ idx3,
                                                               const float* __restrict__ w3,
-                                                              const int32_t* __restrict__ pix2pt, int N, int S, int D,
+                                                              const int32_t* __restrict__ pix2pt, int B, int N, int S, int D,
                                                               int size, int P, float mean, float inv_std,
                                                               float* __restrict__ out_f32, bf16_t* __restrict__ out_bf16)
 {
@@ -158,8 +158,12 @@ __global__ __launch_bounds__(256) void xyz_patch_fused_kernel(const float* __res
     __shared__ float s_lw[kMaxEnt];
     __shared__ int s_cnt;
 
-    const int b = blockIdx.y;
-    const int py = blockIdx.x / P, px = blockIdx.x % P;
+    // XCD-aware ids (workgroup L runs on XCD L % 8): every patch of image b gets the same L % 8, so that image's
+    // [S, D] centre features (3 MB) are gathered through ONE L2 instead of all eight.
+    const int slot = blockIdx.x >> 3, PP = P * P;
+    const int b = (slot / PP) * 8 + (blockIdx.x & 7), patch = slot % PP;
+    if (b >= B) return;
+    const int py = patch / P, px = patch % P;
     const int L = size - 2;
     const int y0 = (py * L) / P, y1 = ((py + 1) * L + P - 1) / P;
     const int x0 = (px * L) / P, x1 = ((px + 1) * L + P - 1) / P;
@@ -212,7 +216,7 @@ __global__ __launch_bounds__(256) void xyz_patch_fused_kernel(const float* __res
     }
     __syncthreads();
 
-    const size_t orow = ((size_t)b * P * P + blockIdx.x) * D;
+    const size_t orow = ((size_t)b * P * P + patch) * D;
     for (int c = tid * 4; c < D; c += 1024) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int i = 0; i < cnt; ++i) {
@@ -280,8 +284,8 @@ extern "C" int cmdiad_xyz_patch_fused(const float* feat, const int32_t* idx3, co
                    maxbin + 2, size, P);
     CMDIAD_REQUIRE((((uintptr_t)feat | (uintptr_t)patch_f32) & 15) == 0 && ((uintptr_t)patch_bf16 & 7) == 0, CMDIAD_ERR_ARG,
                    "cmdiad_xyz_patch_fused: alignment");
-    dim3 grid(P * P, B);
-    hipLaunchKernelGGL(xyz_patch_fused_kernel, grid, dim3(256), 0, (hipStream_t)stream, feat, idx3, w3, pix2pt, N, S, D,
+    dim3 grid((unsigned)((B + 7) / 8 * 8 * P * P));
+    hipLaunchKernelGGL(xyz_patch_fused_kernel, grid, dim3(256), 0, (hipStream_t)stream, feat, idx3, w3, pix2pt, B, N, S, D,
                        size, P, mean, inv_std, patch_f32, (bf16_t*)patch_bf16);
     CMDIAD_CHECK_LAUNCH();
     return CMDIAD_OK;
