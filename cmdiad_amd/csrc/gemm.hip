@@ -276,16 +276,8 @@ template <class S> constexpr int group_max_lds() { return S::LDS_BYTES + (S::BM 
 
 bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
-// Tile choice.  0 = S128 (128x128, 2 blocks/CU), 1 = S256 (256x128, 3 stages), 2 = S2x2 (256x256).
-// Large tiles only once there are enough of them to fill the 256 CUs; CMDIAD_GEMM_TILE forces one (A/B runs).
-int pick_tile(long M, long N, int split)
-{
-    static const int force = getenv("CMDIAD_GEMM_TILE") ? atoi(getenv("CMDIAD_GEMM_TILE")) : -1;
-    if (force >= 0) return force;
-    (void)M; (void)N; (void)split;
-    return 0;  // measured on MI355X (profiles/r1_tile_sweep.md): S128 wins every network GEMM shape; S2x2 only the distance GEMM
-}
-
+// Every network GEMM runs the 128 x 128 shape: the tile sweep on MI355X (profiles/r1_notes.md) had it ahead of
+// 256x128x3-stage and 256x256 on every ViT / Point-MAE shape; the larger shapes serve the distance GEMM only (l2min.hip).
 // one launcher per kernel instantiation: sets the dynamic-LDS attribute once
 template <class S, class Kern, class... Args>
 int launch(Kern kernel, dim3 grid, int lds, hipStream_t s, Args... args)
@@ -346,8 +338,6 @@ extern "C" int cmdiad_gemm_bf16(const cmdiad_gemm_args* a, cmdiad_stream_t strea
     CMDIAD_REQUIRE(split == 1 || (a->out_f32 && !a->out_bf16 && !a->bias && !a->group_bias && !a->residual &&
                                   a->act == CMDIAD_ACT_NONE && !a->out_pre_bf16 && !a->dact_of),
                    CMDIAD_ERR_ARG, "cmdiad_gemm_bf16: split_k > 1 writes raw f32 slabs only");
-    CMDIAD_REQUIRE(pick_tile(a->M, a->N, split) == 0 || (a->act == CMDIAD_ACT_NONE && !a->out_pre_bf16 && !a->dact_of), CMDIAD_ERR_ARG,
-                   "cmdiad_gemm_bf16: CMDIAD_GEMM_TILE shapes carry the plain epilogue only");
     CMDIAD_REQUIRE((!a->out_pre_bf16 || ((uintptr_t)a->out_pre_bf16 & 7) == 0) && (!a->dact_of || ((uintptr_t)a->dact_of & 7) == 0),
                    CMDIAD_ERR_ARG, "cmdiad_gemm_bf16: out_pre_bf16 / dact_of alignment");
     GlobalTile A{(const bf16_t*)a->A, a->lda, a->M}, W{(const bf16_t*)a->W, a->ldw, a->N};
@@ -355,18 +345,13 @@ extern "C" int cmdiad_gemm_bf16(const cmdiad_gemm_args* a, cmdiad_stream_t strea
                 a->out_f32, a->ldo32, (bf16_t*)a->out_bf16, a->ldo16, (bf16_t*)a->out_pre_bf16, (const bf16_t*)a->dact_of, split, 1};
     hipStream_t s = (hipStream_t)stream;
     const bool extras = a->out_pre_bf16 || a->dact_of;
-    const int tile = pick_tile(a->M, a->N, split);
     int rc;
 #define CMDIAD_STD(SH, ACT, EX) launch<SH>(gemm_std_kernel<SH, ACT, EX>, grid_for<SH>(a->M, a->N, split, p.panel), SH::LDS_BYTES, s, A, W, p)
-    if (tile == 2) rc = CMDIAD_STD(S2x2, CMDIAD_ACT_NONE, false);   // A/B shapes (CMDIAD_GEMM_TILE): plain epilogue only
-    else if (tile == 1) rc = CMDIAD_STD(S256, CMDIAD_ACT_NONE, false);
-    else {
-        p.panel = panel_tiles<S128>(a->M, a->N, a->K, split);
-        if (extras) rc = a->act == CMDIAD_ACT_GELU ? CMDIAD_STD(S128, CMDIAD_ACT_GELU, true)
-                       : a->act == CMDIAD_ACT_RELU ? CMDIAD_STD(S128, CMDIAD_ACT_RELU, true) : CMDIAD_STD(S128, CMDIAD_ACT_NONE, true);
-        else rc = a->act == CMDIAD_ACT_GELU ? CMDIAD_STD(S128, CMDIAD_ACT_GELU, false)
-                : a->act == CMDIAD_ACT_RELU ? CMDIAD_STD(S128, CMDIAD_ACT_RELU, false) : CMDIAD_STD(S128, CMDIAD_ACT_NONE, false);
-    }
+    p.panel = panel_tiles<S128>(a->M, a->N, a->K, split);
+    if (extras) rc = a->act == CMDIAD_ACT_GELU ? CMDIAD_STD(S128, CMDIAD_ACT_GELU, true)
+                   : a->act == CMDIAD_ACT_RELU ? CMDIAD_STD(S128, CMDIAD_ACT_RELU, true) : CMDIAD_STD(S128, CMDIAD_ACT_NONE, true);
+    else rc = a->act == CMDIAD_ACT_GELU ? CMDIAD_STD(S128, CMDIAD_ACT_GELU, false)
+            : a->act == CMDIAD_ACT_RELU ? CMDIAD_STD(S128, CMDIAD_ACT_RELU, false) : CMDIAD_STD(S128, CMDIAD_ACT_NONE, false);
 #undef CMDIAD_STD
     if (rc) return rc;
     CMDIAD_CHECK_LAUNCH();
@@ -384,14 +369,7 @@ extern "C" int cmdiad_gemm_qkv(const uint16_t* A, const uint16_t* W, const float
     GlobalTile At{(const bf16_t*)A, C, M}, Wt{(const bf16_t*)W, C, 3 * C};
     QkvParams p{M, T, (T + 63) / 64 * 64, C, C / 64, bias, (bf16_t*)q_out, (bf16_t*)k_out, (bf16_t*)vt_out};
     hipStream_t s = (hipStream_t)stream;
-    int tile = pick_tile(M, 3 * C, 1);
-    if (tile == 2 && C % 256 != 0) tile = 0;  // a 256-wide N tile must not straddle the q|k|v boundary
-    int rc;
-    switch (tile) {
-        case 2: rc = launch<S2x2>(gemm_qkv_kernel<S2x2>, grid_for<S2x2>(M, 3 * C), S2x2::LDS_BYTES, s, At, Wt, p); break;
-        case 1: rc = launch<S256>(gemm_qkv_kernel<S256>, grid_for<S256>(M, 3 * C), S256::LDS_BYTES, s, At, Wt, p); break;
-        default: rc = launch<S128>(gemm_qkv_kernel<S128>, grid_for<S128>(M, 3 * C), S128::LDS_BYTES, s, At, Wt, p);
-    }
+    const int rc = launch<S128>(gemm_qkv_kernel<S128>, grid_for<S128>(M, 3 * C), S128::LDS_BYTES, s, At, Wt, p);
     if (rc) return rc;
     CMDIAD_CHECK_LAUNCH();
     return CMDIAD_OK;
@@ -409,14 +387,8 @@ extern "C" int cmdiad_gemm_groupmax(const uint16_t* A, const uint16_t* W, const 
     GlobalTile At{(const bf16_t*)A, K, M}, Wt{(const bf16_t*)W, K, N};
     GroupMaxParams p{M, N, K, Mg, 1, bias, nullptr, 0, out_f32, (bf16_t*)out_bf16};
     hipStream_t s = (hipStream_t)stream;
-    int rc;
-    switch (pick_tile(M, N, 1)) {
-        case 2: rc = launch<S2x2>(gemm_groupmax_kernel<S2x2>, grid_for<S2x2>(M, N), group_max_lds<S2x2>(), s, At, Wt, p); break;
-        case 1: rc = launch<S256>(gemm_groupmax_kernel<S256>, grid_for<S256>(M, N), group_max_lds<S256>(), s, At, Wt, p); break;
-        default:
-            p.panel = panel_tiles<S128>(M, N, K, 1);
-            rc = launch<S128>(gemm_groupmax_kernel<S128>, grid_for<S128>(M, N, 1, p.panel), group_max_lds<S128>(), s, At, Wt, p);
-    }
+    p.panel = panel_tiles<S128>(M, N, K, 1);
+    const int rc = launch<S128>(gemm_groupmax_kernel<S128>, grid_for<S128>(M, N, 1, p.panel), group_max_lds<S128>(), s, At, Wt, p);
     if (rc) return rc;
     CMDIAD_CHECK_LAUNCH();
     return CMDIAD_OK;
@@ -436,14 +408,8 @@ extern "C" int cmdiad_encoder_stage1(const float* neigh, const float* w1, const 
     GlobalTile Wt{(const bf16_t*)W2, 128, 256};
     GroupMaxParams p{M, 256, 128, Mg, 1, b2, (bf16_t*)h2_out, 256, gmax_out, (bf16_t*)gmax_bf16_out};
     hipStream_t s = (hipStream_t)stream;
-    int rc;
-    switch (pick_tile(M, 256, 1)) {
-        case 2: rc = launch<S2x2>(encoder_stage1_kernel<S2x2>, grid_for<S2x2>(M, 256), group_max_lds<S2x2>(), s, At, Wt, p); break;
-        case 1: rc = launch<S256>(encoder_stage1_kernel<S256>, grid_for<S256>(M, 256), group_max_lds<S256>(), s, At, Wt, p); break;
-        default:
-            p.panel = panel_tiles<S128>(M, 256, 128, 1);
-            rc = launch<S128>(encoder_stage1_kernel<S128>, grid_for<S128>(M, 256, 1, p.panel), group_max_lds<S128>(), s, At, Wt, p);
-    }
+    p.panel = panel_tiles<S128>(M, 256, 128, 1);
+    const int rc = launch<S128>(encoder_stage1_kernel<S128>, grid_for<S128>(M, 256, 1, p.panel), group_max_lds<S128>(), s, At, Wt, p);
     if (rc) return rc;
     CMDIAD_CHECK_LAUNCH();
     return CMDIAD_OK;

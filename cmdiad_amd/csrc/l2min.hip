@@ -11,7 +11,7 @@
 // per generation of resident blocks.
 #include <stdlib.h>
 
-#include "gemm_core.h"
+#include "gemm_wide.h"
 
 namespace {
 
@@ -85,6 +85,66 @@ __global__ __launch_bounds__(S::THREADS, S::WAVES_PER_SIMD) void l2_min_kernel(G
         o = shfl_xor_u64(key, 32);
         key = o < key ? o : key;
         const int m = m0 + wr * (MI * 16) + i * 16 + (lane & 15);
+        if (lane < 16 && m < p.Q) atomicMin(p.keys + m, key);
+    }
+}
+
+// The same contraction on the 4-wave 128 x 128-per-wave shape (gemm_wide.h).
+template <bool F16>
+__global__ __launch_bounds__(256, 1) void l2_min_wide_kernel(GlobalTile A, GlobalTile W, L2Params p)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    using S = SWide;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int gsz = p.qgroup * p.splits;
+    const int within = wg % gsz;
+    const int split = within / p.qgroup, qt = (wg / gsz) * p.qgroup + within % p.qgroup;
+    if (qt >= p.nq_tiles) return;
+    const int per = (p.n_bank_tiles + p.splits - 1) / p.splits;
+    const int nt0 = split * per;
+    const int ntc = min(per, p.n_bank_tiles - nt0);
+    if (ntc <= 0) return;
+    const int m0 = qt * S::BM;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+
+    float best[8], qn[8];
+    int besti[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        best[i] = __builtin_inff();
+        besti[i] = 0;
+        const int m = m0 + wr * 128 + i * 16 + (lane & 15);
+        qn[i] = m < p.Q ? p.q_sqnorm[m] : 0.0f;
+    }
+    float bn[8][4];
+    run_wide<true, F16>(A, W, m0, nt0, ntc, p.D / BK, lds, [&](auto I, f32x4 (&row)[8], int ntile) {
+        constexpr int i = decltype(I)::value;
+        const int nbase = ntile * S::BN + wc * 128 + (lane >> 4) * 4;
+        if constexpr (i == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bn[j][r] = nbase + j * 16 + r < p.Nb ? p.b_sqnorm[nbase + j * 16 + r] : __builtin_inff();
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float d2 = (qn[i] + bn[j][r]) - 2.0f * row[j][r];
+                if (d2 < best[i]) { best[i] = d2; besti[i] = nbase + j * 16 + r; }  // n increases with j, r: first occurrence wins
+            }
+    });
+
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        unsigned long long key = pack_key(fmaxf(best[i], 0.0f), p.row_offset + (unsigned)besti[i]);
+        if (!(best[i] < __builtin_inff())) key = ~0ull;
+        unsigned long long o = shfl_xor_u64(key, 16);
+        key = o < key ? o : key;
+        o = shfl_xor_u64(key, 32);
+        key = o < key ? o : key;
+        const int m = m0 + wr * 128 + i * 16 + (lane & 15);
         if (lane < 16 && m < p.Q) atomicMin(p.keys + m, key);
     }
 }
@@ -334,13 +394,16 @@ bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 }  // namespace
 
+template <class S, bool F16> struct L2Kernel { static constexpr auto fn = l2_min_kernel<S, F16>; };
+template <bool F16> struct L2Kernel<SWide, F16> { static constexpr auto fn = l2_min_wide_kernel<F16>; };
+
 template <class S, bool F16>
 int launch_l2(const uint16_t* q, const float* q_sqnorm, const uint16_t* bank, const float* bank_sqnorm, int Q, int Nb,
               int D, uint32_t row_offset, unsigned long long* keys, hipStream_t stream)
 {
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)l2_min_kernel<S, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, S::LDS_BYTES) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)L2Kernel<S, F16>::fn, hipFuncAttributeMaxDynamicSharedMemorySize, S::LDS_BYTES) != hipSuccess) {
             cmdiad_set_error("cmdiad_l2_min_keys: hipFuncSetAttribute failed");
             return CMDIAD_ERR_LAUNCH;
         }
@@ -351,14 +414,17 @@ int launch_l2(const uint16_t* q, const float* q_sqnorm, const uint16_t* bank, co
     // min stays in registers and the per-block atomics stay negligible
     static const int env_splits = getenv("CMDIAD_L2_SPLITS") ? atoi(getenv("CMDIAD_L2_SPLITS")) : 0;
     static const int env_qgroup = getenv("CMDIAD_L2_QGROUP") ? atoi(getenv("CMDIAD_L2_QGROUP")) : 0;
+    // measured on the bagel xyz library (profiles/r1_notes.md): 8 bank ranges for the 8-wave shapes; the 4-wave wide
+    // shape gains another 5 % from 16-32 (shorter ranges, better tail balance), as long as a range keeps >= 4 tiles
     int splits = env_splits > 0 ? env_splits : 8;
+    if (env_splits <= 0 && std::is_same<S, SWide>::value) splits = nbt / 4 < 1 ? 1 : (nbt / 4 > 32 ? 32 : nbt / 4);
     splits = splits > nbt ? nbt : splits;
     int qgroup = env_qgroup > 0 ? env_qgroup : 4;
     qgroup = qgroup > nq ? nq : qgroup;
     GlobalTile A{(const bf16_t*)q, D, Q}, W{(const bf16_t*)bank, D, Nb};
     L2Params p{Q, Nb, D, q_sqnorm, bank_sqnorm, row_offset, keys, nq, nbt, splits, qgroup};
     const int ngroups = (nq + qgroup - 1) / qgroup;
-    hipLaunchKernelGGL((l2_min_kernel<S, F16>), dim3(ngroups * qgroup * splits), dim3(S::THREADS), S::LDS_BYTES, stream, A, W, p);
+    hipLaunchKernelGGL((L2Kernel<S, F16>::fn), dim3(ngroups * qgroup * splits), dim3(S::THREADS), S::LDS_BYTES, stream, A, W, p);
     return CMDIAD_OK;
 }
 
@@ -371,15 +437,16 @@ extern "C" int cmdiad_l2_min_keys(const uint16_t* q, const float* q_sqnorm, cons
     CMDIAD_REQUIRE(aligned16(q) && aligned16(bank), CMDIAD_ERR_ARG, "cmdiad_l2_min_keys: 16-byte alignment");
     CMDIAD_REQUIRE(dtype == CMDIAD_DT_BF16 || dtype == CMDIAD_DT_F16, CMDIAD_ERR_ARG, "cmdiad_l2_min_keys: dtype");
     if (Q == 0 || Nb == 0) return CMDIAD_OK;
-    static const int force = getenv("CMDIAD_GEMM_TILE") ? atoi(getenv("CMDIAD_GEMM_TILE")) : -1;
-    // 0 S128, 1 S256 (256x128x3), 2 S2x2 (256x256): measured 892 / 826 / 942 TFLOP/s on the bagel xyz library
-    const int tile = force >= 0 ? force : (Q >= 256 * 64 ? 2 : 0);
+    const char* env_tile = getenv("CMDIAD_L2_TILE");  // read per call: the parity tests force each shape on small inputs
+    const int force = env_tile ? atoi(env_tile) : -1;
+    // 0 S128, 2 S2x2 (256x256, 8 waves), 3 SWide (256x256, 4 waves of 128x128); 256x128x3-stage measured slowest, dropped
+    const int tile = force >= 0 ? force : (Q >= 256 * 64 ? 3 : 0);
     hipStream_t s = (hipStream_t)stream;
     const bool h = dtype == CMDIAD_DT_F16;
     int rc;
 #define L2_ARGS q, q_sqnorm, bank, bank_sqnorm, Q, Nb, D, row_offset, keys, s
-    if (tile == 2) rc = h ? launch_l2<S2x2, true>(L2_ARGS) : launch_l2<S2x2, false>(L2_ARGS);
-    else if (tile == 1) rc = h ? launch_l2<S256, true>(L2_ARGS) : launch_l2<S256, false>(L2_ARGS);
+    if (tile == 3) rc = h ? launch_l2<SWide, true>(L2_ARGS) : launch_l2<SWide, false>(L2_ARGS);
+    else if (tile == 2) rc = h ? launch_l2<S2x2, true>(L2_ARGS) : launch_l2<S2x2, false>(L2_ARGS);
     else rc = h ? launch_l2<S128, true>(L2_ARGS) : launch_l2<S128, false>(L2_ARGS);
 #undef L2_ARGS
     if (rc) return rc;

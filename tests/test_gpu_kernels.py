@@ -251,8 +251,11 @@ def test_pointmae_encoder_stages(Mg, panel_min, monkeypatch):
 
 
 # ------------------------------------------------------------------------------------------ scoring
-@pytest.mark.parametrize("Q,Nb,D", [(784, 1500, 768), (3136, 5000, 128), (100, 77, 64)])
-def test_l2_min_and_rescore(Q, Nb, D):
+@pytest.mark.parametrize("Q,Nb,D,tile", [(784, 1500, 768, None), (3136, 5000, 128, None), (100, 77, 64, None),
+                                          (784, 1500, 768, "3"), (3136, 5000, 128, "3"), (100, 77, 64, "3"), (1000, 2100, 256, "2")])
+def test_l2_min_and_rescore(Q, Nb, D, tile, monkeypatch):
+    if tile:  # 3 = the 4-wave 128x128-per-wave shape production uses from Q >= 16384; 2 = the 8-wave 256x256 shape
+        monkeypatch.setenv("CMDIAD_L2_TILE", tile)
     g = torch.Generator().manual_seed(Q + Nb)
     bank = torch.randn(Nb, D, generator=g)
     q = bank[torch.randint(0, Nb, (Q,), generator=g)] + 0.3 * torch.randn(Q, D, generator=g)

@@ -45,6 +45,8 @@ def hot_blocks(asm_path):
             if not t or not line.startswith("\t"):
                 continue
             op = t[0]
+            if op.startswith("scratch_") and "SCRATCH" not in events:
+                events.append("SCRATCH")
             if op.startswith("v_mfma"):
                 n_mfma += 1
             elif n_mfma == 0:
@@ -57,14 +59,34 @@ def hot_blocks(asm_path):
                 n_mfma = 0
 
 
+def wide_kernel_violations(asm_path):
+    """Kernels built on gemm_wide.h keep their accumulators in AGPRs by convention (named in asm text): the compiler
+    must not generate AGPR writes of its own anywhere in them (VGPR spills must go to scratch, not to AGPRs)."""
+    bad, kernel = [], None
+    with open(asm_path) as f:
+        for line in f:
+            if re.match(r"^_Z\w+:", line):
+                kernel = line.split(":")[0] if "_wide_" in line else None
+                continue
+            if kernel is None or not line.startswith("\t"):
+                continue
+            op = line.split()[0] if line.split() else ""
+            if op.startswith("v_accvgpr_write") or op.startswith("v_accvgpr_mov"):
+                bad.append((kernel, "-", [line.strip()]))
+            if op == "s_endpgm":
+                kernel = None
+    return bad
+
+
 def lint(src):
     bad = []
     asm = compile_to_asm(src)
     try:
         for kernel, label, events in hot_blocks(asm):
             before_read = events[: events.index("READ")] if "READ" in events else events
-            if any(re.search(r"vmcnt\(0\)", e) for e in before_read):
+            if any(re.search(r"vmcnt\(0\)", e) for e in before_read) or "SCRATCH" in events:
                 bad.append((kernel, label, events))
+        bad += wide_kernel_violations(asm)
     finally:
         os.unlink(asm)
     return bad
@@ -76,7 +98,7 @@ def main():
     for src in srcs:
         bad = lint(src)
         for kernel, label, events in bad:
-            print(f"{os.path.basename(src)}: {kernel} {label}: vmcnt(0) before the fragment reads: {events}")
+            print(f"{os.path.basename(src)}: {kernel} {label}: {events}")
             rc = 1
         if not bad:
             print(f"{os.path.basename(src)}: main loops clean")
