@@ -52,14 +52,17 @@ class CpuExtractor:
 
 
 class CpuDoubleRGBPoint:
-    """fit (banks + cross-wired statistics, f_coreset = 1) and predict (pre-OCSVM scores)."""
+    """fit (banks + cross-wired statistics, optional greedy coreset) and predict (pre-OCSVM scores)."""
 
-    def __init__(self, extractor, lambdas=(1.0, 1.0, 0.1, 0.1)):
+    def __init__(self, extractor, lambdas=(1.0, 1.0, 0.1, 0.1), f_coreset=1.0, coreset_eps=0.9, random_state=None):
         self.ex = extractor
+        self.f_coreset, self.coreset_eps, self.random_state = f_coreset, coreset_eps, random_state
         self.xyz_s_l, self.xyz_m_l, self.rgb_s_l, self.rgb_m_l = lambdas
         self.timing = {}
 
-    def fit(self, samples):
+    def fit(self, samples, coreset_override=None):
+        """coreset_override = (xyz_idx, rgb_idx): use these selections instead of running the greedy coreset (the
+        selection is chaotic in the last ulp of its input; tests pin it separately, g9_coreset)."""
         rp, xp = zip(*[self.ex(r, p) for r, p in samples])
         xyz_lib, rgb_lib = torch.cat(xp, 0), torch.cat(rp, 0)
         # multiple_features.py:877-880 (cross-wired, SURVEY F5)
@@ -67,6 +70,13 @@ class CpuDoubleRGBPoint:
         self.xyz_std = self.rgb_std = torch.std(rgb_lib)
         self.xyz_lib = (xyz_lib - self.xyz_mean) / self.xyz_std
         self.rgb_lib = (rgb_lib - self.rgb_mean) / self.rgb_std
+        if self.f_coreset < 1:  # multiple_features.py:885-895
+            self.coreset_idx = {}
+            for k, name in enumerate(("xyz_lib", "rgb_lib")):
+                lib = getattr(self, name)
+                idx = scoring.coreset_idx_randomp(lib, int(self.f_coreset * lib.shape[0]), self.coreset_eps, self.random_state)
+                self.coreset_idx[name] = idx
+                setattr(self, name, lib[idx if coreset_override is None else torch.as_tensor(coreset_override[k]).long()])
         return list(zip(rp, xp))
 
     def set_banks(self, xyz_lib, rgb_lib, xyz_mean, xyz_std, rgb_mean, rgb_std):

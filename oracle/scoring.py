@@ -95,3 +95,26 @@ def score_modality(patch, bank, mean, std, blur=True):
     dist = torch.cdist(patch, bank)
     side = int(math.sqrt(patch.shape[0]))
     return single_s_s_map(patch, dist, bank, (side, side), blur=blur)
+
+
+def coreset_idx_randomp(z_lib, n, eps=0.9, random_state=None):
+    """features.py:360-425 get_coreset_idx_randomp with dist_method_coreset='l2', coreset_dtype='FP16', restated for the
+    CPU (the reference hard-codes .to("cuda"), features.py:397-399): sparse random projection, then greedy k-centre
+    selection -- distances of the half-precision rows to the last pick (difference rounded to half, norm accumulated in
+    float, result rounded to half), running minimum, FIRST arg-max, picked entry zeroed.  Pinned by
+    tests/golden/g9_coreset.npz (the reference's own function run with the device string redirected)."""
+    from sklearn import random_projection
+    transformer = random_projection.SparseRandomProjection(eps=eps, random_state=random_state)
+    z = torch.tensor(transformer.fit_transform(z_lib.numpy()))
+    last = z[0:1]
+    min_d = torch.linalg.norm(z - last, dim=1, keepdims=True).half()
+    zh, last = z.half(), last.half()
+    sel = [0]
+    for _ in range(n - 1):
+        d = torch.linalg.norm(zh - last, dim=1, keepdims=True)
+        min_d = torch.minimum(d, min_d)
+        i = int(torch.argmax(min_d))
+        last = zh[i:i + 1]
+        min_d[i] = 0
+        sel.append(i)
+    return torch.tensor(sel)

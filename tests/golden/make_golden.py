@@ -275,6 +275,91 @@ def main():
     np.savez_compressed(os.path.join(HERE, "g7_aupro.npz"), gts=np.array(gts), preds=np.array(preds),
                         au_pro_03=au03, au_pro_001=au001)
 
+
+    # ---------------- G6: the DINO+Point_MAE protocol through the REFERENCE's own glue
+    # (multiple_features.py:800-1015 DoubleRGBPointFeatures; features.py:123-297, 352-358).  The two backbones are
+    # replaced by this repo's CPU restatements (timm / pointnet2_ops / knn_cuda are absent), so the
+    # fixture pins everything the reference itself owns between the backbone outputs and the final scores: patch
+    # extraction, the cross-wired statistics (F5), bank normalisation, cdist + min, the re-weighting, bilinear
+    # up-sampling, the 8-bit blur, the lambda weights, the late-fusion bank and the two one-class SVMs.
+    from cmdiad_amd.synth import synth_rgb
+
+    class FakeModel(torch.nn.Module):
+        def __init__(self, device, rgb_backbone_name, xyz_backbone_name, group_size, num_group):
+            super().__init__()
+            self.sd_vit = onets.synth_state_dict("vit", 31)
+            self.sd_pm = onets.synth_state_dict("pointmae", 21)
+            self.G, self.M = num_group, group_size
+
+        def forward(self, rgb, xyz, out_type="rgb+xyz"):
+            with torch.no_grad():
+                fmap = onets.vit_forward(self.sd_vit, rgb)
+                pts = np.ascontiguousarray(xyz[0].T.numpy())[None]
+                cidx, cen = ok.fps(pts, self.G)
+                idx, nb = ok.knn_group(pts, cen, self.M)
+                center = torch.from_numpy(cen)
+                tok = onets.pointmae_encoder(self.sd_pm, torch.from_numpy(nb))
+                feats = onets.pointmae_transformer(self.sd_pm, tok, center)
+            return fmap, feats, center, torch.from_numpy(idx), torch.from_numpy(cidx)
+
+    rfeat.Model = FakeModel
+    args = _ns(rgb_backbone_name="vit_base_patch8_224_dino", xyz_backbone_name="Point_MAE", group_size=128, num_group=1024,
+               rgb_size=224, xyz_size=224, gt_size=224, f_coreset=0.25, coreset_eps=0.9, coreset_dtype="FP16",
+               random_state=0, dist_method_s="l2", dist_method_coreset="l2", main_modality="", use_hn=False,
+               use_hn_conv=False, use_hn_from_rgb_mlp=False, use_hn_from_rgb_conv=False, use_hrnet=False, use_uff=False,
+               use_depth=False, fusion_module_path="", ocsvm_nu=0.5, ocsvm_maxiter=1000, xyz_s_lambda=1.0,
+               xyz_smap_lambda=1.0, rgb_s_lambda=0.1, rgb_smap_lambda=0.1, fusion_s_lambda=1.0, fusion_smap_lambda=1.0,
+               save_feature_for_fusion=False, save_frgb_xyz=False, save_rgb_fxyz=False, save_seg_results=False,
+               save_raw_results=False, save_path="", save_path_frgb_xyz="", save_path_rgb_fxyz="", experiment_note="", c_hrnet=0)
+    G6_TRAIN, G6_TEST = (201, 202, 203), (211, 212)
+    sample = lambda sd: (synth_rgb(sd), synth_cloud(sd, 0.45, texture=0.004), synth_cloud(sd, 0.45, texture=0.004))
+    m = rmf.DoubleRGBPointFeatures(args)
+    for sd in G6_TRAIN:
+        m.add_sample_to_mem_bank(sample(sd), class_name="synthetic")
+    # f_coreset < 1 as in real runs: with the whole train set in the bank every late-fusion query would match itself and
+    # the scores would be fp32 cancellation noise.  run_coreset reaches get_coreset_idx_randomp, which hard-codes
+    # .to("cuda") (features.py:397-399): that one device string is redirected to the CPU for the call.
+    orig_to = torch.Tensor.to
+    torch.Tensor.to = lambda self, *a, **k: orig_to(self, *[("cpu" if (isinstance(x, str) and x == "cuda") else x) for x in a], **k)
+    picked = []
+    inner = m.get_coreset_idx_randomp
+    m.get_coreset_idx_randomp = lambda *a, **k: (picked.append(inner(*a, **k)), picked[-1])[1]  # record both selections
+    try:
+        m.run_coreset()
+    finally:
+        torch.Tensor.to = orig_to
+    for sd in G6_TRAIN:
+        m.add_sample_to_late_fusion_mem_bank(sample(sd))
+    s_lib = torch.cat(m.s_lib, 0).clone()
+    s_map_lib = torch.cat(m.s_map_lib, 0).clone()
+    m.run_late_fusion()
+    for sd in G6_TEST:
+        m.predict(sample(sd), torch.zeros(1, 224, 224), 0, ["x.png"])
+    g6 = dict(train_seeds=np.array(G6_TRAIN), test_seeds=np.array(G6_TEST), frac=0.45, texture=0.004, f_coreset=0.25, random_state=0,
+              xyz_mean=float(m.xyz_mean), xyz_std=float(m.xyz_std), rgb_mean=float(m.rgb_mean), rgb_std=float(m.rgb_std),
+              xyz_lib_rows=m.patch_xyz_lib.shape[0], rgb_lib_rows=m.patch_rgb_lib.shape[0],
+              xyz_coreset_idx=picked[0].numpy().astype(np.int32), rgb_coreset_idx=picked[1].numpy().astype(np.int32),
+              xyz_lib_sub=m.patch_xyz_lib[::97, ::16].numpy(), rgb_lib_sub=m.patch_rgb_lib[::31, ::16].numpy(),
+              s_lib=s_lib.numpy(), s_map_lib_sub=s_map_lib[::53].numpy(),
+              detect_coef=m.detect_fuser.coef_, detect_offset=m.detect_fuser.offset_,
+              seg_coef=m.seg_fuser.coef_, seg_offset=m.seg_fuser.offset_,
+              image_preds=np.array(m.image_preds).reshape(-1), pred_maps_sub=np.array(m.predictions)[:, ::4, ::4])
+    np.savez_compressed(os.path.join(HERE, "g6_protocol.npz"), **g6)
+
+    # ---------------- G9: get_coreset_idx_randomp (features.py:360-425), which hard-codes .to("cuda"): run here with
+    # that one device string redirected to the CPU (generator-only patch; the arithmetic is the reference's)
+    g = torch.Generator().manual_seed(91)
+    z = torch.randn(2500, 768, generator=g)
+    orig_to = torch.Tensor.to
+    torch.Tensor.to = lambda self, *a, **k: orig_to(self, *[("cpu" if (isinstance(x, str) and x == "cuda") else x) for x in a], **k)
+    try:
+        fake = _ns(args=_ns(dist_method_coreset="l2"), random_state=0)
+        sel = rfeat.Features.get_coreset_idx_randomp(fake, z, n=250, eps=0.9, coreset_dtype="FP16")
+    finally:
+        torch.Tensor.to = orig_to
+    np.savez_compressed(os.path.join(HERE, "g9_coreset.npz"), z_seed=91, rows=2500, dim=768, n=250, eps=0.9, random_state=0,
+                        idx=sel.numpy().astype(np.int64))
+
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KB")

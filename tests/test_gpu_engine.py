@@ -185,6 +185,17 @@ def test_greedy_coreset_matches_fp16_restatement():
     np.testing.assert_array_equal(sel.numpy(), np.array(ref))
 
 
+def test_coreset_vs_reference_golden(golden):
+    """get_coreset_idx_randomp (host sparse projection + cmdiad_coreset_greedy) against the selection the REFERENCE's
+    own function made on the same rows (tests/golden/g9_coreset.npz, features.py:360-425)."""
+    from cmdiad_amd.feature_extractors.features import Features
+    g = golden("g9_coreset.npz")
+    z = torch.randn(int(g["rows"]), int(g["dim"]), generator=torch.Generator().manual_seed(int(g["z_seed"])))
+    fake = types.SimpleNamespace(args=types.SimpleNamespace(dist_method_coreset="l2"), random_state=int(g["random_state"]), device=DEV)
+    sel = Features.get_coreset_idx_randomp(fake, z, n=int(g["n"]), eps=float(g["eps"]), coreset_dtype="FP16")
+    np.testing.assert_array_equal(sel.numpy(), g["idx"])
+
+
 def test_full_protocol_double_rgb_point_vs_oracle(fitted):
     """cmdiad_runner.py:44-92 end to end for DINO+Point_MAE: late-fusion bank, OCSVM fit, predict, metrics --
     the drop-in against the CPU oracle driven through the same protocol (same scikit-learn on both sides)."""

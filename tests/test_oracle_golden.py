@@ -143,3 +143,62 @@ def test_g5_hallucination(golden):
                 t = params[p].detach()
                 got = (t[:8, :8] if t.dim() == 2 else t[:16]).numpy()
                 np.testing.assert_allclose(got, g[f"step{it + 1}_{p}"], rtol=1e-4, atol=1e-6)
+
+
+def test_g9_coreset(golden):
+    """greedy coreset restatement vs the reference's own get_coreset_idx_randomp (features.py:360-425)"""
+    g = golden("g9_coreset.npz")
+    z = torch.randn(int(g["rows"]), int(g["dim"]), generator=torch.Generator().manual_seed(int(g["z_seed"])))
+    sel = scoring.coreset_idx_randomp(z, int(g["n"]), float(g["eps"]), int(g["random_state"]))
+    np.testing.assert_array_equal(sel.numpy(), g["idx"])
+
+
+def test_g6_protocol_through_reference_glue(golden):
+    """The oracle's DINO+Point_MAE protocol (oracle/pipeline.py) against the REFERENCE's DoubleRGBPointFeatures driven
+    over the same backbone restatements (tests/golden/make_golden.py G6): statistics (cross-wired, F5), normalised
+    banks, per-sample (s, s_map) of the late-fusion bank, the two fitted one-class SVMs, and the final image / pixel
+    predictions of two test samples."""
+    from sklearn import linear_model
+    from cmdiad_amd.synth import synth_cloud, synth_rgb
+    from oracle import nets, pipeline
+    g = golden("g6_protocol.npz")
+    sample = lambda sd: (synth_rgb(int(sd)), synth_cloud(int(sd), float(g["frac"]), texture=float(g["texture"])))
+    ex = pipeline.CpuExtractor(nets.synth_state_dict("vit", 31), nets.synth_state_dict("pointmae", 21))
+    cpu = pipeline.CpuDoubleRGBPoint(ex, lambdas=(1.0, 1.0, 0.1, 0.1), f_coreset=float(g["f_coreset"]), random_state=int(g["random_state"]))
+    feats = cpu.fit([sample(sd) for sd in g["train_seeds"]], coreset_override=(g["xyz_coreset_idx"], g["rgb_coreset_idx"]))
+    # the oracle's own greedy selection on ITS features: chaotic in the last ulp of the input, so only the overlap is checked
+    for name, key in (("xyz_lib", "xyz_coreset_idx"), ("rgb_lib", "rgb_coreset_idx")):
+        own, ref = set(cpu.coreset_idx[name].tolist()), set(g[key].tolist())
+        assert len(own & ref) > 0.8 * len(ref), (name, len(own & ref), len(ref))
+    np.testing.assert_allclose([float(cpu.xyz_mean), float(cpu.xyz_std), float(cpu.rgb_mean), float(cpu.rgb_std)],
+                               [g["xyz_mean"], g["xyz_std"], g["rgb_mean"], g["rgb_std"]], rtol=1e-6)
+    assert cpu.xyz_lib.shape[0] == int(g["xyz_lib_rows"]) and cpu.rgb_lib.shape[0] == int(g["rgb_lib_rows"])
+    np.testing.assert_allclose(cpu.xyz_lib[::97, ::16].numpy(), g["xyz_lib_sub"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(cpu.rgb_lib[::31, ::16].numpy(), g["rgb_lib_sub"], rtol=1e-5, atol=1e-5)
+    s_lib, s_map_lib = [], []
+    for rp, xp in feats:
+        s, s_map, _, _ = cpu.score(rp, xp)
+        s_lib.append(s); s_map_lib.append(s_map)
+    s_lib, s_map_lib = torch.cat(s_lib, 0), torch.cat(s_map_lib, 0)
+    # Column 1 (rgb): genuine distances, reproduced to float rounding; its maps pass through the 8-bit blur
+    # (utils/utils.py:71-83), where a last-ulp difference can flip one level = max/255.
+    # Column 0 (xyz): on this synthetic surface neighbouring Point-MAE patch features are near-duplicates, so the xyz
+    # distances (<= 0.03) sit at the error floor of torch.cdist's fp32 |a|^2+|b|^2-2ab form, which moves with the last
+    # ulp of the features (3e-3 absolute) -- absolute tolerance there.
+    np.testing.assert_allclose(s_lib[:, 1].numpy(), g["s_lib"][:, 1], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(s_lib[:, 0].numpy(), g["s_lib"][:, 0], rtol=0, atol=3e-3)
+    lsb = float(np.abs(g["s_map_lib_sub"][:, 1]).max()) / 255.0
+    d1 = np.abs(s_map_lib[::53, 1].numpy() - g["s_map_lib_sub"][:, 1])
+    assert d1.max() <= 1.25 * lsb and (d1 > 1e-4).mean() < 0.02, (d1.max(), lsb, (d1 > 1e-4).mean())  # lsb from the sub-sampled max: a lower bound
+    np.testing.assert_allclose(s_map_lib[::53, 0].numpy(), g["s_map_lib_sub"][:, 0], rtol=0, atol=3e-3)
+    det = linear_model.SGDOneClassSVM(random_state=42, nu=0.5, max_iter=1000).fit(s_lib)
+    seg = linear_model.SGDOneClassSVM(random_state=42, nu=0.5, max_iter=1000).fit(s_map_lib)
+    np.testing.assert_allclose(det.coef_, g["detect_coef"], rtol=5e-2, atol=1e-4)
+    np.testing.assert_allclose(seg.coef_, g["seg_coef"], rtol=5e-2, atol=1e-4)
+    preds, maps = [], []
+    for sd in g["test_seeds"]:
+        s, s_map, _, _ = cpu.predict(*sample(sd))
+        preds.append(float(det.score_samples(s)[0]))
+        maps.append(seg.score_samples(s_map).reshape(224, 224)[::4, ::4])
+    np.testing.assert_allclose(preds, g["image_preds"], rtol=2e-3, atol=1e-5)
+    np.testing.assert_allclose(np.array(maps), g["pred_maps_sub"], rtol=2e-3, atol=2e-2)  # atol: one blur level x seg coef
