@@ -9,8 +9,9 @@ synthetic MVTec-3D-shaped inputs -- BASELINE.json configs[1]: DINO ViT-B/8 + Poi
 One step = one batch of 32 images per GPU through: unorganise -> ViT-B/8 -> FPS -> kNN-group ->
 Point-MAE encoder + transformer -> 3-NN interpolation + 3x3/adaptive pooling (fused) -> normalise ->
 distance GEMM with running (min, argmin) against both libraries -> exact re-score -> re-weighting scan
--> bilinear 224x224 maps -> D2H -> host 8-bit PIL blur + linear one-class-SVM scores (a14, a19 stay on
-the host as in the reference; they run on a thread pool overlapped with the next step's GPU work).
+-> bilinear 224x224 maps -> 8-bit Gaussian blur (Pillow's arithmetic, bit-exact, on device) -> lambda weights and
+the two linear one-class-SVM scores (models fitted on the host, scored on device) -> D2H of the final image
+scores and pixel maps.
 Inputs are resident in HBM before the timed region.  With N > 1 every rank processes its own batch
 (weak scaling) and the library SEARCH is row-sharded: all-gather of the bf16 queries, per-shard
 distance GEMM, one integer-MIN all-reduce of packed keys over RCCL.
@@ -24,7 +25,6 @@ import json
 import os
 import sys
 import time
-from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 import torch
@@ -95,8 +95,9 @@ class Pipeline:
     def __init__(self, st, group, timers, use_graph=True, ring=3):
         self.st, self.group, self.timers = st, group, timers
         self.side = torch.cuda.Stream()
-        self.ring = [(torch.empty((BATCH, 2), dtype=torch.float32, pin_memory=True),
-                      torch.empty((BATCH, 2, 224, 224), dtype=torch.float32, pin_memory=True)) for _ in range(ring)]
+        # host ring: the step's FINAL outputs (image score, pixel map), f64 as sklearn's score_samples returns them
+        self.ring = [(torch.empty((BATCH, 1), dtype=torch.float64, pin_memory=True),
+                      torch.empty((BATCH, 224 * 224), dtype=torch.float64, pin_memory=True)) for _ in range(ring)]
         self.slot = 0
         self.g1 = self.g2 = None
         self.use_graph = use_graph
@@ -137,13 +138,20 @@ class Pipeline:
             keys[name] = k[bank.rank * B * Q:(bank.rank + 1) * B * Q] if self.group is not None else k
         return keys
 
-    # ---- stage 2: exact re-score, re-weighting, bilinear maps
-    def stage2(self, qs, keys):
+    # ---- stage 2: exact re-score, re-weighting, bilinear maps, 8-bit blur (a14), lambda weights + one-class SVMs (a19)
+    def stage2(self, qs, keys, lambdas=(1.0, 1.0, 0.1, 0.1)):
         from cmdiad_amd import engine as eng
+        from cmdiad_amd import ops
         st = self.st
         rx = eng.score_patches_from_keys(qs["xyz"][0], keys["xyz"].contiguous(), st["bank_xyz"], (56, 56))
         rr = eng.score_patches_from_keys(qs["rgb"][0], keys["rgb"].contiguous(), st["bank_rgb"], (28, 28))
-        return torch.stack([rx["s"], rr["s"]], 1), torch.stack([rx["s_map_pre"], rr["s_map_pre"]], 1)
+        s = torch.stack([rx["s"], rr["s"]], 1)                                   # [B,2]
+        maps = torch.stack([rx["s_map_pre"], rr["s_map_pre"]], 1).contiguous()   # [B,2,224,224]
+        B = maps.shape[0]
+        blurred = ops.blur8_maps(maps.view(B * 2, 224, 224), 4.0).view(B, 2, 224 * 224)
+        pix = ops.ocsvm_score_maps(blurred, (lambdas[1], lambdas[3]), st["seg"].coef_, st["seg"].offset_)
+        img = ops.ocsvm_score_maps(s.view(B, 2, 1).contiguous(), (lambdas[0], lambdas[2]), st["det"].coef_, st["det"].offset_)
+        return img, pix
 
     def _capture(self):
         qs = self.stage1()  # one eager pass first: module loading / attribute setting must not happen in capture
@@ -189,31 +197,10 @@ class Pipeline:
         return host_s, host_m, ev
 
 
-def host_post_chunk(maps, s_rows, lo, hi, st, lambdas=(1.0, 1.0, 0.1, 0.1)):
-    """a14 + a19 on the host for images [lo,hi): 8-bit PIL Gaussian blur of both maps (PIL and numpy release
-    the GIL), lambda weights, linear one-class-SVM scores."""
-    from PIL import Image, ImageFilter
-    blur = ImageFilter.GaussianBlur(radius=4)
-    n = hi - lo
-    fused = np.empty((n, 224 * 224, 2), np.float64)
-    for i in range(n):
-        for c, lam in ((0, lambdas[1]), (1, lambdas[3])):
-            m = maps[lo + i, c]
-            mx = float(m.max())
-            u8 = (m / mx * 255.0).astype(np.uint8)
-            bl = np.asarray(Image.fromarray(u8, mode="L").filter(blur), dtype=np.float32) / 255.0 * mx
-            fused[i, :, c] = lam * bl.reshape(-1)
-    s = s_rows[lo:hi].astype(np.float64) * np.array([lambdas[0], lambdas[2]])
-    return st["det"].score_samples(s), st["seg"].score_samples(fused.reshape(-1, 2)).reshape(n, 224, 224)
-
-
-def host_post(host_s, host_m, ev, st, pool, chunks=8):
-    """Waits for the step's D2H copy, then fans the batch out over the thread pool."""
+def collect(host_s, host_m, ev):
+    """Waits for the step's D2H copy and takes the final scores out of the pinned ring slot."""
     ev.synchronize()
-    maps, s_rows = host_m.numpy(), host_s.numpy()
-    B = maps.shape[0]
-    per = (B + chunks - 1) // chunks
-    return [pool.submit(host_post_chunk, maps, s_rows, lo, min(lo + per, B), st) for lo in range(0, B, per)]
+    return host_s.numpy().copy(), host_m.numpy().copy()
 
 
 def cpu_baseline(n_images=3):
@@ -284,21 +271,16 @@ def main():
 
     st = build_state(dev, rank if sharded else 0, world if sharded else 1)
     timers = {"xyz": Timer(), "rgb": Timer()}
-    pool = ThreadPoolExecutor(max_workers=8)
     g = group if sharded else None
     pipe = Pipeline(st, g, timers, use_graph=os.environ.get("CMDIAD_GRAPH", "1") != "0")
 
-    waiter = ThreadPoolExecutor(max_workers=2)
-
     def run(n):
-        steps, out = [], []
+        pending, out = [], []
         for _ in range(n):
-            if len(steps) >= 2:  # pinned ring of 3: the slot reused next must have been consumed
-                out.extend(f.result() for f in steps[-2].result())
-            host_s, host_m, ev = pipe.step()
-            steps.append(waiter.submit(host_post, host_s, host_m, ev, st, pool))
-        for sfut in steps[max(len(steps) - 2, 0):]:
-            out.extend(f.result() for f in sfut.result())
+            if len(pending) >= 2:  # pinned ring of 3: the slot reused next must have been consumed
+                out.append(collect(*pending.pop(0)))
+            pending.append(pipe.step())
+        out.extend(collect(*p) for p in pending)
         return out
 
     run(args.warmup)
@@ -348,8 +330,6 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_images)
         print(json.dumps(out), flush=True)
-    pool.shutdown()
-    waiter.shutdown()
     if group is not None:
         td.destroy_process_group()
 

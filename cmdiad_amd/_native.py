@@ -6,7 +6,7 @@ There is NO CPU fallback: if the shared object is missing or a call fails, this 
 import ctypes
 import os
 import subprocess
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_size_t, c_uint32, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_size_t, c_uint32, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("CMDIAD_HIP_LIB") or os.path.join(_HERE, "libcmdiad_hip.so")  # override: A/B runs of two builds
@@ -26,7 +26,7 @@ class GemmArgs(Structure):
                 ("out_pre_bf16", c_void_p), ("dact_of", c_void_p), ("split_k", c_int)]
 
 
-P, I, F, SZ, U32 = c_void_p, c_int, c_float, c_size_t, c_uint32
+P, I, F, SZ, U32, D = c_void_p, c_int, c_float, c_size_t, c_uint32, c_double
 # name -> argtypes (every entry point declared in include/cmdiad_hip.h; tests check the two agree)
 SIGNATURES = {
     "cmdiad_fps": [P, P, I, I, I, P, P, P, SZ, P],
@@ -58,6 +58,8 @@ SIGNATURES = {
     "cmdiad_im2col_patch8": [P, I, I, P, P],
     "cmdiad_vit_assemble": [P, P, P, I, I, I, P, P],
     "cmdiad_bilinear_up": [P, I, I, I, P, P],
+    "cmdiad_blur8_maps": [P, I, I, I, F, P, P],
+    "cmdiad_ocsvm_score_maps": [P, I, I, I, P, P, D, P, P],
     "cmdiad_linear3": [P, P, SZ, I, I, P, P],
     "cmdiad_cast_bf16": [P, SZ, P, P],
     "cmdiad_transpose_bf16": [P, I, I, P, P],
@@ -66,6 +68,7 @@ SIZE_QUERIES = {
     "cmdiad_fps_workspace_bytes": [I, I],
     "cmdiad_reweight_workspace_bytes": [I, I],
     "cmdiad_coreset_workspace_bytes": [I, I, I],
+    "cmdiad_blur8_lds_bytes": [I, I],
 }
 
 

@@ -256,6 +256,31 @@ def bilinear_up(x, H):
     return out
 
 
+def blur8_maps(maps, radius=4.0):
+    """KNNGaussianBlur (utils/utils.py:71-83) on device: maps [n,H,W] f32 -> [n,H,W] f32, bit-exact with Pillow's 8-bit path."""
+    _chk(maps, torch.float32, "blur8.maps")
+    n, H, W = maps.shape
+    out = torch.empty_like(maps)
+    _call("cmdiad_blur8_maps", _p(maps), n, H, W, float(radius), _p(out), _stream())
+    return out
+
+
+def ocsvm_score_maps(maps, lambdas, coef, offset):
+    """seg_fuser.score_samples over the lambda-weighted map stack: maps [B,K,HW] f32 -> [B,HW] f64
+    (multiple_features.py:985-992; coef / offset from a host-fitted sklearn SGDOneClassSVM)."""
+    import ctypes
+    import numpy as np
+    _chk(maps, torch.float32, "ocsvm.maps")
+    B, K, HW = maps.shape
+    lam = np.ascontiguousarray(lambdas, dtype=np.float32)
+    cf = np.ascontiguousarray(np.asarray(coef).reshape(-1), dtype=np.float64)
+    assert lam.shape == (K,) and cf.shape == (K,)
+    out = torch.empty((B, HW), dtype=torch.float64, device=maps.device)
+    _call("cmdiad_ocsvm_score_maps", _p(maps), B, K, HW, lam.ctypes.data_as(ctypes.c_void_p), cf.ctypes.data_as(ctypes.c_void_p),
+          float(np.asarray(offset).reshape(-1)[0]), _p(out), _stream())
+    return out
+
+
 def linear3(x, wb, act=ACT_NONE):
     """x [M,3] f32, wb [N,4] f32 -> act(W x + b) as bf16 [M,N]."""
     _chk(x, torch.float32, "linear3.x")

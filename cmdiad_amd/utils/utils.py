@@ -1,8 +1,8 @@
 """Host-side helpers with the reference's names (reference utils/utils.py).
 
 * set_seeds / set_multithreading ........ utils/utils.py:11-31
-* KNNGaussianBlur ....................... utils/utils.py:71-83 (8-bit PIL blur kept on the host, SURVEY F8;
-  torchvision is not a dependency here: ToPILImage/ToTensor are restated as mul(255).byte() / div(255))
+* KNNGaussianBlur ....................... utils/utils.py:71-83: the 8-bit quantisation (ToPILImage = mul(255).byte(),
+  ToTensor = /255) and Pillow's GaussianBlur run on the device in cmdiad_blur8_maps, bit-exact
 * MlpBlock / MlpModule .................. utils/utils.py:86-115: parameter containers with the reference's
   state_dict keys (fc1/fc2/fc3 under mlp_module.<i>); their arithmetic runs in the HIP kernels
   (cmdiad_amd.runtime / cmdiad_amd.train), not in torch.
@@ -14,7 +14,6 @@ from pathlib import Path
 
 import numpy as np
 import torch
-from PIL import Image, ImageFilter
 from torch import nn
 
 
@@ -35,18 +34,20 @@ def set_multithreading(cpu_num: int = 8) -> None:
 
 
 class KNNGaussianBlur(torch.nn.Module):
+    """utils/utils.py:71-83.  The reference quantises the map to 8 bits and runs Pillow's GaussianBlur on the host;
+    here the identical integer arithmetic runs in the HIP kernel cmdiad_blur8_maps (bit-exact with Pillow, see
+    oracle orc_pil_gaussian_blur_u8 and tests/test_gpu_kernels.py::test_blur8_maps_bit_exact)."""
+
     def __init__(self, radius: int = 4):
         super().__init__()
         self.radius = radius
-        self.blur_kernel = ImageFilter.GaussianBlur(radius=radius)
 
     def __call__(self, img):
-        """img [1,1,H,W] (any device) -> [1,H,W] CPU f32: normalise by max, quantise to 8 bits, PIL blur."""
-        img = img.detach().to("cpu", torch.float32)
-        map_max = img.max()
-        u8 = (img[0] / map_max).mul(255).byte().squeeze(0).numpy()
-        blurred = Image.fromarray(u8, mode="L").filter(self.blur_kernel)
-        return torch.from_numpy(np.asarray(blurred, dtype=np.uint8).copy()).float().div(255).unsqueeze(0) * map_max
+        """img [1,1,H,W] -> [1,H,W] CPU f32 (the reference's return placement)."""
+        from .. import ops
+        dev = img.device if img.is_cuda else torch.device("cuda")
+        maps = img.detach().to(dev, torch.float32).reshape(1, img.shape[-2], img.shape[-1]).contiguous()
+        return ops.blur8_maps(maps, float(self.radius)).cpu()
 
 
 class MlpBlock(nn.Module):

@@ -231,6 +231,22 @@ int cmdiad_linear3(const float* x, const float* wb, size_t M, int N, int act, ui
 /* Bilinear up-sampling h x h -> H x H, align_corners=False (features.py:294). in [B,h,h], out [B,H,H]. */
 int cmdiad_bilinear_up(const float* in, int B, int h, int H, float* out, cmdiad_stream_t stream);
 
+/* ---- on-device tail of the scorer ---- */
+
+/* KNNGaussianBlur (utils/utils.py:71-83) for n_maps maps [n_maps,H,W] f32: each map is divided by its maximum, quantised
+ * like torchvision's ToPILImage (mul(255).byte()), blurred exactly as Pillow's ImageFilter.GaussianBlur(radius) does on an
+ * 8-bit image (three extended-box passes per axis, 2^24 fixed point; bit-exact with oracle orc_pil_gaussian_blur_u8),
+ * and mapped back (/255 * max).  H, W >= 2*floor(box radius)+2 and 2 padded 8-bit copies must fit the LDS (<= 256 x 256). */
+int cmdiad_blur8_maps(const float* maps, int n_maps, int H, int W, float radius, float* out, cmdiad_stream_t stream);
+size_t cmdiad_blur8_lds_bytes(int H, int W);
+
+/* Per-pixel late fusion (multiple_features.py:985-992: lambda-weighted map pairs -> seg_fuser.score_samples):
+ * out[b,p] = ((sum_k double(float(lambdas[k] * maps[b,k,p])) * coef[k]) - offset) + offset, i.e. sklearn's
+ * SGDOneClassSVM.score_samples for a model fitted on the host.  maps [B,K,HW] f32 (device), lambdas [K] and coef [K]
+ * host arrays, 1 <= K <= 4, out [B,HW] f64 (device). */
+int cmdiad_ocsvm_score_maps(const float* maps, int B, int K, int HW, const float* lambdas, const double* coef, double offset,
+                            double* out, cmdiad_stream_t stream);
+
 /* ---- training side of the FtoF distillation network (models/hallucination_network.py:47-69,
  * hallucination_network_pretrain.py:102-159) ---- */
 

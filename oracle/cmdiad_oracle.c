@@ -273,3 +273,85 @@ void orc_bilinear_up(const float *in, int h, int H, float *out)
         }
     }
 }
+
+/* ------------------------------------------------------------------------------------
+ * 8-bit Gaussian blur as Pillow computes it -- the arithmetic behind the reference's
+ * KNNGaussianBlur (utils/utils.py:71-83: ToPILImage -> ImageFilter.GaussianBlur(radius=4)
+ * -> ToTensor).  Pillow is a third-party dependency of the reference (README.md pins none;
+ * this image has Pillow 12.2); its published algorithm (src/libImaging/BoxBlur.c,
+ * unchanged in substance since Pillow 2.7) is restated here and PINNED by comparing with
+ * the installed Pillow on random images (tests/test_oracle_golden.py::test_pil_blur_restatement).
+ *
+ *   box radius r = l + a from sigma^2 = radius^2 / passes (Gwosdek et al., "Theoretical
+ *   foundations of Gaussian convolution by extended box filtering"), passes = 3;
+ *   per line: running sum over 2*floor(r)+1 pixels with replicated edges, plus the two
+ *   pixels just outside the window weighted by the fractional part; fixed point 2^24,
+ *   round half up;  3 horizontal passes, transpose, 3 horizontal passes, transpose.
+ * in/out [h,w] uint8 (may alias).  Returns 0, or -1 if a side is shorter than 2*floor(r)+2
+ * (Pillow's short-line branch is not restated).
+ * ---------------------------------------------------------------------------------- */
+static float orc_gaussian_box_radius(float radius, int passes)
+{
+    float sigma2, L, l, a;
+    sigma2 = radius * radius / passes;
+    L = sqrt(12.0 * sigma2 + 1.0);
+    l = floor((L - 1.0) / 2.0);
+    a = (2 * l + 1) * (l * (l + 1) - 3 * sigma2);
+    a /= 6 * (sigma2 - (l + 1) * (l + 1));
+    return l + a;
+}
+
+static void orc_line_box_blur8(uint8_t *out, const uint8_t *in, int lastx, int radius, int edgeA, int edgeB,
+                               uint32_t ww, uint32_t fw)
+{
+    int x;
+    uint32_t acc, bulk;
+    acc = in[0] * (radius + 1);
+    for (x = 0; x < edgeA - 1; x++) acc += in[x];
+    acc += in[lastx] * (radius - edgeA + 1);
+    for (x = 0; x < edgeA; x++) {
+        acc += in[x + radius] - in[0];
+        bulk = acc * ww + (in[0] + in[x + radius + 1]) * fw;
+        out[x] = (uint8_t)((bulk + (1 << 23)) >> 24);
+    }
+    for (x = edgeA; x < edgeB; x++) {
+        acc += in[x + radius] - in[x - radius - 1];
+        bulk = acc * ww + (in[x - radius - 1] + in[x + radius + 1]) * fw;
+        out[x] = (uint8_t)((bulk + (1 << 23)) >> 24);
+    }
+    for (x = edgeB; x <= lastx; x++) {
+        acc += in[lastx] - in[x - radius - 1];
+        bulk = acc * ww + (in[x - radius - 1] + in[lastx]) * fw;
+        out[x] = (uint8_t)((bulk + (1 << 23)) >> 24);
+    }
+}
+
+int orc_pil_gaussian_blur_u8(const uint8_t *in, int h, int w, float radius, uint8_t *out)
+{
+    const int passes = 3;
+    const float fr = orc_gaussian_box_radius(radius, passes);
+    const int r = (int)fr;
+    if (w < 2 * r + 2 || h < 2 * r + 2) return -1;
+    const uint32_t ww = (uint32_t)((uint32_t)(1 << 24) / (fr * 2 + 1));
+    const uint32_t fw = ((1 << 24) - (r * 2 + 1) * ww) / 2;
+    uint8_t *a = (uint8_t *)malloc((size_t)h * w), *t = (uint8_t *)malloc((size_t)h * w);
+    uint8_t *line = (uint8_t *)malloc((size_t)(h > w ? h : w));
+    memcpy(a, in, (size_t)h * w);
+    for (int dim = 0; dim < 2; ++dim) {
+        const int rows = dim == 0 ? h : w, cols = dim == 0 ? w : h;
+        uint8_t *cur = dim == 0 ? a : t;
+        if (dim == 1)
+            for (int y = 0; y < h; ++y)
+                for (int x = 0; x < w; ++x) t[(size_t)x * h + y] = a[(size_t)y * w + x];
+        const int edgeA = r + 1 < cols ? r + 1 : cols, edgeB = cols - r - 1 > 0 ? cols - r - 1 : 0;
+        for (int p = 0; p < passes; ++p)
+            for (int y = 0; y < rows; ++y) {
+                orc_line_box_blur8(line, cur + (size_t)y * cols, cols - 1, r, edgeA, edgeB, ww, fw);
+                memcpy(cur + (size_t)y * cols, line, (size_t)cols);
+            }
+    }
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) out[(size_t)y * w + x] = t[(size_t)x * h + y];
+    free(a); free(t); free(line);
+    return 0;
+}

@@ -94,3 +94,15 @@ def bilinear_up(img, H):
     out = np.empty((H, H), np.float32)
     lib().orc_bilinear_up(_p(img), h, H, _p(out))
     return out
+
+
+def pil_gaussian_blur_u8(img, radius=4.0):
+    """Pillow's ImageFilter.GaussianBlur on an 8-bit image (restated: oracle/cmdiad_oracle.c orc_pil_gaussian_blur_u8)."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    out = np.empty_like(img)
+    f = lib().orc_pil_gaussian_blur_u8
+    f.restype = ctypes.c_int
+    rc = f(_p(img), ctypes.c_int(img.shape[0]), ctypes.c_int(img.shape[1]), ctypes.c_float(radius), _p(out))
+    if rc != 0:
+        raise ValueError("image side shorter than the box window")
+    return out

@@ -309,3 +309,54 @@ def test_im2col_assemble_bilinear_transpose():
     np.testing.assert_allclose(up[0].cpu().numpy(), ok.bilinear_up(m[0].numpy(), 224), rtol=1e-6, atol=1e-7)
     t = torch.randn(130, 70, generator=g).bfloat16()
     np.testing.assert_array_equal(ops.transpose_bf16(t.to(DEV)).float().cpu().numpy(), t.float().T.numpy())
+
+
+# ------------------------------------------------------------------------------------------ on-device scorer tail (f3)
+@pytest.mark.parametrize("n,H,W,radius", [(5, 224, 224, 4.0), (3, 64, 80, 4.0), (2, 100, 37, 1.5), (1, 256, 256, 7.3)])
+def test_blur8_maps_bit_exact(n, H, W, radius):
+    """cmdiad_blur8_maps vs the reference's KNNGaussianBlur arithmetic: quantisation in torch as utils/utils.py:81-82
+    does it, Pillow's blur from the C oracle (pinned to Pillow itself on the CPU) -- every output element identical."""
+    g = torch.Generator().manual_seed(n * H + W)
+    maps = torch.rand(n, H, W, generator=g) ** 2 * 3.7
+    maps[0, : H // 2] *= 0.01
+    if n > 1:
+        maps[1] = torch.linspace(0, 1, H * W).reshape(H, W)  # many values that sit on a quantisation boundary
+    out = ops.blur8_maps(maps.to(DEV), radius).cpu()
+    for i in range(n):
+        mx = maps[i].max()
+        u8 = (maps[i] / mx).mul(255).byte().numpy()
+        ref = torch.from_numpy(ok.pil_gaussian_blur_u8(u8, radius)).float().div(255) * mx
+        np.testing.assert_array_equal(out[i].numpy(), ref.numpy())
+
+
+def test_knn_gaussian_blur_vs_reference_golden(golden):
+    """The drop-in KNNGaussianBlur (device kernel) against the output of the REFERENCE's own KNNGaussianBlur
+    (utils/utils.py:71-83 with real Pillow; tests/golden/g4_score.npz) -- identical bits."""
+    from cmdiad_amd.utils.utils import KNNGaussianBlur
+    g = golden("g4_score.npz")
+    gen = torch.Generator().manual_seed(int(g["blur_seed"]))
+    smooth = torch.nn.functional.interpolate(torch.rand(1, 1, 56, 56, generator=gen) * 3.0, size=(224, 224), mode="bilinear")
+    out = KNNGaussianBlur(4)(smooth.to(DEV))
+    assert out.device.type == "cpu" and out.shape == (1, 224, 224)
+    np.testing.assert_array_equal(out.numpy()[:, ::2, ::2], g["blur_out"])
+    np.testing.assert_array_equal(KNNGaussianBlur(4)(smooth).numpy(), out.numpy())  # CPU input: moved to the device
+
+
+def test_blur8_maps_rejects_short_lines():
+    from cmdiad_amd._native import NativeError
+    with pytest.raises(NativeError):
+        ops.blur8_maps(torch.rand(1, 6, 224, device=DEV), 4.0)
+
+
+def test_ocsvm_score_maps_vs_sklearn():
+    """cmdiad_ocsvm_score_maps vs SGDOneClassSVM.score_samples (features.py:114-115, 352-358; call site
+    multiple_features.py:985-992) on lambda-weighted map pairs."""
+    from sklearn import linear_model
+    g = torch.Generator().manual_seed(3)
+    maps = torch.rand(3, 2, 224 * 224, generator=g) * torch.tensor([2.0, 20.0]).view(1, 2, 1)
+    lam = (1.0, 0.1)
+    X = torch.stack([lam[0] * maps[:, 0], lam[1] * maps[:, 1]], -1).reshape(-1, 2)  # as the reference builds s_map
+    svm = linear_model.SGDOneClassSVM(random_state=42, nu=0.5, max_iter=1000).fit(X[::7])
+    want = svm.score_samples(X).reshape(3, -1)
+    got = ops.ocsvm_score_maps(maps.to(DEV), lam, svm.coef_, svm.offset_).cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-12)  # f64 dot of two terms: summation order only

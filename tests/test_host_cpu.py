@@ -92,14 +92,9 @@ def test_lr_schedule_and_shard_ranges():
             assert all(lo % 128 == 0 for lo, hi in spans if hi > lo)
 
 
-def test_blur_and_unorganize_host_helpers(golden):
+def test_unorganize_host_helper(golden):
     from cmdiad_amd.feature_extractors.multiple_features import organized_pc_to_unorganized_pc_no_zeros
     from cmdiad_amd.synth import synth_cloud
-    from cmdiad_amd.utils.utils import KNNGaussianBlur
-    g = golden("g4_score.npz")
-    gen = torch.Generator().manual_seed(int(g["blur_seed"]))
-    smooth = torch.nn.functional.interpolate(torch.rand(1, 1, 56, 56, generator=gen) * 3.0, size=(224, 224), mode="bilinear")
-    np.testing.assert_array_equal(KNNGaussianBlur(4)(smooth).numpy()[:, ::2, ::2], g["blur_out"])
     g1 = golden("g1b_unorganize.npz")
     pc, nz = organized_pc_to_unorganized_pc_no_zeros((None, synth_cloud(int(g1["seed"]), float(g1["frac"]))))
     assert pc.shape[2] == int(g1["n"]) and nz.sum() == g1["nz_sum"]

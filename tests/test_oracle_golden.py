@@ -202,3 +202,25 @@ def test_g6_protocol_through_reference_glue(golden):
         maps.append(seg.score_samples(s_map).reshape(224, 224)[::4, ::4])
     np.testing.assert_allclose(preds, g["image_preds"], rtol=2e-3, atol=1e-5)
     np.testing.assert_allclose(np.array(maps), g["pred_maps_sub"], rtol=2e-3, atol=2e-2)  # atol: one blur level x seg coef
+
+
+def test_pil_blur_restatement():
+    """orc_pil_gaussian_blur_u8 (the oracle for cmdiad_blur8_maps) against the installed Pillow, bit for bit: random
+    noise, smooth ramps, constant and extreme images, several sizes and radii (the reference uses radius 4 on 224x224,
+    utils/utils.py:71-83)."""
+    from PIL import Image, ImageFilter
+    rs = np.random.RandomState(5)
+    cases = [(224, 224, 4.0), (224, 224, 4.0), (64, 80, 4.0), (224, 224, 2.0), (100, 37, 1.5), (56, 56, 7.3), (224, 224, 0.7)]
+    for n, (h, w, rad) in enumerate(cases):
+        if n % 4 == 0:
+            img = (rs.rand(h, w) * 256).astype(np.uint8)
+        elif n % 4 == 1:
+            img = np.clip(rs.randn(h, w).cumsum(1) * 3 + 128, 0, 255).astype(np.uint8)
+        elif n % 4 == 2:
+            img = np.full((h, w), 255, np.uint8); img[h // 3: h // 2, : w // 2] = 0
+        else:
+            img = (np.add.outer(np.arange(h), np.arange(w)) % 256).astype(np.uint8)
+        ref = np.asarray(Image.fromarray(img, mode="L").filter(ImageFilter.GaussianBlur(radius=rad)))
+        np.testing.assert_array_equal(ok.pil_gaussian_blur_u8(img, rad), ref)
+    with np.testing.assert_raises(ValueError):
+        ok.pil_gaussian_blur_u8(np.zeros((6, 224), np.uint8), 4.0)  # shorter than the box window: not restated
