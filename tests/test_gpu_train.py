@@ -1,5 +1,7 @@
 """GPU: training path of the FtoF distillation net (losses, gradients, Adam steps) against the reference's
 golden vectors (G5, produced by the reference's own module + torch.optim.Adam) and a torch fp32 reference."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -105,3 +107,41 @@ def test_config3_step_shape_runs():
     opt.step()
     torch.cuda.synchronize()
     assert torch.isfinite(lx).item() and torch.isfinite(lr_).item()
+
+
+def test_feature_ring_on_device(tmp_path):
+    """FeatureRing with pinned staging + copy stream: every batch equals the files it was built from, also when the
+    consumer lags (ring slots are recycled only behind the consumer's queued work)."""
+    from cmdiad_amd.dataset import FeatureRing, PreTrainTensorDataset
+    g = torch.Generator().manual_seed(9)
+    for i in range(13):
+        torch.save(torch.randn(64, 1536, generator=g), tmp_path / f"cable{i}.pt")
+    ds = PreTrainTensorDataset(str(tmp_path))
+    t, lab = ds[3]
+    assert t.is_cuda and t.shape == (64, 1536) and lab == 0
+    torch.manual_seed(1)
+    ring = FeatureRing(str(tmp_path), 4, shuffle=True, drop_last=True, device="cuda", depth=3, readers=3)
+    torch.manual_seed(1)
+    plan = ring.batches()
+    torch.manual_seed(1)
+    sums = []
+    for x, lab in ring:
+        assert x.is_cuda and x.shape == (4, 64, 1536)
+        y = x
+        for _ in range(20):  # keep the stream busy so the refill has to wait for this batch's consumers
+            y = y * 1.0000001
+        sums.append((x.double().sum(dim=(1, 2)), y))
+    assert len(sums) == len(plan) == 3
+    files = os.listdir(tmp_path)
+    for (s, _), idxs in zip(sums, plan):
+        want = torch.stack([torch.load(tmp_path / files[i]).double().sum() for i in idxs])
+        np.testing.assert_allclose(s.cpu().numpy(), want.numpy(), rtol=1e-12)
+    # later epochs are served from the HBM-resident cache (samples seen so far) or from disk (the rest): same contents
+    for epoch in range(3):
+        torch.manual_seed(10 + epoch)
+        plan = ring.batches()
+        torch.manual_seed(10 + epoch)
+        for (x, _), idxs in zip(ring, plan):
+            want = torch.stack([torch.load(tmp_path / files[i]) for i in idxs])
+            assert torch.equal(x.cpu(), want)
+    assert sum(ring._cached) >= 12

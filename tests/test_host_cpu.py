@@ -100,6 +100,38 @@ def test_unorganize_host_helper(golden):
     assert pc.shape[2] == int(g1["n"]) and nz.sum() == g1["nz_sum"]
 
 
+def test_feature_ring_reproduces_dataloader_order(tmp_path):
+    """cmdiad_amd.dataset.FeatureRing vs torch's DataLoader over the reference's PreTrainTensorDataset protocol
+    (dataset.py:247-265, hallucination_network_pretrain.py:216-225): same batches in the same order for two epochs and
+    the same global-RNG state afterwards, for shuffle / drop_last combinations."""
+    from torch.utils.data import DataLoader, Dataset
+    from cmdiad_amd.dataset import FeatureRing
+    for i in range(11):
+        torch.save(torch.full((4, 6), float(i)), tmp_path / f"bagel{i}.pt")
+
+    class Files(Dataset):  # the reference's dataset, minus map_location='cuda'
+        def __init__(self, root):
+            self.root, self.paths = root, os.listdir(root)
+
+        def __len__(self):
+            return len(self.paths)
+
+        def __getitem__(self, i):
+            return torch.load(os.path.join(self.root, self.paths[i])), 0
+
+    for shuffle, drop in ((True, True), (True, False), (False, False)):
+        torch.manual_seed(3407)
+        dl = DataLoader(Files(str(tmp_path)), shuffle=shuffle, batch_size=4, drop_last=drop)
+        want = [[b[0] for b in dl] for _ in range(2)]
+        rng_after = torch.rand(1).item()
+        torch.manual_seed(3407)
+        ring = FeatureRing(str(tmp_path), 4, shuffle=shuffle, drop_last=drop, device="cpu", depth=3, readers=2)
+        got = [[x.clone() for x, _ in ring] for _ in range(2)]
+        assert len(ring) == len(want[0])
+        assert all(torch.equal(a, b) for e in range(2) for a, b in zip(want[e], got[e])) and len(got[1]) == len(want[1])
+        assert rng_after == torch.rand(1).item()
+
+
 _GLOO_WORKER = r"""
 import os, sys
 sys.path.insert(0, {repo!r})
