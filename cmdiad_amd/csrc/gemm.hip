@@ -5,7 +5,7 @@
 #include <mutex>
 #include <set>
 
-#include "gemm_core.h"
+#include "gemm_wide.h"
 
 namespace {
 
@@ -274,6 +274,111 @@ __global__ __launch_bounds__(S::THREADS, S::WAVES_PER_SIMD) void encoder_stage1_
 
 template <class S> constexpr int group_max_lds() { return S::LDS_BYTES + (S::BM / 32) * S::BN * (int)sizeof(float); }
 
+// ------------------------------------------------------------------------------------------------
+// The same two products on the 4-wave 256-row shapes of gemm_wide.h (256 x 256 or 256 x 128 blocks): half / three
+// quarters of the operand bytes per FLOP through the L1 / LDS-DMA path, which is what bounds the 128 x 128 shape on
+// the tall short-K products (a 128 x 128 x 64 step moves 32 KiB per 512 MFMA cycles = the path's 64 B/clk/CU).
+// Epilogue terms supported: bias, group bias, activation, bf16 and/or f32 output (no residual / training extras).
+// ------------------------------------------------------------------------------------------------
+template <int NJ, int ACT>
+__global__ __launch_bounds__(256, 1) void gemm_std_wide_kernel(GlobalTile A, GlobalTile W, StdParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    using S = WideShape<NJ>;
+    const int n_tiles_n = (p.N + S::BN - 1) / S::BN;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int groups = (n_tiles_n + p.panel - 1) / p.panel;
+    const int m0 = (wg / groups) * S::BM, nt0 = (wg % groups) * p.panel;
+    const int count = min(p.panel, n_tiles_n - nt0);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+
+    run_wide<true, false, NJ>(A, W, m0, nt0, count, p.K / BK, lds, [&](auto I, f32x4 (&row)[NJ], int ntile) {
+        const int m = m0 + wr * 128 + decltype(I)::value * 16 + (lane & 15);
+        if (m >= p.M) return;
+        const float* gb = p.group_bias ? p.group_bias + (size_t)(m / p.group_rows) * p.N : nullptr;
+        float* o32 = p.out_f32 ? p.out_f32 + (size_t)m * p.ldo32 : nullptr;
+        bf16_t* o16 = p.out_bf16 ? p.out_bf16 + (size_t)m * p.ldo16 : nullptr;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int n = ntile * S::BN + wc * S::WCOLS + j * 16 + (lane >> 4) * 4;
+            if (n >= p.N) continue;
+            f32x4 v = row[j];
+            if (p.bias) { const float4 b = *reinterpret_cast<const float4*>(p.bias + n); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+            if (gb) { const float4 b = *reinterpret_cast<const float4*>(gb + n); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+            if constexpr (ACT == CMDIAD_ACT_GELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+            } else if constexpr (ACT == CMDIAD_ACT_RELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
+            }
+            if (o32) *reinterpret_cast<f32x4*>(o32 + n) = v;
+            if (o16) {
+                bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+                *reinterpret_cast<bf16x4*>(o16 + n) = o;
+            }
+        }
+    });
+}
+
+// Per-group max pooling on the wide shapes.  A wave owns 128 consecutive rows = whole groups (Mg in {32, 64, 128}), so
+// the row maximum never leaves the wave: running max over the 16-row blocks of a group per lane, then over the 16 row
+// lanes by shuffles; no LDS table, no extra barrier.
+template <int NJ>
+__global__ __launch_bounds__(256, 1) void gemm_groupmax_wide_kernel(GlobalTile A, GlobalTile W, GroupMaxParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    using S = WideShape<NJ>;
+    const int n_tiles_n = (p.N + S::BN - 1) / S::BN;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int groups = (n_tiles_n + p.panel - 1) / p.panel;
+    const int m0 = (wg / groups) * S::BM, nt0 = (wg % groups) * p.panel;
+    const int count = min(p.panel, n_tiles_n - nt0);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int blocks_per_group = p.Mg / 16;  // 2, 4 or 8 row blocks
+
+    f32x4 mx[NJ];
+    run_wide<true, false, NJ>(A, W, m0, nt0, count, p.K / BK, lds, [&](auto I, f32x4 (&row)[NJ], int ntile) {
+        constexpr int i = decltype(I)::value;
+        const bool first = (i % blocks_per_group) == 0, last = ((i + 1) % blocks_per_group) == 0;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            if (first) mx[j] = row[j];
+            else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx[j][r] = fmaxf(mx[j][r], row[j][r]);
+            }
+        }
+        if (!last) return;
+        const int grow = m0 + wr * 128 + (i / blocks_per_group) * p.Mg;  // first row of the finished group
+        const int grp = grow / p.Mg;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int n = ntile * S::BN + wc * S::WCOLS + j * 16 + (lane >> 4) * 4;
+            f32x4 v = mx[j];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float t = v[r];
+                t = fmaxf(t, __shfl_xor(t, 1, 64));
+                t = fmaxf(t, __shfl_xor(t, 2, 64));
+                t = fmaxf(t, __shfl_xor(t, 4, 64));
+                t = fmaxf(t, __shfl_xor(t, 8, 64));
+                v[r] = t;
+            }
+            if ((lane & 15) == 0 && n < p.N && grow < p.M) {
+                if (p.bias) { const float4 b = *reinterpret_cast<const float4*>(p.bias + n); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+                if (p.max_f32) *reinterpret_cast<f32x4*>(p.max_f32 + (size_t)grp * p.N + n) = v;
+                if (p.max_bf16) {
+                    bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+                    *reinterpret_cast<bf16x4*>(p.max_bf16 + (size_t)grp * p.N + n) = o;
+                }
+            }
+        }
+    });
+}
+
 bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 // Every network GEMM runs the 128 x 128 shape: the tile sweep on MI355X (profiles/r1_notes.md) had it ahead of
@@ -312,6 +417,42 @@ int panel_tiles(long M, long N, long K, int split)
     return (int)(ntl < 8 ? ntl : 8);
 }
 
+// Wide-shape choice for a product: 0 = keep 128 x 128, 8 = 256 x 256, 4 = 256 x 128.  Measured on MI355X
+// (profiles/r1_notes.md): the 4-wave shapes pay for issuing all LDS-DMA pieces from the MFMA-issuing wave and only win
+// on the tallest short-K product with a 256-multiple N (Point-MAE encoder 4.2M x 512 x 256: 2.34 vs 2.57 ms); every ViT /
+// transformer shape and the N = 384 product are faster on 128 x 128.  CMDIAD_GEMM_WIDE=0 disables, =4 / =8 force a shape
+// (A/B runs; read per call so the parity tests cover every shape on small inputs).
+int wide_choice(long M, long N, long K, bool plain_epilogue, int split)
+{
+    const char* e = getenv("CMDIAD_GEMM_WIDE");
+    const int force = e ? atoi(e) : -1;
+    if (!plain_epilogue || split > 1 || force == 0) return 0;
+    if (force == 4 || force == 8) return force;
+    return (M >= (1 << 20) && K <= 256 && N % 256 == 0) ? 8 : 0;
+}
+
+template <class SW, class Kern, class P>
+int launch_wide(Kern kernel, long M, long N, long K, P& p, const GlobalTile& A, const GlobalTile& W, hipStream_t s)
+{
+    const long ntl = (N + SW::BN - 1) / SW::BN;
+    p.panel = (K <= 512 && ntl <= 8) ? (int)ntl : 1;  // short K: walk the whole N panel in one block
+    const long blocks = ((M + SW::BM - 1) / SW::BM) * ((ntl + p.panel - 1) / p.panel);
+    static std::mutex mu;
+    static std::set<const void*> configured;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        if (!configured.count((const void*)kernel)) {
+            if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SW::LDS_BYTES) != hipSuccess) {
+                cmdiad_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d) failed", SW::LDS_BYTES);
+                return CMDIAD_ERR_LAUNCH;
+            }
+            configured.insert((const void*)kernel);
+        }
+    }
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(256), SW::LDS_BYTES, s, A, W, p);
+    return CMDIAD_OK;
+}
+
 template <class S>
 dim3 grid_for(long M, long N, int y = 1, int panel = 1)
 {
@@ -346,6 +487,16 @@ extern "C" int cmdiad_gemm_bf16(const cmdiad_gemm_args* a, cmdiad_stream_t strea
     hipStream_t s = (hipStream_t)stream;
     const bool extras = a->out_pre_bf16 || a->dact_of;
     int rc;
+    const int wide = wide_choice(a->M, a->N, a->K, !extras && !a->residual && a->ldo16 % 4 == 0, split);
+    if (wide) {
+#define CMDIAD_WIDE(NJ, ACT) launch_wide<WideShape<NJ>>(gemm_std_wide_kernel<NJ, ACT>, a->M, a->N, a->K, p, A, W, s)
+        if (wide == 8) rc = a->act == CMDIAD_ACT_GELU ? CMDIAD_WIDE(8, CMDIAD_ACT_GELU) : a->act == CMDIAD_ACT_RELU ? CMDIAD_WIDE(8, CMDIAD_ACT_RELU) : CMDIAD_WIDE(8, CMDIAD_ACT_NONE);
+        else rc = a->act == CMDIAD_ACT_GELU ? CMDIAD_WIDE(4, CMDIAD_ACT_GELU) : a->act == CMDIAD_ACT_RELU ? CMDIAD_WIDE(4, CMDIAD_ACT_RELU) : CMDIAD_WIDE(4, CMDIAD_ACT_NONE);
+#undef CMDIAD_WIDE
+        if (rc) return rc;
+        CMDIAD_CHECK_LAUNCH();
+        return CMDIAD_OK;
+    }
 #define CMDIAD_STD(SH, ACT, EX) launch<SH>(gemm_std_kernel<SH, ACT, EX>, grid_for<SH>(a->M, a->N, split, p.panel), SH::LDS_BYTES, s, A, W, p)
     p.panel = panel_tiles<S128>(a->M, a->N, a->K, split);
     if (extras) rc = a->act == CMDIAD_ACT_GELU ? CMDIAD_STD(S128, CMDIAD_ACT_GELU, true)
@@ -387,6 +538,14 @@ extern "C" int cmdiad_gemm_groupmax(const uint16_t* A, const uint16_t* W, const 
     GlobalTile At{(const bf16_t*)A, K, M}, Wt{(const bf16_t*)W, K, N};
     GroupMaxParams p{M, N, K, Mg, 1, bias, nullptr, 0, out_f32, (bf16_t*)out_bf16};
     hipStream_t s = (hipStream_t)stream;
+    const int wide = wide_choice(M, N, K, true, 1);
+    if (wide) {
+        const int rcw = wide == 8 ? launch_wide<WideShape<8>>(gemm_groupmax_wide_kernel<8>, M, N, K, p, At, Wt, s)
+                                  : launch_wide<WideShape<4>>(gemm_groupmax_wide_kernel<4>, M, N, K, p, At, Wt, s);
+        if (rcw) return rcw;
+        CMDIAD_CHECK_LAUNCH();
+        return CMDIAD_OK;
+    }
     p.panel = panel_tiles<S128>(M, N, K, 1);
     const int rc = launch<S128>(gemm_groupmax_kernel<S128>, grid_for<S128>(M, N, 1, p.panel), group_max_lds<S128>(), s, At, Wt, p);
     if (rc) return rc;

@@ -20,10 +20,16 @@
 
 namespace gemm {
 
-struct SWide {
-    static constexpr int BM = 256, BN = 256, WAVES = 4, THREADS = 256, MI = 8, NJ = 8;
-    static constexpr int STAGE_BYTES = (BM + BN) * BK * 2, LDS_BYTES = 2 * STAGE_BYTES;  // 2 x 64 KiB, one block per CU
+// NJ = 8: 256 x 256 block (the shape described above).  NJ = 4: 256 x 128 block, 128 x 64 per wave (128 accumulator
+// registers) for products whose N is not a multiple of 256 (the Point-MAE encoder's 384) -- still 256 rows per pass
+// over the weights, i.e. 25 % fewer operand bytes through the L1 / LDS-DMA path per FLOP than 128 x 128 tiles.
+template <int NJ_>
+struct WideShape {
+    static constexpr int BM = 256, NJ = NJ_, BN = 32 * NJ_, WAVES = 4, THREADS = 256, MI = 8;
+    static constexpr int STAGE_BYTES = (BM + BN) * BK * 2, LDS_BYTES = 2 * STAGE_BYTES;  // one block per CU
+    static constexpr int WCOLS = 16 * NJ_;                                               // columns per wave
 };
+typedef WideShape<8> SWide;
 
 #define CMDIAD_A8(b) "a" #b "0", "a" #b "1", "a" #b "2", "a" #b "3", "a" #b "4", "a" #b "5", "a" #b "6", "a" #b "7", "a" #b "8", "a" #b "9"
 #define CMDIAD_ALL_AGPRS                                                                                                   \
@@ -60,26 +66,26 @@ __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int
 template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
-// one accumulator row block (8 tiles) of one 32-deep half of a K-step
-template <int I, bool SWAP, bool ZERO, class Frag>
-__device__ __forceinline__ void wide_row(const Frag& a, const Frag (&wf)[8])
+// one accumulator row block (NJ tiles) of one 32-deep half of a K-step
+template <int I, bool SWAP, bool ZERO, class Frag, int NJ>
+__device__ __forceinline__ void wide_row(const Frag& a, const Frag (&wf)[NJ])
 {
-    static_for<8>([&](auto J) {
-        constexpr int T = I * 8 + decltype(J)::value;
+    static_for<NJ>([&](auto J) {
+        constexpr int T = I * NJ + decltype(J)::value;
         if constexpr (SWAP) wide_mfma<T, ZERO>(wf[decltype(J)::value], a);
         else wide_mfma<T, ZERO>(a, wf[decltype(J)::value]);
     });
 }
 
 // Same contract as gemm::run (flattened (n-tile, k-tile) pipeline, one barrier per K-step), except that the epilogue is
-// called per accumulator ROW BLOCK: epi(std::integral_constant<int, I>, f32x4 (&row)[8], nt) for I = 0..7, where
+// called per accumulator ROW BLOCK: epi(std::integral_constant<int, I>, f32x4 (&row)[NJ], nt) for I = 0..7, where
 // row[j][r] is the element the SWAP / non-SWAP layouts of gemm_core.h put at acc[I][j][r].
-template <bool SWAP, bool F16, class Epi>
+template <bool SWAP, bool F16, int NJ = 8, class Epi>
 __device__ __forceinline__ void run_wide(const GlobalTile& A, const GlobalTile& W, int m0, int nt0, int n_tiles, int KT, char* lds,
                                          Epi&& epi)
 {
     using frag = typename std::conditional<F16, f16x8, bf16x8>::type;
-    using S = SWide;
+    using S = WideShape<NJ>;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int total = n_tiles * KT;
@@ -93,22 +99,25 @@ __device__ __forceinline__ void run_wide(const GlobalTile& A, const GlobalTile& 
     const int lchunk = (lane & 7) ^ ((lane >> 3) & 7);            // logical 16-byte chunk this lane fetches (XOR swizzle)
     const bool a_full = m0 + S::BM <= A.rows;
     const char* pa = reinterpret_cast<const char*>(A.base) + ((size_t)(m0 + r_in) * A.ld + lchunk * 8) * 2;
-    auto dma_tile = [&](const char* p, int ld, int k0, char* tile) {
+    auto dma_tile = [&](const char* p, int ld, int k0, char* tile, auto ROWS_PER_WAVE) {
+        constexpr int RPW = decltype(ROWS_PER_WAVE)::value;
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
+        for (int j = 0; j < RPW / 8; ++j)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p + (size_t)k0 * 2 + (size_t)j * 8 * ld * 2),
-                                             (__attribute__((address_space(3))) void*)(tile + (swave * 64 + j * 8) * (BK * 2)), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(tile + (swave * RPW + j * 8) * (BK * 2)), 16, 0, 0);
     };
+    constexpr int WRPW = S::BN / 4;  // W rows staged per wave
+    const int rw_in = swave * WRPW + (lane >> 3);
     auto stage_a = [&](int slot) {
         char* tile = lds + slot * S::STAGE_BYTES;
-        if (a_full) dma_tile(pa, A.ld, kt_s * BK, tile);
+        if (a_full) dma_tile(pa, A.ld, kt_s * BK, tile, std::integral_constant<int, 64>{});
         else A.template stage<S::BM, S::WAVES>(tile, m0, kt_s * BK, tid);
     };
     auto stage_w = [&](int slot) {
         char* tile = lds + slot * S::STAGE_BYTES + S::BM * BK * 2;
         if (nt_s * S::BN + S::BN <= W.rows) {
-            const char* pw = reinterpret_cast<const char*>(W.base) + ((size_t)(nt_s * S::BN + r_in) * W.ld + lchunk * 8) * 2;
-            dma_tile(pw, W.ld, kt_s * BK, tile);
+            const char* pw = reinterpret_cast<const char*>(W.base) + ((size_t)(nt_s * S::BN + rw_in) * W.ld + lchunk * 8) * 2;
+            dma_tile(pw, W.ld, kt_s * BK, tile, std::integral_constant<int, WRPW>{});
         } else W.template stage<S::BN, S::WAVES>(tile, nt_s * S::BN, kt_s * BK, tid);
         if (++kt_s == KT) { kt_s = 0; ++nt_s; }
     };
@@ -124,16 +133,16 @@ __device__ __forceinline__ void run_wide(const GlobalTile& A, const GlobalTile& 
         // Fragment schedule (96 VGPRs): both halves' W fragments and the first half's A fragments are requested up
         // front; the second half's A fragment i replaces the first half's as soon as row block i has been issued, so
         // those reads travel under the remaining MFMAs of the first half.
-        frag af[8], wf[2][8];
+        frag af[8], wf[2][NJ];
         const int c0 = lane >> 4;
         auto a_frag = [&](int i, int chunk) { return *reinterpret_cast<const frag*>(ta + lds_off(wr * 128 + i * 16 + (lane & 15), chunk)); };
-        auto w_frag = [&](int j, int chunk) { return *reinterpret_cast<const frag*>(tw + lds_off(wc * 128 + j * 16 + (lane & 15), chunk)); };
+        auto w_frag = [&](int j, int chunk) { return *reinterpret_cast<const frag*>(tw + lds_off(wc * S::WCOLS + j * 16 + (lane & 15), chunk)); };
 #pragma unroll
-        for (int j = 0; j < 8; ++j) wf[0][j] = w_frag(j, c0);
+        for (int j = 0; j < NJ; ++j) wf[0][j] = w_frag(j, c0);
 #pragma unroll
         for (int i = 0; i < 8; ++i) af[i] = a_frag(i, c0);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) wf[1][j] = w_frag(j, 4 + c0);
+        for (int j = 0; j < NJ; ++j) wf[1][j] = w_frag(j, 4 + c0);
         // The next K-step's LDS-DMA (that stage was last read in step it-1, which every wave has left) is issued from
         // inside the first half, after row blocks 0 and 1: its address arithmetic then runs in the shadow of MFMAs that
         // are already executing instead of in front of the first one.
@@ -154,9 +163,9 @@ __device__ __forceinline__ void run_wide(const GlobalTile& A, const GlobalTile& 
         if (kt == KT - 1) {
             asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the compiler does not know the asm above are MFMAs
             static_for<8>([&](auto I) {
-                f32x4 row[8];
-                static_for<8>([&](auto J) {
-                    constexpr int R = (decltype(I)::value * 8 + decltype(J)::value) * 4;
+                f32x4 row[NJ];
+                static_for<NJ>([&](auto J) {
+                    constexpr int R = (decltype(I)::value * NJ + decltype(J)::value) * 4;
                     row[decltype(J)::value] = f32x4{wide_read<R>(), wide_read<R + 1>(), wide_read<R + 2>(), wide_read<R + 3>()};
                 });
                 epi(I, row, nt);

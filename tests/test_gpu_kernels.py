@@ -126,11 +126,15 @@ def test_interp3nn_indices_bit_exact_and_patch_fused():
 
 
 # ------------------------------------------------------------------------------------------ GEMM family
-@pytest.mark.parametrize("M,N,K,panel_min", [(128, 128, 64, None), (300, 384, 192, None), (785, 768, 768, None),
-                                              (1000, 1920, 768, None), (300, 384, 192, "1"), (1000, 1156, 512, "1")])
-def test_gemm_epilogues(M, N, K, panel_min, monkeypatch):
+@pytest.mark.parametrize("M,N,K,panel_min,wide", [(128, 128, 64, None, None), (300, 384, 192, None, None), (785, 768, 768, None, None),
+                                                   (1000, 1920, 768, None, None), (300, 384, 192, "1", None), (1000, 1156, 512, "1", None),
+                                                   (300, 384, 192, None, "8"), (1000, 1156, 512, None, "4"), (785, 768, 768, None, "8"),
+                                                   (600, 640, 1024, None, "4")])
+def test_gemm_epilogues(M, N, K, panel_min, wide, monkeypatch):
     if panel_min:  # panel mode: one block walks up to 8 N tiles (K <= 512 products)
         monkeypatch.setenv("CMDIAD_GEMM_PANEL_MIN", panel_min)
+    if wide:  # the 4-wave 256-row shapes (gemm_wide.h): 8 = 256x256, 4 = 256x128; ragged M and N tiles included
+        monkeypatch.setenv("CMDIAD_GEMM_WIDE", wide)
     g = torch.Generator().manual_seed(M + N + K)
     A = _bf(torch.randn(M, K, generator=g))
     W = _bf(torch.randn(N, K, generator=g) / K ** 0.5)
@@ -227,11 +231,13 @@ def test_layernorm(M, C):
     np.testing.assert_allclose(o32[:, C:].cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("Mg,panel_min", [(32, None), (128, None), (128, "1"), (32, "1")])
-def test_pointmae_encoder_stages(Mg, panel_min, monkeypatch):
+@pytest.mark.parametrize("Mg,panel_min,wide", [(32, None, "0"), (128, None, "0"), (128, "1", "0"), (32, "1", "0"),
+                                                (128, None, "8"), (32, None, "4"), (64, None, "4"), (128, None, "4")])
+def test_pointmae_encoder_stages(Mg, panel_min, wide, monkeypatch):
     from oracle import nets
-    if panel_min:  # one block walks every N tile of its M panel (the production path at M = 4.2 M rows)
+    if panel_min:  # one block walks every N tile of its M panel
         monkeypatch.setenv("CMDIAD_GEMM_PANEL_MIN", panel_min)
+    monkeypatch.setenv("CMDIAD_GEMM_WIDE", wide)  # "0": 128x128 shape; "4"/"8": the 256-row shapes production picks at 4.2 M rows
     sd = nets.synth_state_dict("pointmae", 21)
     groups = 24
     g = torch.Generator().manual_seed(Mg)
