@@ -13,8 +13,9 @@ distance GEMM with running (min, argmin) against both libraries -> exact re-scor
 the two linear one-class-SVM scores (models fitted on the host, scored on device) -> D2H of the final image
 scores and pixel maps.
 Inputs are resident in HBM before the timed region.  With N > 1 every rank processes its own batch
-(weak scaling) and the library SEARCH is row-sharded: all-gather of the bf16 queries, per-shard
-distance GEMM, one integer-MIN all-reduce of packed keys over RCCL.
+(weak scaling; images are independent, so there is no collective on the data path -- only the barrier and the
+max-over-ranks of the timing).  CMDIAD_BANK=sharded switches the library SEARCH to row shards: all-gather of the
+16-bit queries, per-shard distance GEMM, one integer-MIN all-reduce of packed keys over RCCL.
 
 Prints ONE JSON line (rank 0) with the fields of the bench contract plus `roofline` (dominant kernel:
 the xyz-library distance GEMM, MFMA-bound) and, at N = 1, `cpu_baseline` (the CPU oracle pipeline timed
@@ -267,7 +268,11 @@ def main():
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29571", RANK="0", WORLD_SIZE="1")
         td.init_process_group("nccl", device_id=dev)
         group = td.group.WORLD
-    sharded = (world > 1 or force_dist) and os.environ.get("CMDIAD_BANK", "sharded") == "sharded"
+    # Images are independent (SURVEY 8e axis ii): by default every rank scores its own batch against its own full copy of
+    # the libraries (353 MB of 288 GB) -- no collective on the data path.  CMDIAD_BANK=sharded selects the row-sharded
+    # search (axis i: all-gather of the queries, per-shard distance GEMM, integer-MIN all-reduce of packed keys over RCCL),
+    # the mode for libraries that do not fit one GPU.
+    sharded = (world > 1 or force_dist) and os.environ.get("CMDIAD_BANK", "replicated") == "sharded"
 
     st = build_state(dev, rank if sharded else 0, world if sharded else 1)
     timers = {"xyz": Timer(), "rgb": Timer()}
@@ -316,7 +321,7 @@ def main():
             "config": {"workload": "configs[1]: DINO ViT-B/8 + Point-MAE predict (DoubleRGBPointFeatures), 224x224 RGB + "
                                    "24576-point clouds (1024 groups x 128), batch 32/GPU, bagel-sized banks "
                                    "(xyz 76518x768, rgb 19129x768)",
-                       "batch_per_gpu": BATCH, "bank": "row-sharded search + RCCL min-reduce" if sharded else "single",
+                       "batch_per_gpu": BATCH, "bank": "row-sharded search + RCCL min-reduce" if sharded else ("replicated per rank, images sharded, no data-path collective" if world > 1 else "single"),
                        "hip_graphs": bool(pipe.use_graph), "search_operands": "fp16 (fp32 accumulate, exact fp32 re-score)",
                        "weights": "seeded random init (no checkpoints offline)"},
             "roofline": {"kernel": "l2_min_wide_kernel (xyz library distance GEMM + running min/argmin)", "bound": "mfma",
