@@ -418,17 +418,18 @@ int panel_tiles(long M, long N, long K, int split)
 }
 
 // Wide-shape choice for a product: 0 = keep 128 x 128, 8 = 256 x 256, 4 = 256 x 128.  Measured on MI355X
-// (profiles/r1_notes.md): the 4-wave shapes pay for issuing all LDS-DMA pieces from the MFMA-issuing wave and only win
-// on the tallest short-K product with a 256-multiple N (Point-MAE encoder 4.2M x 512 x 256: 2.34 vs 2.57 ms); every ViT /
-// transformer shape and the N = 384 product are faster on 128 x 128.  CMDIAD_GEMM_WIDE=0 disables, =4 / =8 force a shape
-// (A/B runs; read per call so the parity tests cover every shape on small inputs).
+// (profiles/r1_notes.md): the 4-wave shapes pay for issuing all LDS-DMA pieces from the MFMA-issuing wave; the only shape
+// they win as a bare product (4.2M x 512 x 256: 2.34 vs 2.57 ms) they lose again inside the encoder, where that GEMM
+// carries the group-bias + ReLU epilogue (encoder 8.6-8.9 vs 7.9 ms).  So no network GEMM selects them; the distance GEMM
+// does (l2min.hip).  CMDIAD_GEMM_WIDE=4 / =8 force a shape (A/B runs and the parity tests; read per call).
 int wide_choice(long M, long N, long K, bool plain_epilogue, int split)
 {
     const char* e = getenv("CMDIAD_GEMM_WIDE");
     const int force = e ? atoi(e) : -1;
     if (!plain_epilogue || split > 1 || force == 0) return 0;
     if (force == 4 || force == 8) return force;
-    return (M >= (1 << 20) && K <= 256 && N % 256 == 0) ? 8 : 0;
+    (void)M; (void)N; (void)K;
+    return 0;
 }
 
 template <class SW, class Kern, class P>
