@@ -150,6 +150,26 @@ class Features(torch.nn.Module):
             out += [[xmap], ex.center, ex.ori_idx, ex.center_idx, LazyInterpolated(ex)]
         return out[0] if len(out) == 1 else tuple(out)
 
+    def _extract_device(self, rgb, organized_pc, want_rgb=True, want_xyz=True):
+        """Device-resident form of (organized_pc_to_unorganized_pc_no_zeros + __call__) for the method classes' own use:
+        the zero-pixel compaction runs in cmdiad_unorganize (bit-identical order to the host numpy form) and nothing is
+        copied back to the host.  Returns the Extraction the patch getters consume."""
+        dev = self.device
+        ex = eng.Extraction()
+        ex.size = self.xyz_size
+        with torch.no_grad():
+            if want_xyz:
+                opc = organized_pc.to(dev, torch.float32).contiguous()
+                xyz, nz, pix2pt, nv = ops.unorganize(opc, None)
+                n = int(nv[0].item())  # the only host round trip: sizes the exact-N tensors the B = 1 path works on
+                ex.xyz, ex.nz, ex.pix2pt, ex.n_valid = xyz[:, :n].contiguous(), nz[:, :n], pix2pt, None
+            if want_rgb:
+                ex.rgb_tokens = self._engine.vit.forward_tokens(rgb.to(dev).float())
+            if want_xyz:
+                ex.xyz_feats, ex.center, ex.ori_idx, ex.center_idx = self._engine.pm.forward(ex.xyz)
+                ex.idx3, ex.w3 = ops.interp3nn(ex.xyz, ex.center)
+        return ex
+
     def get_rgb_patch(self, rgb_feature_maps):
         """features.py:160-167 -> (rgb_patch [784,768], rgb_patch2 [3136,768]) on the GPU."""
         ex = getattr(rgb_feature_maps[0], "_cmdiad", None)

@@ -38,10 +38,15 @@ def _side(patch):
 class _MethodBase(Features):
     """Shared plumbing of the method classes (not part of the reference's public surface)."""
 
-    def _extract(self, sample):
-        pc, nz = organized_pc_to_unorganized_pc_no_zeros(sample)
-        rgb_maps, xyz_maps, center, nbr_idx, center_idx, interp = self(sample[0], pc.contiguous())
-        return rgb_maps, xyz_maps, interp, nz
+    def _extract(self, sample, want_rgb=True, want_xyz=True):
+        """(rgb_maps, xyz_maps, interpolated, nonzero_indices) as the reference's methods name them.  The two map lists
+        are handles onto the device-resident extraction (the public Features.__call__ still returns the CPU copies the
+        reference returns; the method classes themselves never need them)."""
+        from .features import LazyInterpolated
+        ex = self._extract_device(sample[0], sample[1], want_rgb, want_xyz)
+        handle = torch.empty(0)
+        handle._cmdiad = ex
+        return [handle], [handle], LazyInterpolated(ex), None
 
     def _coreset(self, lib, name):
         if self.f_coreset < 1:
@@ -67,8 +72,8 @@ class _MethodBase(Features):
         s_map = torch.tensor(self.seg_fuser.score_samples(s_map)).view(1, self.gt_size, self.gt_size)
         self.image_preds.append(s.numpy())
         self.image_labels.append(label)
-        self.pixel_preds.extend(s_map.flatten().numpy())
-        self.pixel_labels.extend(mask.flatten().numpy())
+        self.pixel_preds.extend(s_map.flatten().tolist())   # python floats: 10x faster to append than numpy scalars
+        self.pixel_labels.extend(mask.flatten().tolist())
         self.predictions.append(s_map.detach().cpu().squeeze().numpy())
         self.gts.append(mask.detach().cpu().squeeze().numpy())
         self.img_name.append(rgb_path)
@@ -81,7 +86,7 @@ class _MethodBase(Features):
 class RGBFeatures(_MethodBase):
     def add_sample_to_mem_bank(self, sample, class_name=None):
         self.class_name = class_name
-        rgb_maps, _, _, _ = self._extract(sample)
+        rgb_maps, _, _, _ = self._extract(sample, want_xyz=False)
         self.patch_rgb_lib.append(self.get_rgb_patch(rgb_maps)[0])
 
     def run_coreset(self):
@@ -90,7 +95,7 @@ class RGBFeatures(_MethodBase):
         self.patch_rgb_lib = self._coreset(eng.normalize(self.patch_rgb_lib, self.rgb_mean, self.rgb_std), 'patch_rgb_lib')
 
     def _s(self, sample):
-        rgb_maps, _, _, _ = self._extract(sample)
+        rgb_maps, _, _, _ = self._extract(sample, want_xyz=False)
         s_rgb, m_rgb = self._score(self.get_rgb_patch(rgb_maps)[0], self.rgb_mean, self.rgb_std, 'rgb')
         return self._fuse_inputs([(self.args.rgb_s_lambda, s_rgb, self.args.rgb_smap_lambda, m_rgb)])
 
@@ -107,7 +112,7 @@ class RGBFeatures(_MethodBase):
 class PointFeatures(_MethodBase):
     def add_sample_to_mem_bank(self, sample, class_name=None):
         self.class_name = class_name
-        _, xyz_maps, interp, nz = self._extract(sample)
+        _, xyz_maps, interp, nz = self._extract(sample, want_rgb=False)
         self.patch_xyz_lib.append(self.get_xyz_patch(xyz_maps, interp, nz))
 
     def run_coreset(self):
@@ -116,7 +121,7 @@ class PointFeatures(_MethodBase):
         self.patch_xyz_lib = self._coreset(eng.normalize(self.patch_xyz_lib, self.xyz_mean, self.xyz_std), 'patch_xyz_lib')
 
     def _s(self, sample):
-        _, xyz_maps, interp, nz = self._extract(sample)
+        _, xyz_maps, interp, nz = self._extract(sample, want_rgb=False)
         s_xyz, m_xyz = self._score(self.get_xyz_patch(xyz_maps, interp, nz), self.xyz_mean, self.xyz_std, 'xyz')
         return self._fuse_inputs([(self.args.xyz_s_lambda, s_xyz, self.args.xyz_smap_lambda, m_xyz)])
 
