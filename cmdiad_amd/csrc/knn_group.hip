@@ -160,6 +160,7 @@ extern "C" int cmdiad_knn_group(const float* xyz, const int32_t* n_valid, const 
                                 int G, int K, int64_t* idx_out, float* neigh_out, cmdiad_stream_t stream)
 {
     CMDIAD_REQUIRE(xyz && center, CMDIAD_ERR_ARG, "cmdiad_knn_group: null pointer");
+    CMDIAD_REQUIRE(K <= N, CMDIAD_ERR_ARG, "cmdiad_knn_group: K = %d neighbours requested from clouds of N = %d points", K, N);
     CMDIAD_REQUIRE(B >= 0 && N > 0 && G >= 0 && K > 0 && K <= 128, CMDIAD_ERR_ARG,
                    "cmdiad_knn_group: bad sizes B=%d N=%d G=%d K=%d (K<=128)", B, N, G, K);
     if (B == 0 || G == 0) return CMDIAD_OK;

@@ -162,6 +162,9 @@ class Features(torch.nn.Module):
                 opc = organized_pc.to(dev, torch.float32).contiguous()
                 xyz, nz, pix2pt, nv = ops.unorganize(opc, None)
                 n = int(nv[0].item())  # the only host round trip: sizes the exact-N tensors the B = 1 path works on
+                if n < self.args.group_size:
+                    raise ValueError(f"point cloud has {n} valid points; the {self.args.group_size}-nearest-neighbour grouping "
+                                     f"(models/models.py:88-113) needs at least {self.args.group_size}")
                 ex.xyz, ex.nz, ex.pix2pt, ex.n_valid = xyz[:, :n].contiguous(), nz[:, :n], pix2pt, None
             if want_rgb:
                 ex.rgb_tokens = self._engine.vit.forward_tokens(rgb.to(dev).float())

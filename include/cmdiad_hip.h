@@ -53,7 +53,8 @@ int cmdiad_fps(const float* xyz, const int32_t* n_valid, int B, int N, int G, in
  * plus the gathered, centre-subtracted neighbourhood.
  * Replaces knn_cuda.KNN(k, transpose_mode=True)(ref[B,N,3], query[B,G,3]) -> idx int64[B,G,k]
  * (models/models.py:86,100) and the gather/subtract at models/models.py:105-112.
- * idx_out [B,G,K] int64 (NULL allowed), neigh_out [B,G,K,3] f32 (NULL allowed).  K <= 128.
+ * idx_out [B,G,K] int64 (NULL allowed), neigh_out [B,G,K,3] f32 (NULL allowed).  K <= 128 and K <= N
+ * (every cloud, i.e. K <= n_valid[b], must hold at least K points: the reference library has no defined result otherwise).
  * Bit-exact with oracle/cmdiad_oracle.c:orc_knn_group. */
 int cmdiad_knn_group(const float* xyz, const int32_t* n_valid, const float* center, int B, int N, int G,
                      int K, int64_t* idx_out, float* neigh_out, cmdiad_stream_t stream);

@@ -366,3 +366,45 @@ def test_ocsvm_score_maps_vs_sklearn():
     want = svm.score_samples(X).reshape(3, -1)
     got = ops.ocsvm_score_maps(maps.to(DEV), lam, svm.coef_, svm.offset_).cpu().numpy()
     np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-12)  # f64 dot of two terms: summation order only
+
+
+# ------------------------------------------------------------------------------------------ edge cases of the point-cloud front end
+def test_full_frame_cloud_maximum_size():
+    """Every pixel valid: N = 224*224 = 50 176, the largest cloud the path can see (FPS memory-resident fallback)."""
+    pc = synth_cloud(21, 3.0)  # ellipse larger than the frame -> no background
+    xyz, nz, pix2pt, nv = ops.unorganize(pc.to(DEV))
+    assert int(nv[0]) == 224 * 224 and torch.equal(nz[0].cpu(), torch.arange(224 * 224, dtype=torch.int32))
+    pts = xyz.cpu().numpy()
+    idx, cen = ops.fps(xyz, 256)
+    idx_ref, cen_ref = ok.fps(pts, 256)
+    np.testing.assert_array_equal(idx.cpu().numpy(), idx_ref)
+    gi, nb = ops.knn_group(xyz, cen, 128)
+    ir, nr = ok.knn_group(pts, cen_ref, 128)
+    np.testing.assert_array_equal(gi.cpu().numpy(), ir)
+    np.testing.assert_array_equal(nb.cpu().numpy(), nr)
+
+
+def test_tiny_clouds():
+    """Fewer points than groups (FPS then repeats points: every running minimum is 0 and the lowest index wins) and
+    exactly K points (the neighbourhood is the whole cloud); K > N is rejected."""
+    from cmdiad_amd._native import NativeError
+    xyz, _ = _cloud(22, 0.05)
+    few = np.ascontiguousarray(xyz[:40])
+    idx, cen = ops.fps(torch.from_numpy(few[None]).to(DEV), 64)
+    idx_ref, cen_ref = ok.fps(few[None], 64)
+    np.testing.assert_array_equal(idx.cpu().numpy(), idx_ref)
+    np.testing.assert_array_equal(cen.cpu().numpy(), cen_ref)
+    gi, nb = ops.knn_group(torch.from_numpy(few[None]).to(DEV), cen, 40)
+    ir, nr = ok.knn_group(few[None], cen_ref, 40)
+    np.testing.assert_array_equal(gi.cpu().numpy(), ir)
+    np.testing.assert_array_equal(nb.cpu().numpy(), nr)
+    assert all(sorted(row) == list(range(40)) for row in gi[0].cpu().tolist())
+    with pytest.raises(NativeError):
+        ops.knn_group(torch.from_numpy(few[None]).to(DEV), cen, 41)
+
+
+def test_empty_frame_is_reported():
+    """An all-background frame has no points: unorganize reports n = 0 and the drop-in raises instead of sampling."""
+    pc = torch.zeros(1, 3, 224, 224)
+    xyz, nz, pix2pt, nv = ops.unorganize(pc.to(DEV))
+    assert int(nv[0]) == 0 and bool((pix2pt == -1).all())
