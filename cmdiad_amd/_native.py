@@ -58,6 +58,8 @@ SIGNATURES = {
     "cmdiad_im2col_patch8": [P, I, I, P, P],
     "cmdiad_vit_assemble": [P, P, P, I, I, I, P, P],
     "cmdiad_bilinear_up": [P, I, I, I, P, P],
+    "cmdiad_ball_query": [P, P, P, I, I, I, F, I, P, P],
+    "cmdiad_gather_points": [P, P, I, I, I, I, P, P],
     "cmdiad_blur8_maps": [P, I, I, I, F, P, P],
     "cmdiad_ocsvm_score_maps": [P, I, I, I, P, P, D, P, P],
     "cmdiad_linear3": [P, P, SZ, I, I, P, P],

@@ -83,6 +83,26 @@ def unorganize(organized_pc, n_max=None):
     return xyz, nz, pix2pt, n_valid
 
 
+def ball_query(radius, nsample, xyz, new_xyz, n_valid=None):
+    """pointnet2_ops ball_query: xyz [B,N,3], new_xyz [B,M,3] -> idx [B,M,nsample] int32."""
+    _chk(xyz, torch.float32, "ball_query.xyz"); _chk(new_xyz, torch.float32, "ball_query.new_xyz")
+    B, N, _ = xyz.shape
+    M = new_xyz.shape[1]
+    idx = torch.empty((B, M, nsample), dtype=torch.int32, device=xyz.device)
+    _call("cmdiad_ball_query", _p(xyz), _p(n_valid), _p(new_xyz), B, N, M, float(radius), int(nsample), _p(idx), _stream())
+    return idx
+
+
+def gather_points(feat, idx):
+    """feat [B,C,N] f32, idx [B,...] int32 -> [B,C,...] (gather_operation / grouping_operation)."""
+    _chk(feat, torch.float32, "gather.feat"); _chk(idx, torch.int32, "gather.idx")
+    B, C, N = feat.shape
+    J = idx[0].numel()
+    out = torch.empty((B, C, *idx.shape[1:]), dtype=torch.float32, device=feat.device)
+    _call("cmdiad_gather_points", _p(feat), _p(idx), B, C, N, J, _p(out), _stream())
+    return out
+
+
 def interp3nn(xyz, center, n_valid=None):
     """-> (idx3 [B,N,3] i32, w3 [B,N,3] f32).  models/pointnet2_utils.py:45-71."""
     _chk(xyz, torch.float32, "interp3nn.xyz"); _chk(center, torch.float32, "interp3nn.center")

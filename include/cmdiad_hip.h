@@ -232,6 +232,19 @@ int cmdiad_linear3(const float* x, const float* wb, size_t M, int N, int act, ui
 /* Bilinear up-sampling h x h -> H x H, align_corners=False (features.py:294). in [B,h,h], out [B,H,H]. */
 int cmdiad_bilinear_up(const float* in, int B, int h, int H, float* out, cmdiad_stream_t stream);
 
+/* ---- rest of the pointnet2_ops surface (the reference imports the package at models/models.py:5 but
+ * only calls furthest_point_sample and gather_operation) ---- */
+
+/* pointnet2_utils.ball_query(radius, nsample, xyz[B,N,3], new_xyz[B,M,3]) -> idx int32 [B,M,nsample]: the first nsample
+ * points in index order with squared distance < radius^2, the first hit pre-filling every slot, zeros when nothing is in
+ * range.  n_valid as in cmdiad_fps (NULL = N).  Bit-exact with oracle orc_ball_query. */
+int cmdiad_ball_query(const float* xyz, const int32_t* n_valid, const float* new_xyz, int B, int N, int M, float radius,
+                      int nsample, int32_t* idx_out, cmdiad_stream_t stream);
+
+/* out[b,c,j] = feat[b,c,idx[b,j]]: pointnet2_utils.gather_operation (feat [B,C,N], idx [B,M] -> [B,C,M], models/models.py:77)
+ * and grouping_operation (idx [B,M,nsample] flattened to J = M*nsample -> [B,C,M,nsample]).  idx int32, feat / out f32. */
+int cmdiad_gather_points(const float* feat, const int32_t* idx, int B, int C, int N, int J, float* out, cmdiad_stream_t stream);
+
 /* ---- on-device tail of the scorer ---- */
 
 /* KNNGaussianBlur (utils/utils.py:71-83) for n_maps maps [n_maps,H,W] f32: each map is divided by its maximum, quantised

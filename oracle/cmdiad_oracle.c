@@ -355,3 +355,33 @@ int orc_pil_gaussian_blur_u8(const uint8_t *in, int h, int w, float radius, uint
     free(a); free(t); free(line);
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------
+ * Ball query.  pointnet2_ops.pointnet2_utils.ball_query [external, un-vendored; named by the task's
+ * north_star, not called by the reference -- SURVEY F7].  Published algorithm restated: for every query point walk the
+ * cloud in index order; a point is inside when dx*dx + dy*dy + dz*dz < radius^2; the first hit fills all nsample slots,
+ * later hits overwrite slots 1, 2, ... until nsample points are found; no hit leaves zeros.  "Parity unpinned".
+ * xyz [B,N,3], new_xyz [B,M,3] -> idx [B,M,nsample] int32.
+ * ---------------------------------------------------------------------------------- */
+void orc_ball_query(const float *xyz, const float *new_xyz, int B, int N, int M, float radius, int nsample, int32_t *idx)
+{
+    const float r2 = radius * radius;
+    for (int b = 0; b < B; ++b)
+        for (int j = 0; j < M; ++j) {
+            const float *q = new_xyz + ((size_t)b * M + j) * 3;
+            int32_t *out = idx + ((size_t)b * M + j) * nsample;
+            for (int l = 0; l < nsample; ++l) out[l] = 0;
+            int cnt = 0;
+            for (int k = 0; k < N && cnt < nsample; ++k) {
+                const float *p = xyz + ((size_t)b * N + k) * 3;
+                const float dx = q[0] - p[0], dy = q[1] - p[1], dz = q[2] - p[2];
+                const float d2 = (dx * dx + dy * dy) + dz * dz;
+                if (d2 < r2) {
+                    if (cnt == 0)
+                        for (int l = 0; l < nsample; ++l) out[l] = k;
+                    out[cnt] = k;
+                    ++cnt;
+                }
+            }
+        }
+}

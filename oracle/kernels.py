@@ -106,3 +106,13 @@ def pil_gaussian_blur_u8(img, radius=4.0):
     if rc != 0:
         raise ValueError("image side shorter than the box window")
     return out
+
+
+def ball_query(radius, nsample, xyz, new_xyz):
+    """pointnet2_ops ball_query restated (oracle/cmdiad_oracle.c orc_ball_query): xyz [B,N,3], new_xyz [B,M,3] -> idx [B,M,nsample] int32."""
+    xyz, new_xyz = _f32(xyz), _f32(new_xyz)
+    B, N, _ = xyz.shape
+    M = new_xyz.shape[1]
+    idx = np.empty((B, M, nsample), np.int32)
+    lib().orc_ball_query(_p(xyz), _p(new_xyz), B, N, M, ctypes.c_float(radius), nsample, _p(idx, ctypes.c_int32))
+    return idx

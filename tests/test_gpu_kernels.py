@@ -408,3 +408,41 @@ def test_empty_frame_is_reported():
     pc = torch.zeros(1, 3, 224, 224)
     xyz, nz, pix2pt, nv = ops.unorganize(pc.to(DEV))
     assert int(nv[0]) == 0 and bool((pix2pt == -1).all())
+
+
+# ------------------------------------------------------------------------------------------ pointnet2_ops / knn_cuda surface (f4)
+@pytest.mark.parametrize("radius,nsample", [(0.004, 16), (0.02, 64), (0.0005, 8)])
+def test_ball_query_bit_exact(radius, nsample):
+    a, _ = _cloud(31, 0.08)
+    b, _ = _cloud(32, 0.06)
+    N = min(len(a), len(b))
+    xyz = np.stack([a[:N], b[:N]])
+    cen = np.stack([ok.fps(a[None, :N], 100)[1][0], ok.fps(b[None, :N], 100)[1][0]])
+    cen[0, 7] += 1.0  # a query with nothing in range -> zeros
+    ref = ok.ball_query(radius, nsample, xyz, cen)
+    got = ops.ball_query(radius, nsample, torch.from_numpy(xyz).to(DEV), torch.from_numpy(cen).to(DEV))
+    np.testing.assert_array_equal(got.cpu().numpy(), ref)
+    assert (ref[0, 7] == 0).all()
+
+
+def test_reference_models_run_on_compat_shims():
+    """pointnet2_ops.pointnet2_utils / knn_cuda stand-ins: the wheel's call signatures (models/models.py:70-113 usage) give
+    the same indices and gathers as the C oracle; QueryAndGroup = ball query + gather + centre subtraction."""
+    from cmdiad_amd.compat import knn_cuda, pointnet2_utils as p2
+    a, _ = _cloud(33, 0.1)
+    xyz = torch.from_numpy(a[None]).to(DEV)
+    idx = p2.furthest_point_sample(xyz, 128)
+    assert idx.dtype == torch.int32
+    idx_ref, cen_ref = ok.fps(a[None], 128)
+    np.testing.assert_array_equal(idx.cpu().numpy(), idx_ref)
+    center = p2.gather_operation(xyz.transpose(1, 2).contiguous(), idx).transpose(1, 2).contiguous()  # models.py:76-77
+    np.testing.assert_array_equal(center.cpu().numpy(), cen_ref)
+    dist, nn_idx = knn_cuda.KNN(k=32, transpose_mode=True)(xyz, center)                                # models.py:86,100
+    ir, nr = ok.knn_group(a[None], cen_ref, 32)
+    assert nn_idx.dtype == torch.int64
+    np.testing.assert_array_equal(nn_idx.cpu().numpy(), ir)
+    np.testing.assert_allclose(dist.cpu().numpy(), np.sqrt((nr ** 2).sum(-1)), rtol=1e-6)
+    g = p2.QueryAndGroup(0.01, 24)(xyz, center)
+    bq = ok.ball_query(0.01, 24, a[None], cen_ref)
+    want = a[bq[0]] - cen_ref[0][:, None, :]                                                            # [M,ns,3]
+    np.testing.assert_array_equal(g[0].permute(1, 2, 0).cpu().numpy(), want)

@@ -176,6 +176,16 @@ def test_sharded_merge_world2_gloo(tmp_path):
     assert all(p.returncode == 0 for p in procs), outs
 
 
+def test_compat_shims_register_the_cuda_wheel_module_paths():
+    code = ("import sys; sys.path.insert(0, %r); import cmdiad_amd.compat as c; c.install();"
+            "from pointnet2_ops import pointnet2_utils; from knn_cuda import KNN;"
+            "assert all(hasattr(pointnet2_utils, n) for n in ('furthest_point_sample', 'gather_operation', 'ball_query',"
+            " 'grouping_operation', 'QueryAndGroup', 'GroupAll'));"
+            "k = KNN(k=128, transpose_mode=True); assert k.k == 128; print('ok')") % REPO
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr
+
+
 def test_install_dropin_redirects_reference_module_paths():
     code = ("import sys; sys.path.insert(0, %r); import cmdiad_amd; cmdiad_amd.install_dropin();"
             "from feature_extractors import multiple_features;"
