@@ -14,7 +14,7 @@ the two linear one-class-SVM scores (models fitted on the host, scored on device
 scores and pixel maps.
 Inputs are resident in HBM before the timed region.  With N > 1 every rank processes its own batch
 (weak scaling; images are independent, so there is no collective on the data path -- only the barrier and the
-max-over-ranks of the timing).  CMDIAD_BANK=sharded switches the library SEARCH to row shards: all-gather of the
+max-over-ranks of the timing).  --bank sharded (or CMDIAD_BANK=sharded) switches the library SEARCH to row shards: all-gather of the
 16-bit queries, per-shard distance GEMM, one integer-MIN all-reduce of packed keys over RCCL.
 
 Prints ONE JSON line (rank 0) with the fields of the bench contract plus `roofline` (dominant kernel:
@@ -251,6 +251,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=3)
+    ap.add_argument("--bank", choices=("replicated", "sharded"), default=os.environ.get("CMDIAD_BANK", "replicated"),
+                    help="N > 1: 'replicated' = every rank scores its own images against a full copy of the libraries (no "
+                         "data-path collective); 'sharded' = row-sharded library search with RCCL all-gather + MIN all-reduce")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -272,7 +275,7 @@ def main():
     # the libraries (353 MB of 288 GB) -- no collective on the data path.  CMDIAD_BANK=sharded selects the row-sharded
     # search (axis i: all-gather of the queries, per-shard distance GEMM, integer-MIN all-reduce of packed keys over RCCL),
     # the mode for libraries that do not fit one GPU.
-    sharded = (world > 1 or force_dist) and os.environ.get("CMDIAD_BANK", "replicated") == "sharded"
+    sharded = (world > 1 or force_dist) and args.bank == "sharded"
 
     st = build_state(dev, rank if sharded else 0, world if sharded else 1)
     timers = {"xyz": Timer(), "rgb": Timer()}
