@@ -58,7 +58,7 @@ def main():
     rows.sort(key=lambda r: -(r.get("fetch_bytes", 0) + r.get("write_bytes", 0)))
     json.dump(rows, open(out_json, "w"), indent=1)
     cols = ["fetch_bytes", "write_bytes", "l2_hit", "parked", "issue_stall", "issuing", "mfma_busy", "lds_conflict"]
-    print("| kernel | grid | launches | fetch MB (x2 corrected) | write MB | L2 hit | parked | issue-stall | issuing | MFMA busy | LDS conflict |")
+    print("| kernel | grid | launches | fetch MB (x2 corrected) | write MB | L2 hit | parked | issue-stall | issuing | MFMA_BUSY/BUSY_CU (raw, 4 SIMDs per CU) | LDS conflict |")
     print("|---|---|---|---|---|---|---|---|---|---|---|")
     for r in rows[:40]:
         f = lambda k, s=1.0, fmt="{:.1f}": fmt.format(r[k] / s) if k in r else "-"
