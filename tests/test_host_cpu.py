@@ -176,6 +176,18 @@ def test_sharded_merge_world2_gloo(tmp_path):
     assert all(p.returncode == 0 for p in procs), outs
 
 
+def test_isa_lint_main_loops():
+    """tools/isa_lint.py on the compiled gfx950 ISA of the GEMM files (cross-compiled, no GPU): no vmcnt(0) between the
+    LDS-DMA issue and the fragment reads of an MFMA loop, no scratch traffic in an MFMA block, no compiler-generated AGPR
+    writes in the kernels that keep their accumulators in AGPRs by convention (gemm_wide.h)."""
+    import shutil
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not on PATH")
+    out = subprocess.run([sys.executable, os.path.join(REPO, "tools", "isa_lint.py")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count("main loops clean") == 2
+
+
 def test_compat_shims_register_the_cuda_wheel_module_paths():
     code = ("import sys; sys.path.insert(0, %r); import cmdiad_amd.compat as c; c.install();"
             "from pointnet2_ops import pointnet2_utils; from knn_cuda import KNN;"
