@@ -1,19 +1,18 @@
 // bf16 MFMA GEMM core for gfx950: C[M,N] = A[M,K] . W[N,K]^T ("NT": both operands K-contiguous,
 // the layout of nn.Linear weights, of token matrices and of the query / bank matrices).
 //
-// Shape<BM, STAGES>: block tile BM x 128 x 64 with BM/32 waves (4 waves at BM=128, 8 at BM=256) in a
-// (BM/64) x 2 grid; every wave owns a 64 x 64 output as 4 x 4 tiles of v_mfma_f32_16x16x32_bf16
-// (16 f32x4 accumulators = 64 VGPRs).
-//   Shape<128,2>:  64 KiB LDS, 2 blocks/CU  -- small grids (keeps all 256 CUs busy on few tiles)
-//   Shape<256,3>: 144 KiB LDS, 1 block/CU, 8 waves -- large grids: the A panel is reused over twice the
-//                 rows and the LDS-DMA prefetch runs TWO K-steps ahead.
+// Shape<BM, BN, WAVES, STAGES>: block tile BM x BN x 64; waves in a (WAVES / (BN/64)) x (BN/64) grid, every wave owning
+// (MI*16) x 64 outputs as MI x 4 tiles of v_mfma_f32_16x16x32 (MI = 4: 64 accumulator VGPRs, MI = 8: 128).
+//   S128 = Shape<128,128,4,2>:  64 KiB LDS, 2 blocks/CU -- every network GEMM (two 4-wave blocks per CU hide each
+//                               other's LDS-DMA issue and barrier stalls; measured fastest on all ViT / Point-MAE shapes)
+//   S2x2 = Shape<256,256,8,2>: 128 KiB LDS, 1 block/CU, 8 waves of 128 x 64 -- distance GEMM fallback / A-B reference for
+//                               the 4-wave 256 x 256 shape of gemm_wide.h, which is what the distance GEMM runs
 // LDS stage = A tile + W tile, [rows][64 bf16] with 128-byte rows whose 16-byte chunks are XOR-swizzled by
 // (row & 7): the ds_read_b128 fragment reads (16 rows x 4 k-chunks per 16-lane service group) touch 16
 // distinct 16-byte slots of the 256-byte bank row -> conflict-free.
 // Staging is LDS-DMA (global_load_lds_dwordx4, no staging VGPRs): step t issues the loads of step
-// t+STAGES-1, computes on stage t, then waits with a COUNTED s_waitcnt vmcnt -- only the loads of step
-// t+1 must have landed, the younger ones stay in flight across the raw s_barrier (guide T3/T4;
-// __syncthreads() would drain them with vmcnt(0)).  ONE barrier per K-step.
+// t+STAGES-1, computes on stage t, then waits for step t+1 to land (with 3 stages a COUNTED s_waitcnt vmcnt leaves the
+// youngest step in flight across the raw s_barrier; guide T3/T4) -- ONE barrier per K-step.
 // The (n-tile, k-tile) iteration space is flattened so a block that owns several N tiles (the distance
 // GEMM's running-min loop) keeps the pipeline full across tile boundaries.
 //
@@ -43,7 +42,6 @@ struct Shape {
     static_assert(WM * WN == WAVES_ && MI * 16 * WM == BM_ && (MI == 4 || MI == 8), "wave grid");
 };
 typedef Shape<128, 128, 4, 2> S128;   //  64 KiB LDS, 2 blocks/CU: small grids
-typedef Shape<256, 128, 8, 3> S256;   // 144 KiB, 1 block/CU, 3-stage counted-vmcnt pipeline
 typedef Shape<256, 256, 8, 2> S2x2;   // 128 KiB, 1 block/CU: half the L2->LDS bytes per FLOP of S128
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * (BK * 2) + ((chunk ^ (row & 7)) << 4); }

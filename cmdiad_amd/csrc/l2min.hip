@@ -1,14 +1,15 @@
 // Patch-library nearest-neighbour scoring kernels (reference feature_extractors/features.py:186-190
 // calculate_dist = torch.cdist, :227 torch.min(dist, dim=1), :235-254 re-weighting scan).
 //
-// cmdiad_l2_min_keys: the Q x Nb x D distance contraction never leaves the chip.  Each block owns one
-// 128-query tile and a contiguous range of 128-row bank tiles; per bank tile the bf16 MFMA mainloop
-// (gemm_core.h, swapped orientation: a lane holds 4 bank rows for ONE query) produces q.b, the
-// epilogue forms d2 = |q|^2 + |b|^2 - 2 q.b and keeps a per-lane running (min, first index).  After
-// the last tile the four 16-lane groups and the two column waves are merged with packed 64-bit
-// keys (value bits << 32 | global row) and ONE atomicMin per query per block.  Blocks that share a
-// bank range get consecutive ids on one XCD, so a bank tile is fetched into that XCD's L2 once
-// per generation of resident blocks.
+// cmdiad_l2_min_keys: the Q x Nb x D distance contraction never leaves the chip.  Each block owns one query tile
+// (256 queries on the production shape) and a contiguous range of bank tiles; per bank tile the 16-bit MFMA mainloop
+// (fp16 or bf16 operands, fp32 accumulate; swapped orientation: a lane holds 4 bank rows for ONE query) produces q.b,
+// the epilogue forms d2 = |q|^2 + |b|^2 - 2 q.b and keeps a per-lane running (min, first index).  After the last tile
+// the four 16-lane groups are merged by shuffles and every query gets ONE 64-bit atomicMin per block on its packed key
+// (value bits << 32 | global row: integer order = (distance, row) order).  Blocks are dealt to the XCDs in groups of
+// `qgroup` query tiles x `splits` bank ranges, so a streamed bank tile is shared through that XCD's L2.
+// Shapes: l2_min_wide_kernel (gemm_wide.h: 256 x 256, 4 waves of 128 x 128) from Q >= 16 384; l2_min_kernel<S128> below that;
+// l2_min_kernel<S2x2> (8 waves) kept as the A/B reference (CMDIAD_L2_TILE).
 #include <stdlib.h>
 
 #include "gemm_wide.h"
@@ -439,7 +440,7 @@ extern "C" int cmdiad_l2_min_keys(const uint16_t* q, const float* q_sqnorm, cons
     if (Q == 0 || Nb == 0) return CMDIAD_OK;
     const char* env_tile = getenv("CMDIAD_L2_TILE");  // read per call: the parity tests force each shape on small inputs
     const int force = env_tile ? atoi(env_tile) : -1;
-    // 0 S128, 2 S2x2 (256x256, 8 waves), 3 SWide (256x256, 4 waves of 128x128); 256x128x3-stage measured slowest, dropped
+    // 0 S128, 2 S2x2 (256x256, 8 waves), 3 SWide (256x256, 4 waves of 128x128)
     const int tile = force >= 0 ? force : (Q >= 256 * 64 ? 3 : 0);
     hipStream_t s = (hipStream_t)stream;
     const bool h = dtype == CMDIAD_DT_F16;
