@@ -40,9 +40,10 @@ PEAK_BF16_TFLOPS = 2500.0           # dense bf16 MFMA, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 
 
-def build_state(dev, rank, world):
+def build_state(dev, rank, world, workload="dino_pointmae"):
     from cmdiad_amd import engine as eng
     from cmdiad_amd import runtime
+    from cmdiad_amd.models.hallucination_network import HallucinationCrossModalityNetwork
     from cmdiad_amd.models.models import PointTransformer, VisionTransformer
     from cmdiad_amd.synth import synth_bank, synth_cloud_fixed_n, synth_rgb
     torch.manual_seed(0)  # random-init weights of the named architectures (no checkpoints offline)
@@ -52,7 +53,15 @@ def build_state(dev, rank, world):
     rgb = torch.cat([synth_rgb(rank * BATCH + i) for i in range(BATCH)]).to(dev)
     pcs = torch.cat([synth_cloud_fixed_n(1000 + rank * BATCH + i, N_POINTS) for i in range(BATCH)]).to(dev)
     bank_xyz = eng.Bank(synth_bank(XYZ_ROWS, 768, 4321).to(dev), rank, world)
-    bank_rgb = eng.Bank(synth_bank(RGB_ROWS, 768, 4322).to(dev), rank, world)
+    if workload == "mtfi":
+        # MTFI feature-to-feature, main modality xyz (multiple_features.py:312-573): the rgb sensor is absent at test time;
+        # its features are hallucinated from the xyz patches and scored against the library of hallucinated train features
+        # (one row per 56 x 56 patch -> as many rows as the xyz library)
+        bank_rgb = eng.Bank(synth_bank(XYZ_ROWS, 768, 4323).to(dev), rank, world)
+        halluc = runtime.PackedHallucination(HallucinationCrossModalityNetwork(None, 768, 768).state_dict(), device=dev)
+    else:
+        bank_rgb = eng.Bank(synth_bank(RGB_ROWS, 768, 4322).to(dev), rank, world)
+        halluc = None
     # scalar library statistics (cross-wired as the reference): synthetic banks are N(0,1)
     stats = dict(xyz_mean=0.0, xyz_std=1.0, rgb_mean=0.0, rgb_std=1.0)
     # late-fusion linear one-class SVMs fitted on synthetic score rows (host sklearn)
@@ -60,7 +69,8 @@ def build_state(dev, rank, world):
     rs = np.random.RandomState(0)
     det = linear_model.SGDOneClassSVM(random_state=42, nu=0.5, max_iter=1000).fit(rs.rand(64, 2))
     seg = linear_model.SGDOneClassSVM(random_state=42, nu=0.5, max_iter=1000).fit(rs.rand(4096, 2))
-    return dict(engine=e, rgb=rgb, pcs=pcs, bank_xyz=bank_xyz, bank_rgb=bank_rgb, stats=stats, det=det, seg=seg)
+    return dict(engine=e, rgb=rgb, pcs=pcs, bank_xyz=bank_xyz, bank_rgb=bank_rgb, stats=stats, det=det, seg=seg,
+                halluc=halluc, workload=workload)
 
 
 class Timer:
@@ -110,9 +120,16 @@ class Pipeline:
         from cmdiad_amd import ops
         st = self.st
         e, s = st["engine"], st["stats"]
-        ex = e.extract(st["rgb"], st["pcs"], n_max=N_POINTS, side_stream=self.side)
-        xyz_q = e.xyz_patch(ex, 56, s["xyz_mean"], 1.0 / s["xyz_std"])        # a9 + a11 fused
-        rgb_q = eng.normalize(e.rgb_patch(ex).contiguous(), s["rgb_mean"], s["rgb_std"])
+        if st["workload"] == "mtfi":
+            ex = e.extract(None, st["pcs"], want_rgb=False, n_max=N_POINTS)
+            xyz_raw = e.xyz_patch(ex, 56)                                       # a9
+            hall = st["halluc"].generate(xyz_raw, "xyz")                        # a15: hallucinated rgb features [B,3136,768]
+            xyz_q = eng.normalize(xyz_raw, s["xyz_mean"], s["xyz_std"])         # a11
+            rgb_q = eng.normalize(hall, s["rgb_mean"], s["rgb_std"])
+        else:
+            ex = e.extract(st["rgb"], st["pcs"], n_max=N_POINTS, side_stream=self.side)
+            xyz_q = e.xyz_patch(ex, 56, s["xyz_mean"], 1.0 / s["xyz_std"])        # a9 + a11 fused
+            rgb_q = eng.normalize(e.rgb_patch(ex).contiguous(), s["rgb_mean"], s["rgb_std"])
         out = {}
         for name, q in (("xyz", xyz_q), ("rgb", rgb_q)):
             B, Q, D = q.shape
@@ -145,7 +162,8 @@ class Pipeline:
         from cmdiad_amd import ops
         st = self.st
         rx = eng.score_patches_from_keys(qs["xyz"][0], keys["xyz"].contiguous(), st["bank_xyz"], (56, 56))
-        rr = eng.score_patches_from_keys(qs["rgb"][0], keys["rgb"].contiguous(), st["bank_rgb"], (28, 28))
+        side = (56, 56) if st["workload"] == "mtfi" else (28, 28)
+        rr = eng.score_patches_from_keys(qs["rgb"][0], keys["rgb"].contiguous(), st["bank_rgb"], side)
         s = torch.stack([rx["s"], rr["s"]], 1)                                   # [B,2]
         maps = torch.stack([rx["s_map_pre"], rr["s_map_pre"]], 1).contiguous()   # [B,2,224,224]
         B = maps.shape[0]
@@ -251,6 +269,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=3)
+    ap.add_argument("--workload", choices=("dino_pointmae", "mtfi"), default="dino_pointmae",
+                    help="dino_pointmae = BASELINE configs[1] (both modalities extracted, the headline workload); mtfi = the "
+                         "per-GPU work of configs[4]: Point-MAE extraction + hallucinated rgb features + two library searches")
     ap.add_argument("--bank", choices=("replicated", "sharded"), default=os.environ.get("CMDIAD_BANK", "replicated"),
                     help="N > 1: 'replicated' = every rank scores its own images against a full copy of the libraries (no "
                          "data-path collective); 'sharded' = row-sharded library search with RCCL all-gather + MIN all-reduce")
@@ -277,7 +298,7 @@ def main():
     # the mode for libraries that do not fit one GPU.
     sharded = (world > 1 or force_dist) and args.bank == "sharded"
 
-    st = build_state(dev, rank if sharded else 0, world if sharded else 1)
+    st = build_state(dev, rank if sharded else 0, world if sharded else 1, args.workload)
     timers = {"xyz": Timer(), "rgb": Timer()}
     g = group if sharded else None
     pipe = Pipeline(st, g, timers, use_graph=os.environ.get("CMDIAD_GRAPH", "1") != "0")
@@ -318,12 +339,17 @@ def main():
         achieved = flops / (l2_ms * 1e-3) / 1e12
         bytes_alg = (rows + q_total) * 768 * 2 + 12 * q_total
         out = {
-            "metric": "images/sec end-to-end (extract+kNN score)", "value": round(images / dt, 2), "unit": "images/s",
+            "metric": "images/sec end-to-end (extract+distill+kNN score)", "value": round(images / dt, 2), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "configs[1]: DINO ViT-B/8 + Point-MAE predict (DoubleRGBPointFeatures), 224x224 RGB + "
-                                   "24576-point clouds (1024 groups x 128), batch 32/GPU, bagel-sized banks "
-                                   "(xyz 76518x768, rgb 19129x768)",
+            "config": {"workload": ("configs[1]: DINO ViT-B/8 + Point-MAE predict (DoubleRGBPointFeatures: both modalities are "
+                                    "extracted, this method has no distillation step at test time), 224x224 RGB + "
+                                    "24576-point clouds (1024 groups x 128), batch 32/GPU, bagel-sized banks "
+                                    "(xyz 76518x768, rgb 19129x768)") if args.workload == "dino_pointmae" else
+                                   ("configs[4] per-GPU work: MTFI FtoF predict (RGBorXYZWithOneHallucination, main modality "
+                                    "xyz): Point-MAE extraction + hallucinated rgb features (distillation network) + kNN "
+                                    "score against the xyz and the hallucinated-feature libraries (76518x768 each), "
+                                    "24576-point clouds, batch 32/GPU"),
                        "batch_per_gpu": BATCH, "bank": "row-sharded search + RCCL min-reduce" if sharded else ("replicated per rank, images sharded, no data-path collective" if world > 1 else "single"),
                        "hip_graphs": bool(pipe.use_graph), "search_operands": "fp16 (fp32 accumulate, exact fp32 re-score)",
                        "weights": "seeded random init (no checkpoints offline)"},
