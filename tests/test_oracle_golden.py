@@ -224,3 +224,31 @@ def test_pil_blur_restatement():
         np.testing.assert_array_equal(ok.pil_gaussian_blur_u8(img, rad), ref)
     with np.testing.assert_raises(ValueError):
         ok.pil_gaussian_blur_u8(np.zeros((6, 224), np.uint8), 4.0)  # shorter than the box window: not restated
+
+
+def test_fps_knn_oracle_against_independent_torch_restatement():
+    """orc_fps / orc_knn_group are 'parity unpinned' (pointnet2_ops and KNN_CUDA are CUDA-only wheels absent here), so they
+    are cross-checked against a second, independently written restatement of the published algorithms in plain torch:
+    FPS = repeated arg-max of the running minimum squared distance starting from point 0; kNN = the k smallest squared
+    distances of torch.cdist-style brute force, ascending."""
+    pc, _ = scoring.unorganize_no_zeros(synth_cloud(41, 0.12))
+    xyz = np.ascontiguousarray(pc[0].T.numpy())[None]                       # [1,N,3]
+    G, K = 96, 24
+    idx, cen = ok.fps(xyz, G)
+    p = torch.from_numpy(xyz[0])
+    d = torch.full((p.shape[0],), 1e10)
+    cur, picks = 0, [0]
+    for _ in range(G - 1):
+        diff = p - p[cur]
+        d = torch.minimum(d, (diff[:, 0] * diff[:, 0] + diff[:, 1] * diff[:, 1]) + diff[:, 2] * diff[:, 2])
+        cur = int(torch.argmax(d))                                          # first maximum = lowest index
+        picks.append(cur)
+    np.testing.assert_array_equal(idx[0], np.array(picks, np.int32))
+    np.testing.assert_array_equal(cen[0], xyz[0][picks])
+    nn_idx, nb = ok.knn_group(xyz, cen, K)
+    c = torch.from_numpy(cen[0])
+    diff = p[None, :, :] - c[:, None, :]
+    d2 = (diff[..., 0] * diff[..., 0] + diff[..., 1] * diff[..., 1]) + diff[..., 2] * diff[..., 2]   # [G,N]
+    order = torch.argsort(d2, dim=1, stable=True)[:, :K]                    # ascending (d2, index)
+    np.testing.assert_array_equal(nn_idx[0], order.numpy())
+    np.testing.assert_array_equal(nb[0], (p[order] - c[:, None, :]).numpy())
