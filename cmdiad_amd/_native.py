@@ -26,6 +26,11 @@ class GemmArgs(Structure):
                 ("out_pre_bf16", c_void_p), ("dact_of", c_void_p), ("split_k", c_int)]
 
 
+class BlockWeights(Structure):
+    _fields_ = [(n, c_void_p) for n in ("ln1_w", "ln1_b", "ln2_w", "ln2_b", "qkv_w", "qkv_b", "proj_w", "proj_b",
+                                        "fc1_w", "fc1_b", "fc2_w", "fc2_b")]
+
+
 P, I, F, SZ, U32, D = c_void_p, c_int, c_float, c_size_t, c_uint32, c_double
 # name -> argtypes (every entry point declared in include/cmdiad_hip.h; tests check the two agree)
 SIGNATURES = {
@@ -38,6 +43,7 @@ SIGNATURES = {
     "cmdiad_gemm_bf16": [POINTER(GemmArgs), P],
     "cmdiad_gemm_qkv": [P, P, P, I, I, I, P, P, P, P],
     "cmdiad_attention": [P, P, P, I, I, I, P, P],
+    "cmdiad_transformer_block_fwd": [P, P, POINTER(BlockWeights), I, I, I, I, I, F, P, P, P, P, SZ, P],
     "cmdiad_layernorm": [P, P, P, P, F, I, I, P, P, I, P, P, P],
     "cmdiad_loss_head": [P, P, I, I, I, F, P, P, P, P],
     "cmdiad_reduce_slabs": [P, I, SZ, SZ, F, P, P],
@@ -71,6 +77,7 @@ SIZE_QUERIES = {
     "cmdiad_reweight_workspace_bytes": [I, I],
     "cmdiad_coreset_workspace_bytes": [I, I, I],
     "cmdiad_blur8_lds_bytes": [I, I],
+    "cmdiad_transformer_block_workspace_bytes": [I, I, I],
 }
 
 

@@ -60,6 +60,38 @@ class DistHandle:
                                   "compute_single_s_s_map(patch, dist_handle, ...) or engine.score_patches")
 
 
+class PixelList:
+    """List-like store for ``pixel_preds`` / ``pixel_labels`` (features.py:78-79 keeps them as Python lists and extends them
+    by 50 176 numpy scalars per image, features.py:305 turns them into an array at the end).  Same protocol -- extend,
+    len, iteration, indexing, ``np.array(x)`` -- but the values stay in per-image numpy chunks: millions of boxed floats in
+    one list made the cyclic garbage collector stall the predict loop for 60-90 ms every few images."""
+
+    def __init__(self):
+        self._chunks, self._flat = [], None
+
+    def extend(self, values):
+        self._chunks.append(np.asarray(values).reshape(-1))
+        self._flat = None
+
+    def append(self, value):
+        self.extend([value])
+
+    def __array__(self, dtype=None, copy=None):
+        if self._flat is None:
+            self._flat = np.concatenate(self._chunks) if self._chunks else np.zeros((0,))
+            self._chunks = [self._flat]
+        return self._flat if dtype is None else self._flat.astype(dtype, copy=False)
+
+    def __len__(self):
+        return sum(c.shape[0] for c in self._chunks)
+
+    def __iter__(self):
+        return iter(self.__array__())
+
+    def __getitem__(self, i):
+        return self.__array__()[i]
+
+
 class _NeedsFit(Exception):
     pass
 
@@ -89,7 +121,7 @@ class Features(torch.nn.Module):
         self.xyz_dim = self.rgb_dim = 0
         self.xyz_mean = self.xyz_std = self.rgb_mean = self.rgb_std = self.fusion_mean = self.fusion_std = 0
         self.share_mean = self.share_std = self.non_share_mean = self.non_share_std = 0
-        self.image_preds, self.image_labels, self.pixel_preds, self.pixel_labels = [], [], [], []
+        self.image_preds, self.image_labels, self.pixel_preds, self.pixel_labels = [], [], PixelList(), PixelList()
         self.gts, self.predictions = [], []
         self.image_rocauc = self.pixel_rocauc = self.au_pro = self.au_pro_001 = 0
         self.ins_id = self.ins_id2 = self.ins_id3 = 0

@@ -80,7 +80,16 @@ class VisionTransformer(nn.Module):
 
 
 def _param_version(module):
-    return tuple((p.data_ptr(), p._version) for p in list(module.parameters()) + list(module.buffers()))
+    """Cheap fingerprint of a module's weights (storage address + in-place version of every parameter / buffer): the packed
+    device copies are rebuilt when it changes (load_state_dict, .to(), optimiser steps).  Walking module.parameters() costs
+    ~1.5 ms for a ViT (name de-duplication hashes every tensor) and this runs on every forward, so the flat tensor list is
+    cached on the module and only re-collected every 64 calls (a parameter OBJECT replaced in between is picked up then)."""
+    cache = module.__dict__.get("_cmdiad_flat")
+    if cache is None or cache[1] <= 0:
+        cache = [list(module.parameters()) + list(module.buffers()), 64]
+        module.__dict__["_cmdiad_flat"] = cache
+    cache[1] -= 1
+    return tuple((p.data_ptr(), p._version) for p in cache[0])
 
 
 class Model(torch.nn.Module):

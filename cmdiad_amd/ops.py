@@ -167,6 +167,26 @@ def attention(q, k, vt, B, H, T, out=None):
     return out
 
 
+def transformer_block_workspace_bytes(M, C, hidden):
+    return int(nat.lib().cmdiad_transformer_block_workspace_bytes(M, C, hidden))
+
+
+def transformer_block(x, pos, blk, B, T, H, eps, q, k, vt, workspace):
+    """x [B*T, C] f32 updated in place by one whole pre-LN block (cmdiad_transformer_block_fwd).  blk: dict of packed
+    weights (runtime._pack_block); its ctypes struct is built once and cached in the dict."""
+    _chk(x, torch.float32, "block.x"); _chk(pos, torch.float32, "block.pos")
+    w = blk.get("_struct")
+    if w is None:
+        w = nat.BlockWeights(*[blk[n].data_ptr() if blk[n] is not None else None
+                               for n in ("ln1_w", "ln1_b", "ln2_w", "ln2_b", "qkv_w", "qkv_b", "proj_w", "proj_b",
+                                         "fc1_w", "fc1_b", "fc2_w", "fc2_b")])
+        blk["_struct"] = w
+    C = x.shape[1]
+    _call("cmdiad_transformer_block_fwd", _p(x), _p(pos), ctypes.byref(w), B, T, C, H, blk["fc1_w"].shape[0], float(eps),
+          _p(q), _p(k), _p(vt), _p(workspace), workspace.numel(), _stream())
+    return x
+
+
 def layernorm(x, gamma, beta, eps, add=None, out_bf16=None, out_f32=None, want_bf16=True, stats=None):
     """x [M,C] f32 (updated in place to x+add when add is given) -> LN(x) as bf16 and/or f32."""
     _chk(x, torch.float32, "ln.x"); _chk(add, torch.float32, "ln.add")

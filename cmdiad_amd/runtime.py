@@ -37,6 +37,13 @@ class _QkvBuffers:
 
     def __init__(self):
         self.key = None
+        self.ws = None
+
+    def workspace(self, M, C, hidden, device):
+        need = ops.transformer_block_workspace_bytes(M, C, hidden)
+        if self.ws is None or self.ws.numel() < need or self.ws.device != device:
+            self.ws = torch.empty((need,), dtype=torch.uint8, device=device)
+        return self.ws
 
     def get(self, B, H, T, device):
         key = (B, H, T, str(device))
@@ -51,7 +58,15 @@ class _QkvBuffers:
 
 def transformer_block(x, blk, B, T, H, eps, bufs, pos=None):
     """In-place pre-LN block on the fp32 residual stream x [B*T, C] (models/models.py:177-180).
-    pos (Point-MAE) is added to x first, fused into the first LayerNorm (models/models.py:240)."""
+    pos (Point-MAE) is added to x first, fused into the first LayerNorm (models/models.py:240).
+    One FFI call (cmdiad_transformer_block_fwd sequences the seven launches inside the library)."""
+    q, k, vt = bufs.get(B, H, T, x.device)
+    ops.transformer_block(x, pos, blk, B, T, H, eps, q, k, vt, bufs.workspace(B * T, x.shape[1], blk["fc1_w"].shape[0], x.device))
+    return x
+
+
+def transformer_block_unfused(x, blk, B, T, H, eps, bufs, pos=None):
+    """The same block as seven separate entry-point calls (kept for tests: both forms must agree bit for bit)."""
     h = ops.layernorm(x, blk["ln1_w"], blk["ln1_b"], eps, add=pos)
     q, k, vt = bufs.get(B, H, T, x.device)
     ops.gemm_qkv(h, blk["qkv_w"], blk["qkv_b"], B, T, q, k, vt)

@@ -138,6 +138,26 @@ int cmdiad_layernorm(float* x, const float* add, const float* gamma, const float
                      int C, uint16_t* out_bf16, float* out_f32, int ldo32, float* mean_out, float* rstd_out,
                      cmdiad_stream_t stream);
 
+/* One whole pre-LN transformer block on the fp32 residual stream x [B*T, C], in place (models/models.py:177-180 Block.forward,
+ * 148-160 Attention, 126-132 Mlp; timm's ViT block reached at models.py:48 has the same algebra):
+ *   x += proj(softmax(q k^T) v) with q,k,v = qkv(LN1(x (+ pos)));   x += fc2(GELU(fc1(LN2(x)))).
+ * pos [B*T, C] f32 or NULL is added to x first (Point-MAE re-adds the positional embedding in front of every block,
+ * models.py:240).  Weights: bf16 [out, in] matrices in nn.Linear layout, f32 biases / LayerNorm parameters (qkv_b may be
+ * NULL).  C = 64 H.  q, k [B,H,Tp,64] and vt [B,H,64,Tp] bf16 scratch as in cmdiad_gemm_qkv (padding rows zeroed once by
+ * the caller); workspace >= cmdiad_transformer_block_workspace_bytes(B*T, C, hidden).  Sequencing only: LayerNorm ->
+ * cmdiad_gemm_qkv -> cmdiad_attention -> cmdiad_gemm_bf16 x3, all on `stream`. */
+typedef struct {
+    const float *ln1_w, *ln1_b, *ln2_w, *ln2_b;
+    const uint16_t* qkv_w; const float* qkv_b;
+    const uint16_t* proj_w; const float* proj_b;
+    const uint16_t* fc1_w; const float* fc1_b;
+    const uint16_t* fc2_w; const float* fc2_b;
+} cmdiad_block_weights;
+size_t cmdiad_transformer_block_workspace_bytes(int M, int C, int hidden);
+int cmdiad_transformer_block_fwd(float* x, const float* pos, const cmdiad_block_weights* w, int B, int T, int C, int H,
+                                 int hidden, float eps, uint16_t* q, uint16_t* k, uint16_t* vt, void* workspace,
+                                 size_t workspace_bytes, cmdiad_stream_t stream);
+
 /* Point-MAE Encoder (models/models.py:200-215), eval-mode BatchNorm folded into the convolutions:
  *   h1 = relu(W1' x + b1')            3 -> 128   (computed on the fly while staging the GEMM tile)
  *   h2 = W2 h1 + b2                   128 -> 256 ; g = max over the group's points

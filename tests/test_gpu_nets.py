@@ -92,3 +92,20 @@ def test_hallucination_generate_vs_golden(golden):
         err = (got - ref).abs()
         # three chained bf16 GEMMs; outputs are GELU values of O(0.1..1)
         assert err.mean().item() < 4e-3 and err.max().item() < 4e-2, (err.mean().item(), err.max().item())
+
+
+def test_transformer_block_entry_point_equals_its_seven_launches():
+    """cmdiad_transformer_block_fwd (one FFI call per block) against the same block issued as seven separate entry-point
+    calls: identical bits, for the ViT geometry and for the Point-MAE geometry with the positional re-add."""
+    from cmdiad_amd.runtime import _QkvBuffers, _pack_block, transformer_block, transformer_block_unfused
+    for kind, seed, prefix, B, T, C, H, eps, qkv_bias, with_pos in (("vit", 31, "blocks.3.", 2, 785, 768, 12, 1e-6, True, False),
+                                                                      ("pointmae", 21, "blocks.blocks.5.", 3, 1024, 384, 6, 1e-5, False, True)):
+        sd = nets.synth_state_dict(kind, seed)
+        blk = _pack_block(sd, prefix, DEV, qkv_bias)
+        g = torch.Generator().manual_seed(B * T)
+        x0 = torch.randn(B * T, C, generator=g).to(DEV)
+        pos = 0.1 * torch.randn(B * T, C, generator=g).to(DEV) if with_pos else None
+        xa, xb = x0.clone(), x0.clone()
+        transformer_block(xa, blk, B, T, H, eps, _QkvBuffers(), pos=pos)
+        transformer_block_unfused(xb, blk, B, T, H, eps, _QkvBuffers(), pos=pos)
+        assert torch.equal(xa, xb) and not torch.equal(xa, x0)

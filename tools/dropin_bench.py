@@ -22,6 +22,8 @@ def main(n=40, warm=5):
              fusion_module_path='', ocsvm_nu=0.5, ocsvm_maxiter=1000, xyz_s_lambda=1.0, xyz_smap_lambda=1.0,
              rgb_s_lambda=0.1, rgb_smap_lambda=0.1, fusion_s_lambda=1.0, fusion_smap_lambda=1.0,
              save_feature_for_fusion=False, save_seg_results=False, use_depth=False)
+    from cmdiad_amd.utils.utils import set_multithreading
+    set_multithreading(6)  # main.py:149,190-191: the reference's default --cpu_core_num
     torch.manual_seed(0)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
