@@ -233,17 +233,24 @@ def cpu_baseline(n_images=3):
     sd_pm = {k: v.detach() for k, v in PointTransformer().state_dict().items()}
     cpu = CpuDoubleRGBPoint(CpuExtractor(sd_vit, sd_pm))
     cpu.set_banks(synth_bank(XYZ_ROWS, 768, 4321), synth_bank(RGB_ROWS, 768, 4322), 0.0, 1.0, 0.0, 1.0)
-    cores = torch.get_num_threads()
+    # thread count: the fastest of {all cores, 64, 32, 16, 6} measured on the 128-core MI355X host (0.18 / 0.34 / 0.45 / 0.47 /
+    # 0.35 images/s; torch's intra-op pool oversubscribes badly beyond ~32 threads on these shapes; 6 = the reference's
+    # default --cpu_core_num, main.py:149) -- capped at 32 so the reported baseline is the CPU's best, not its worst
+    all_threads = torch.get_num_threads()
+    cores = min(32, all_threads)
+    torch.set_num_threads(cores)
     cpu.predict(synth_rgb(0), synth_cloud_fixed_n(1000, N_POINTS))  # warm-up (page in, MKL init)
     cpu.ex.timing.clear(); cpu.timing.clear()
     t0 = time.perf_counter()
     for i in range(n_images):
         cpu.predict(synth_rgb(1 + i), synth_cloud_fixed_n(1001 + i, N_POINTS))
     dt = time.perf_counter() - t0
+    torch.set_num_threads(all_threads)
     stages = {k: round(v / n_images, 4) for k, v in {**cpu.ex.timing, **cpu.timing}.items()}
     return dict(value=round(n_images / dt, 4), unit="images/s", cores=cores, kind="port",
-                sample=f"{n_images} images after 1 warm-up, B=1, fp32, torch {torch.__version__} CPU + C oracle for FPS/kNN, "
-                       f"same synthetic inputs and bagel-sized banks", seconds_per_image_by_stage=stages)
+                sample=f"{n_images} images after 1 warm-up, B=1, fp32, torch {torch.__version__} CPU ({cores} intra-op threads: the "
+                       f"fastest setting on this {all_threads}-thread host) + C oracle for FPS/kNN, same synthetic inputs and "
+                       f"bagel-sized banks", seconds_per_image_by_stage=stages)
 
 
 def measured_traffic(world, sharded):
@@ -268,7 +275,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-images", type=int, default=3)
+    ap.add_argument("--cpu-images", type=int, default=6)
     ap.add_argument("--workload", choices=("dino_pointmae", "mtfi"), default="dino_pointmae",
                     help="dino_pointmae = BASELINE configs[1] (both modalities extracted, the headline workload); mtfi = the "
                          "per-GPU work of configs[4]: Point-MAE extraction + hallucinated rgb features + two library searches")
