@@ -268,15 +268,28 @@ __global__ __launch_bounds__(kScanWaves * 64) void reweight_scan_kernel(const fl
     }
 }
 
-__global__ void reweight_merge_kernel(const unsigned long long* __restrict__ partial, int R, int nblocks,
-                                      unsigned long long* __restrict__ top3)
+// One wave per probe: lanes take the partial keys round-robin into a private top-3, then the three global minima are
+// extracted by wave-wide min + pop (keys are unique: they carry the bank row).
+__global__ __launch_bounds__(64) void reweight_merge_kernel(const unsigned long long* __restrict__ partial, int R, int nblocks,
+                                                            unsigned long long* __restrict__ top3)
 {
-    const int pr = blockIdx.x;
-    if (threadIdx.x != 0 || pr >= R) return;
-    unsigned long long m[3] = {top3[pr * 3], top3[pr * 3 + 1], top3[pr * 3 + 2]};
+    const int pr = blockIdx.x, lane = threadIdx.x;
+    if (pr >= R) return;
+    unsigned long long m[3] = {~0ull, ~0ull, ~0ull};
+    if (lane < 3) m[0] = top3[pr * 3 + lane];  // the running list (earlier shards / calls) joins the candidates
     const unsigned long long* src = partial + (size_t)pr * nblocks * 3;
-    for (int i = 0; i < nblocks * 3; ++i) top3_insert(m, src[i]);
-    top3[pr * 3] = m[0]; top3[pr * 3 + 1] = m[1]; top3[pr * 3 + 2] = m[2];
+    for (int i = lane; i < nblocks * 3; i += 64) top3_insert(m, src[i]);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        unsigned long long best = m[0];
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) {
+            const unsigned long long o = shfl_xor_u64(best, sft);
+            best = o < best ? o : best;
+        }
+        if (m[0] == best && best != ~0ull) { m[0] = m[1]; m[1] = m[2]; m[2] = ~0ull; }  // the owner pops it
+        if (lane == 0) top3[pr * 3 + r] = best;
+    }
 }
 
 // (x - mean) * inv_std -> bf16 (+ optional f32 copy, + optional |row|^2 of the ROUNDED values).
