@@ -205,14 +205,13 @@ __global__ __launch_bounds__(256) void xyz_patch_fused_kernel(const float* __res
     }
     __syncthreads();
     const int cnt = s_cnt;
-    // order the short list by centre index so the channel sums are run-to-run reproducible
-    if (tid == 0) {
-        for (int i = 1; i < cnt; ++i) {
-            const int g = s_lg[i]; const float w = s_lw[i];
-            int j = i - 1;
-            while (j >= 0 && s_lg[j] > g) { s_lg[j + 1] = s_lg[j]; s_lw[j + 1] = s_lw[j]; --j; }
-            s_lg[j + 1] = g; s_lw[j + 1] = w;
-        }
+    // order the short list by centre index so the channel sums are run-to-run reproducible: rank sort, one thread per
+    // entry (centres are distinct after the fold), into the entry arrays that are no longer needed
+    for (int e = tid; e < cnt; e += 256) {
+        const int g = s_lg[e];
+        int rank = 0;
+        for (int j = 0; j < cnt; ++j) rank += s_lg[j] < g;
+        s_g[rank] = g; s_w[rank] = s_lw[e];
     }
     __syncthreads();
 
@@ -220,8 +219,8 @@ __global__ __launch_bounds__(256) void xyz_patch_fused_kernel(const float* __res
     for (int c = tid * 4; c < D; c += 1024) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int i = 0; i < cnt; ++i) {
-            const float w = s_lw[i];
-            const float4 f = *reinterpret_cast<const float4*>(feat + ((size_t)b * S + s_lg[i]) * D + c);
+            const float w = s_w[i];
+            const float4 f = *reinterpret_cast<const float4*>(feat + ((size_t)b * S + s_g[i]) * D + c);
             acc.x += w * f.x; acc.y += w * f.y; acc.z += w * f.z; acc.w += w * f.w;
         }
         acc.x = (acc.x - mean) * inv_std; acc.y = (acc.y - mean) * inv_std;
