@@ -1,0 +1,132 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep of the kernels against the CPU oracle / float64 references (development QA, not part of the
+pytest suites): random shapes including ragged tiles, tiny and odd sizes.  `python tools/fuzz_gpu.py [seconds] [seed]`."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cmdiad_amd import ops  # noqa: E402
+from oracle import kernels as ok  # noqa: E402
+
+DEV = "cuda"
+
+
+def cloud(rs, n):
+    p = rs.rand(n, 3).astype(np.float32) * 0.2
+    p[:, 2] += 0.5
+    return p
+
+
+def case_fps_knn(rs):
+    B = int(rs.randint(1, 4))
+    ns = [int(rs.randint(130, 6000)) for _ in range(B)]
+    N = max(ns)
+    xyz = np.zeros((B, N, 3), np.float32)
+    for b, n in enumerate(ns):
+        xyz[b, :n] = cloud(rs, n)
+    G, K = int(rs.randint(1, 200)), int(rs.randint(1, 129))
+    nv = torch.tensor(ns, dtype=torch.int32, device=DEV)
+    idx, cen = ops.fps(torch.from_numpy(xyz).to(DEV), G, n_valid=nv)
+    gi, nb = ops.knn_group(torch.from_numpy(xyz).to(DEV), cen, K, n_valid=nv)
+    for b, n in enumerate(ns):
+        ir, cr = ok.fps(xyz[b:b + 1, :n], G)
+        assert np.array_equal(idx[b].cpu().numpy(), ir[0]), ("fps", ns, G)
+        kr, nr = ok.knn_group(xyz[b:b + 1, :n], cr, K)
+        assert np.array_equal(gi[b].cpu().numpy(), kr[0]) and np.array_equal(nb[b].cpu().numpy(), nr[0]), ("knn", ns, G, K)
+    r = float(rs.uniform(0.005, 0.08)); nsamp = int(rs.randint(1, 40))
+    bq = ops.ball_query(r, nsamp, torch.from_numpy(xyz).to(DEV), cen, n_valid=nv)
+    for b, n in enumerate(ns):
+        assert np.array_equal(bq[b].cpu().numpy(), ok.ball_query(r, nsamp, xyz[b:b + 1, :n], cen[b:b + 1].cpu().numpy())[0]), ("ball", ns, r)
+
+
+def case_gemm(rs):
+    M, N, K = int(rs.randint(1, 1500)), 4 * int(rs.randint(1, 300)), 64 * int(rs.randint(1, 9))
+    A = torch.from_numpy(rs.randn(M, K).astype(np.float32)).bfloat16()
+    W = torch.from_numpy((rs.randn(N, K) / np.sqrt(K)).astype(np.float32)).bfloat16()
+    bias = torch.from_numpy(rs.randn(N).astype(np.float32))
+    for env in (None, "4", "8"):
+        if env:
+            os.environ["CMDIAD_GEMM_WIDE"] = env
+        else:
+            os.environ.pop("CMDIAD_GEMM_WIDE", None)
+        act = [ops.ACT_NONE, ops.ACT_RELU, ops.ACT_GELU][int(rs.randint(3))]
+        o32, o16 = ops.gemm(A.to(DEV), W.to(DEV), bias=bias.to(DEV), act=act, want_f32=True)
+        ref = A.double() @ W.double().T + bias.double()
+        ref = ref if act == ops.ACT_NONE else (torch.relu(ref) if act == ops.ACT_RELU else torch.nn.functional.gelu(ref))
+        assert torch.allclose(o32.cpu().double(), ref, rtol=2e-4, atol=2e-4), ("gemm", M, N, K, env, act)
+        assert torch.allclose(o16.cpu().double(), ref, rtol=1e-2, atol=1e-2), ("gemm16", M, N, K, env, act)
+    os.environ.pop("CMDIAD_GEMM_WIDE", None)
+
+
+def case_l2(rs):
+    Q, Nb, D = int(rs.randint(1, 3000)), int(rs.randint(1, 4000)), 64 * int(rs.randint(1, 13))
+    bank = torch.from_numpy(rs.randn(Nb, D).astype(np.float32))
+    q = bank[torch.from_numpy(rs.randint(0, Nb, Q))] + 0.4 * torch.from_numpy(rs.randn(Q, D).astype(np.float32))
+    b16, b32, bsq = ops.normalize_cast(bank.to(DEV), want_f32=True)
+    q16, q32, qsq = ops.normalize_cast(q.to(DEV), want_f32=True)
+    d = torch.cdist(q.double(), bank.double())
+    rv, ri = d.min(1)
+    for tile in (None, "2", "3"):
+        if tile:
+            os.environ["CMDIAD_L2_TILE"] = tile
+        else:
+            os.environ.pop("CMDIAD_L2_TILE", None)
+        keys = ops.l2_min_keys(q16, qsq, b16, bsq, ops.new_keys(Q, DEV))
+        mv, mi = ops.l2_rescore(q32, b32, keys)
+        agree = mi.cpu() == ri
+        assert agree.float().mean() > 0.97, ("l2 agree", Q, Nb, D, tile, agree.float().mean())
+        assert torch.allclose(mv.cpu()[agree].double(), rv[agree], rtol=1e-4, atol=1e-4), ("l2 val", Q, Nb, D, tile)
+        assert torch.allclose(mv.cpu()[~agree].double(), rv[~agree], rtol=5e-3, atol=1e-3), ("l2 near", Q, Nb, D, tile)
+    os.environ.pop("CMDIAD_L2_TILE", None)
+
+
+def case_attention(rs):
+    B, H, T = int(rs.randint(1, 4)), int(rs.randint(1, 7)), int(rs.randint(1, 1100))
+    Tp = (T + 63) // 64 * 64
+    q = torch.zeros(B, H, Tp, 64); k = torch.zeros(B, H, Tp, 64); v = torch.zeros(B, H, Tp, 64)
+    q[:, :, :T] = torch.from_numpy(rs.randn(B, H, T, 64).astype(np.float32))
+    k[:, :, :T] = torch.from_numpy(rs.randn(B, H, T, 64).astype(np.float32))
+    v[:, :, :T] = torch.from_numpy(rs.randn(B, H, T, 64).astype(np.float32))
+    qb, kb, vb = q.bfloat16(), k.bfloat16(), v.bfloat16()
+    out = ops.attention(qb.to(DEV), kb.to(DEV), vb.transpose(2, 3).contiguous().to(DEV), B, H, T).float().cpu()
+    p = torch.softmax(qb[:, :, :T].double() @ kb[:, :, :T].double().transpose(2, 3) * np.log(2.0), -1)
+    ref = (p @ vb[:, :, :T].double()).permute(0, 2, 1, 3).reshape(B * T, H * 64)
+    assert torch.allclose(out.double(), ref, rtol=3e-2, atol=3e-2), ("attention", B, H, T)
+
+
+def case_blur(rs):
+    n, H, W = int(rs.randint(1, 5)), int(rs.randint(12, 257)), int(rs.randint(12, 257))
+    radius = float(rs.uniform(0.6, 4.5))
+    maps = torch.from_numpy(rs.rand(n, H, W).astype(np.float32)) * float(rs.uniform(0.1, 30))
+    try:
+        out = ops.blur8_maps(maps.to(DEV), radius).cpu()
+    except Exception as e:  # short lines are rejected by design
+        assert "shorter" in str(e), e
+        return
+    for i in range(n):
+        mx = maps[i].max()
+        u8 = (maps[i] / mx).mul(255).byte().numpy()
+        ref = torch.from_numpy(ok.pil_gaussian_blur_u8(u8, radius)).float().div(255) * mx
+        assert torch.equal(out[i], ref), ("blur", n, H, W, radius)
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    rs = np.random.RandomState(seed)
+    cases = [case_fps_knn, case_gemm, case_l2, case_attention, case_blur]
+    counts = {c.__name__: 0 for c in cases}
+    t0 = time.time()
+    while time.time() - t0 < budget:
+        c = cases[int(rs.randint(len(cases)))]
+        c(rs)
+        counts[c.__name__] += 1
+    print("fuzz ok", counts)
+
+
+if __name__ == "__main__":
+    main()
