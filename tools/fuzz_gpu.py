@@ -43,6 +43,39 @@ def case_fps_knn(rs):
         assert np.array_equal(bq[b].cpu().numpy(), ok.ball_query(r, nsamp, xyz[b:b + 1, :n], cen[b:b + 1].cpu().numpy())[0]), ("ball", ns, r)
 
 
+def case_fps_big(rs):
+    """large single clouds: every FPS kernel configuration (register-resident 1024x{4,8,16}, 512x{40,48,56}, memory fallback)"""
+    n = int(rs.choice([int(rs.randint(3000, 9000)), int(rs.randint(15000, 28672)), int(rs.randint(28673, 50177))]))
+    G = int(rs.randint(64, 1025))
+    xyz = cloud(rs, n)[None]
+    idx, cen = ops.fps(torch.from_numpy(xyz).to(DEV), G)
+    ir, cr = ok.fps(xyz, G)
+    assert np.array_equal(idx.cpu().numpy(), ir) and np.array_equal(cen.cpu().numpy(), cr), ("fps_big", n, G)
+    K = int(rs.choice([32, 64, 128]))
+    Gk = min(G, 96)
+    gi, nb = ops.knn_group(torch.from_numpy(xyz).to(DEV), cen[:, :Gk].contiguous(), K)
+    kr, nr = ok.knn_group(xyz, cr[:, :Gk], K)
+    assert np.array_equal(gi.cpu().numpy(), kr) and np.array_equal(nb.cpu().numpy(), nr), ("knn_big", n, Gk, K)
+
+
+def case_l2_big(rs):
+    """production-sized query counts (the 4-wave wide kernel is selected automatically from Q >= 16 384)"""
+    Q, Nb, D = int(rs.randint(16384, 40000)), int(rs.randint(300, 9000)), 64 * int(rs.choice([2, 6, 12]))
+    g = torch.Generator().manual_seed(int(rs.randint(1 << 30)))
+    bank = torch.randn(Nb, D, generator=g).to(DEV)
+    q = bank[torch.randint(0, Nb, (Q,), generator=g).to(DEV)] + 0.4 * torch.randn(Q, D, generator=g).to(DEV)
+    b16, b32, bsq = ops.normalize_cast(bank, want_f32=True)
+    q16, q32, qsq = ops.normalize_cast(q, want_f32=True)
+    keys = ops.l2_min_keys(q16, qsq, b16, bsq, ops.new_keys(Q, DEV))
+    mv, mi = ops.l2_rescore(q32, b32, keys)
+    sel = torch.randint(0, Q, (512,), generator=g).to(DEV)
+    rv, ri = torch.cdist(q32[sel].double(), b32.double()).min(1)
+    agree = mi[sel] == ri
+    assert agree.float().mean() > 0.97, ("l2_big agree", Q, Nb, D, agree.float().mean().item())
+    assert torch.allclose(mv[sel][agree].double(), rv[agree], rtol=1e-4, atol=1e-4), ("l2_big val", Q, Nb, D)
+    assert torch.allclose(mv[sel][~agree].double(), rv[~agree], rtol=5e-3, atol=1e-3), ("l2_big near", Q, Nb, D)
+
+
 def case_gemm(rs):
     M, N, K = int(rs.randint(1, 1500)), 4 * int(rs.randint(1, 300)), 64 * int(rs.randint(1, 9))
     A = torch.from_numpy(rs.randn(M, K).astype(np.float32)).bfloat16()
@@ -118,7 +151,7 @@ def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     rs = np.random.RandomState(seed)
-    cases = [case_fps_knn, case_gemm, case_l2, case_attention, case_blur]
+    cases = [case_fps_knn, case_gemm, case_l2, case_attention, case_blur, case_fps_big, case_l2_big]
     counts = {c.__name__: 0 for c in cases}
     t0 = time.time()
     while time.time() - t0 < budget:
