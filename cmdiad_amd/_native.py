@@ -43,6 +43,7 @@ SIGNATURES = {
     "cmdiad_gemm_bf16": [POINTER(GemmArgs), P],
     "cmdiad_gemm_qkv": [P, P, P, I, I, I, P, P, P, P],
     "cmdiad_attention": [P, P, P, I, I, I, P, P],
+    "cmdiad_encoder_tail": [P, P, P, P, P, I, I, P, P],
     "cmdiad_transformer_block_fwd": [P, P, POINTER(BlockWeights), I, I, I, I, I, F, P, P, P, P, SZ, P],
     "cmdiad_layernorm": [P, P, P, P, F, I, I, P, P, I, P, P, P],
     "cmdiad_loss_head": [P, P, I, I, I, F, P, P, P, P],

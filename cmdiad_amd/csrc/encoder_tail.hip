@@ -1,0 +1,185 @@
+// Point-MAE encoder, second half, in ONE kernel (models/models.py:204-215 after the first max-pool):
+//   h3  = ReLU(W3b . h2 + gb[group])          [rows, 512]   (gb = W3a . groupmax(h2) + b3, the broadcast half of conv3)
+//   tok = max over the group's rows of (W4 . h3 + b4)        [groups, 384]
+// The separate kernels write h3 (4.3 GB per batch of 32) and read it back; here a block of 8 waves owns 128 rows, keeps its
+// h2 tile (64 KiB) in LDS, produces h3 in four 128-column chunks that only ever exist in LDS (32 KiB), and accumulates the
+// 128 x 384 output across the chunks in registers (96 per lane).  LDS = 64 + 32 + 2 x 16 (weight stages) = 128 KiB, one
+// block (two waves per SIMD) per CU.  Every phase is a 128 x 128 x 64 product against one streamed weight tile
+// (40 tiles per block: 4 chunks x (4 K-steps of W3b + 3 output chunks x 2 K-steps of W4)), one barrier per phase.
+// Arithmetic order equals the two-kernel path (same bf16 rounding of h3, same K order of the fp32 accumulation), so
+// the tokens are bit-identical to gemm_bf16 + gemm_groupmax.  The group maximum is combined across the blocks / waves
+// that share a group with an ordered-integer atomic max into tok (pre-filled with -inf by the launcher).
+#include "gemm_core.h"
+
+namespace {
+
+using namespace gemm;
+
+constexpr int TM = 128;                         // rows per block
+constexpr int TW = 8;                           // waves per block: 4 x 2 grid of 32 x 64 accumulator tiles
+constexpr int KB_BYTES = TM * BK * 2;           // one [64][64] bf16 k-block: 8 KiB
+constexpr int A2_BYTES = 4 * KB_BYTES;          // h2 tile, K = 256
+constexpr int A3_BYTES = 2 * KB_BYTES;          // h3 chunk, 128 columns = K of the next product
+constexpr int W_STAGE = 128 * BK * 2;           // one [128][64] weight tile: 16 KiB
+constexpr int TAIL_LDS = A2_BYTES + A3_BYTES + 2 * W_STAGE;
+
+struct TailParams {
+    int M, Mg;
+    const float* gb;   // [groups, 512]
+    const float* b4;   // [384]
+    float* tok;        // [groups, 384], pre-filled with -inf
+};
+
+__device__ __forceinline__ void atomic_max_float(float* addr, float v)
+{
+    if (v >= 0.0f) atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
+    else atomicMin(reinterpret_cast<unsigned*>(addr), __float_as_uint(v));
+}
+
+// acc[2][4] += A(32 rows of this wave, k-block `ta`) . W(64 columns of this wave, tile `tw`)^T, swapped orientation
+__device__ __forceinline__ void phase(f32x4 (&acc)[2][4], const char* ta, const char* tw, int wr, int wc, int lane)
+{
+    bf16x8 af[2][2], wf[2][4];  // both 32-deep halves requested up front: the second half's LDS latency hides under the first's MFMAs
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int chunk = kk * 4 + (lane >> 4);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[kk][i] = *reinterpret_cast<const bf16x8*>(ta + lds_off(wr * 32 + i * 16 + (lane & 15), chunk));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wf[kk][j] = *reinterpret_cast<const bf16x8*>(tw + lds_off(wc * 64 + j * 16 + (lane & 15), chunk));
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(wf[kk][j], af[kk][i], acc[i][j]);
+}
+
+__global__ __launch_bounds__(TW * 64, 2) void encoder_tail_kernel(GlobalTile H2, GlobalTile W3, GlobalTile W4, TailParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char* A2 = lds;
+    char* A3 = lds + A2_BYTES;
+    char* WS = A3 + A3_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int m0 = blockIdx.x * TM;
+
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) H2.stage<TM, TW>(A2 + kb * KB_BYTES, m0, kb * BK, tid);
+    // weight tile t of the block's sequence: chunk c = t / 10; u = t % 10: u < 4 -> W3b rows [128c, +128), K-step u;
+    // else output chunk o = (u - 4) / 2, K-step k2 = (u - 4) % 2 of W4 rows [128 o, +128), columns 128 c + 64 k2
+    auto stage_w = [&](int t, int slot) {
+        const int c = t / 10, u = t - c * 10;
+        char* buf = WS + slot * W_STAGE;
+        if (u < 4) W3.stage<128, TW>(buf, c * 128, u * BK, tid);
+        else W4.stage<128, TW>(buf, ((u - 4) >> 1) * 128, c * 128 + ((u - 4) & 1) * BK, tid);
+    };
+    stage_w(0, 0);
+    wait_vmcnt<0>();
+    block_barrier();
+
+    f32x4 acc3[2][4], acco[3][2][4];
+#pragma unroll
+    for (int o = 0; o < 3; ++o)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acco[o][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int row0 = m0 + wr * 32;                 // this wave's 32 rows share a group (32 | Mg)
+    const float* gb = p.gb + (size_t)(min(row0, p.M - 1) / p.Mg) * 512;
+
+    // one phase = (prefetch the next weight tile) + 16 MFMAs per wave + barrier; t counts the 40 tiles of the block
+    int t = 0;
+    auto step = [&](f32x4 (&acc)[2][4], const char* ta) {
+        if (t + 1 < 40) stage_w(t + 1, (t + 1) & 1);
+        phase(acc, ta, WS + (t & 1) * W_STAGE, wr, wc, lane);
+        ++t;
+    };
+    auto sync = [&]() {
+        wait_vmcnt<0>();
+        block_barrier();
+    };
+#pragma unroll 1
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc3[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int u = 0; u < 4; ++u) {
+            step(acc3, A2 + u * KB_BYTES);
+            if (u < 3) sync();
+        }
+        // h3 chunk c: + group bias, ReLU, bf16, into LDS in the A-operand layout of the next product
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = wc * 64 + j * 16 + (lane >> 4) * 4;  // column inside the chunk
+            const float4 b = *reinterpret_cast<const float4*>(gb + c * 128 + n);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int m = wr * 32 + i * 16 + (lane & 15);
+                const f32x4 v = acc3[i][j];
+                bf16x4 o = {f2bf(fmaxf(v[0] + b.x, 0.f)), f2bf(fmaxf(v[1] + b.y, 0.f)), f2bf(fmaxf(v[2] + b.z, 0.f)),
+                            f2bf(fmaxf(v[3] + b.w, 0.f))};
+                *reinterpret_cast<bf16x4*>(A3 + (n >> 6) * KB_BYTES + lds_off(m, (n & 63) >> 3) + (n & 7) * 2) = o;
+            }
+        }
+        sync();
+        step(acco[0], A3); sync(); step(acco[0], A3 + KB_BYTES); sync();
+        step(acco[1], A3); sync(); step(acco[1], A3 + KB_BYTES); sync();
+        step(acco[2], A3); sync(); step(acco[2], A3 + KB_BYTES); sync();
+    }
+
+    if (row0 >= p.M) return;
+    float* tok = p.tok + (size_t)(row0 / p.Mg) * 384;
+#pragma unroll
+    for (int o = 0; o < 3; ++o)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = o * 128 + wc * 64 + j * 16 + (lane >> 4) * 4;
+            const float4 b = *reinterpret_cast<const float4*>(p.b4 + n);
+            const float bb[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = fmaxf(acco[o][0][j][r], acco[o][1][j][r]);
+                v = fmaxf(v, __shfl_xor(v, 1, 64));
+                v = fmaxf(v, __shfl_xor(v, 2, 64));
+                v = fmaxf(v, __shfl_xor(v, 4, 64));
+                v = fmaxf(v, __shfl_xor(v, 8, 64));
+                if ((lane & 15) == 0) atomic_max_float(tok + n + r, v + bb[r]);
+            }
+        }
+}
+
+}  // namespace
+
+extern "C" int cmdiad_encoder_tail(const uint16_t* h2, const float* gb, const uint16_t* W3b, const uint16_t* W4, const float* b4,
+                                   int groups, int Mg, float* tok_out, cmdiad_stream_t stream)
+{
+    CMDIAD_REQUIRE(h2 && gb && W3b && W4 && b4 && tok_out, CMDIAD_ERR_ARG, "cmdiad_encoder_tail: null pointer");
+    CMDIAD_REQUIRE(groups > 0 && (Mg == 32 || Mg == 64 || Mg == 128), CMDIAD_ERR_ARG, "cmdiad_encoder_tail: Mg in {32,64,128} (Mg=%d)", Mg);
+    CMDIAD_REQUIRE(((((uintptr_t)h2 | (uintptr_t)W3b | (uintptr_t)W4 | (uintptr_t)gb | (uintptr_t)b4) & 15) == 0), CMDIAD_ERR_ARG,
+                   "cmdiad_encoder_tail: 16-byte alignment");
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)encoder_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TAIL_LDS) != hipSuccess) {
+            cmdiad_set_error("cmdiad_encoder_tail: hipFuncSetAttribute failed");
+            return CMDIAD_ERR_LAUNCH;
+        }
+        attr = true;
+    }
+    const int M = groups * Mg;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetD32Async((hipDeviceptr_t)tok_out, (int)0xFF800000u, (size_t)groups * 384, s) != hipSuccess) {
+        cmdiad_set_error("cmdiad_encoder_tail: memset failed");
+        return CMDIAD_ERR_LAUNCH;
+    }
+    GlobalTile H2{(const bf16_t*)h2, 256, M}, W3{(const bf16_t*)W3b, 256, 512}, W4t{(const bf16_t*)W4, 512, 384};
+    TailParams p{M, Mg, gb, b4, tok_out};
+    hipLaunchKernelGGL(encoder_tail_kernel, dim3((M + TM - 1) / TM), dim3(TW * 64), TAIL_LDS, s, H2, W3, W4t, p);
+    CMDIAD_CHECK_LAUNCH();
+    return CMDIAD_OK;
+}

@@ -167,6 +167,14 @@ def attention(q, k, vt, B, H, T, out=None):
     return out
 
 
+def encoder_tail(h2, gb, W3b, W4, b4, groups, Mg):
+    """h2 [groups*Mg,256] bf16, gb [groups,512] f32 -> tokens [groups,384] f32 (cmdiad_encoder_tail: h3 never leaves LDS)."""
+    _chk(h2, torch.bfloat16, "tail.h2"); _chk(gb, torch.float32, "tail.gb")
+    tok = torch.empty((groups, 384), dtype=torch.float32, device=h2.device)
+    _call("cmdiad_encoder_tail", _p(h2), _p(gb), _p(W3b), _p(W4), _p(b4), groups, Mg, _p(tok), _stream())
+    return tok
+
+
 def transformer_block_workspace_bytes(M, C, hidden):
     return int(nat.lib().cmdiad_transformer_block_workspace_bytes(M, C, hidden))
 

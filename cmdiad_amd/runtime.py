@@ -7,6 +7,8 @@ Reference anchors: ViT-B/8 models/models.py:35-53 (timm VisionTransformer [exter
 Point-MAE models/models.py:183-243, 352-373; hallucination MLP models/hallucination_network.py:34-45,
 utils/utils.py:86-115.
 """
+import os
+
 import torch
 
 from . import ops
@@ -157,6 +159,9 @@ class PackedPointMAE:
         e = self.enc
         h2, _, g16 = ops.encoder_stage1(neighborhood.reshape(-1, 3), e["w1b1"], e["W2"], e["b2"], B * G, Mg)
         gb, _ = ops.gemm(g16, e["W3a"], bias=e["b3"], want_f32=True, want_bf16=False)
+        if os.environ.get("CMDIAD_ENCODER_TAIL", "1") == "1":
+            # conv3 (per-point half) + ReLU + conv4 + group max in one kernel: h3 (4.3 GB at batch 32) never leaves LDS
+            return ops.encoder_tail(h2, gb, e["W3b"], e["W4"], e["b4"], B * G, Mg)
         _, h3 = ops.gemm(h2, e["W3b"], act=ops.ACT_RELU, group_bias=gb, group_rows=Mg)
         tok, _ = ops.gemm_groupmax(h3, e["W4"], e["b4"], B * G, Mg)
         return tok

@@ -138,6 +138,13 @@ int cmdiad_layernorm(float* x, const float* add, const float* gamma, const float
                      int C, uint16_t* out_bf16, float* out_f32, int ldo32, float* mean_out, float* rstd_out,
                      cmdiad_stream_t stream);
 
+/* Second half of the Point-MAE encoder in one kernel (models/models.py:204-215): h3 = ReLU(W3b . h2 + gb[group]) is produced
+ * and consumed in LDS, tok[g] = max over the group's rows of (W4 . h3 + b4).  h2 [groups*Mg, 256] bf16 and gb [groups, 512] f32
+ * (= W3a . groupmax(h2) + b3) as produced by cmdiad_encoder_stage1 + cmdiad_gemm_bf16; W3b [512,256], W4 [384,512] bf16;
+ * tok_out [groups, 384] f32.  Bit-identical to cmdiad_gemm_bf16(ReLU, group_bias) followed by cmdiad_gemm_groupmax. */
+int cmdiad_encoder_tail(const uint16_t* h2, const float* gb, const uint16_t* W3b, const uint16_t* W4, const float* b4,
+                        int groups, int Mg, float* tok_out, cmdiad_stream_t stream);
+
 /* One whole pre-LN transformer block on the fp32 residual stream x [B*T, C], in place (models/models.py:177-180 Block.forward,
  * 148-160 Attention, 126-132 Mlp; timm's ViT block reached at models.py:48 has the same algebra):
  *   x += proj(softmax(q k^T) v) with q,k,v = qkv(LN1(x (+ pos)));   x += fc2(GELU(fc1(LN2(x)))).

@@ -446,3 +446,20 @@ def test_reference_models_run_on_compat_shims():
     bq = ok.ball_query(0.01, 24, a[None], cen_ref)
     want = a[bq[0]] - cen_ref[0][:, None, :]                                                            # [M,ns,3]
     np.testing.assert_array_equal(g[0].permute(1, 2, 0).cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("Mg,groups", [(128, 24), (64, 9), (32, 7), (32, 50)])
+def test_encoder_tail_equals_two_kernel_path(Mg, groups):
+    """cmdiad_encoder_tail (h3 produced and consumed in LDS) against cmdiad_gemm_bf16(ReLU, group bias) + cmdiad_gemm_groupmax:
+    the same bf16 rounding of h3 and the same K order of the fp32 accumulation -> identical tokens, for every group size
+    (blocks of 64 rows hold half a group, one group or two groups) and a ragged last block."""
+    from oracle import nets
+    from cmdiad_amd.runtime import fold_pointmae_encoder
+    w = fold_pointmae_encoder(nets.synth_state_dict("pointmae", 21), "encoder.", DEV)
+    g = torch.Generator().manual_seed(Mg + groups)
+    h2 = torch.randn(groups * Mg, 256, generator=g).to(DEV).bfloat16()
+    gb = torch.randn(groups, 512, generator=g).to(DEV)
+    _, h3 = ops.gemm(h2, w["W3b"], act=ops.ACT_RELU, group_bias=gb, group_rows=Mg)
+    want, _ = ops.gemm_groupmax(h3, w["W4"], w["b4"], groups, Mg)
+    got = ops.encoder_tail(h2, gb, w["W3b"], w["W4"], w["b4"], groups, Mg)
+    assert torch.equal(got, want)
