@@ -26,6 +26,13 @@ class GemmArgs(Structure):
                 ("out_pre_bf16", c_void_p), ("dact_of", c_void_p), ("split_k", c_int)]
 
 
+class ConvArgs(Structure):
+    _fields_ = [("x", c_void_p), ("B", c_int), ("H", c_int), ("Wd", c_int), ("C", c_int),
+                ("W", c_void_p), ("N", c_int), ("ksize", c_int), ("stride", c_int),
+                ("bias", c_void_p), ("act", c_int), ("residual", c_void_p), ("ldr", c_int),
+                ("out_f32", c_void_p), ("ldo32", c_int), ("out_bf16", c_void_p), ("ldo16", c_int)]
+
+
 class BlockWeights(Structure):
     _fields_ = [(n, c_void_p) for n in ("ln1_w", "ln1_b", "ln2_w", "ln2_b", "qkv_w", "qkv_b", "proj_w", "proj_b",
                                         "fc1_w", "fc1_b", "fc2_w", "fc2_b")]
@@ -44,6 +51,9 @@ SIGNATURES = {
     "cmdiad_gemm_qkv": [P, P, P, I, I, I, P, P, P, P],
     "cmdiad_attention": [P, P, P, I, I, I, P, P],
     "cmdiad_encoder_tail": [P, P, P, P, P, I, I, P, P],
+    "cmdiad_conv2d_nhwc_bf16": [POINTER(ConvArgs), P],
+    "cmdiad_conv_stem": [P, P, P, I, I, I, I, I, I, P, P],
+    "cmdiad_upsample_bicubic": [P, I, I, I, I, I, I, I, P, I, P, P],
     "cmdiad_transformer_block_fwd": [P, P, POINTER(BlockWeights), I, I, I, I, I, F, P, P, P, P, SZ, P],
     "cmdiad_layernorm": [P, P, P, P, F, I, I, P, P, I, P, P, P],
     "cmdiad_loss_head": [P, P, I, I, I, F, P, P, P, P],

@@ -8,13 +8,61 @@ inference through cmdiad_amd.runtime.PackedHallucination, training (forward + lo
 cmdiad_amd.train, exposed to autograd so ``loss.backward()`` / ``torch.optim.Adam`` in
 hallucination_network_pretrain.py keep working unchanged.
 
-The conv / feature-to-input heads of the reference file (lines 72-220) are out of scope.
+The other heads of the reference file -- HallucinationCrossModalityConv (72-143), HallucinationRGBFeatureToXYZInputMLP
+(146-182), HallucinationFeatureToInputConv (185-220) -- are INFERENCE drop-ins: same constructors,
+state_dict keys and ``hallucination_generation`` / ``forward`` signatures; eval-mode arithmetic (BatchNorm running
+statistics folded into the convolution weights) on the implicit-GEMM convolution kernel (cmdiad_conv2d_nhwc_bf16) and
+cmdiad_upsample_bicubic.  ``forward`` returns the loss value without an autograd graph: training these heads is not
+implemented (train them with the reference, load the checkpoint here).
 """
 import torch
 import torch.nn as nn
 
 from .. import runtime
 from ..utils.utils import MlpModule
+
+
+def feature_reshape(feature):
+    """[B, HW, C] token matrix -> [B, C, H, W] (hallucination_network.py:6-9)."""
+    side = int(round(feature.shape[1] ** 0.5))
+    return feature.transpose(1, 2).reshape(feature.shape[0], feature.shape[2], side, side)
+
+
+def feature_reshape_back(feature):
+    """[B, C, H, W] -> [B, HW, C] (hallucination_network.py:12-15)."""
+    return feature.reshape(feature.shape[0], feature.shape[1], -1).transpose(1, 2)
+
+
+class _PackedHead(nn.Module):
+    """Caches the device-side packing of an inference head and refreshes it when a parameter changes."""
+    _packer = None
+
+    def _pack(self):
+        flat = self.__dict__.get("_cmdiad_flat")  # the module walk costs ms; re-collected every 64 calls (models._param_version)
+        if flat is None or flat[1] <= 0:
+            flat = [list(self.parameters()) + list(self.buffers()), 64]
+            self.__dict__["_cmdiad_flat"] = flat
+        flat[1] -= 1
+        tensors = flat[0]
+        ver = tuple((t.data_ptr(), t._version) for t in tensors)
+        cached = self.__dict__.get("_cmdiad_packed")
+        if cached is None or cached[0] != ver:
+            dev = tensors[0].device
+            if dev.type != "cuda":
+                raise RuntimeError(f"{type(self).__name__}: move the module to the GPU first (cmdiad_amd has no CPU path)")
+            cached = (ver, type(self)._packer(self.state_dict(), dev))
+            self.__dict__["_cmdiad_packed"] = cached
+        return cached[1]
+
+    def _no_training(self):
+        if self.training and torch.is_grad_enabled():
+            raise NotImplementedError(f"{type(self).__name__}: training (batch statistics + backward) is not implemented in "
+                                      "cmdiad_amd; call .eval() / torch.no_grad() for the loss value")
+
+    @staticmethod
+    def _mean_row_norm(a, b, dim):
+        d = torch.linalg.norm(a - b, dim=dim)
+        return torch.sum(d) / d.shape[0]
 
 
 class HallucinationCrossModalityNetwork(nn.Module):
@@ -59,3 +107,103 @@ class HallucinationCrossModalityNetwork(nn.Module):
         loss_xyz = train.direction_loss(self, 'rgb', rgb_feature, xyz_feature, dist_method)  # rgb -> hallucinated xyz
         loss_rgb = train.direction_loss(self, 'xyz', xyz_feature, rgb_feature, dist_method)  # xyz -> hallucinated rgb
         return loss_xyz, loss_rgb
+
+
+class HallucinationCrossModalityConv(_PackedHead):
+    """hallucination_network.py:72-143: per direction four 3x3 convolutions 768 -> 768 on the 56 x 56 feature map, the
+    first three followed by BatchNorm + ReLU."""
+    _packer = staticmethod(lambda sd, dev: runtime.PackedConvFtoF(sd, device=dev))
+
+    def __init__(self, args, xyz_dim, rgb_dim):
+        super().__init__()
+        self.args, self.xyz_dim, self.rgb_dim = args, xyz_dim, rgb_dim
+
+        def tower(cin):
+            layers = []
+            for i in range(4):
+                layers.append(nn.Conv2d(cin if i == 0 else 768, 768, kernel_size=(3, 3), stride=(1, 1), padding=1, bias=False))
+                if i < 3:
+                    layers += [nn.BatchNorm2d(768), nn.ReLU()]
+            return nn.Sequential(*layers)
+
+        self.xyz_conv = tower(xyz_dim)
+        self.rgb_conv = tower(rgb_dim)
+        self.sig = nn.Sigmoid()
+
+    def hallucination_generation(self, xyz_feature, rgb_feature, out_type):
+        """[B,3136,768] tokens in, tokens out (hallucination_network.py:113-131); 'xyz' = hallucinated xyz features from
+        the rgb features, 'rgb' the reverse, 'train' = (xyz_hallucination, rgb_hallucination)."""
+        pk = self._pack()
+        if out_type == 'train':
+            return pk.generate(rgb_feature, 'rgb'), pk.generate(xyz_feature, 'xyz')
+        elif out_type == 'xyz':
+            return pk.generate(rgb_feature, 'rgb')
+        elif out_type == 'rgb':
+            return pk.generate(xyz_feature, 'xyz')
+
+    def forward(self, xyz_feature, rgb_feature, sigmoid, dist_method):
+        self._no_training()
+        with torch.no_grad():
+            xyz_h, rgb_h = self.hallucination_generation(xyz_feature, rgb_feature, 'train')
+            assert tuple(xyz_h.shape[1:]) == (3136, 768)
+            xyz_feature, rgb_feature = xyz_feature.to(xyz_h.device), rgb_feature.to(rgb_h.device)
+            if sigmoid is True:
+                return (self._mean_row_norm(self.sig(xyz_h), self.sig(xyz_feature), 2),
+                        self._mean_row_norm(self.sig(rgb_h), self.sig(rgb_feature), 2))
+            return self._mean_row_norm(xyz_h, xyz_feature, 2), self._mean_row_norm(rgb_h, rgb_feature, 2)
+
+
+class HallucinationRGBFeatureToXYZInputMLP(_PackedHead):
+    """hallucination_network.py:146-182: LayerNorm -> 768 -> 1152 -> 384 -> 96 -> 3 (or 1 with --estimate_depth) with GELU
+    between, then bicubic 56 -> 224."""
+    _packer = staticmethod(lambda sd, dev: runtime.PackedFtoIMLP(sd, device=dev))
+
+    def __init__(self, args, rgb_dim):
+        super().__init__()
+        self.args = args
+        out_dim = 1 if getattr(args, "estimate_depth", False) else 3
+        self.rgb_dim = rgb_dim
+        self.rgb_norm = nn.LayerNorm(rgb_dim)
+        widths = (rgb_dim, 1152, 384, 96, out_dim)
+        layers = []
+        for i in range(4):
+            layers.append(nn.Linear(widths[i], widths[i + 1]))
+            if i < 3:
+                layers.append(nn.GELU())
+        self.mlp = nn.Sequential(*layers)
+
+    def hallucination_generation(self, x):
+        """[B,3136,768] -> [B,out_dim,224,224] f32 on the GPU."""
+        return self._pack().generate(x)
+
+    def forward(self, rgb_feature, xyz):
+        self._no_training()
+        with torch.no_grad():
+            h = self.hallucination_generation(rgb_feature.reshape(rgb_feature.shape[0], rgb_feature.shape[1], -1))
+            return self._mean_row_norm(h, xyz.to(h.device), 1)
+
+
+class HallucinationFeatureToInputConv(_PackedHead):
+    """hallucination_network.py:185-220: conv 768 -> 384 at 56 x 56, bicubic to 224 x 224, conv 384 -> 96 -> 32 -> 3 with
+    ReLU between (``norm`` exists in the state_dict but the reference's forward never applies it)."""
+    _packer = staticmethod(lambda sd, dev: runtime.PackedFtoIConv(sd, device=dev))
+
+    def __init__(self, args=None, dim=768):
+        super().__init__()
+        self.args, self.dim = args, dim
+        self.norm = nn.LayerNorm(dim)
+        widths = (dim, 384, 96, 32, 3)
+        for i in range(4):
+            setattr(self, f"conv{i + 1}", nn.Conv2d(widths[i], widths[i + 1], kernel_size=(3, 3), stride=(1, 1), padding=1))
+        self.act = nn.ReLU(inplace=True)
+
+    def hallucination_generation(self, feature):
+        """[B,3136,768] -> [B,3,224,224] f32 on the GPU."""
+        return self._pack().generate(feature)
+
+    def forward(self, feature, img):
+        self._no_training()
+        with torch.no_grad():
+            h = self.hallucination_generation(feature)
+            assert h.shape[1:] == (3, 224, 224) and img.shape[1:] == (3, 224, 224)
+            return self._mean_row_norm(h, img.to(h.device), 1)

@@ -8,7 +8,7 @@ import torch
 
 from . import _native as nat
 
-ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
+ACT_NONE, ACT_GELU, ACT_RELU, ACT_RELU_POST = 0, 1, 2, 3
 U64_MAX = -1  # as int64 bit pattern
 
 
@@ -173,6 +173,52 @@ def encoder_tail(h2, gb, W3b, W4, b4, groups, Mg):
     tok = torch.empty((groups, 384), dtype=torch.float32, device=h2.device)
     _call("cmdiad_encoder_tail", _p(h2), _p(gb), _p(W3b), _p(W4), _p(b4), groups, Mg, _p(tok), _stream())
     return tok
+
+
+def conv2d_nhwc(x, W, N, ksize=3, stride=1, bias=None, act=ACT_NONE, residual=None, out_f32=None, out_bf16=None,
+                want_f32=False, want_bf16=True):
+    """x [B,H,W,C] bf16 NHWC, W [N, ksize*ksize*C] bf16 (tap-major) -> (out_f32 | None, out_bf16 | None), each [B,Ho,Wo,ld]
+    with ld = the given buffer's last dimension (>= N; extra columns are left untouched).  cmdiad_conv2d_nhwc_bf16."""
+    _chk(x, torch.bfloat16, "conv.x"); _chk(W, torch.bfloat16, "conv.W"); _chk(residual, torch.float32, "conv.residual")
+    B, H, Wd, C = x.shape
+    pad = 1 if ksize == 3 else 0
+    Ho, Wo = (H + 2 * pad - ksize) // stride + 1, (Wd + 2 * pad - ksize) // stride + 1
+    if out_f32 is None and want_f32:
+        out_f32 = torch.empty((B, Ho, Wo, N), dtype=torch.float32, device=x.device)
+    if out_bf16 is None and want_bf16:
+        out_bf16 = torch.empty((B, Ho, Wo, N), dtype=torch.bfloat16, device=x.device)
+    a = nat.ConvArgs(_p(x), B, H, Wd, C, _p(W), N, ksize, stride, _p(bias), act,
+                     _p(residual), residual.shape[-1] if residual is not None else 0,
+                     _p(out_f32), out_f32.shape[-1] if out_f32 is not None else 0,
+                     _p(out_bf16), out_bf16.shape[-1] if out_bf16 is not None else 0)
+    _call("cmdiad_conv2d_nhwc_bf16", ctypes.byref(a), _stream())
+    return out_f32, out_bf16
+
+
+def conv_stem(x, w, bias, stride=2):
+    """x [B,Cin<=4,H,W] f32 NCHW, w [Cout,Cin,3,3] f32 (BatchNorm folded), bias [Cout] -> ReLU(conv) as bf16 NHWC."""
+    _chk(x, torch.float32, "stem.x"); _chk(w, torch.float32, "stem.w"); _chk(bias, torch.float32, "stem.bias")
+    B, Cin, H, Wd = x.shape
+    Cout = w.shape[0]
+    Ho, Wo = (H - 1) // stride + 1, (Wd - 1) // stride + 1
+    out = torch.empty((B, Ho, Wo, Cout), dtype=torch.bfloat16, device=x.device)
+    _call("cmdiad_conv_stem", _p(x), _p(w), _p(bias), B, Cin, H, Wd, Cout, stride, _p(out), _stream())
+    return out
+
+
+def upsample_bicubic(x, C, H, W, out_bf16=None, nchw=False):
+    """x [B,h,w,ld] f32 NHWC (first C channels used) -> bf16 NHWC [B,H,W,ldo] (given or allocated with ldo = C) or, with
+    nchw=True, f32 [B,C,H,W].  torch's bicubic, align_corners=False (cmdiad_upsample_bicubic)."""
+    _chk(x, torch.float32, "bicubic.x")
+    B, h, w, ld = x.shape
+    if nchw:
+        out = torch.empty((B, C, H, W), dtype=torch.float32, device=x.device)
+        _call("cmdiad_upsample_bicubic", _p(x), B, h, w, C, ld, H, W, None, 0, _p(out), _stream())
+        return out
+    if out_bf16 is None:
+        out_bf16 = torch.empty((B, H, W, C), dtype=torch.bfloat16, device=x.device)
+    _call("cmdiad_upsample_bicubic", _p(x), B, h, w, C, ld, H, W, _p(out_bf16), out_bf16.shape[-1], None, _stream())
+    return out_bf16
 
 
 def transformer_block_workspace_bytes(M, C, hidden):

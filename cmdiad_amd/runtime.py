@@ -218,3 +218,153 @@ class PackedHallucination:
         _, h = ops.gemm(h, w["w2"], bias=w["b2"], act=ops.ACT_GELU)
         out, _ = ops.gemm(h, w["w3"], bias=w["b3"], act=ops.ACT_GELU, want_f32=True, want_bf16=False)
         return out.view(*shape[:-1], out.shape[-1])
+
+
+# ------------------------------------------------------------------------------------------- convolution heads (8f/f4)
+def _fold_conv_bn(sd, conv, bn, device, cin_pad=None, n_pad=None, eps=1e-5):
+    """Conv2d weight [N,C,k,k] (+ optional bias) with an eval-mode BatchNorm2d folded in -> (W [N', k*k*C'] bf16 tap-major,
+    bias [N'] f32 or None).  Zero rows / channels pad N and C up to n_pad / cin_pad (a zero output column stays zero
+    through ReLU, so padded activations feed the next layer's padded channels)."""
+    w = sd[conv + ".weight"].detach().float()
+    b = sd[conv + ".bias"].detach().float() if (conv + ".bias") in sd else None
+    if bn is not None:
+        g = sd[bn + ".weight"].detach().float() / torch.sqrt(sd[bn + ".running_var"].detach().float() + eps)
+        w = w * g.view(-1, 1, 1, 1)
+        b = sd[bn + ".bias"].detach().float() - sd[bn + ".running_mean"].detach().float() * g + (b * g if b is not None else 0)
+    N, C, kh, kw = w.shape
+    Np, Cp = n_pad or N, cin_pad or C
+    wp = torch.zeros((Np, kh, kw, Cp), dtype=torch.float32)
+    wp[:N, :, :, :C] = w.permute(0, 2, 3, 1).cpu()
+    bias = None
+    if b is not None:
+        bias = torch.zeros(Np, dtype=torch.float32)
+        bias[:N] = b.cpu()
+        bias = bias.to(device)
+    return wp.reshape(Np, -1).to(device).to(torch.bfloat16).contiguous(), bias
+
+
+def _tokens_as_image(x, device):
+    """[B, HW, C] f32 tokens -> bf16 NHWC image [B, H, W, C] (hallucination_network.py:6-9 is only a reshape)."""
+    B, T, C = x.shape
+    side = int(round(T ** 0.5))
+    if side * side != T:
+        raise ValueError(f"token count {T} is not a square feature map")
+    return ops.cast_bf16(x.to(device, torch.float32).contiguous()).view(B, side, side, C)
+
+
+class PackedConvFtoF:
+    """HallucinationCrossModalityConv (models/hallucination_network.py:72-143), eval mode: per direction
+    [conv3x3 + BN + ReLU] x 3 + conv3x3, 768 channels on the 56 x 56 token map, as four implicit-GEMM launches."""
+
+    def __init__(self, sd, device="cuda"):
+        self.device = device
+        self.dir = {}
+        for name in ("xyz", "rgb"):
+            layers = []
+            for i in range(4):
+                bn = f"{name}_conv.{3 * i + 1}" if i < 3 else None
+                layers.append(_fold_conv_bn(sd, f"{name}_conv.{3 * i}", bn, device))
+            self.dir[name] = layers
+
+    def generate(self, x, src):
+        """src='xyz': xyz features -> hallucinated rgb features (xyz_conv); src='rgb': the reverse.  [B,3136,768] -> same."""
+        h = _tokens_as_image(x, self.device)
+        B, H, W, _ = h.shape
+        for i, (w, b) in enumerate(self.dir[src]):
+            last = i == 3
+            o32, o16 = ops.conv2d_nhwc(h, w, w.shape[0], 3, 1, bias=b, act=ops.ACT_NONE if last else ops.ACT_RELU,
+                                       want_f32=last, want_bf16=not last)
+            h = o32 if last else o16
+        return h.view(B, H * W, h.shape[-1])
+
+
+class PackedFtoIConv:
+    """HallucinationFeatureToInputConv (models/hallucination_network.py:185-220): conv 768 -> 384 on the 56 x 56 map, bicubic
+    to 224 x 224, conv 384 -> 96 (ReLU) -> 32 (ReLU) -> 3.  Channel counts that are not multiples of 64 are zero-padded."""
+
+    def __init__(self, sd, device="cuda"):
+        self.device = device
+        self.c1 = _fold_conv_bn(sd, "conv1", None, device)
+        self.c2 = _fold_conv_bn(sd, "conv2", None, device, n_pad=128)
+        self.c3 = _fold_conv_bn(sd, "conv3", None, device, cin_pad=128, n_pad=64)
+        self.c4 = _fold_conv_bn(sd, "conv4", None, device, cin_pad=64, n_pad=4)
+        self.out_dim = sd["conv4.weight"].shape[0]
+
+    def generate(self, feature):
+        h = _tokens_as_image(feature, self.device)
+        B = h.shape[0]
+        f32, _ = ops.conv2d_nhwc(h, self.c1[0], 384, 3, 1, bias=self.c1[1], want_f32=True, want_bf16=False)
+        h = ops.upsample_bicubic(f32, 384, 224, 224)
+        _, h = ops.conv2d_nhwc(h, self.c2[0], 128, 3, 1, bias=self.c2[1], act=ops.ACT_RELU)
+        _, h = ops.conv2d_nhwc(h, self.c3[0], 64, 3, 1, bias=self.c3[1], act=ops.ACT_RELU)
+        out, _ = ops.conv2d_nhwc(h, self.c4[0], 4, 3, 1, bias=self.c4[1], want_f32=True, want_bf16=False)
+        return out.view(B, 224, 224, 4)[..., :self.out_dim].permute(0, 3, 1, 2).contiguous()
+
+
+class PackedFtoIMLP:
+    """HallucinationRGBFeatureToXYZInputMLP (models/hallucination_network.py:146-182): LayerNorm, 768 -> 1152 -> 384 -> 96 ->
+    out_dim with GELU between, bicubic 56 -> 224.  The 96-wide layer is zero-padded to 128 (K % 64 == 0), out_dim to 4."""
+
+    def __init__(self, sd, device="cuda"):
+        self.device = device
+        self.ln = (_dev(sd["rgb_norm.weight"], device), _dev(sd["rgb_norm.bias"], device))
+        self.out_dim = sd["mlp.6.weight"].shape[0]
+
+        def lin(i, n_pad=None, k_pad=None):
+            w, b = sd[f"mlp.{i}.weight"].detach().float().cpu(), sd[f"mlp.{i}.bias"].detach().float().cpu()
+            wp = torch.zeros((n_pad or w.shape[0], k_pad or w.shape[1]))
+            wp[:w.shape[0], :w.shape[1]] = w
+            bp = torch.zeros(wp.shape[0])
+            bp[:b.shape[0]] = b
+            return wp.to(device).to(torch.bfloat16).contiguous(), bp.to(device)
+
+        self.l = [lin(0), lin(2), lin(4, n_pad=128), lin(6, n_pad=4, k_pad=128)]
+
+    def generate(self, x):
+        B, T, C = x.shape
+        side = int(round(T ** 0.5))
+        h = ops.layernorm(x.to(self.device, torch.float32).reshape(B * T, C).contiguous().clone(), self.ln[0], self.ln[1], 1e-5)
+        for w, b in self.l[:3]:
+            _, h = ops.gemm(h, w, bias=b, act=ops.ACT_GELU)
+        out, _ = ops.gemm(h, self.l[3][0], bias=self.l[3][1], want_f32=True, want_bf16=False)
+        return ops.upsample_bicubic(out.view(B, side, side, 4), self.out_dim, 224, 224, nchw=True)
+
+
+class PackedHRNet:
+    """The trunk models/hrnet.py actually runs (hrnet.py:251-288): stem 3 -> 64 -> 128 (3x3, stride 2, BN, ReLU), twelve
+    Bottlenecks 512 -> 128 -> 128 -> 512 (layer1-3; the first one widens 128 -> 512 through its `downsample` branch), 1x1
+    final_layer.  The residual trunk stays fp32, every convolution operand is bf16."""
+
+    def __init__(self, sd, device="cuda"):
+        self.device = device
+        g = sd["bn1.weight"].detach().float() / torch.sqrt(sd["bn1.running_var"].detach().float() + 1e-5)
+        self.stem_w = (sd["conv1.weight"].detach().float() * g.view(-1, 1, 1, 1)).to(device).contiguous()
+        self.stem_b = (sd["bn1.bias"].detach().float() - sd["bn1.running_mean"].detach().float() * g).to(device).contiguous()
+        self.stem2 = _fold_conv_bn(sd, "conv2", "bn2", device)
+        self.blocks = []
+        for layer in (1, 2, 3):
+            for i in range(4):
+                p = f"layer{layer}.{i}."
+                blk = [_fold_conv_bn(sd, p + f"conv{k}", p + f"bn{k}", device) for k in (1, 2, 3)]
+                down = _fold_conv_bn(sd, p + "downsample.0", p + "downsample.1", device) if (p + "downsample.0.weight") in sd else None
+                self.blocks.append((blk, down))
+        self.final = _fold_conv_bn(sd, "final_layer", None, device)
+        if self.final[0].shape[1] != 512:
+            raise ValueError(f"HRNet(c={self.final[0].shape[1]}): final_layer expects c channels but the trunk is 512 wide "
+                             "(hrnet.py:248,286) -- construct it with c=512 (--c_hrnet 512)")
+
+    def generate(self, img):
+        """[B,3,H,W] f32 -> tokens [B, (H/4)*(W/4), nof_joints] f32."""
+        x = ops.conv_stem(img.to(self.device, torch.float32).contiguous(), self.stem_w, self.stem_b, 2)
+        _, x16 = ops.conv2d_nhwc(x, self.stem2[0], 128, 3, 2, bias=self.stem2[1], act=ops.ACT_RELU)
+        x32 = None
+        for (c1, c2, c3), down in self.blocks:
+            if down is not None:
+                x32, _ = ops.conv2d_nhwc(x16, down[0], down[0].shape[0], 1, 1, bias=down[1], want_f32=True, want_bf16=False)
+            _, t = ops.conv2d_nhwc(x16, c1[0], c1[0].shape[0], 1, 1, bias=c1[1], act=ops.ACT_RELU)
+            _, t = ops.conv2d_nhwc(t, c2[0], c2[0].shape[0], 3, 1, bias=c2[1], act=ops.ACT_RELU)
+            x32, x16 = ops.conv2d_nhwc(t, c3[0], c3[0].shape[0], 1, 1, bias=c3[1], act=ops.ACT_RELU_POST, residual=x32,
+                                       want_f32=True, want_bf16=True)
+        out, _ = ops.conv2d_nhwc(x16, self.final[0], self.final[0].shape[0], 1, 1, bias=self.final[1], want_f32=True, want_bf16=False)
+        B, H, W, N = out.shape
+        return out.view(B, H * W, N)

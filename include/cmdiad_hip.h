@@ -99,7 +99,8 @@ int cmdiad_xyz_patch_fused(const float* feat, const int32_t* idx3, const float* 
 /* out[M,N] = epilogue(A[M,K] . W[N,K]^T): bf16 MFMA, fp32 accumulate.  K % 64 == 0.
  * Epilogue, in order: + bias[N]; + group_bias[m / group_rows][N]; activation; + residual[M,N] (f32);
  * stores to out_f32 and/or out_bf16 (either may be NULL; out_f32 may alias residual). */
-enum { CMDIAD_ACT_NONE = 0, CMDIAD_ACT_GELU = 1, CMDIAD_ACT_RELU = 2 };
+enum { CMDIAD_ACT_NONE = 0, CMDIAD_ACT_GELU = 1, CMDIAD_ACT_RELU = 2,
+       CMDIAD_ACT_RELU_POST = 3 /* ReLU AFTER the residual; cmdiad_conv2d_nhwc_bf16 only */ };
 typedef struct {
     const uint16_t* A; int lda;      /* [M,K] bf16 */
     const uint16_t* W; int ldw;      /* [N,K] bf16 (nn.Linear weight layout) */
@@ -144,6 +145,41 @@ int cmdiad_layernorm(float* x, const float* add, const float* gamma, const float
  * tok_out [groups, 384] f32.  Bit-identical to cmdiad_gemm_bf16(ReLU, group_bias) followed by cmdiad_gemm_groupmax. */
 int cmdiad_encoder_tail(const uint16_t* h2, const float* gb, const uint16_t* W3b, const uint16_t* W4, const float* b4,
                         int groups, int Mg, float* tok_out, cmdiad_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Convolution heads of the distillation networks: models/hallucination_network.py:72-143
+ * (HallucinationCrossModalityConv), 146-182 (HallucinationRGBFeatureToXYZInputMLP), 185-220
+ * (HallucinationFeatureToInputConv), models/hrnet.py:8-43,146-290 (HRNet stem + Bottlenecks).
+ * Replaces the torch.nn.Conv2d / BatchNorm2d / interpolate calls those modules make (cuDNN in the reference).
+ * ------------------------------------------------------------------------------------------- */
+
+/* 3x3 (stride 1 or 2, padding 1) or 1x1 convolution as an implicit GEMM: x [B,H,W,C] bf16 NHWC (a token matrix
+ * [B, H*W, C] is exactly that), W [N][ksize*ksize][C] bf16 (tap-major: the torch weight [N,C,kh,kw] permuted to
+ * [N,kh,kw,C]; BatchNorm folded by the caller), C % 64 == 0, N % 4 == 0.  Output rows m = (b, yo, xo) with
+ * Ho = (H + 2 pad - ksize) / stride + 1.  Epilogue: + bias[N]; ReLU (act = RELU); + residual[M,N] f32; ReLU
+ * (act = RELU_POST); stores to out_f32 and/or out_bf16 with leading dimensions ldo32 / ldo16 (columns >= N untouched). */
+typedef struct {
+    const uint16_t* x; int B, H, Wd, C;
+    const uint16_t* W; int N;
+    int ksize, stride;
+    const float* bias;               /* [N] or NULL */
+    int act;                         /* CMDIAD_ACT_NONE / RELU / RELU_POST */
+    const float* residual; int ldr;  /* [M,N] f32 or NULL */
+    float* out_f32; int ldo32;
+    uint16_t* out_bf16; int ldo16;
+} cmdiad_conv_args;
+int cmdiad_conv2d_nhwc_bf16(const cmdiad_conv_args* args, cmdiad_stream_t stream);
+
+/* Stem convolution (hrnet.py:150-151,252-254): 3x3, padding 1, stride 1 or 2 on an f32 NCHW image with Cin <= 4 planes,
+ * folded BatchNorm bias, ReLU, bf16 NHWC output [B,Ho,Wo,Cout].  w [Cout][Cin][3][3] f32 (torch layout), Cout % 8 == 0. */
+int cmdiad_conv_stem(const float* x, const float* w, const float* bias, int B, int Cin, int H, int W, int Cout,
+                     int stride, uint16_t* out, cmdiad_stream_t stream);
+
+/* torch.nn.functional.interpolate(mode='bicubic', align_corners=False) (hallucination_network.py:171,204).
+ * in f32 NHWC [B,h,w,ldi] of which C channels are used; exactly one output: out_bf16_nhwc [B,H,W,ldo] (the next
+ * convolution's operand; columns >= C untouched) or out_f32_nchw [B,C,H,W]. */
+int cmdiad_upsample_bicubic(const float* in, int B, int h, int w, int C, int ldi, int H, int W,
+                            uint16_t* out_bf16_nhwc, int ldo, float* out_f32_nchw, cmdiad_stream_t stream);
 
 /* One whole pre-LN transformer block on the fp32 residual stream x [B*T, C], in place (models/models.py:177-180 Block.forward,
  * 148-160 Attention, 126-132 Mlp; timm's ViT block reached at models.py:48 has the same algebra):

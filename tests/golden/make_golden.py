@@ -95,9 +95,57 @@ def _ns(**kw):
     return types.SimpleNamespace(**kw)
 
 
+def golden_heads():
+    """G10: the conv / feature-to-input / HRNet distillation heads (models/hallucination_network.py:72-220,
+    models/hrnet.py), eval mode, on the synthetic weights of oracle.heads.synth_head_state_dict: outputs of
+    hallucination_generation (sub-sampled), the loss each forward() returns, and checksums of a seeded default init."""
+    from oracle import heads as oh
+    from models import hallucination_network as rhn
+    from models.hrnet import HRNet as RefHRNet
+    g = torch.Generator().manual_seed(101)
+    xyz_tok, rgb_tok = torch.randn(1, 3136, 768, generator=g), torch.randn(1, 3136, 768, generator=g)
+    img = torch.randn(1, 3, 224, 224, generator=g)
+    out = dict(tok_seed=101)
+    build = {"conv_ftof": lambda: rhn.HallucinationCrossModalityConv(None, 768, 768),
+             "ftoi_mlp": lambda: rhn.HallucinationRGBFeatureToXYZInputMLP(_ns(estimate_depth=False), 768),
+             "ftoi_conv": lambda: rhn.HallucinationFeatureToInputConv(None, 768),
+             "hrnet": lambda: RefHRNet(512, 768, 0.1)}
+    with torch.no_grad():
+        for kind, make in build.items():
+            torch.manual_seed(777)
+            m = make()
+            for k, v in m.state_dict().items():  # seeded default init: construction order == RNG consumption order
+                out[f"init/{kind}/{k}"] = np.array([v.double().sum().item(), v.double().abs().sum().item()])
+            sd = oh.synth_head_state_dict(kind, 41)
+            print(kind, m.load_state_dict(sd))
+            m.eval()
+            if kind == "conv_ftof":
+                xh, rh = m.hallucination_generation(xyz_tok, rgb_tok, "train")
+                assert torch.allclose(xh, oh.conv_ftof(sd, rgb_tok, "rgb"), atol=1e-4) and torch.allclose(rh, oh.conv_ftof(sd, xyz_tok, "xyz"), atol=1e-4)
+                out["conv_ftof/xyz_h"], out["conv_ftof/rgb_h"] = xh[0, ::7, ::8].numpy(), rh[0, ::7, ::8].numpy()
+                out["conv_ftof/loss"] = np.array([float(v) for v in m(xyz_tok, rgb_tok, False, "l2")])
+                out["conv_ftof/loss_sigmoid"] = np.array([float(v) for v in m(xyz_tok, rgb_tok, True, "l2")])
+            elif kind == "ftoi_mlp":
+                y = m.hallucination_generation(rgb_tok)
+                assert torch.allclose(y, oh.ftoi_mlp(sd, rgb_tok), atol=1e-5)
+                out["ftoi_mlp/y"], out["ftoi_mlp/loss"] = y[0, :, ::4, ::4].numpy(), float(m(rgb_tok, img))
+            elif kind == "ftoi_conv":
+                y = m.hallucination_generation(xyz_tok)
+                assert torch.allclose(y, oh.ftoi_conv(sd, xyz_tok), atol=1e-4)
+                out["ftoi_conv/y"], out["ftoi_conv/loss"] = y[0, :, ::4, ::4].numpy(), float(m(xyz_tok, img))
+            else:
+                y = m.hallucination_generation(img)
+                assert torch.allclose(y, oh.hrnet(sd, img), atol=1e-4)
+                out["hrnet/y"], out["hrnet/loss"] = y[0, ::8, ::2, ::2].numpy(), float(m(img, xyz_tok))
+    np.savez_compressed(os.path.join(HERE, "g10_heads.npz"), **out)
+    print("g10_heads.npz", os.path.getsize(os.path.join(HERE, "g10_heads.npz")) // 1024, "KB")
+
+
 def main():
     _install_stubs()
     sys.path.insert(0, REF)
+    if len(sys.argv) > 1 and sys.argv[1] == "g10":  # only the distillation-head fixture
+        return golden_heads()
     from models import models as rmodels
     from models import pointnet2_utils as rp2
     from models.hallucination_network import HallucinationCrossModalityNetwork
@@ -359,6 +407,8 @@ def main():
         torch.Tensor.to = orig_to
     np.savez_compressed(os.path.join(HERE, "g9_coreset.npz"), z_seed=91, rows=2500, dim=768, n=250, eps=0.9, random_state=0,
                         idx=sel.numpy().astype(np.int64))
+
+    golden_heads()
 
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

@@ -60,6 +60,27 @@ def test_seeded_init_matches_reference_checksums(golden):
         np.testing.assert_allclose([v.double().sum().item(), v.double().abs().sum().item()], g["hn/" + k], rtol=1e-9, atol=1e-9)
 
 
+def test_distillation_head_modules_match_reference_names_and_seeded_init(golden):
+    """Conv / FtoI / HRNet heads: same state_dict keys as the reference's modules and the same values after a
+    seeded default construction (same construction order => same RNG consumption; tests/golden/make_golden.py G10)."""
+    from cmdiad_amd.models import hallucination_network as hn
+    from cmdiad_amd.models.hrnet import HRNet
+    g = golden("g10_heads.npz")
+    build = {"conv_ftof": lambda: hn.HallucinationCrossModalityConv(None, 768, 768),
+             "ftoi_mlp": lambda: hn.HallucinationRGBFeatureToXYZInputMLP(types.SimpleNamespace(estimate_depth=False), 768),
+             "ftoi_conv": lambda: hn.HallucinationFeatureToInputConv(None, 768),
+             "hrnet": lambda: HRNet(512, 768, 0.1)}
+    for kind, make in build.items():
+        torch.manual_seed(777)
+        sd = make().state_dict()
+        ref = {k[len(f"init/{kind}/"):]: g[k] for k in g.files if k.startswith(f"init/{kind}/")}
+        assert set(sd) == set(ref), kind
+        for k, v in sd.items():
+            np.testing.assert_allclose([v.double().sum().item(), v.double().abs().sum().item()], ref[k], rtol=1e-9, atol=1e-9, err_msg=f"{kind}/{k}")
+    with pytest.raises(RuntimeError, match="GPU"):
+        build["ftoi_conv"]().hallucination_generation(torch.zeros(1, 3136, 768))
+
+
 def test_vit_state_dict_uses_timm_names():
     from cmdiad_amd.models.models import VisionTransformer
     from oracle import nets

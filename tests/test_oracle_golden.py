@@ -252,3 +252,31 @@ def test_fps_knn_oracle_against_independent_torch_restatement():
     order = torch.argsort(d2, dim=1, stable=True)[:, :K]                    # ascending (d2, index)
     np.testing.assert_array_equal(nn_idx[0], order.numpy())
     np.testing.assert_array_equal(nb[0], (p[order] - c[:, None, :]).numpy())
+
+
+def test_g10_distillation_heads(golden):
+    """oracle/heads.py against the reference's own conv / FtoI / HRNet modules (tests/golden/make_golden.py G10)."""
+    from oracle import heads
+    g = golden("g10_heads.npz")
+    gen = torch.Generator().manual_seed(int(g["tok_seed"]))
+    xyz_tok, rgb_tok = torch.randn(1, 3136, 768, generator=gen), torch.randn(1, 3136, 768, generator=gen)
+    img = torch.randn(1, 3, 224, 224, generator=gen)
+    with torch.no_grad():
+        sd = heads.synth_head_state_dict("conv_ftof", 41)
+        xh, rh = heads.conv_ftof(sd, rgb_tok, "rgb"), heads.conv_ftof(sd, xyz_tok, "xyz")
+        np.testing.assert_allclose(xh[0, ::7, ::8].numpy(), g["conv_ftof/xyz_h"], atol=2e-4)
+        np.testing.assert_allclose(rh[0, ::7, ::8].numpy(), g["conv_ftof/rgb_h"], atol=2e-4)
+        np.testing.assert_allclose([float(heads.mean_row_norm(xh, xyz_tok, 2)), float(heads.mean_row_norm(rh, rgb_tok, 2))],
+                                   g["conv_ftof/loss"], rtol=1e-5)
+        np.testing.assert_allclose([float(heads.mean_row_norm(xh.sigmoid(), xyz_tok.sigmoid(), 2)),
+                                    float(heads.mean_row_norm(rh.sigmoid(), rgb_tok.sigmoid(), 2))], g["conv_ftof/loss_sigmoid"], rtol=1e-5)
+        y = heads.ftoi_mlp(heads.synth_head_state_dict("ftoi_mlp", 41), rgb_tok)
+        np.testing.assert_allclose(y[0, :, ::4, ::4].numpy(), g["ftoi_mlp/y"], atol=1e-5)
+        np.testing.assert_allclose(float(heads.mean_row_norm(y, img, 1)), float(g["ftoi_mlp/loss"]), rtol=1e-5)
+        y = heads.ftoi_conv(heads.synth_head_state_dict("ftoi_conv", 41), xyz_tok)
+        np.testing.assert_allclose(y[0, :, ::4, ::4].numpy(), g["ftoi_conv/y"], atol=2e-4)
+        np.testing.assert_allclose(float(heads.mean_row_norm(y, img, 1)), float(g["ftoi_conv/loss"]), rtol=1e-5)
+        y = heads.hrnet(heads.synth_head_state_dict("hrnet", 41), img)
+        np.testing.assert_allclose(y[0, ::8, ::2, ::2].numpy(), g["hrnet/y"], atol=2e-4)
+        np.testing.assert_allclose(float(heads.mean_row_norm(y.reshape(1, 768, -1).transpose(1, 2), xyz_tok, 2)),
+                                   float(g["hrnet/loss"]), rtol=1e-5)
