@@ -13,6 +13,7 @@ _DROPIN = {
     "models.models": "cmdiad_amd.models.models",
     "models.pointnet2_utils": "cmdiad_amd.models.pointnet2_utils",
     "models.hallucination_network": "cmdiad_amd.models.hallucination_network",
+    "models.hrnet": "cmdiad_amd.models.hrnet",
     "utils.utils": "cmdiad_amd.utils.utils",
     "utils.lr_sched": "cmdiad_amd.utils.lr_sched",
     "utils.au_pro_util": "cmdiad_amd.utils.au_pro_util",

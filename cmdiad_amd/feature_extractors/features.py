@@ -126,14 +126,25 @@ class Features(torch.nn.Module):
         self.image_rocauc = self.pixel_rocauc = self.au_pro = self.au_pro_001 = 0
         self.ins_id = self.ins_id2 = self.ins_id3 = 0
 
+        # features.py:91-105.  Every head goes to the GPU (the reference forgets .cuda() for two of them and then feeds them
+        # CUDA tensors); later flags override earlier ones, as there.
+        from ..models import hallucination_network as hn
         if getattr(args, "use_hn", False):
-            from ..models.hallucination_network import HallucinationCrossModalityNetwork
-            self.fusion = HallucinationCrossModalityNetwork(args, 768, 768, hidden_ratio=2.5)
+            self.fusion = hn.HallucinationCrossModalityNetwork(args, 768, 768, hidden_ratio=2.5)
+        if getattr(args, "use_hn_conv", False):
+            self.fusion = hn.HallucinationCrossModalityConv(args, 768, 768)
+        if getattr(args, "use_hn_from_rgb_mlp", False):
+            self.fusion = hn.HallucinationRGBFeatureToXYZInputMLP(args, 768)
+        if getattr(args, "use_hn_from_rgb_conv", False):
+            self.fusion = hn.HallucinationFeatureToInputConv(args, 768)
+        if getattr(args, "use_hrnet", False):
+            from ..models.hrnet import HRNet
+            self.fusion = HRNet(args.c_hrnet, 768, 0.1)
+        if getattr(self, "fusion", None) is not None:
             self.fusion.to(self.device)
-        for flag in ("use_hn_conv", "use_hn_from_rgb_mlp", "use_hn_from_rgb_conv", "use_hrnet", "use_uff"):
-            if getattr(args, flag, False):
-                raise NotImplementedError(f"--{flag}: the conv / FtoI / HRNet distillation heads are out of scope "
-                                          f"(SURVEY 2.1); cmdiad_amd implements the FtoF MLP head (--use_hn)")
+        if getattr(args, "use_uff", False):
+            raise NotImplementedError("--use_uff calls fusion.feature_fusion(), which no module of the reference defines "
+                                      "(multiple_features.py:324; a leftover of M3DM's UFF)")
         if getattr(args, "fusion_module_path", "") != "":
             ckpt = torch.load(args.fusion_module_path, map_location="cpu")["model"]
             print("[Fusion Block]", self.fusion.load_state_dict(ckpt))

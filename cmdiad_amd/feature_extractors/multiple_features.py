@@ -191,29 +191,35 @@ class DoubleRGBPointFeatures(_MethodBase):
 
 
 class RGBorXYZWithOneHallucination(_MethodBase):
-    """MTFI feature-to-feature: the main modality's real features plus the hallucinated features of the
-    other modality (``--use_hn``; multiple_features.py:312-573)."""
+    """MTFI with one real and one hallucinated modality (multiple_features.py:312-573): the main modality's real features
+    plus the other modality's features hallucinated either from the main modality's FEATURES (``--use_hn``: the FtoF MLP, or
+    the FtoF conv head when ``--use_hn_conv`` is given as well) or from the main modality's INPUT (``--use_hrnet``, ItoF)."""
 
-    def _hallucinate(self, xyz_patch, rgb_patch2):
+    def _hallucinate(self, sample, xyz_patch, rgb_patch2):
+        a = self.args
+        if a.main_modality not in ('rgb', 'xyz'):
+            raise Exception('Unknown modality')
         with torch.no_grad():
-            if self.args.main_modality == 'rgb':
+            if getattr(a, "use_hrnet", False):  # multiple_features.py:326-331, 343-348: from the raw image / point map
+                src = sample[0] if a.main_modality == 'rgb' else sample[1]
+                h = self.fusion.hallucination_tokens(src.to(self.device))
+                assert tuple(h.shape[1:]) == (3136, 768)
+            elif a.main_modality == 'rgb':
                 h = self.fusion.hallucination_generation(rgb_feature=rgb_patch2.unsqueeze(0), out_type='xyz')
-            elif self.args.main_modality == 'xyz':
-                h = self.fusion.hallucination_generation(xyz_feature=xyz_patch.unsqueeze(0), out_type='rgb')
             else:
-                raise Exception('Unknown modality')
+                h = self.fusion.hallucination_generation(xyz_feature=xyz_patch.unsqueeze(0), out_type='rgb')
         assert len(h.shape) == 3
         return h.reshape(-1, h.shape[2]).detach()
 
-    def _patches(self, sample):
+    def _patches(self, sample, fit=False):
         rgb_maps, xyz_maps, interp, nz = self._extract(sample)
         xyz_patch = self.get_xyz_patch(xyz_maps, interp, nz)
         rgb_patch, rgb_patch2 = self.get_rgb_patch(rgb_maps)
-        return xyz_patch, rgb_patch, self._hallucinate(xyz_patch, rgb_patch2)
+        return xyz_patch, rgb_patch, self._hallucinate(sample, xyz_patch, rgb_patch2)
 
     def add_sample_to_mem_bank(self, sample, class_name=None):
         self.class_name = class_name
-        xyz_patch, rgb_patch, hall = self._patches(sample)
+        xyz_patch, rgb_patch, hall = self._patches(sample, fit=True)
         self.patch_rgb_lib.append(rgb_patch)
         self.patch_xyz_lib.append(xyz_patch)
         self.patch_fusion_lib.append(hall)
@@ -254,14 +260,36 @@ class RGBorXYZWithOneHallucination(_MethodBase):
         self._record(s, s_map, mask, label, rgb_path)
 
 
-class RGBorXYZWithOneHallucinationFromFeature(_MethodBase):
-    """multiple_features.py:576-797 is the feature-to-INPUT (FtoI) variant: it hallucinates an RGB image /
-    organised point cloud with HallucinationRGBFeatureToXYZInputMLP / HallucinationFeatureToInputConv
-    (models/hallucination_network.py:146-220) and re-extracts features from it.  Those heads are outside
-    the hot path this package implements (SURVEY 2.1 "OUT OF SCOPE", 8f row f4); the class exists so that
-    ``cmdiad_runner`` fails with a clear message instead of an AttributeError."""
+class RGBorXYZWithOneHallucinationFromFeature(RGBorXYZWithOneHallucination):
+    """MTFI feature-to-INPUT (multiple_features.py:576-797; ``--use_hn_from_rgb_mlp`` / ``--use_hn_from_rgb_conv``): the head
+    turns the main modality's features into the OTHER modality's input -- an organised point map [1,3,224,224] from rgb
+    features, or an RGB image from xyz features -- and the frozen extractor of that modality is run on it; those
+    re-extracted features are the "hallucination" library / query.  Banks, statistics, coreset and scoring are
+    the parent's (the reference repeats them verbatim, :614-648, :754-797).
 
-    def __init__(self, args, *a, **k):
-        raise NotImplementedError(
-            "--method_name WithHallucinationFromFeature needs the FtoI distillation heads, which cmdiad_amd does "
-            "not implement (SURVEY 8f/f4); use WithHallucination (FtoF, --use_hn)")
+    As in the reference, with main_modality == 'rgb' the real point cloud is only read while the memory bank is built
+    (its patches feed the cross-wired statistics, :582,605,612-618); late fusion and predict never touch it (:651-663,
+    :701-719), so the 3-D branch of the extractor is skipped there."""
+
+    def _patches(self, sample, fit=False):
+        a = self.args
+        if a.main_modality == 'rgb':
+            ex = self._extract_device(sample[0], sample[1], want_rgb=True, want_xyz=fit)
+            rgb_patch, rgb_patch2 = eng.Engine.rgb_patch(ex)[0], eng.Engine.rgb_patch56(ex)[0]
+            xyz_patch = self._engine.xyz_patch(ex, P=56)[0] if fit else None
+            with torch.no_grad():
+                pc = self.fusion.hallucination_generation(rgb_patch2.unsqueeze(0))  # [1,3,224,224] hallucinated point map
+            assert tuple(pc.shape) == (1, 3, self.xyz_size, self.xyz_size), tuple(pc.shape)
+            hx = self._extract_device(None, pc, want_rgb=False, want_xyz=True)   # zero-coordinate pixels dropped as :592-594
+            hall = self._engine.xyz_patch(hx, P=56)[0]
+        elif a.main_modality == 'xyz':
+            ex = self._extract_device(sample[0], sample[1], want_rgb=fit, want_xyz=True)
+            xyz_patch = self._engine.xyz_patch(ex, P=56)[0]
+            rgb_patch = eng.Engine.rgb_patch(ex)[0] if fit else None
+            with torch.no_grad():
+                img = self.fusion.hallucination_generation(xyz_patch.unsqueeze(0))
+            assert tuple(img.shape) == tuple(sample[0].shape), (tuple(img.shape), tuple(sample[0].shape))
+            hall = eng.Engine.rgb_patch(self._extract_device(img, None, want_rgb=True, want_xyz=False))[0]
+        else:
+            raise NotImplementedError
+        return xyz_patch, rgb_patch, hall

@@ -130,9 +130,11 @@ class HallucinationCrossModalityConv(_PackedHead):
         self.rgb_conv = tower(rgb_dim)
         self.sig = nn.Sigmoid()
 
-    def hallucination_generation(self, xyz_feature, rgb_feature, out_type):
+    def hallucination_generation(self, xyz_feature=None, rgb_feature=None, out_type='train'):
         """[B,3136,768] tokens in, tokens out (hallucination_network.py:113-131); 'xyz' = hallucinated xyz features from
-        the rgb features, 'rgb' the reverse, 'train' = (xyz_hallucination, rgb_hallucination)."""
+        the rgb features, 'rgb' the reverse, 'train' = (xyz_hallucination, rgb_hallucination).  The unused feature may be
+        omitted (the reference's signature makes both positional, so its own keyword call sites,
+        multiple_features.py:335,351, raise TypeError with this head; the defaults are a superset)."""
         pk = self._pack()
         if out_type == 'train':
             return pk.generate(rgb_feature, 'rgb'), pk.generate(xyz_feature, 'xyz')

@@ -118,3 +118,49 @@ def test_head_repacks_after_weight_update_and_refuses_training():
     m.train()
     with pytest.raises(NotImplementedError, match="training"):
         m(tok, torch.zeros(1, 3, 224, 224, device=DEV))
+
+
+@pytest.mark.parametrize("flags,cls_name,head_kind", [
+    (dict(use_hrnet=True, c_hrnet=512, main_modality='rgb'), "RGBorXYZWithOneHallucination", "hrnet"),
+    (dict(use_hrnet=True, c_hrnet=512, main_modality='xyz'), "RGBorXYZWithOneHallucination", "hrnet"),
+    (dict(use_hn=True, use_hn_conv=True, main_modality='xyz'), "RGBorXYZWithOneHallucination", "conv_ftof"),
+    (dict(use_hn_from_rgb_conv=True, main_modality='xyz'), "RGBorXYZWithOneHallucinationFromFeature", "ftoi_conv"),
+    (dict(use_hn_from_rgb_mlp=True, main_modality='rgb'), "RGBorXYZWithOneHallucinationFromFeature", "ftoi_mlp"),
+])
+def test_method_classes_run_the_protocol_with_each_head(flags, cls_name, head_kind):
+    """cmdiad_runner.py:44-92 (fit, coreset, late fusion, predict, metrics) through the ItoF / conv FtoF / FtoI variants of the
+    one-hallucination method classes (multiple_features.py:312-797): runs on the GPU path and produces finite, well-formed
+    results; the hallucination bank has the modality's row count."""
+    import warnings
+    from test_gpu_engine import make_args, synth_sample
+    from cmdiad_amd.feature_extractors import multiple_features as mf
+    from oracle import nets
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = getattr(mf, cls_name)(make_args(**flags))
+    m.deep_feature_extractor.rgb_backbone.load_state_dict(nets.synth_state_dict("vit", 31))
+    m.deep_feature_extractor.xyz_backbone.load_state_dict(nets.synth_state_dict("pointmae", 21))
+    sd = heads.synth_head_state_dict(head_kind, 7)
+    if head_kind == "ftoi_mlp":  # a usable synthetic point map: metres-scale coordinates around a plane
+        sd["mlp.6.bias"] = torch.tensor([0.0, 0.0, 0.5])
+        sd["mlp.6.weight"] = sd["mlp.6.weight"] * 0.05
+    m.fusion.load_state_dict(sd)
+    m.fusion.eval()
+    train = [synth_sample(60 + i) for i in range(2)]
+    for rgb, pc in train:
+        m.add_sample_to_mem_bank((rgb, pc, pc), class_name="synth")
+    rows = 784 if (cls_name.endswith("FromFeature") and flags["main_modality"] == "xyz") else 3136
+    assert sum(p.shape[0] for p in m.patch_fusion_lib) == 2 * rows
+    m.run_coreset()
+    for rgb, pc in train:
+        m.add_sample_to_late_fusion_mem_bank((rgb, pc, pc))
+    m.run_late_fusion()
+    for i, anomalous in ((70, False), (71, True)):
+        rgb, pc = synth_sample(i, anomalous)
+        mask = torch.zeros(1, 1, 224, 224)
+        if anomalous:
+            mask[..., 100:120, 100:120] = 1
+        m.predict((rgb, pc, pc), mask, np.array([int(anomalous)]), [f"synth/{i}.png"])
+    m.calculate_metrics()
+    assert np.isfinite([m.image_rocauc, m.pixel_rocauc, m.au_pro]).all()
+    assert m.predictions[0].shape == (224, 224) and np.isfinite(m.predictions[0]).all()

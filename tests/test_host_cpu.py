@@ -222,7 +222,8 @@ def test_compat_shims_register_the_cuda_wheel_module_paths():
 def test_install_dropin_redirects_reference_module_paths():
     code = ("import sys; sys.path.insert(0, %r); import cmdiad_amd; cmdiad_amd.install_dropin();"
             "from feature_extractors import multiple_features;"
-            "from models.hallucination_network import HallucinationCrossModalityNetwork;"
+            "from models.hallucination_network import HallucinationCrossModalityNetwork, HallucinationRGBFeatureToXYZInputMLP,"
+            " HallucinationFeatureToInputConv, HallucinationCrossModalityConv; from models.hrnet import HRNet;"
             "import utils.lr_sched as l; from utils.utils import set_seeds, KNNGaussianBlur;"
             "from models.models import Model, PointTransformer, fps;"
             "assert multiple_features.DoubleRGBPointFeatures.__module__.startswith('cmdiad_amd');"
