@@ -263,6 +263,71 @@ __global__ __launch_bounds__(256) void bicubic_kernel(const float* __restrict__ 
     }
 }
 
+// Exact 4x upsampling (56 -> 224, the only case the heads use) to bf16 NHWC: the 4 x 4 outputs of input cell (ky, kx)
+// read the same 5 x 5 input pixels (src = k + (j - 1.5) / 4: floor = k-1 for j < 2, k for j >= 2, taps floor-1 .. floor+2), so
+// one thread produces the whole block for 4 channels from 25 float4 loads instead of 256 -- the generic kernel is bound by
+// its 16 L1 loads per output, this one by the output stores.  Rows are combined in increasing order like torch's
+// cubic_interp1d, with the same fp32 weights.
+__global__ __launch_bounds__(256) void bicubic4x_kernel(const float* __restrict__ in, int B, int h, int w, int C, int ldi,
+                                                        bf16_t* __restrict__ out, int ldo)
+{
+    const int cgroups = C / 4;
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)B * h * w * cgroups) return;
+    const int cg = (int)(t % cgroups);
+    const long cell = t / cgroups;
+    const int kx = (int)(cell % w), ky = (int)((cell / w) % h), b = (int)(cell / ((long)w * h));
+    const int c = cg * 4;
+    float wt[4][4];  // weights of output phase j = 0..3 (same along x and y)
+    cubic_weights(0.625f, wt[0]);
+    cubic_weights(0.875f, wt[1]);
+    cubic_weights(0.125f, wt[2]);
+    cubic_weights(0.375f, wt[3]);
+    float acc[4][4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[i][j][q] = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+        const int yy = min(max(ky - 2 + r, 0), h - 1);
+        float4 px[5];
+#pragma unroll
+        for (int e = 0; e < 5; ++e) {
+            const int xx = min(max(kx - 2 + e, 0), w - 1);
+            px[e] = *reinterpret_cast<const float4*>(in + (((size_t)b * h + yy) * w + xx) * ldi + c);
+        }
+        float hz[4][4];  // horizontal interpolants of this input row for the 4 output columns
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int e0 = j < 2 ? 0 : 1;  // first tap column (relative to kx-2)
+            hz[j][0] = px[e0].x * wt[j][0] + px[e0 + 1].x * wt[j][1] + px[e0 + 2].x * wt[j][2] + px[e0 + 3].x * wt[j][3];
+            hz[j][1] = px[e0].y * wt[j][0] + px[e0 + 1].y * wt[j][1] + px[e0 + 2].y * wt[j][2] + px[e0 + 3].y * wt[j][3];
+            hz[j][2] = px[e0].z * wt[j][0] + px[e0 + 1].z * wt[j][1] + px[e0 + 2].z * wt[j][2] + px[e0 + 3].z * wt[j][3];
+            hz[j][3] = px[e0].w * wt[j][0] + px[e0 + 1].w * wt[j][1] + px[e0 + 2].w * wt[j][2] + px[e0 + 3].w * wt[j][3];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int a = r - (i < 2 ? 0 : 1);  // which of output row i's four taps this input row is
+            if (a < 0 || a > 3) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[i][j][q] += hz[j][q] * wt[i][a];
+        }
+    }
+    const int W = 4 * w;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bf16x4 o = {f2bf(acc[i][j][0]), f2bf(acc[i][j][1]), f2bf(acc[i][j][2]), f2bf(acc[i][j][3])};
+            *reinterpret_cast<bf16x4*>(out + (((size_t)b * 4 * h + 4 * ky + i) * W + 4 * kx + j) * ldo + c) = o;
+        }
+}
+
 bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 }  // namespace
@@ -329,6 +394,13 @@ extern "C" int cmdiad_upsample_bicubic(const float* in, int B, int h, int w, int
                    CMDIAD_ERR_ARG, "cmdiad_upsample_bicubic: alignment (ldi%%4, ldo%%4)");
     const long threads = (long)B * H * W * ((C + 3) / 4);
     const dim3 grid((unsigned)((threads + 255) / 256));
+    if (out_bf16_nhwc && H == 4 * h && W == 4 * w && C % 4 == 0) {
+        const long cells = (long)B * h * w * (C / 4);
+        hipLaunchKernelGGL(bicubic4x_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, B, h, w, C, ldi,
+                           (bf16_t*)out_bf16_nhwc, ldo);
+        CMDIAD_CHECK_LAUNCH();
+        return CMDIAD_OK;
+    }
     if (out_f32_nchw)
         hipLaunchKernelGGL(bicubic_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, in, B, h, w, C, ldi, H, W, (bf16_t*)nullptr, 0, out_f32_nchw);
     else

@@ -91,7 +91,8 @@ def test_conv_stem_vs_torch(stride, Cin, Cout, H, W):
     assert (got - ref).abs().max().item() <= 2 ** -8 * ref.abs().max().item() + 1e-5  # one bf16 rounding of the output
 
 
-@pytest.mark.parametrize("B,h,w,C,H,W", [(2, 56, 56, 384, 224, 224), (1, 56, 56, 3, 224, 224), (2, 7, 5, 6, 19, 23), (1, 56, 56, 1, 224, 224)])
+@pytest.mark.parametrize("B,h,w,C,H,W", [(2, 56, 56, 384, 224, 224), (1, 56, 56, 3, 224, 224), (2, 7, 5, 6, 19, 23), (1, 56, 56, 1, 224, 224),
+                                         (3, 6, 5, 8, 24, 20), (1, 2, 1, 4, 8, 4)])  # exact 4x: the block kernel, borders everywhere
 def test_bicubic_vs_torch(B, h, w, C, H, W):
     g = torch.Generator().manual_seed(C)
     ld = (C + 3) // 4 * 4
