@@ -12,6 +12,7 @@ Differences a caller can observe (also listed in INTEGRATION.md):
     l1 / cos branches are broken).
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -200,20 +201,38 @@ class Features(torch.nn.Module):
         dev = self.device
         ex = eng.Extraction()
         ex.size = self.xyz_size
+        both = want_rgb and want_xyz and os.environ.get("CMDIAD_B1_OVERLAP", "1") != "0"
         with torch.no_grad():
             if want_xyz:
                 opc = organized_pc.to(dev, torch.float32).contiguous()
                 xyz, nz, pix2pt, nv = ops.unorganize(opc, None)
+            if want_rgb and both:
+                # the ViT goes to a second HIP stream: at B = 1 farthest-point sampling is a 2.7 ms chain on ONE compute unit
+                # and the ViT (1.9 ms of small GEMMs) fits beside it.  Its ~100 launches are queued before the host waits
+                # for the point count, so that wait costs nothing either.
+                side = self.__dict__.get("_vit_stream")
+                if side is None:
+                    side = self.__dict__["_vit_stream"] = torch.cuda.Stream()
+                cur = torch.cuda.current_stream()
+                rgb_dev = rgb.to(dev).float()
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    ex.rgb_tokens = self._engine.vit.forward_tokens(rgb_dev)
+                rgb_dev.record_stream(side)
+            if want_xyz:
                 n = int(nv[0].item())  # the only host round trip: sizes the exact-N tensors the B = 1 path works on
                 if n < self.args.group_size:
                     raise ValueError(f"point cloud has {n} valid points; the {self.args.group_size}-nearest-neighbour grouping "
                                      f"(models/models.py:88-113) needs at least {self.args.group_size}")
                 ex.xyz, ex.nz, ex.pix2pt, ex.n_valid = xyz[:, :n].contiguous(), nz[:, :n], pix2pt, None
-            if want_rgb:
+            if want_rgb and not both:
                 ex.rgb_tokens = self._engine.vit.forward_tokens(rgb.to(dev).float())
             if want_xyz:
                 ex.xyz_feats, ex.center, ex.ori_idx, ex.center_idx = self._engine.pm.forward(ex.xyz)
                 ex.idx3, ex.w3 = ops.interp3nn(ex.xyz, ex.center)
+            if want_rgb and both:
+                cur.wait_stream(side)
+                ex.rgb_tokens.record_stream(cur)
         return ex
 
     def get_rgb_patch(self, rgb_feature_maps):

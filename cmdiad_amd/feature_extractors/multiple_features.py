@@ -61,6 +61,22 @@ class _MethodBase(Features):
         dist = self.calculate_dist(patch, getattr(self, f"patch_{modal}_lib"))
         return self.compute_single_s_s_map(patch, dist, _side(patch), modal=modal)
 
+    def _score_many(self, items):
+        """[(patch, mean, std, modal)] -> [(s, s_map)], each pair as _score returns it.  The device work of every modality
+        is queued first, then ONE blur launch (a block per map) and ONE device->host copy: at B = 1 the per-modality
+        blur + copy of compute_single_s_s_map left the GPU idle while the host queued the next modality."""
+        from .. import ops
+        gt = self.gt_size
+        rs = []
+        for patch, mean, std, modal in items:
+            patch = eng.normalize(patch.to(self.device).float(), mean, std)
+            rs.append(eng.score_patches(patch.unsqueeze(0).contiguous(), self._bank(getattr(self, f"patch_{modal}_lib")),
+                                        _side(patch), gt))
+        k = len(rs)
+        maps = ops.blur8_maps(torch.cat([r["s_map_pre"].reshape(1, gt, gt) for r in rs]).contiguous(), float(self.blur.radius))
+        host = torch.cat([maps.reshape(-1)] + [r["s"][:1].float() for r in rs]).cpu()
+        return [(host[k * gt * gt + i], host[i * gt * gt:(i + 1) * gt * gt].view(1, gt, gt)) for i in range(k)]
+
     def _fuse_inputs(self, pairs):
         """pairs: [(lambda_s, s, lambda_map, s_map)] -> (s [1,k], s_map [gt*gt, k]) as the reference stacks them."""
         s = torch.tensor([[float(ls * sv) for ls, sv, _, _ in pairs]])
@@ -175,8 +191,8 @@ class DoubleRGBPointFeatures(_MethodBase):
             torch.save(torch.cat([xyz_patch, rgb_patch2], dim=1).cpu(),
                        os.path.join(self.args.save_path, 'test', self.class_name + str(self.ins_id) + '.pt'))
             self.ins_id += 1
-        s_xyz, m_xyz = self._score(xyz_patch, self.xyz_mean, self.xyz_std, 'xyz')
-        s_rgb, m_rgb = self._score(rgb_patch, self.rgb_mean, self.rgb_std, 'rgb')
+        (s_xyz, m_xyz), (s_rgb, m_rgb) = self._score_many([(xyz_patch, self.xyz_mean, self.xyz_std, 'xyz'),
+                                                            (rgb_patch, self.rgb_mean, self.rgb_std, 'rgb')])
         return self._fuse_inputs([(self.args.xyz_s_lambda, s_xyz, self.args.xyz_smap_lambda, m_xyz),
                                   (self.args.rgb_s_lambda, s_rgb, self.args.rgb_smap_lambda, m_rgb)])
 
@@ -240,13 +256,13 @@ class RGBorXYZWithOneHallucination(_MethodBase):
 
     def _s(self, sample):
         xyz_patch, rgb_patch, hall = self._patches(sample)
-        s_f, m_f = self._score(hall, self.fusion_mean, self.fusion_std, 'fusion')
         a = self.args
+        main_item = ((rgb_patch, self.rgb_mean, self.rgb_std, 'rgb') if a.main_modality == 'rgb'
+                     else (xyz_patch, self.xyz_mean, self.xyz_std, 'xyz'))
+        (s_f, m_f), (s_m, m_m) = self._score_many([(hall, self.fusion_mean, self.fusion_std, 'fusion'), main_item])
         if a.main_modality == 'rgb':
-            s_m, m_m = self._score(rgb_patch, self.rgb_mean, self.rgb_std, 'rgb')
             main = (a.rgb_s_lambda, s_m, a.rgb_smap_lambda, m_m)
         else:
-            s_m, m_m = self._score(xyz_patch, self.xyz_mean, self.xyz_std, 'xyz')
             main = (a.xyz_s_lambda, s_m, a.xyz_smap_lambda, m_m)
         return self._fuse_inputs([main, (a.fusion_s_lambda, s_f, a.fusion_smap_lambda, m_f)])
 
