@@ -13,6 +13,8 @@
 // per lane, a 6-step wave64 shuffle reduction of a packed (value, ~index) key, one LDS
 // hand-off across the 16 waves (double-buffered, so ONE barrier per round) and a scalar
 // (SGPR) fetch of the winner's coordinates.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -103,6 +105,126 @@ __global__ __launch_bounds__(kThreads) void fps_reg_kernel(const float* __restri
     }
 }
 
+// Second formulation of the same round, built for VALU throughput: one CU retires 64 lanes x 4 SIMDs / 4 cycles, and the
+// round above spends 12 VALU operations per point (48 points per lane: ~4 600 cycles, most of the 2.6 us round).  Here
+//   * two points share each arithmetic instruction (v_pk_add_f32 / v_pk_mul_f32 are IEEE per element: same roundings),
+//   * the lane keeps only the running MAXIMUM VALUE (v_max3_f32: half an operation per point) instead of (value, slot),
+//   * the wave maximum is an integer max of the float bits over DPP row permutes + 4 readlanes (values are >= +0), and
+//   * the winner's index is recovered AFTER that: one v_cmp_eq per slot against the wave maximum writes a lane mask to
+//     SGPRs, the scalar unit picks the lowest slot with a match and its lowest lane (= lowest point index, the tie rule).
+// 6.5 operations per point instead of 12.  Same (value, ~index) keys across the waves, so results are bit-identical.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned dpp_max_u32(unsigned v)
+{
+    // xor 1, xor 2 within quads; mirror within 8, within 16: afterwards every row of 16 lanes holds its maximum
+    unsigned o;
+    o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false); v = o > v ? o : v;
+    o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false); v = o > v ? o : v;
+    o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false); v = o > v ? o : v;
+    o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false); v = o > v ? o : v;
+    const unsigned a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    const unsigned c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    const unsigned ab = a > b ? a : b, cd = c > d ? c : d;
+    return ab > cd ? ab : cd;
+}
+
+template <int kThreads, int PPT>
+__global__ __launch_bounds__(kThreads) void fps_pk_kernel(const float* __restrict__ xyz,
+                                                          const int32_t* __restrict__ n_valid, int N, int G,
+                                                          int32_t* __restrict__ idx_out,
+                                                          float* __restrict__ center_out)
+{
+    static_assert(PPT % 2 == 0, "two points per packed operation");
+    constexpr int kWaves = kThreads / 64, H = PPT / 2;
+    __shared__ unsigned long long s_key[2][kWaves];
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int n = n_valid ? n_valid[b] : N;
+    const float* p = xyz + (size_t)b * N * 3;
+    int32_t* out = idx_out + (size_t)b * G;
+    float* cen = center_out ? center_out + (size_t)b * G * 3 : nullptr;
+
+    f32x2 px[H], py[H], pz[H], t[H];  // slot s = 2h + e holds point s * kThreads + tid
+#pragma unroll
+    for (int h = 0; h < H; ++h)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int k = (2 * h + e) * kThreads + tid;
+            float x = 0.f, y = 0.f, z = 0.f;
+            if (k < n) { x = p[k * 3 + 0]; y = p[k * 3 + 1]; z = p[k * 3 + 2]; }
+            px[h][e] = x; py[h][e] = y; pz[h][e] = z;
+            const float mag = (x * x + y * y) + z * z;
+            t[h][e] = (k < n && !(mag <= 1e-3f)) ? 1e10f : -__builtin_inff();
+        }
+
+    int old = 0;
+    if (tid == 0 && G > 0) {
+        out[0] = 0;
+        if (cen) { cen[0] = p[0]; cen[1] = p[1]; cen[2] = p[2]; }
+    }
+    for (int j = 1; j < G; ++j) {
+        const int so = __builtin_amdgcn_readfirstlane(old);
+        const float x1 = p[so * 3 + 0], y1 = p[so * 3 + 1], z1 = p[so * 3 + 2];
+        const f32x2 X1 = {x1, x1}, Y1 = {y1, y1}, Z1 = {z1, z1};
+        // From here on the values are handled as their bit patterns: distances are >= +0 (sums of squares) and skipped
+        // points carry -inf, so signed-integer min / max / == order them exactly like the float operations would -- without
+        // the canonicalising multiply the compiler puts in front of every v_min_f32 / v_max_f32.
+        int best = 0;
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            const f32x2 dx = px[h] - X1, dy = py[h] - Y1, dz = pz[h] - Z1;
+            const f32x2 d = (dx * dx + dy * dy) + dz * dz;
+            const int a = min((int)__float_as_uint(d[0]), (int)__float_as_uint(t[h][0]));
+            const int c = min((int)__float_as_uint(d[1]), (int)__float_as_uint(t[h][1]));
+            t[h][0] = __uint_as_float((unsigned)a);
+            t[h][1] = __uint_as_float((unsigned)c);
+            best = max(best, max(a, c));
+        }
+        const unsigned wbits = dpp_max_u32((unsigned)best);
+        // lowest slot, then lowest lane, whose running minimum IS the wave maximum (none if the wave holds no valid point).
+        // Eight slots at a time with an early exit: the lane masks of one chunk fit the scalar registers.
+        int slot = -1;
+        unsigned long long lanes = 0ull;
+#pragma unroll
+        for (int c0 = 0; c0 < PPT; c0 += 8) {
+            unsigned long long m[8];
+            unsigned long long any = 0ull;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int sl = c0 + e;
+                m[e] = sl < PPT ? __ballot(__float_as_uint(t[sl >> 1][sl & 1]) == wbits) : 0ull;
+                any |= m[e];
+            }
+            if (any != 0ull) {
+#pragma unroll
+                for (int e = 7; e >= 0; --e)
+                    if (m[e] != 0ull) { slot = c0 + e; lanes = m[e]; }
+                break;
+            }
+        }
+        unsigned long long key = 0ull;
+        if (slot >= 0) {
+            const int besti = slot * kThreads + (tid & ~63) + (__ffsll((long long)lanes) - 1);
+            key = ((unsigned long long)wbits << 32) | (0xFFFFFFFFu - (unsigned)besti);
+        }
+        const int buf = j & 1;
+        if ((tid & 63) == 0) s_key[buf][tid >> 6] = key;
+        __syncthreads();
+        unsigned long long m = s_key[buf][0];
+#pragma unroll
+        for (int w = 1; w < kWaves; ++w) {
+            const unsigned long long o = s_key[buf][w];
+            m = o > m ? o : m;
+        }
+        old = m == 0ull ? 0 : (int)(0xFFFFFFFFu - (unsigned)(m & 0xFFFFFFFFull));
+        if (tid == 0) {
+            out[j] = old;
+            if (cen) { cen[j * 3 + 0] = p[old * 3 + 0]; cen[j * 3 + 1] = p[old * 3 + 1]; cen[j * 3 + 2] = p[old * 3 + 2]; }
+        }
+    }
+}
+
 // Fallback for clouds that do not fit the register file of one CU (N > 24*1024): running min in
 // a caller-provided global workspace (L2-resident), coordinates re-read every round.
 __global__ __launch_bounds__(kThreads) void fps_mem_kernel(const float* __restrict__ xyz,
@@ -176,7 +298,14 @@ extern "C" int cmdiad_fps(const float* xyz, const int32_t* n_valid, int B, int N
     CMDIAD_REQUIRE(B >= 0 && N > 0 && G >= 0, CMDIAD_ERR_ARG, "cmdiad_fps: bad sizes B=%d N=%d G=%d", B, N, G);
     if (B == 0 || G == 0) return CMDIAD_OK;
     hipStream_t s = (hipStream_t)stream;
-#define FPS_LAUNCH(T, P) hipLaunchKernelGGL((fps_reg_kernel<T, P>), dim3(B), dim3(T), 0, s, xyz, n_valid, N, G, idx_out, center_out)
+    // CMDIAD_FPS_PK=0 selects the first formulation (A/B runs and the parity tests; read per call)
+    const char* e = getenv("CMDIAD_FPS_PK");
+    const bool pk = !(e && e[0] == '0');
+#define FPS_LAUNCH(T, P)                                                                                                      \
+    do {                                                                                                                      \
+        if (pk) hipLaunchKernelGGL((fps_pk_kernel<T, P>), dim3(B), dim3(T), 0, s, xyz, n_valid, N, G, idx_out, center_out);   \
+        else hipLaunchKernelGGL((fps_reg_kernel<T, P>), dim3(B), dim3(T), 0, s, xyz, n_valid, N, G, idx_out, center_out);     \
+    } while (0)
     // 1024 threads (4 waves/SIMD, 128 VGPRs) hold 16 points per lane; larger clouds use 512 threads
     // (2 waves/SIMD, 256 VGPRs): the register file of ONE CU bounds the resident cloud at ~28k points.
     if (N <= 1024 * 4) FPS_LAUNCH(1024, 4);

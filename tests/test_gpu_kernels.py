@@ -25,8 +25,14 @@ def _bf(x):
 
 
 # ------------------------------------------------------------------------------------------ FPS / kNN
+@pytest.fixture(params=["1", "0"], ids=["pk", "reg"])
+def fps_variant(request, monkeypatch):
+    """Both formulations of the FPS round (fps.hip: packed-math + deferred argmax, and the per-slot (value, slot) one)."""
+    monkeypatch.setenv("CMDIAD_FPS_PK", request.param)
+
+
 @pytest.mark.parametrize("frac,G", [(0.06, 64), (0.2, 256), (0.45, 1024), (0.62, 128)])
-def test_fps_bit_exact(frac, G):
+def test_fps_bit_exact(frac, G, fps_variant):
     xyz, _ = _cloud(3, frac)  # N ~ 3k / 10k / 22.6k (register path, 512x48) / 31k (memory fallback)
     idx_ref, cen_ref = ok.fps(xyz[None], G)
     idx, cen = ops.fps(torch.from_numpy(xyz[None]).to(DEV), G)
@@ -34,7 +40,7 @@ def test_fps_bit_exact(frac, G):
     np.testing.assert_array_equal(cen.cpu().numpy(), cen_ref)
 
 
-def test_fps_batched_ragged_and_skip_rule():
+def test_fps_batched_ragged_and_skip_rule(fps_variant):
     a, _ = _cloud(4, 0.1)
     b, _ = _cloud(5, 0.07)
     b[17] = 0.001  # |p|^2 <= 1e-3 -> skipped by the sampler (never selected), cmdiad_oracle.c:orc_fps
@@ -50,11 +56,27 @@ def test_fps_batched_ragged_and_skip_rule():
     assert 17 not in ref_b
 
 
-def test_fps_duplicate_points_tie_rule():
+def test_fps_duplicate_points_tie_rule(fps_variant):
     xyz, _ = _cloud(6, 0.05)
     xyz = np.concatenate([xyz, xyz[:500]], 0)  # exact duplicates -> exact distance ties -> lowest index wins
     idx, _ = ops.fps(torch.from_numpy(xyz[None]).to(DEV), 200)
     np.testing.assert_array_equal(idx.cpu().numpy(), ok.fps(xyz[None], 200)[0])
+
+
+def test_fps_mostly_skipped_and_all_skipped_clouds(fps_variant):
+    """Whole waves of skipped points (|p|^2 <= 1e-3), more samples than valid points (running minima reach 0: ties at 0
+    resolve to the lowest index), and a cloud with no valid point at all (every pick is index 0)."""
+    rs = np.random.RandomState(3)
+    xyz = (rs.rand(3000, 3).astype(np.float32) - 0.5) * 0.02  # all inside the skip radius
+    xyz[2000:2040] = rs.rand(40, 3).astype(np.float32) + 0.5   # 40 valid points in the middle
+    idx, cen = ops.fps(torch.from_numpy(xyz[None]).to(DEV), 64)
+    ref_idx, ref_cen = ok.fps(xyz[None], 64)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ref_idx)
+    np.testing.assert_array_equal(cen.cpu().numpy(), ref_cen)
+    xyz[2000:2040] *= 0.001
+    idx, _ = ops.fps(torch.from_numpy(xyz[None]).to(DEV), 16)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ok.fps(xyz[None], 16)[0])
+    assert (idx == 0).all()
 
 
 @pytest.mark.parametrize("frac,G,K", [(0.06, 64, 32), (0.3, 128, 128)])
