@@ -152,6 +152,16 @@ def gemm(A, W, bias=None, act=ACT_NONE, residual=None, group_bias=None, group_ro
     return out_f32, out_bf16
 
 
+def gemm_tn(P, Q, split_k=1):
+    """sum_m P[m,:]^T Q[m,:]: P [M,N1], Q [M,N2] bf16 row-major -> f32 [N1,N2] (split_k == 1) or slabs [split_k,N1,N2]."""
+    _chk(P, torch.bfloat16, "gemm_tn.P"); _chk(Q, torch.bfloat16, "gemm_tn.Q")
+    M, N1 = P.shape
+    N2 = Q.shape[1]
+    out = torch.empty((split_k, N1, N2) if split_k > 1 else (N1, N2), dtype=torch.float32, device=P.device)
+    _call("cmdiad_gemm_tn_bf16", _p(P), N1, _p(Q), N2, M, N1, N2, split_k, _p(out), N2, _stream())
+    return out
+
+
 def gemm_qkv(A, W, bias, B, T, q, k, vt):
     """A [B*T,C] bf16 -> q,k [B,H,Tp,64], vt [B,H,64,Tp] (pre-allocated, zero-initialised padding)."""
     _chk(A, torch.bfloat16, "qkv.A"); _chk(W, torch.bfloat16, "qkv.W")

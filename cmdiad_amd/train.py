@@ -16,6 +16,8 @@ unchanged.  Forward and backward are computed together by the kernels:
 ``FusedAdam`` is an optional torch.optim.Optimizer with the update of torch.optim.Adam (no weight decay,
 no amsgrad) running in one HIP kernel per parameter.
 """
+import os
+
 import torch
 
 from . import _native as nat
@@ -35,14 +37,20 @@ def _reduce_slabs(slabs, S, n, out, scale=1.0):
     return out
 
 
-def _dw(dz_t, a_t, out_shape):
-    """dW [dout, din] = dz^T [dout, M] . a^T[din, M]^T, split-K over the token dimension M."""
-    M = dz_t.shape[1]
+def _dw(dz, a, out_shape):
+    """dW [dout, din] = sum over the M tokens of dz[m, :]^T a[m, :], split-K over M.  Both operands stay row-major
+    (cmdiad_gemm_tn_bf16 gathers its MFMA fragments with transposing LDS reads); CMDIAD_TRAIN_TN=0 selects the earlier
+    form -- transpose both operands, then the K-contiguous GEMM -- for A/B runs."""
+    dz, a = _pad_rows(dz), _pad_rows(a)
+    M = dz.shape[0]
     split = SPLIT_K if M >= 64 * SPLIT_K * 4 else 1
-    slabs, _ = ops.gemm(dz_t, a_t, want_f32=True, want_bf16=False, split_k=split)
+    if os.environ.get("CMDIAD_TRAIN_TN", "1") != "0":
+        slabs = ops.gemm_tn(dz, a, split_k=split)
+    else:
+        slabs, _ = ops.gemm(ops.transpose_bf16(dz), ops.transpose_bf16(a), want_f32=True, want_bf16=False, split_k=split)
     if split == 1:
         return slabs
-    out = torch.empty(out_shape, dtype=torch.float32, device=dz_t.device)
+    out = torch.empty(out_shape, dtype=torch.float32, device=dz.device)
     return _reduce_slabs(slabs, split, out.numel(), out)
 
 
@@ -95,9 +103,9 @@ def forward_backward(x, target, params, dist_method, batch, need_grad=True):
     _, dz2 = ops.gemm(dz3, w3t, dact_of=z2)                       # [M,H]  = (dz3 W3) * GELU'(z2)
     _, dz1 = ops.gemm(dz2, w2t, dact_of=z1)                       # [M,H]
     dh0, _ = ops.gemm(dz1, w1t, want_f32=True, want_bf16=False)   # [M,D] f32
-    g_w3 = _dw(ops.transpose_bf16(_pad_rows(dz3)), ops.transpose_bf16(_pad_rows(a2)), w3.shape)
-    g_w2 = _dw(ops.transpose_bf16(_pad_rows(dz2)), ops.transpose_bf16(_pad_rows(a1)), w2.shape)
-    g_w1 = _dw(ops.transpose_bf16(_pad_rows(dz1)), ops.transpose_bf16(_pad_rows(h0)), w1.shape)
+    g_w3 = _dw(dz3, a2, w3.shape)
+    g_w2 = _dw(dz2, a1, w2.shape)
+    g_w1 = _dw(dz1, h0, w1.shape)
     g_b3, g_b2, g_b1 = _db(dz3), _db(dz2), _db(dz1)
     pg = torch.empty((CHUNKS, D), dtype=torch.float32, device=dev)
     pb = torch.empty((CHUNKS, D), dtype=torch.float32, device=dev)

@@ -145,3 +145,22 @@ def test_feature_ring_on_device(tmp_path):
             want = torch.stack([torch.load(tmp_path / files[i]) for i in idxs])
             assert torch.equal(x.cpu(), want)
     assert sum(ring._cached) >= 12
+
+
+@pytest.mark.parametrize("M,N1,N2,split", [(512, 768, 1920, 1), (4096, 1920, 1920, 8), (1024, 136, 72, 3), (64, 8, 8, 1),
+                                           (640, 200, 328, 16)])
+def test_gemm_tn_vs_torch(M, N1, N2, split):
+    """cmdiad_gemm_tn_bf16 (the weight-gradient product with both operands row-major, transposing LDS reads) against
+    P^T Q in float64 on the bf16-rounded operands: fp32 accumulation, error <= 1e-3 of the output scale.  Ragged N (not a
+    tile multiple), an uneven / over-long split (empty slabs must be written as zeros), the smallest legal shape."""
+    from cmdiad_amd import ops
+    g = torch.Generator().manual_seed(M + N1)
+    P = torch.randn(M, N1, generator=g).to(torch.bfloat16)
+    Q = (torch.randn(M, N2, generator=g) + 0.1 * torch.arange(N2)[None] / N2).to(torch.bfloat16)  # asymmetric columns
+    ref = P.double().T @ Q.double()
+    if split > M // 64:
+        split = M // 64
+    out = ops.gemm_tn(P.cuda(), Q.cuda(), split_k=split)
+    got = (out.sum(0) if split > 1 else out).double().cpu()
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max().item() <= 1e-3 * ref.abs().max().item() + 1e-4
