@@ -49,7 +49,7 @@ SIGNATURES = {
     "cmdiad_xyz_patch_fused": [P, P, P, P, I, I, I, I, I, I, F, F, P, P, P],
     "cmdiad_gemm_bf16": [POINTER(GemmArgs), P],
     "cmdiad_gemm_qkv": [P, P, P, I, I, I, P, P, P, P],
-    "cmdiad_gemm_tn_bf16": [P, I, P, I, I, I, I, I, P, I, P],
+    "cmdiad_gemm_tn_bf16": [P, I, P, I, I, I, I, I, P, I, P, P],
     "cmdiad_attention": [P, P, P, I, I, I, P, P],
     "cmdiad_encoder_tail": [P, P, P, P, P, I, I, P, P],
     "cmdiad_conv2d_nhwc_bf16": [POINTER(ConvArgs), P],

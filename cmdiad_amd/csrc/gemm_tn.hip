@@ -32,6 +32,7 @@ struct TnParams {
     int M, N1, N2;
     float* out; int ldo;
     int split;
+    float* colsum;  // optional [split][N1]: sum over m of P[m, n1] (the bias gradient), produced by the n2-tile-0 blocks
 };
 
 __device__ __forceinline__ int row_xor(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
@@ -86,6 +87,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnParams p)
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // bias gradient: P^T . 1 as four more MFMAs per 32 rows, in the blocks of the first n2 tile only (their wc == 0 waves)
+    const bool want_colsum = p.colsum != nullptr && n2_0 == 0 && wc == 0;
+    f32x4 csum[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) csum[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
 
     auto stage = [&](int slot, int kt) {
         char* buf = lds + slot * STAGE_BYTES;
@@ -120,9 +129,22 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnParams p)
             for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int b = 0; b < 4; ++b) acc[a][b] = mfma16(qf[kk][b], pf[kk][a], acc[a][b]);
+        if (want_colsum) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int a = 0; a < 4; ++a) csum[a] = mfma16(ones, pf[kk][a], csum[a]);
+        }
         __builtin_amdgcn_s_setprio(0);
         wait_vmcnt<0>();
         block_barrier();
+    }
+    if (want_colsum && lane < 16) {  // every row of the ones-product is the column sum: take row 0 (lanes 0..15, element 0)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int n1 = n1_0 + wr * 64 + a * 16 + lane;
+            if (n1 < p.N1) p.colsum[(size_t)blockIdx.y * p.N1 + n1] = csum[a][0];
+        }
     }
 
     float* out = p.out + (size_t)blockIdx.y * p.N1 * p.ldo;
@@ -142,7 +164,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnParams p)
 }  // namespace
 
 extern "C" int cmdiad_gemm_tn_bf16(const uint16_t* P, int ldp, const uint16_t* Q, int ldq, int M, int N1, int N2,
-                                   int split_k, float* out_f32, int ldo, cmdiad_stream_t stream)
+                                   int split_k, float* out_f32, int ldo, float* colsum_out, cmdiad_stream_t stream)
 {
     CMDIAD_REQUIRE(P && Q && out_f32, CMDIAD_ERR_ARG, "cmdiad_gemm_tn_bf16: null pointer");
     CMDIAD_REQUIRE(M > 0 && M % 64 == 0 && N1 >= 8 && N2 >= 8 && N1 % 8 == 0 && N2 % 8 == 0, CMDIAD_ERR_ARG,
@@ -156,7 +178,7 @@ extern "C" int cmdiad_gemm_tn_bf16(const uint16_t* P, int ldp, const uint16_t* Q
     static hipError_t attr = hipSuccess;
     std::call_once(once, [] { attr = hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); });
     CMDIAD_REQUIRE(attr == hipSuccess, CMDIAD_ERR_LAUNCH, "hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d) failed", LDS_BYTES);
-    TnParams p{(const bf16_t*)P, ldp, (const bf16_t*)Q, ldq, M, N1, N2, out_f32, ldo, split};
+    TnParams p{(const bf16_t*)P, ldp, (const bf16_t*)Q, ldq, M, N1, N2, out_f32, ldo, split, colsum_out};
     const unsigned blocks = (unsigned)(((N1 + TN - 1) / TN) * ((N2 + TN - 1) / TN));
     hipLaunchKernelGGL(gemm_tn_kernel, dim3(blocks, split), dim3(256), LDS_BYTES, (hipStream_t)stream, p);
     CMDIAD_CHECK_LAUNCH();

@@ -104,6 +104,11 @@ class HallucinationCrossModalityNetwork(nn.Module):
         from .. import train
         assert len(xyz_feature.shape) == 3 and len(rgb_feature.shape) == 3
         assert xyz_feature.shape[2] == self.xyz_dim and rgb_feature.shape[2] == self.rgb_dim
+        dev = self.xyz_norm.weight.device
+        # one contiguous fp32 copy per modality (the trainer hands in slices of a [B,T,1536] batch): each is the input of one
+        # direction and the target of the other
+        xyz_feature = xyz_feature.to(dev).float().contiguous()
+        rgb_feature = rgb_feature.to(dev).float().contiguous()
         loss_xyz = train.direction_loss(self, 'rgb', rgb_feature, xyz_feature, dist_method)  # rgb -> hallucinated xyz
         loss_rgb = train.direction_loss(self, 'xyz', xyz_feature, rgb_feature, dist_method)  # xyz -> hallucinated rgb
         return loss_xyz, loss_rgb

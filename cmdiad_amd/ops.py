@@ -152,14 +152,16 @@ def gemm(A, W, bias=None, act=ACT_NONE, residual=None, group_bias=None, group_ro
     return out_f32, out_bf16
 
 
-def gemm_tn(P, Q, split_k=1):
-    """sum_m P[m,:]^T Q[m,:]: P [M,N1], Q [M,N2] bf16 row-major -> f32 [N1,N2] (split_k == 1) or slabs [split_k,N1,N2]."""
+def gemm_tn(P, Q, split_k=1, want_colsum=False):
+    """sum_m P[m,:]^T Q[m,:]: P [M,N1], Q [M,N2] bf16 row-major -> f32 [N1,N2] (split_k == 1) or slabs [split_k,N1,N2];
+    with want_colsum also the column sums of P ([N1] or [split_k,N1]) -> (out, colsum)."""
     _chk(P, torch.bfloat16, "gemm_tn.P"); _chk(Q, torch.bfloat16, "gemm_tn.Q")
     M, N1 = P.shape
     N2 = Q.shape[1]
     out = torch.empty((split_k, N1, N2) if split_k > 1 else (N1, N2), dtype=torch.float32, device=P.device)
-    _call("cmdiad_gemm_tn_bf16", _p(P), N1, _p(Q), N2, M, N1, N2, split_k, _p(out), N2, _stream())
-    return out
+    cs = torch.empty((split_k, N1) if split_k > 1 else (N1,), dtype=torch.float32, device=P.device) if want_colsum else None
+    _call("cmdiad_gemm_tn_bf16", _p(P), N1, _p(Q), N2, M, N1, N2, split_k, _p(out), N2, _p(cs), _stream())
+    return (out, cs) if want_colsum else out
 
 
 def gemm_qkv(A, W, bias, B, T, q, k, vt):

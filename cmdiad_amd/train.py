@@ -38,20 +38,23 @@ def _reduce_slabs(slabs, S, n, out, scale=1.0):
 
 
 def _dw(dz, a, out_shape):
-    """dW [dout, din] = sum over the M tokens of dz[m, :]^T a[m, :], split-K over M.  Both operands stay row-major
-    (cmdiad_gemm_tn_bf16 gathers its MFMA fragments with transposing LDS reads); CMDIAD_TRAIN_TN=0 selects the earlier
-    form -- transpose both operands, then the K-contiguous GEMM -- for A/B runs."""
-    dz, a = _pad_rows(dz), _pad_rows(a)
-    M = dz.shape[0]
+    """(dW [dout, din], db [dout]) = sums over the M tokens of dz[m, :]^T a[m, :] and of dz[m, :], split-K over M.  Both
+    operands stay row-major (cmdiad_gemm_tn_bf16 gathers its MFMA fragments with transposing LDS reads and adds the column
+    sums of dz from the tiles it has staged anyway); CMDIAD_TRAIN_TN=0 selects the earlier form -- transpose both operands,
+    the K-contiguous GEMM, a separate column-sum kernel -- for A/B runs."""
+    dzp, ap = _pad_rows(dz), _pad_rows(a)
+    M = dzp.shape[0]
     split = SPLIT_K if M >= 64 * SPLIT_K * 4 else 1
     if os.environ.get("CMDIAD_TRAIN_TN", "1") != "0":
-        slabs = ops.gemm_tn(dz, a, split_k=split)
+        slabs, cs = ops.gemm_tn(dzp, ap, split_k=split, want_colsum=True)
+        db = cs if split == 1 else _reduce_slabs(cs, split, cs.shape[1], torch.empty((cs.shape[1],), dtype=torch.float32, device=dz.device))
     else:
-        slabs, _ = ops.gemm(ops.transpose_bf16(dz), ops.transpose_bf16(a), want_f32=True, want_bf16=False, split_k=split)
+        slabs, _ = ops.gemm(ops.transpose_bf16(dzp), ops.transpose_bf16(ap), want_f32=True, want_bf16=False, split_k=split)
+        db = _db(dz)
     if split == 1:
-        return slabs
+        return slabs, db
     out = torch.empty(out_shape, dtype=torch.float32, device=dz.device)
-    return _reduce_slabs(slabs, split, out.numel(), out)
+    return _reduce_slabs(slabs, split, out.numel(), out), db
 
 
 def _db(dz):
@@ -103,10 +106,9 @@ def forward_backward(x, target, params, dist_method, batch, need_grad=True):
     _, dz2 = ops.gemm(dz3, w3t, dact_of=z2)                       # [M,H]  = (dz3 W3) * GELU'(z2)
     _, dz1 = ops.gemm(dz2, w2t, dact_of=z1)                       # [M,H]
     dh0, _ = ops.gemm(dz1, w1t, want_f32=True, want_bf16=False)   # [M,D] f32
-    g_w3 = _dw(dz3, a2, w3.shape)
-    g_w2 = _dw(dz2, a1, w2.shape)
-    g_w1 = _dw(dz1, h0, w1.shape)
-    g_b3, g_b2, g_b1 = _db(dz3), _db(dz2), _db(dz1)
+    g_w3, g_b3 = _dw(dz3, a2, w3.shape)
+    g_w2, g_b2 = _dw(dz2, a1, w2.shape)
+    g_w1, g_b1 = _dw(dz1, h0, w1.shape)
     pg = torch.empty((CHUNKS, D), dtype=torch.float32, device=dev)
     pb = torch.empty((CHUNKS, D), dtype=torch.float32, device=dev)
     _call("cmdiad_ln_param_grad", ops._p(dh0), ops._p(x), ops._p(mean), ops._p(rstd), M, D, CHUNKS, ops._p(pg), ops._p(pb),

@@ -121,9 +121,11 @@ int cmdiad_gemm_bf16(const cmdiad_gemm_args* args, cmdiad_stream_t stream);
 /* Weight-gradient product of the trainer (hallucination_network_pretrain.py:114-131, loss.backward() through
  * utils/utils.py:94-100): C[N1,N2] = sum_m P[m,n1] * Q[m,n2] with BOTH operands row-major bf16 (P = dZ [M,N1], Q = the
  * layer input [M,N2]) -- no transposed copies.  M % 64 == 0, N1 % 8 == 0, N2 % 8 == 0.  split_k > 1: grid.y slices of M, slab s
- * of out_f32 ([split_k][N1][ldo]) receives partial sum s (cmdiad_reduce_slabs adds them); every slab is fully written. */
+ * of out_f32 ([split_k][N1][ldo]) receives partial sum s (cmdiad_reduce_slabs adds them); every slab is fully written.
+ * colsum_out (NULL allowed) [split_k][N1] f32: partial column sums of P, i.e. the bias gradient sum_m dZ[m, n1], from the
+ * tiles already staged for the product. */
 int cmdiad_gemm_tn_bf16(const uint16_t* P, int ldp, const uint16_t* Q, int ldq, int M, int N1, int N2, int split_k,
-                        float* out_f32, int ldo, cmdiad_stream_t stream);
+                        float* out_f32, int ldo, float* colsum_out, cmdiad_stream_t stream);
 
 /* QKV projection with head-split stores for the attention kernel (models/models.py:150-151):
  * A [B*T, C] bf16, W [3C, C], bias [3C] or NULL.  head_dim = 64, C = H*64.

@@ -160,7 +160,11 @@ def test_gemm_tn_vs_torch(M, N1, N2, split):
     ref = P.double().T @ Q.double()
     if split > M // 64:
         split = M // 64
-    out = ops.gemm_tn(P.cuda(), Q.cuda(), split_k=split)
+    out, cs = ops.gemm_tn(P.cuda(), Q.cuda(), split_k=split, want_colsum=True)
     got = (out.sum(0) if split > 1 else out).double().cpu()
     assert got.shape == ref.shape
     assert (got - ref).abs().max().item() <= 1e-3 * ref.abs().max().item() + 1e-4
+    cs = (cs.sum(0) if split > 1 else cs).double().cpu()   # the bias gradient from the same staged tiles
+    ref_cs = P.double().sum(0)
+    assert cs.shape == ref_cs.shape and (cs - ref_cs).abs().max().item() <= 1e-3 * ref_cs.abs().max().item() + 1e-3
+    assert torch.equal(ops.gemm_tn(P.cuda(), Q.cuda(), split_k=split), out)
