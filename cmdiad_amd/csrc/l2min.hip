@@ -150,6 +150,248 @@ __global__ __launch_bounds__(256, 1) void l2_min_wide_kernel(GlobalTile A, Globa
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same contraction as a two-group ("ping-pong") pipeline: 256 x 256 block tile, 8 waves of 128 x 64 in two groups of
+// four (one wave of each group per SIMD) that run HALF A PHASE apart, so one group's LDS reads and LDS-DMA issue sit
+// under the other group's MFMAs -- in the 4-wave kernel above one wave per SIMD has to issue its 16 DMA pieces per K-step
+// (60-185 issue cycles each) in the same instruction stream as its 128 MFMAs.
+//
+// A K-tile (64 deep) is 4 phases of 16 MFMAs (one 64 x 32 quadrant of the wave's tile):
+//   phase 0: read B lo (4 x ds_read_b128) + A lo (8), multiply A lo x B lo      phase 2: read A hi (8), A hi x B hi
+//   phase 1: read B hi (4),                     multiply A lo x B hi            phase 3: no reads,      A hi x B lo (kept)
+// and each phase = { fragment reads, 2 DMA pieces, counted s_waitcnt vmcnt(8) } barrier { MFMAs } barrier.
+// Staging is in four 16-KiB UNITS per K-tile, cut by WHEN they are last read, not by position:
+//   U0 = A rows {0..63, 128..191} (the "lo" halves of both groups' query rows; read in phase 0)     U3 = the A "hi" halves (phase 2)
+//   U1 = B rows = 0..31 mod 64 (every wave's "lo" bank columns; phase 0)                            U2 = B rows = 32..63 mod 64 (phase 1)
+// One unit is issued per phase, 16 pieces over the 8 waves:  phase 0: U2 of tile T+1,  1: U3 of T+1,  2: U0 of T+2,  3: U1 of T+2
+// (two LDS buffers, tile T in buffer T & 1).  With that order
+//   * every unit is overwritten >= 2 phases after the phase that last read its predecessor in the same buffer (the later
+//     group finishes those reads one barrier after the earlier one: two phases is the safe distance),
+//   * vmcnt(8) after a phase's issue leaves the four newest units in flight and retires the unit issued four phases
+//     earlier -- which is read one phase LATER at the earliest (U0: +2, U1/U2/U3: +1), after one more barrier that both
+//     groups' waits precede.  The counter is never drained inside the stream; phases with nothing left to issue wait vmcnt(0).
+// Bank norms for the epilogue travel through LDS: wave 0 fetches the tile's 256 norms in the first K-tile of a bank tile and
+// parks them three phases later -- both in inline asm with a COUNTED wait, because a compiler-visible load (or LDS read)
+// next to the DMA stream gets an s_waitcnt vmcnt(0), i.e. a drain of the whole prefetch queue, per bank tile.  The kernel
+// therefore takes WHOLE bank tiles only (Nb % 256 == 0): the launcher hands the last Nb % 256 rows to l2_min_kernel<S128>,
+// whose keys merge through the same atomicMin.  Same keys as the other kernels.  Needs D >= 192 (three K-tiles).
+// ------------------------------------------------------------------------------------------------
+struct SPingPong {
+    static constexpr int BM = 256, BN = 256, THREADS = 512;
+    static constexpr int BUF = 32768;                       // one buffer of one operand: 256 rows x 128 B
+    static constexpr int LDS_BYTES = 4 * BUF + 2 * 256 * 4;  // [A buf0][A buf1][B buf0][B buf1][bank norms x 2]
+};
+
+__device__ __forceinline__ void pp_barrier() { asm volatile("s_barrier" ::: "memory"); }
+
+template <bool F16>
+__global__ __launch_bounds__(512, 1) void l2_min_pp_kernel(GlobalTile A, GlobalTile W, L2Params p)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    using S = SPingPong;
+    using frag = typename std::conditional<F16, f16x8, bf16x8>::type;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int gsz = p.qgroup * p.splits;
+    const int within = wg % gsz;
+    const int split = within / p.qgroup, qt = (wg / gsz) * p.qgroup + within % p.qgroup;
+    if (qt >= p.nq_tiles) return;
+    const int per = (p.n_bank_tiles + p.splits - 1) / p.splits;
+    const int nt0 = split * per;
+    const int ntc = min(per, p.n_bank_tiles - nt0);
+    if (ntc <= 0) return;
+    const int m0 = qt * S::BM;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int KT = p.D / BK, T_total = ntc * KT;
+    // LDS byte address of the [2][256] bank-norm area (the inline-asm accesses take raw LDS addresses)
+    const unsigned bn_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(lds + 4 * S::BUF);
+
+    float best[8], qn[8];
+    int besti[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        best[i] = __builtin_inff();
+        besti[i] = 0;
+        const int m = m0 + wr * 128 + i * 16 + (lane & 15);
+        qn[i] = m < p.Q ? p.q_sqnorm[m] : 0.0f;
+    }
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- staging: piece e (0, 1) of unit u for this wave; rows of a piece are 8 consecutive tile rows
+    const int pc0 = wave * 2;
+    const int src_chunk = ((lane & 7) ^ (lane >> 3)) * 8;  // element offset of the 16-byte chunk this lane fetches (rule 21)
+    auto piece_row = [&](int u, int e) {                   // first tile row of the piece
+        const int pc = pc0 + e;
+        if (u == 0) return (pc >> 3) * 128 + (pc & 7) * 8;
+        if (u == 3) return (pc >> 3) * 128 + 64 + (pc & 7) * 8;
+        if (u == 1) return (pc >> 2) * 64 + (pc & 3) * 8;
+        return (pc >> 2) * 64 + 32 + (pc & 3) * 8;
+    };
+    auto stage_unit = [&](int u, int nt, int kt, int buf) {
+        const bool isA = u == 0 || u == 3;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int r0 = piece_row(u, e);
+            const int r = r0 + (lane >> 3);
+            const bf16_t* src = isA ? A.base + (size_t)min(m0 + r, A.rows - 1) * A.ld + kt * BK + src_chunk
+                                    : W.base + (size_t)min(nt * S::BN + r, W.rows - 1) * W.ld + kt * BK + src_chunk;
+            char* dst = lds + (isA ? 0 : 2 * S::BUF) + buf * S::BUF + r0 * 128;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    };
+    // cursors of the four unit streams (tile index, bank tile, k tile): advanced after every issue
+    int uT[4], uN[4], uK[4];
+    auto advance = [&](int u) {
+        ++uT[u];
+        if (++uK[u] == KT) { uK[u] = 0; ++uN[u]; }
+    };
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { uT[u] = 0; uN[u] = nt0; uK[u] = 0; }
+    // prologue: tile 0 complete, U0 and U1 of tile 1
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { stage_unit(u, uN[u], uK[u], 0); advance(u); }
+    if (T_total > 1) {
+        stage_unit(0, uN[0], uK[0], 1); advance(0);
+        stage_unit(1, uN[1], uK[1], 1); advance(1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    pp_barrier();
+    if (wr == 1) pp_barrier();  // the second group runs one barrier (half a phase) behind the first
+
+    // ---- fragment addresses: row*128 + ((chunk ^ (row & 7)) << 4), chunk = kk*4 + (lane >> 4); kk = 1 flips bit 6
+    const int arow = wr * 128 + (lane & 15), brow = wc * 64 + (lane & 15);
+    int a_base = arow * 128 + ((((lane >> 4)) ^ (arow & 7)) << 4);
+    int b_base = 2 * S::BUF + brow * 128 + ((((lane >> 4)) ^ (brow & 7)) << 4);
+    auto lda = [&](int i, int kk) { return *reinterpret_cast<const frag*>(lds + ((a_base + i * 2048) ^ (kk << 6))); };
+    auto ldb = [&](int j, int kk) { return *reinterpret_cast<const frag*>(lds + ((b_base + j * 2048) ^ (kk << 6))); };
+
+    frag af[4][2], wlo[2][2], whi[2][2];
+    int nt_c = nt0, kt_c = 0;
+    for (int T = 0; T < T_total; ++T) {
+        const int buf = T & 1;
+        f32x4 bnv;  // wave 0: this bank tile's squared norms on their way to LDS
+        // ================= phase 0: B lo + A lo
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) wlo[j][kk] = ldb(j, kk);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) af[i][kk] = lda(i, kk);
+        const bool bn_fetch = wave == 0 && kt_c == 0;  // wave-uniform
+        if (bn_fetch) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bnv) : "v"(p.b_sqnorm + (size_t)nt_c * S::BN + lane * 4) : "memory");
+        if (uT[2] < T_total) { stage_unit(2, uN[2], uK[2], buf ^ 1); advance(2); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        pp_barrier();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(wlo[j][kk], af[i][kk], acc[i][j]);
+        __builtin_amdgcn_s_setprio(0);
+        pp_barrier();
+        // ================= phase 1: B hi
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) whi[j][kk] = ldb(2 + j, kk);
+        if (uT[3] < T_total) { stage_unit(3, uN[3], uK[3], buf ^ 1); advance(3); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        pp_barrier();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][2 + j] = mfma16(whi[j][kk], af[i][kk], acc[i][2 + j]);
+        __builtin_amdgcn_s_setprio(0);
+        pp_barrier();
+        // ================= phase 2: A hi
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) af[i][kk] = lda(4 + i, kk);
+        if (uT[0] < T_total) { stage_unit(0, uN[0], uK[0], buf); advance(0); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        pp_barrier();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[4 + i][2 + j] = mfma16(whi[j][kk], af[i][kk], acc[4 + i][2 + j]);
+        __builtin_amdgcn_s_setprio(0);
+        pp_barrier();
+        // ================= phase 3: no reads (B lo is still in registers)
+        if (bn_fetch)  // 6 DMA pieces were issued after the fetch (phases 0-2): a counted wait, then park the norms in LDS
+            asm volatile("s_waitcnt vmcnt(6)\n\tds_write_b128 %0, %1" ::"v"(bn_lds + (unsigned)((nt_c & 1) * 1024 + lane * 16)), "v"(bnv) : "memory");
+        if (uT[1] < T_total) { stage_unit(1, uN[1], uK[1], buf); advance(1); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        pp_barrier();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[4 + i][j] = mfma16(wlo[j][kk], af[i][kk], acc[4 + i][j]);
+        __builtin_amdgcn_s_setprio(0);
+        if (kt_c == KT - 1) {  // bank tile finished: d2 = |q|^2 + |b|^2 - 2 q.b, running (min, first index) per lane
+            const int nbase = nt_c * S::BN + wc * 64 + (lane >> 4) * 4;
+            f32x4 b4[4];
+            {
+                const unsigned ra = bn_lds + (unsigned)((nt_c & 1) * 1024 + (wc * 64 + (lane >> 4) * 4) * 4);
+                asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:64\n\tds_read_b128 %2, %4 offset:128\n\t"
+                             "ds_read_b128 %3, %4 offset:192\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(b4[0]), "=&v"(b4[1]), "=&v"(b4[2]), "=&v"(b4[3]) : "v"(ra) : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float d2 = (qn[i] + b4[j][r]) - 2.0f * acc[i][j][r];
+                        if (d2 < best[i]) { best[i] = d2; besti[i] = nbase + j * 16 + r; }
+                    }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        pp_barrier();
+        if (++kt_c == KT) { kt_c = 0; ++nt_c; }
+        a_base ^= S::BUF;
+        b_base ^= S::BUF;
+    }
+    if (wr == 0) pp_barrier();  // both groups execute the same number of barriers
+
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        unsigned long long key = pack_key(fmaxf(best[i], 0.0f), p.row_offset + (unsigned)besti[i]);
+        if (!(best[i] < __builtin_inff())) key = ~0ull;
+        unsigned long long o = shfl_xor_u64(key, 16);
+        key = o < key ? o : key;
+        o = shfl_xor_u64(key, 32);
+        key = o < key ? o : key;
+        const int m = m0 + wr * 128 + i * 16 + (lane & 15);
+        if (lane < 16 && m < p.Q) atomicMin(p.keys + m, key);
+    }
+}
+
 // Exact fp32 distance to the winning row: one wave per query.
 __global__ __launch_bounds__(256) void l2_rescore_kernel(const float* __restrict__ q, const float* __restrict__ bank,
                                                          const unsigned long long* __restrict__ keys, int Q, int Nb,
@@ -410,6 +652,7 @@ bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 template <class S, bool F16> struct L2Kernel { static constexpr auto fn = l2_min_kernel<S, F16>; };
 template <bool F16> struct L2Kernel<SWide, F16> { static constexpr auto fn = l2_min_wide_kernel<F16>; };
+template <bool F16> struct L2Kernel<SPingPong, F16> { static constexpr auto fn = l2_min_pp_kernel<F16>; };
 
 template <class S, bool F16>
 int launch_l2(const uint16_t* q, const float* q_sqnorm, const uint16_t* bank, const float* bank_sqnorm, int Q, int Nb,
@@ -431,7 +674,7 @@ int launch_l2(const uint16_t* q, const float* q_sqnorm, const uint16_t* bank, co
     // measured on the bagel xyz library (profiles/r1_notes.md): 8 bank ranges for the 8-wave shapes; the 4-wave wide
     // shape gains another 5 % from 16-32 (shorter ranges, better tail balance), as long as a range keeps >= 4 tiles
     int splits = env_splits > 0 ? env_splits : 8;
-    if (env_splits <= 0 && std::is_same<S, SWide>::value) splits = nbt / 4 < 1 ? 1 : (nbt / 4 > 32 ? 32 : nbt / 4);
+    if (env_splits <= 0 && (std::is_same<S, SWide>::value || std::is_same<S, SPingPong>::value)) splits = nbt / 4 < 1 ? 1 : (nbt / 4 > 32 ? 32 : nbt / 4);
     splits = splits > nbt ? nbt : splits;
     int qgroup = env_qgroup > 0 ? env_qgroup : 4;
     qgroup = qgroup > nq ? nq : qgroup;
@@ -453,13 +696,24 @@ extern "C" int cmdiad_l2_min_keys(const uint16_t* q, const float* q_sqnorm, cons
     if (Q == 0 || Nb == 0) return CMDIAD_OK;
     const char* env_tile = getenv("CMDIAD_L2_TILE");  // read per call: the parity tests force each shape on small inputs
     const int force = env_tile ? atoi(env_tile) : -1;
-    // 0 S128, 2 S2x2 (256x256, 8 waves), 3 SWide (256x256, 4 waves of 128x128)
-    const int tile = force >= 0 ? force : (Q >= 256 * 64 ? 3 : 0);
+    // 0 S128, 2 S2x2 (256x256, 8 waves), 3 SWide (256x256, 4 waves of 128x128), 4 SPingPong (256x256, 2 groups of 4 waves)
+    int tile = force >= 0 ? force : (Q >= 256 * 64 ? 3 : 0);
+    if (tile == 4 && D < 192) tile = 3;  // the ping-pong schedule assumes >= 3 K-tiles per bank tile
     hipStream_t s = (hipStream_t)stream;
     const bool h = dtype == CMDIAD_DT_F16;
     int rc;
 #define L2_ARGS q, q_sqnorm, bank, bank_sqnorm, Q, Nb, D, row_offset, keys, s
-    if (tile == 3) rc = h ? launch_l2<SWide, true>(L2_ARGS) : launch_l2<SWide, false>(L2_ARGS);
+    if (tile == 4) {
+        const int full = Nb / 256 * 256, rest = Nb - full;
+        rc = CMDIAD_OK;
+        if (full > 0) rc = h ? launch_l2<SPingPong, true>(q, q_sqnorm, bank, bank_sqnorm, Q, full, D, row_offset, keys, s)
+                             : launch_l2<SPingPong, false>(q, q_sqnorm, bank, bank_sqnorm, Q, full, D, row_offset, keys, s);
+        if (rc == CMDIAD_OK && rest > 0) {
+            const uint16_t* b2 = bank + (size_t)full * D;
+            rc = h ? launch_l2<S128, true>(q, q_sqnorm, b2, bank_sqnorm + full, Q, rest, D, row_offset + full, keys, s)
+                   : launch_l2<S128, false>(q, q_sqnorm, b2, bank_sqnorm + full, Q, rest, D, row_offset + full, keys, s);
+        }
+    } else if (tile == 3) rc = h ? launch_l2<SWide, true>(L2_ARGS) : launch_l2<SWide, false>(L2_ARGS);
     else if (tile == 2) rc = h ? launch_l2<S2x2, true>(L2_ARGS) : launch_l2<S2x2, false>(L2_ARGS);
     else rc = h ? launch_l2<S128, true>(L2_ARGS) : launch_l2<S128, false>(L2_ARGS);
 #undef L2_ARGS

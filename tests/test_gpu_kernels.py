@@ -280,9 +280,12 @@ def test_pointmae_encoder_stages(Mg, panel_min, wide, monkeypatch):
 
 # ------------------------------------------------------------------------------------------ scoring
 @pytest.mark.parametrize("Q,Nb,D,tile", [(784, 1500, 768, None), (3136, 5000, 128, None), (100, 77, 64, None),
-                                          (784, 1500, 768, "3"), (3136, 5000, 128, "3"), (100, 77, 64, "3"), (1000, 2100, 256, "2")])
+                                          (784, 1500, 768, "3"), (3136, 5000, 128, "3"), (100, 77, 64, "3"), (1000, 2100, 256, "2"),
+                                          (784, 1500, 768, "4"), (3136, 5000, 192, "4"), (100, 77, 64, "4"), (1000, 2100, 256, "4"),
+                                          (700, 512, 768, "4"), (515, 9000, 320, "4")])
 def test_l2_min_and_rescore(Q, Nb, D, tile, monkeypatch):
-    if tile:  # 3 = the 4-wave 128x128-per-wave shape production uses from Q >= 16384; 2 = the 8-wave 256x256 shape
+    if tile:  # 3 = 4-wave 128x128-per-wave shape; 2 = 8-wave 256x256 shape; 4 = the two-group (ping-pong) 256x256 pipeline
+        # (whole bank tiles only: the remainder rows go through the 128x128 kernel; D < 192 falls back to 3)
         monkeypatch.setenv("CMDIAD_L2_TILE", tile)
     g = torch.Generator().manual_seed(Q + Nb)
     bank = torch.randn(Nb, D, generator=g)

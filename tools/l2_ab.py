@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Same-process A/B of the distance-GEMM tile variants (CMDIAD_L2_TILE) on the bench shape: interleaved rounds, median and min."""
+import os, sys, statistics, torch
+sys.path.insert(0, os.getcwd())
+from cmdiad_amd import ops
+from tools.microbench import timeit
+g = torch.Generator().manual_seed(0)
+Q, Nb = int(os.environ.get("L2_Q", 100352)), int(os.environ.get("L2_NB", 76518))
+bank = torch.randn(Nb, 768, generator=g).cuda(); qq = torch.randn(Q, 768, generator=g).cuda()
+b16, b32, bsq = ops.normalize_cast(bank, want_f32=True); q16, q32, qsq = ops.normalize_cast(qq, want_f32=True)
+res, keys = {}, {}
+variants = os.environ.get("L2_VARIANTS", "3,4").split(",")
+for rnd in range(5):
+    for v in variants:
+        os.environ["CMDIAD_L2_TILE"] = v
+        k = ops.new_keys(Q, "cuda")
+        ms = timeit(lambda: ops.l2_min_keys(q16, qsq, b16, bsq, k), iters=3, warm=1)
+        res.setdefault(v, []).append(ms)
+        keys[v] = k
+for v in variants:
+    r = res[v]
+    print(f"tile {v}: median {statistics.median(r):.3f} ms  min {min(r):.3f} ms  -> {2.0 * Q * Nb * 768 / statistics.median(r) / 1e9:.0f} TFLOP/s", flush=True)
+a, b = keys[variants[0]], keys[variants[-1]]
+print("argmin agreement between variants:", (a & 0xFFFFFFFF == b & 0xFFFFFFFF).float().mean().item(), " identical keys:", (a == b).float().mean().item())
