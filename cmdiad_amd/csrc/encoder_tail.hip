@@ -3,9 +3,12 @@
 //   tok = max over the group's rows of (W4 . h3 + b4)        [groups, 384]
 // The separate kernels write h3 (4.3 GB per batch of 32) and read it back; here a block of 8 waves owns 128 rows, keeps its
 // h2 tile (64 KiB) in LDS, produces h3 in four 128-column chunks that only ever exist in LDS (32 KiB), and accumulates the
-// 128 x 384 output across the chunks in registers (96 per lane).  LDS = 64 + 32 + 2 x 16 (weight stages) = 128 KiB, one
+// 128 x 384 output across the chunks in registers (96 per lane).  LDS = 64 + 32 + 4 x 16 (weight stages) = 160 KiB, one
 // block (two waves per SIMD) per CU.  Every phase is a 128 x 128 x 64 product against one streamed weight tile
 // (40 tiles per block: 4 chunks x (4 K-steps of W3b + 3 output chunks x 2 K-steps of W4)), one barrier per phase.
+// A phase is only ~0.2 us of MFMAs and the weights come from L2 (~0.6 us away), so the weight stream runs THREE tiles
+// ahead with a counted s_waitcnt vmcnt (never drained inside the block): with one tile ahead and a drain per phase every
+// phase waited for an L2 round trip (5.8 ms per batch; see profiles/r1_notes.md for the staged comparison).
 // Arithmetic order equals the two-kernel path (same bf16 rounding of h3, same K order of the fp32 accumulation), so
 // the tokens are bit-identical to gemm_bf16 + gemm_groupmax.  The group maximum is combined across the blocks / waves
 // that share a group with an ordered-integer atomic max into tok (pre-filled with -inf by the launcher).
@@ -21,7 +24,13 @@ constexpr int KB_BYTES = TM * BK * 2;           // one [64][64] bf16 k-block: 8 
 constexpr int A2_BYTES = 4 * KB_BYTES;          // h2 tile, K = 256
 constexpr int A3_BYTES = 2 * KB_BYTES;          // h3 chunk, 128 columns = K of the next product
 constexpr int W_STAGE = 128 * BK * 2;           // one [128][64] weight tile: 16 KiB
-constexpr int TAIL_LDS = A2_BYTES + A3_BYTES + 2 * W_STAGE;
+#ifndef CMDIAD_TAIL_STAGES
+#define CMDIAD_TAIL_STAGES 4
+#endif
+constexpr int NST = CMDIAD_TAIL_STAGES;         // weight stages in LDS: NST - 1 tiles stay in flight across the barriers
+constexpr int AHEAD = NST - 1;
+constexpr int TAIL_LDS = A2_BYTES + A3_BYTES + NST * W_STAGE;  // 160 KiB at 4 stages
+static_assert(NST >= 2 && NST <= 4 && TAIL_LDS <= 160 * 1024, "weight stages");
 
 struct TailParams {
     int M, Mg;
@@ -76,8 +85,23 @@ __global__ __launch_bounds__(TW * 64, 2) void encoder_tail_kernel(GlobalTile H2,
         if (u < 4) W3.stage<128, TW>(buf, c * 128, u * BK, tid);
         else W4.stage<128, TW>(buf, ((u - 4) >> 1) * 128, c * 128 + ((u - 4) & 1) * BK, tid);
     };
-    stage_w(0, 0);
-    wait_vmcnt<0>();
+    // Group-bias values of a chunk (16 per lane) are fetched long before they are used, by inline asm: a load the compiler
+    // can see gets a compiler-placed s_waitcnt vmcnt(0) at its use -- a drain of the weight stream per chunk.  In-order
+    // retirement makes the counted waits of the phases in between (>= 4) cover them.
+    const int row0 = m0 + wr * 32;                 // this wave's 32 rows share a group (32 | Mg)
+    const float* gb = p.gb + (size_t)(min(row0, p.M - 1) / p.Mg) * 512 + wc * 64 + (lane >> 4) * 4;
+    f32x4 gbv[4];
+    auto fetch_gb = [&](int c) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(gbv[j]) : "v"(gb + c * 128 + j * 16) : "memory");
+    };
+    fetch_gb(0);
+#pragma unroll
+    for (int t0 = 0; t0 < AHEAD; ++t0) stage_w(t0, t0);
+    // tile 0 (and the h2 tile, issued before it: the counter retires in order) landed; AHEAD - 1 tiles stay in flight
+    if constexpr (AHEAD == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (AHEAD == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     block_barrier();
 
     f32x4 acc3[2][4], acco[3][2][4];
@@ -88,18 +112,25 @@ __global__ __launch_bounds__(TW * 64, 2) void encoder_tail_kernel(GlobalTile H2,
 #pragma unroll
             for (int j = 0; j < 4; ++j) acco[o][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int row0 = m0 + wr * 32;                 // this wave's 32 rows share a group (32 | Mg)
-    const float* gb = p.gb + (size_t)(min(row0, p.M - 1) / p.Mg) * 512;
-
-    // one phase = (prefetch the next weight tile) + 16 MFMAs per wave + barrier; t counts the 40 tiles of the block
+    // one phase = (issue the weight tile AHEAD steps on, into the stage the previous phase just left) + 16 MFMAs per wave
+    // + counted wait + barrier; t counts the 40 tiles of the block
     int t = 0;
     auto step = [&](f32x4 (&acc)[2][4], const char* ta) {
-        if (t + 1 < 40) stage_w(t + 1, (t + 1) & 1);
-        phase(acc, ta, WS + (t & 1) * W_STAGE, wr, wc, lane);
+        if (t + AHEAD < 40) stage_w(t + AHEAD, (t + AHEAD) % NST);
+        phase(acc, ta, WS + (t % NST) * W_STAGE, wr, wc, lane);
         ++t;
     };
-    auto sync = [&]() {
-        wait_vmcnt<0>();
+    int gb_young = 0;  // syncs for which the 4 group-bias loads are still YOUNGER than the tile being waited for
+    auto sync = [&]() {  // tile t must have landed; the loads issued after it (2 pieces per wave per tile) may stay in flight
+        const int n = min(t - 1 + AHEAD, 39) - t;
+        if (gb_young > 0) {  // only in the body of the stream, where n == AHEAD - 1
+            --gb_young;
+            if constexpr (AHEAD == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if constexpr (AHEAD == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else if (n >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (n == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         block_barrier();
     };
 #pragma unroll 1
@@ -108,7 +139,7 @@ __global__ __launch_bounds__(TW * 64, 2) void encoder_tail_kernel(GlobalTile H2,
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc3[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
+#pragma unroll
         for (int u = 0; u < 4; ++u) {
             step(acc3, A2 + u * KB_BYTES);
             if (u < 3) sync();
@@ -117,16 +148,17 @@ __global__ __launch_bounds__(TW * 64, 2) void encoder_tail_kernel(GlobalTile H2,
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int n = wc * 64 + j * 16 + (lane >> 4) * 4;  // column inside the chunk
-            const float4 b = *reinterpret_cast<const float4*>(gb + c * 128 + n);
+            const f32x4 b = gbv[j];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int m = wr * 32 + i * 16 + (lane & 15);
                 const f32x4 v = acc3[i][j];
-                bf16x4 o = {f2bf(fmaxf(v[0] + b.x, 0.f)), f2bf(fmaxf(v[1] + b.y, 0.f)), f2bf(fmaxf(v[2] + b.z, 0.f)),
-                            f2bf(fmaxf(v[3] + b.w, 0.f))};
+                bf16x4 o = {f2bf(fmaxf(v[0] + b[0], 0.f)), f2bf(fmaxf(v[1] + b[1], 0.f)), f2bf(fmaxf(v[2] + b[2], 0.f)),
+                            f2bf(fmaxf(v[3] + b[3], 0.f))};
                 *reinterpret_cast<bf16x4*>(A3 + (n >> 6) * KB_BYTES + lds_off(m, (n & 63) >> 3) + (n & 7) * 2) = o;
             }
         }
+        if (c < 3) { fetch_gb(c + 1); gb_young = AHEAD; }  // used six phases on; younger than the awaited tile for AHEAD syncs
         sync();
         step(acco[0], A3); sync(); step(acco[0], A3 + KB_BYTES); sync();
         step(acco[1], A3); sync(); step(acco[1], A3 + KB_BYTES); sync();
