@@ -80,9 +80,14 @@ __device__ __forceinline__ void wide_row(const Frag& a, const Frag (&wf)[NJ])
 // Same contract as gemm::run (flattened (n-tile, k-tile) pipeline, one barrier per K-step), except that the epilogue is
 // called per accumulator ROW BLOCK: epi(std::integral_constant<int, I>, f32x4 (&row)[NJ], nt) for I = 0..7, where
 // row[j][r] is the element the SWAP / non-SWAP layouts of gemm_core.h put at acc[I][j][r].
-template <bool SWAP, bool F16, int NJ = 8, class Epi>
+struct NoTileHook {
+    __device__ __forceinline__ void operator()(int) const {}
+};
+
+// pre(nt) runs at the first K-step of every N tile, before that step's MFMAs (e.g. early fetches for the tile's epilogue)
+template <bool SWAP, bool F16, int NJ = 8, class Epi, class Pre = NoTileHook>
 __device__ __forceinline__ void run_wide(const GlobalTile& A, const GlobalTile& W, int m0, int nt0, int n_tiles, int KT, char* lds,
-                                         Epi&& epi)
+                                         Epi&& epi, Pre&& pre = Pre())
 {
     using frag = typename std::conditional<F16, f16x8, bf16x8>::type;
     using S = WideShape<NJ>;
@@ -157,8 +162,10 @@ __device__ __forceinline__ void run_wide(const GlobalTile& A, const GlobalTile& 
                 if constexpr (i == 1) { if (more) stage_w(nslot); }
             });
         };
-        if (kt == 0) first_half(std::true_type{});
-        else first_half(std::false_type{});
+        if (kt == 0) {
+            pre(nt);
+            first_half(std::true_type{});
+        } else first_half(std::false_type{});
         static_for<8>([&](auto I) { wide_row<decltype(I)::value, SWAP, false>(af[decltype(I)::value], wf[1]); });
         if (kt == KT - 1) {
             asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the compiler does not know the asm above are MFMAs

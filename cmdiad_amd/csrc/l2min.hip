@@ -118,16 +118,15 @@ __global__ __launch_bounds__(256, 1) void l2_min_wide_kernel(GlobalTile A, Globa
         const int m = m0 + wr * 128 + i * 16 + (lane & 15);
         qn[i] = m < p.Q ? p.q_sqnorm[m] : 0.0f;
     }
-    float bn[8][4];
+    // The tile's bank norms are fetched at its FIRST K-step by inline asm and retire with that step's wait.  Loaded where they
+    // are used (the epilogue, which runs after the next tile's first DMA has been issued) the compiler guards them with
+    // s_waitcnt vmcnt(0): the ~2 us of epilogue arithmetic then starts only after that DMA has landed instead of covering
+    // its flight.  Whole bank tiles only (the launcher gives the last Nb % 256 rows to l2_min_kernel<S128>).
+    f32x4 bn[8];
+    const float* bnp = p.b_sqnorm + wc * 128 + (lane >> 4) * 4;
     run_wide<true, F16>(A, W, m0, nt0, ntc, p.D / BK, lds, [&](auto I, f32x4 (&row)[8], int ntile) {
         constexpr int i = decltype(I)::value;
         const int nbase = ntile * S::BN + wc * 128 + (lane >> 4) * 4;
-        if constexpr (i == 0) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) bn[j][r] = nbase + j * 16 + r < p.Nb ? p.b_sqnorm[nbase + j * 16 + r] : __builtin_inff();
-        }
 #pragma unroll
         for (int j = 0; j < 8; ++j)
 #pragma unroll
@@ -135,6 +134,10 @@ __global__ __launch_bounds__(256, 1) void l2_min_wide_kernel(GlobalTile A, Globa
                 const float d2 = (qn[i] + bn[j][r]) - 2.0f * row[j][r];
                 if (d2 < best[i]) { best[i] = d2; besti[i] = nbase + j * 16 + r; }  // n increases with j, r: first occurrence wins
             }
+    }, [&](int ntile) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bn[j]) : "v"(bnp + (size_t)ntile * S::BN + j * 16) : "memory");
     });
 
 #pragma unroll
@@ -713,7 +716,17 @@ extern "C" int cmdiad_l2_min_keys(const uint16_t* q, const float* q_sqnorm, cons
             rc = h ? launch_l2<S128, true>(q, q_sqnorm, b2, bank_sqnorm + full, Q, rest, D, row_offset + full, keys, s)
                    : launch_l2<S128, false>(q, q_sqnorm, b2, bank_sqnorm + full, Q, rest, D, row_offset + full, keys, s);
         }
-    } else if (tile == 3) rc = h ? launch_l2<SWide, true>(L2_ARGS) : launch_l2<SWide, false>(L2_ARGS);
+    } else if (tile == 3) {
+        const int full = Nb / 256 * 256, rest = Nb - full;
+        rc = CMDIAD_OK;
+        if (full > 0) rc = h ? launch_l2<SWide, true>(q, q_sqnorm, bank, bank_sqnorm, Q, full, D, row_offset, keys, s)
+                             : launch_l2<SWide, false>(q, q_sqnorm, bank, bank_sqnorm, Q, full, D, row_offset, keys, s);
+        if (rc == CMDIAD_OK && rest > 0) {
+            const uint16_t* b2 = bank + (size_t)full * D;
+            rc = h ? launch_l2<S128, true>(q, q_sqnorm, b2, bank_sqnorm + full, Q, rest, D, row_offset + full, keys, s)
+                   : launch_l2<S128, false>(q, q_sqnorm, b2, bank_sqnorm + full, Q, rest, D, row_offset + full, keys, s);
+        }
+    }
     else if (tile == 2) rc = h ? launch_l2<S2x2, true>(L2_ARGS) : launch_l2<S2x2, false>(L2_ARGS);
     else rc = h ? launch_l2<S128, true>(L2_ARGS) : launch_l2<S128, false>(L2_ARGS);
 #undef L2_ARGS
