@@ -16,6 +16,8 @@
 //   * chunks are visited in a coprime-strided order (see the kernel) so the threshold converges fast
 //     even though organised clouds arrive in raster order;
 //   * the final sort leaves the K winners in ascending order; the epilogue gathers p[idx] - c.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -154,6 +156,179 @@ __global__ __launch_bounds__(kThreads) void knn_group_kernel(const float* __rest
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Second formulation: a WAVE owns its centres end to end -- no workgroup barriers, no LDS atomics, no 1024-key LDS sort.
+// The block-wide kernel above spends most of its time in bitonic_sort_1024 (55 barrier-separated LDS passes per prune,
+// ~18 prunes per block) and holds 32 KiB of LDS per block, which also keeps the ViT's GEMM blocks off the CU while it runs.
+// Here: 4 waves per block (1 for small batches), 4 centres per wave (one stream of the cloud feeds four distance evaluations), per centre
+//   * the running K best (K <= 128) live SORTED in registers: element e = r*64 + lane, r = 0, 1 (two 64-bit keys per lane);
+//   * a passing key (key < tau, tau = current K-th best, a wave-uniform scalar) is appended to a 128-key LDS list at
+//     cnt + popcount(earlier passing lanes) -- cnt is a scalar of the wave, no atomic;
+//   * when more than 64 candidates wait, the list is sorted in registers (bitonic network over 2 x 64 keys: cross-lane
+//     compare-exchange by shuffles, the distance-64 step inside the lane), reversed, min-merged against the running best
+//     (the result is bitonic and holds the 128 smallest of both) and re-sorted with the 7-step bitonic merge.
+// ~550 instructions per prune, ~12 prunes per centre.  Keys are unique ((d2, index) pairs), so the selected set and its
+// ascending order are those of the oracle bit for bit, whatever the visiting order.
+// ------------------------------------------------------------------------------------------------
+constexpr int kStepPts = 128;     // points per streaming step (two per lane)
+
+__device__ __forceinline__ unsigned long long shfl_u64(unsigned long long v, int src)
+{
+    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+    lo = __shfl(lo, src, 64);
+    hi = __shfl(hi, src, 64);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// compare-exchange across lanes at distance j (< 64) for one register: ascending block if `up`
+__device__ __forceinline__ unsigned long long cex_lane(unsigned long long v, int j, bool up, int lane)
+{
+    const unsigned long long o = shfl_xor_u64(v, j);
+    const bool lower = (lane & j) == 0;            // this lane holds the lower-indexed element of the pair
+    const bool take_min = lower == up;
+    const unsigned long long mn = o < v ? o : v, mx = o < v ? v : o;
+    return take_min ? mn : mx;
+}
+
+// ascending bitonic sort of 128 keys held as (a = elements 0..63, b = elements 64..127), element = r*64 + lane
+__device__ __forceinline__ void sort128(unsigned long long& a, unsigned long long& b, int lane)
+{
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            // direction of the k-block containing element e: up when (e & k) == 0; register b is elements 64 + lane
+            const bool up_a = (lane & k) == 0;
+            const bool up_b = k == 64 ? false : ((lane & k) == 0);  // (64 + lane) & 64 != 0 when k == 64
+            a = cex_lane(a, j, up_a, lane);
+            b = cex_lane(b, j, up_b, lane);
+        }
+    }
+    // k = 128: one ascending block; j = 64 is the in-lane pair (a, b), then j = 32 .. 1 across lanes
+    {
+        const unsigned long long mn = b < a ? b : a, mx = b < a ? a : b;
+        a = mn; b = mx;
+    }
+#pragma unroll
+    for (int j = 32; j > 0; j >>= 1) {
+        a = cex_lane(a, j, true, lane);
+        b = cex_lane(b, j, true, lane);
+    }
+}
+
+// (ta, tb) sorted ascending, (ca, cb) sorted ascending -> (ta, tb) = the 128 smallest of the 256, sorted ascending
+__device__ __forceinline__ void merge128(unsigned long long& ta, unsigned long long& tb, unsigned long long ca, unsigned long long cb, int lane)
+{
+    // reversed candidates: element e <- element 127 - e, i.e. register swap + lane mirror
+    const unsigned long long ra = shfl_u64(cb, 63 - lane), rb = shfl_u64(ca, 63 - lane);
+    ta = ra < ta ? ra : ta;   // bitonic sequence holding the 128 smallest
+    tb = rb < tb ? rb : tb;
+    {
+        const unsigned long long mn = tb < ta ? tb : ta, mx = tb < ta ? ta : tb;
+        ta = mn; tb = mx;
+    }
+#pragma unroll
+    for (int j = 32; j > 0; j >>= 1) {
+        ta = cex_lane(ta, j, true, lane);
+        tb = cex_lane(tb, j, true, lane);
+    }
+}
+
+// kWaves waves per block, kWaveCentres centres per wave: <4, 4> when that grid fills the chip, <1, 1> for small batches
+// (a wave is a serial walk over the cloud: fewer centres per wave = shorter walk, more waves)
+template <int kWaves, int kWaveCentres>
+__global__ __launch_bounds__(kWaves * 64) void knn_wave_kernel(const float* __restrict__ xyz, const int32_t* __restrict__ n_valid,
+                                                              const float* __restrict__ center, int N, int G, int K,
+                                                              int64_t* __restrict__ idx_out, float* __restrict__ neigh_out)
+{
+    __shared__ unsigned long long s_cand[kWaves][kWaveCentres][128];
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g0 = (blockIdx.x * kWaves + wave) * kWaveCentres;
+    if (g0 >= G) return;
+    const int n = n_valid ? n_valid[b] : N;
+    const float* p = xyz + (size_t)b * N * 3;
+
+    float cx[kWaveCentres], cy[kWaveCentres], cz[kWaveCentres];
+    unsigned long long ta[kWaveCentres], tb[kWaveCentres], tau[kWaveCentres];
+    int cnt[kWaveCentres];
+#pragma unroll
+    for (int c = 0; c < kWaveCentres; ++c) {
+        const float* cc = center + ((size_t)b * G + min(g0 + c, G - 1)) * 3;
+        cx[c] = cc[0]; cy[c] = cc[1]; cz[c] = cc[2];
+        ta[c] = tb[c] = tau[c] = kInf;
+        cnt[c] = 0;
+    }
+    auto prune = [&](int c) {
+        unsigned long long* buf = s_cand[wave][c];
+        unsigned long long ca = lane < cnt[c] ? buf[lane] : kInf;
+        unsigned long long cb = lane + 64 < cnt[c] ? buf[lane + 64] : kInf;
+        sort128(ca, cb, lane);
+        merge128(ta[c], tb[c], ca, cb, lane);
+        const unsigned long long kth = K <= 64 ? ta[c] : tb[c];   // element K-1 = (r, lane) = ((K-1) >> 6, (K-1) & 63)
+        tau[c] = shfl_u64(kth, (K - 1) & 63);
+        tau[c] = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(tau[c] >> 32)) << 32) |
+                 __builtin_amdgcn_readfirstlane((unsigned)tau[c]);
+        cnt[c] = 0;
+    };
+
+    // scattered (coprime-strided) visiting order of the 128-point steps: an organised cloud arrives in raster order, and a
+    // raster walk approaches every centre monotonically (almost every point would beat the running threshold)
+    const int nsteps = (n + kStepPts - 1) / kStepPts;
+    int sstride = (int)(0.6180339887f * (float)nsteps) | 1;
+    for (;; sstride += 2) {
+        int a = sstride, bb = nsteps;
+        while (bb) { const int t = a % bb; a = bb; bb = t; }
+        if (a == 1) break;
+    }
+    int sidx = 0;
+    for (int step = 0; step < nsteps; ++step) {
+        const int base = sidx * kStepPts;
+        sidx += sstride;
+        if (sidx >= nsteps) sidx %= nsteps;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int k = base + h * 64 + lane;
+            const bool inb = k < n;
+            float x = 0.f, y = 0.f, z = 0.f;
+            if (inb) { x = p[k * 3 + 0]; y = p[k * 3 + 1]; z = p[k * 3 + 2]; }
+#pragma unroll
+            for (int c = 0; c < kWaveCentres; ++c) {
+                const float dx = x - cx[c], dy = y - cy[c], dz = z - cz[c];
+                const float d = (dx * dx + dy * dy) + dz * dz;
+                const unsigned long long key = pack_key(d, (unsigned)k);
+                const bool pass = inb && key < tau[c];
+                const unsigned long long m = __ballot(pass);
+                if (m) {  // wave-uniform
+                    if (pass) s_cand[wave][c][cnt[c] + __popcll(m & ((1ull << lane) - 1ull))] = key;
+                    cnt[c] += __popcll(m);
+                    if (cnt[c] > 64) prune(c);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < kWaveCentres; ++c) {
+        if (cnt[c] > 0) prune(c);
+        const int g = g0 + c;
+        if (g >= G) continue;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int k = r * 64 + lane;
+            if (k >= K) continue;
+            const unsigned long long key = r == 0 ? ta[c] : tb[c];
+            const int i = key == kInf ? 0 : (int)(key & 0xFFFFFFFFull);
+            const size_t o = ((size_t)b * G + g) * K + k;
+            if (idx_out) idx_out[o] = i;
+            if (neigh_out) {
+                neigh_out[o * 3 + 0] = p[i * 3 + 0] - cx[c];
+                neigh_out[o * 3 + 1] = p[i * 3 + 1] - cy[c];
+                neigh_out[o * 3 + 2] = p[i * 3 + 2] - cz[c];
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int cmdiad_knn_group(const float* xyz, const int32_t* n_valid, const float* center, int B, int N,
@@ -164,9 +339,24 @@ extern "C" int cmdiad_knn_group(const float* xyz, const int32_t* n_valid, const 
     CMDIAD_REQUIRE(B >= 0 && N > 0 && G >= 0 && K > 0 && K <= 128, CMDIAD_ERR_ARG,
                    "cmdiad_knn_group: bad sizes B=%d N=%d G=%d K=%d (K<=128)", B, N, G, K);
     if (B == 0 || G == 0) return CMDIAD_OK;
-    dim3 grid((G + kCPB - 1) / kCPB, B);
-    hipLaunchKernelGGL(knn_group_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, xyz, n_valid, center, N, G,
-                       K, idx_out, neigh_out);
+    // CMDIAD_KNN_WAVE=0 selects the block-wide formulation (A/B runs and the parity tests; read per call)
+    const char* e = getenv("CMDIAD_KNN_WAVE");
+    if (!(e && e[0] == '0')) {
+        if ((long)B * ((G + 15) / 16) >= 512) {
+            hipLaunchKernelGGL((knn_wave_kernel<4, 4>), dim3((G + 15) / 16, B), dim3(256), 0, (hipStream_t)stream, xyz, n_valid, center, N, G, K,
+                               idx_out, neigh_out);
+        } else if ((long)B * ((G + 3) / 4) >= 2048) {
+            hipLaunchKernelGGL((knn_wave_kernel<1, 4>), dim3((G + 3) / 4, B), dim3(64), 0, (hipStream_t)stream, xyz, n_valid, center, N, G, K,
+                               idx_out, neigh_out);
+        } else {
+            hipLaunchKernelGGL((knn_wave_kernel<1, 1>), dim3(G, B), dim3(64), 0, (hipStream_t)stream, xyz, n_valid, center, N, G, K, idx_out,
+                               neigh_out);
+        }
+    } else {
+        dim3 grid((G + kCPB - 1) / kCPB, B);
+        hipLaunchKernelGGL(knn_group_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, xyz, n_valid, center, N, G,
+                           K, idx_out, neigh_out);
+    }
     CMDIAD_CHECK_LAUNCH();
     return CMDIAD_OK;
 }

@@ -79,8 +79,15 @@ def test_fps_mostly_skipped_and_all_skipped_clouds(fps_variant):
     assert (idx == 0).all()
 
 
-@pytest.mark.parametrize("frac,G,K", [(0.06, 64, 32), (0.3, 128, 128)])
-def test_knn_group_bit_exact(frac, G, K):
+@pytest.fixture(params=["1", "0"], ids=["wave", "block"])
+def knn_variant(request, monkeypatch):
+    """Both formulations of the kNN grouping (knn_group.hip: a wave owns its centres with an in-register sorting network, and
+    the block-wide LDS bitonic sort)."""
+    monkeypatch.setenv("CMDIAD_KNN_WAVE", request.param)
+
+
+@pytest.mark.parametrize("frac,G,K", [(0.06, 64, 32), (0.3, 128, 128), (0.1, 70, 100), (0.45, 1024, 128), (0.05, 5, 1), (0.05, 33, 64), (0.05, 16, 65)])
+def test_knn_group_bit_exact(frac, G, K, knn_variant):
     xyz, _ = _cloud(7, frac)
     _, cen = ok.fps(xyz[None], G)
     idx_ref, nb_ref = ok.knn_group(xyz[None], cen, K)
@@ -89,7 +96,7 @@ def test_knn_group_bit_exact(frac, G, K):
     np.testing.assert_array_equal(nb.cpu().numpy(), nb_ref)
 
 
-def test_knn_group_ties_and_ragged():
+def test_knn_group_ties_and_ragged(knn_variant):
     a, _ = _cloud(8, 0.08)
     a = np.concatenate([a, a[:300]], 0)  # duplicates: ties at equal d2 resolved by index
     b, _ = _cloud(9, 0.05)
