@@ -29,11 +29,7 @@ struct StdParams {
     int panel;                    // N tiles walked by one block (see panel_tiles)
 };
 
-__device__ __forceinline__ float gelu_grad_f(float x)
-{
-    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-    return cdf + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
-}
+__device__ __forceinline__ float gelu_grad_f(float x) { return gelu_erf_grad(x); }
 
 // block -> (m tile, n tile) with the XCD remap; lane/wave coordinates shared by every epilogue
 template <class S>

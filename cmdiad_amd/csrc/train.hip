@@ -10,12 +10,7 @@
 
 namespace {
 
-__device__ __forceinline__ float gelu_grad(float x)
-{
-    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
-    return cdf + x * pdf;
-}
+__device__ __forceinline__ float gelu_grad(float x) { return gelu_erf_grad(x); }
 
 // mode 0: l2 (sum_rows ||y-t||), 1: cos_dist (sum_rows 1-cos), 2: smooth_l1 (sum of elements, beta 1).
 // One wave per row, D % 4 == 0.  scale = grad_scale / B is folded into dz.
