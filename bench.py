@@ -101,11 +101,14 @@ class Pipeline:
 
     The two graphs remove the Python/ctypes launch path of ~300 small launches per step from the critical
     path (guide G9: the C ABI never synchronises or allocates, so capture is legal); set CMDIAD_GRAPH=0 to run
-    everything eagerly."""
+    everything eagerly.  With graphs, two buffer sets alternate and stage2 + D2H of step i run on a second stream beside
+    stage1 of step i+1 (step()); main() asserts that every step of the run returns identical outputs."""
 
     def __init__(self, st, group, timers, use_graph=True, ring=3):
         self.st, self.group, self.timers = st, group, timers
         self.side = torch.cuda.Stream()
+        self.post = torch.cuda.Stream()   # scoring tail of the previous step (see step())
+        self.step_no = 0
         # host ring: the step's FINAL outputs (image score, pixel map), f64 as sklearn's score_samples returns them
         self.ring = [(torch.empty((BATCH, 1), dtype=torch.float64, pin_memory=True),
                       torch.empty((BATCH, 224 * 224), dtype=torch.float64, pin_memory=True)) for _ in range(ring)]
@@ -138,7 +141,7 @@ class Pipeline:
         return out
 
     # ---- search: eager (HIP events around the distance GEMM; RCCL collectives when sharded)
-    def search(self, qs):
+    def search(self, qs, buf=0):
         from cmdiad_amd import engine as eng
         from cmdiad_amd import ops
         keys = {}
@@ -146,9 +149,9 @@ class Pipeline:
             q, q16, qsq = qs[name]
             B, Q, D = q.shape
             q_all, s_all = eng.gather_queries(q16, qsq, self.group)
-            k = self.static.get("keys_" + name)
+            k = self.static.get(f"keys_{name}_{buf}")
             if k is None or k.shape[0] != q_all.shape[0]:
-                k = self.static["keys_" + name] = torch.empty((q_all.shape[0],), dtype=torch.int64, device=q.device)
+                k = self.static[f"keys_{name}_{buf}"] = torch.empty((q_all.shape[0],), dtype=torch.int64, device=q.device)
             k.fill_(-1)
             with self.timers[name]:
                 ops.l2_min_keys(q_all, s_all, bank.bf16, bank.sqnorm, k, bank.row_offset)
@@ -174,22 +177,26 @@ class Pipeline:
 
     def _capture(self):
         qs = self.stage1()  # one eager pass first: module loading / attribute setting must not happen in capture
-        self.stage2(qs, self.search(qs))
+        self.stage2(qs, self.search(qs, 0))
         torch.cuda.synchronize()
         try:
-            self.g1 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g1):
-                self.static["qs"] = self.stage1()
-            self.g1.replay()
-            keys = self.search(self.static["qs"])
-            self.static["k"] = {n: k.contiguous() for n, k in keys.items()}
-            self.g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g2):
-                self.static["out"] = self.stage2(self.static["qs"], self.static["k"])
-            torch.cuda.synchronize()
+            self.sets = []
+            for s in range(2):  # two complete buffer sets: step i+1's extraction overlaps step i's scoring tail
+                g1 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g1):
+                    qs = self.stage1()
+                g1.replay()
+                keys = self.search(qs, s)
+                k = {n: v.contiguous() for n, v in keys.items()}
+                g2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g2):
+                    out = self.stage2(qs, k)
+                torch.cuda.synchronize()
+                self.sets.append(dict(g1=g1, g2=g2, qs=qs, k=k, out=out, done=None))
+            self.g1 = self.sets[0]["g1"]
         except Exception as exc:  # capture is an optimisation, never a requirement
             print(f"[bench] HIP graph capture unavailable ({type(exc).__name__}: {exc}); running eagerly", file=sys.stderr)
-            self.g1 = self.g2 = None
+            self.g1 = None
             self.use_graph = False
             torch.cuda.synchronize()
 
@@ -197,16 +204,34 @@ class Pipeline:
         if self.use_graph and self.g1 is None:
             self._capture()
         if self.use_graph:
-            self.g1.replay()
-            keys = self.search(self.static["qs"])
+            # Software pipeline across batches: the scoring tail of step i (re-score, re-weighting scans, maps, blur, one-class
+            # SVMs, D2H: ~2 ms of small bandwidth-bound kernels) runs on a second stream beside the extraction of step i+1,
+            # which leaves most of the chip idle while farthest-point sampling walks its chain.  Two buffer sets alternate; a
+            # set is reused only after its own tail has finished (event wait below).
+            st = self.sets[self.step_no & 1]
+            self.step_no += 1
+            cur = torch.cuda.current_stream()
+            if st["done"] is not None:
+                cur.wait_event(st["done"])
+            st["g1"].replay()
+            keys = self.search(st["qs"], self.sets.index(st))
             for n, k in keys.items():
-                if k.data_ptr() != self.static["k"][n].data_ptr():
-                    self.static["k"][n].copy_(k)
-            self.g2.replay()
-            s_dev, maps_dev = self.static["out"]
-        else:
-            qs = self.stage1()
-            s_dev, maps_dev = self.stage2(qs, self.search(qs))
+                if k.data_ptr() != st["k"][n].data_ptr():
+                    st["k"][n].copy_(k)
+            self.post.wait_stream(cur)
+            host_s, host_m = self.ring[self.slot]
+            self.slot = (self.slot + 1) % len(self.ring)
+            with torch.cuda.stream(self.post):
+                st["g2"].replay()
+                s_dev, maps_dev = st["out"]
+                host_s.copy_(s_dev, non_blocking=True)
+                host_m.copy_(maps_dev, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+            st["done"] = ev
+            return host_s, host_m, ev
+        qs = self.stage1()
+        s_dev, maps_dev = self.stage2(qs, self.search(qs, 0))
         host_s, host_m = self.ring[self.slot]
         self.slot = (self.slot + 1) % len(self.ring)
         host_s.copy_(s_dev, non_blocking=True)
@@ -336,6 +361,8 @@ def main():
         td.all_reduce(tmax, op=td.ReduceOp.MAX)
     dt = float(tmax.item())
     assert all(np.isfinite(r[0]).all() and np.isfinite(r[1]).all() for r in res)
+    # every step scores the same synthetic batch: identical outputs step after step (also guards the two-set pipelining)
+    assert all(np.array_equal(r[0], res[0][0]) and np.array_equal(r[1], res[0][1]) for r in res), "steps disagree"
 
     if rank == 0:
         images = BATCH * world * args.steps
