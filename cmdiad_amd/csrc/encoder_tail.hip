@@ -10,8 +10,8 @@
 // ahead with a counted s_waitcnt vmcnt (never drained inside the block): with one tile ahead and a drain per phase every
 // phase waited for an L2 round trip (5.8 ms per batch; see profiles/r1_notes.md for the staged comparison).
 // Arithmetic order equals the two-kernel path (same bf16 rounding of h3, same K order of the fp32 accumulation), so
-// the tokens are bit-identical to gemm_bf16 + gemm_groupmax.  The group maximum is combined across the blocks / waves
-// that share a group with an ordered-integer atomic max into tok (pre-filled with -inf by the launcher).
+// the tokens are bit-identical to gemm_bf16 + gemm_groupmax.  The group maximum is combined across the four 32-row wave
+// rows of the block through LDS; a block always owns whole groups, so every output is stored exactly once.
 #include "gemm_core.h"
 
 namespace {
@@ -36,14 +36,8 @@ struct TailParams {
     int M, Mg;
     const float* gb;   // [groups, 512]
     const float* b4;   // [384]
-    float* tok;        // [groups, 384], pre-filled with -inf
+    float* tok;        // [groups, 384]
 };
-
-__device__ __forceinline__ void atomic_max_float(float* addr, float v)
-{
-    if (v >= 0.0f) atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
-    else atomicMin(reinterpret_cast<unsigned*>(addr), __float_as_uint(v));
-}
 
 // acc[2][4] += A(32 rows of this wave, k-block `ta`) . W(64 columns of this wave, tile `tw`)^T, swapped orientation
 __device__ __forceinline__ void phase(f32x4 (&acc)[2][4], const char* ta, const char* tw, int wr, int wc, int lane)
@@ -165,15 +159,15 @@ __global__ __launch_bounds__(TW * 64, 2) void encoder_tail_kernel(GlobalTile H2,
         step(acco[2], A3); sync(); step(acco[2], A3 + KB_BYTES); sync();
     }
 
-    if (row0 >= p.M) return;
-    float* tok = p.tok + (size_t)(row0 / p.Mg) * 384;
+    // Group maximum.  A block's 128 rows are whole groups (Mg divides 128 and blocks start at multiples of 128), so nothing
+    // is shared between blocks: the four 32-row partial maxima meet in LDS (the h2 tile is dead by now) and each output is
+    // stored once -- no atomics (they were 1 536 per block, 50 M per batch, 1.2 GB of L2 atomic traffic) and no pre-fill.
+    float* s_part = reinterpret_cast<float*>(A2);  // [4 row blocks][384]
 #pragma unroll
     for (int o = 0; o < 3; ++o)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int n = o * 128 + wc * 64 + j * 16 + (lane >> 4) * 4;
-            const float4 b = *reinterpret_cast<const float4*>(p.b4 + n);
-            const float bb[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float v = fmaxf(acco[o][0][j][r], acco[o][1][j][r]);
@@ -181,9 +175,19 @@ __global__ __launch_bounds__(TW * 64, 2) void encoder_tail_kernel(GlobalTile H2,
                 v = fmaxf(v, __shfl_xor(v, 2, 64));
                 v = fmaxf(v, __shfl_xor(v, 4, 64));
                 v = fmaxf(v, __shfl_xor(v, 8, 64));
-                if ((lane & 15) == 0) atomic_max_float(tok + n + r, v + bb[r]);
+                if ((lane & 15) == 0) s_part[wr * 384 + n + r] = v;
             }
         }
+    __syncthreads();
+    const int per = p.Mg / 32;                     // 32-row blocks per group: 1, 2 or 4
+    for (int e = tid; e < (4 / per) * 384; e += TW * 64) {
+        const int g = e / 384, n = e - g * 384;
+        const int row = m0 + g * p.Mg;
+        if (row >= p.M) continue;
+        float v = s_part[(g * per) * 384 + n];
+        for (int q = 1; q < per; ++q) v = fmaxf(v, s_part[(g * per + q) * 384 + n]);
+        p.tok[(size_t)(row / p.Mg) * 384 + n] = v + p.b4[n];
+    }
 }
 
 }  // namespace
@@ -205,10 +209,6 @@ extern "C" int cmdiad_encoder_tail(const uint16_t* h2, const float* gb, const ui
     }
     const int M = groups * Mg;
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetD32Async((hipDeviceptr_t)tok_out, (int)0xFF800000u, (size_t)groups * 384, s) != hipSuccess) {
-        cmdiad_set_error("cmdiad_encoder_tail: memset failed");
-        return CMDIAD_ERR_LAUNCH;
-    }
     GlobalTile H2{(const bf16_t*)h2, 256, M}, W3{(const bf16_t*)W3b, 256, 512}, W4t{(const bf16_t*)W4, 512, 384};
     TailParams p{M, Mg, gb, b4, tok_out};
     hipLaunchKernelGGL(encoder_tail_kernel, dim3((M + TM - 1) / TM), dim3(TW * 64), TAIL_LDS, s, H2, W3, W4t, p);

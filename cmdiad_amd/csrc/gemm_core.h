@@ -80,18 +80,31 @@ struct Conv1Tile {
     const float* neigh;  // [rows,3]
     const float4* wb;    // [128] = {w_x, w_y, w_z, b} with BatchNorm folded in
     int rows;
+    // A block stages the SAME rows once per (N tile, K tile) step -- four times in the encoder's first stage -- so the
+    // coordinates a thread needs are fetched from memory once per block and kept: every further fetch would put one HBM
+    // round trip in front of that step's MFMAs (1.78 -> see profiles/r1_notes.md).
+    mutable float px[4], py[4], pz[4];
+    mutable int have_row0 = -1;
     template <int ROWS, int WAVES>
     __device__ __forceinline__ void stage(char* tile, int row0, int k0, int tid) const
     {
         constexpr int STEP = WAVES * 8;  // rows covered per pass
+        static_assert(ROWS / STEP <= 4, "coordinate cache size");
         float4 w[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) w[e] = wb[k0 + (tid & 7) * 8 + e];
+        if (row0 != have_row0) {  // block-uniform
+            have_row0 = row0;
+#pragma unroll
+            for (int i = 0; i < ROWS / STEP; ++i) {
+                const int row = min(row0 + (tid >> 3) + STEP * i, rows - 1);
+                px[i] = neigh[(size_t)row * 3]; py[i] = neigh[(size_t)row * 3 + 1]; pz[i] = neigh[(size_t)row * 3 + 2];
+            }
+        }
 #pragma unroll
         for (int i = 0; i < ROWS / STEP; ++i) {
             const int r = (tid >> 3) + STEP * i;
-            const int row = min(row0 + r, rows - 1);
-            const float x = neigh[(size_t)row * 3], y = neigh[(size_t)row * 3 + 1], z = neigh[(size_t)row * 3 + 2];
+            const float x = px[i], y = py[i], z = pz[i];
             bf16x8 h;
 #pragma unroll
             for (int e = 0; e < 8; ++e) h[e] = f2bf(fmaxf(w[e].x * x + w[e].y * y + w[e].z * z + w[e].w, 0.0f));

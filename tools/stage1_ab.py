@@ -1,0 +1,13 @@
+#!/usr/bin/env python3
+"""Timing of cmdiad_encoder_stage1 at the bench shape (32 x 1024 groups x 128 points)."""
+import os, sys, torch
+sys.path.insert(0, os.getcwd())
+from cmdiad_amd import ops
+from cmdiad_amd.runtime import fold_pointmae_encoder
+from oracle import nets
+from tools.microbench import timeit
+w = fold_pointmae_encoder(nets.synth_state_dict("pointmae", 21), "encoder.", "cuda")
+groups, Mg = 32 * 1024, 128
+nb = (0.02 * torch.randn(groups * Mg, 3, generator=torch.Generator().manual_seed(0))).cuda()
+ms = timeit(lambda: ops.encoder_stage1(nb, w["w1b1"], w["W2"], w["b2"], groups, Mg), iters=5, warm=2)
+print(f"encoder_stage1 {ms:.3f} ms  h2 write {groups * Mg * 256 * 2 / ms / 1e6:.0f} GB/s", flush=True)
