@@ -27,6 +27,7 @@ struct StdParams {
     const bf16_t* dact_of;        // acc *= GELU'(dact_of[m][n]) first (backward through an activation)
     int split_k;                  // > 1: block y handles K/split_k, writes slab y of out_f32 (no epilogue terms)
     int panel;                    // N tiles walked by one block (see panel_tiles)
+    int group_m;                  // M tiles per L2 group (Coord)
 };
 
 __device__ __forceinline__ float gelu_grad_f(float x) { return gelu_erf_grad(x); }
@@ -37,12 +38,24 @@ struct Coord {
     int m0, nt, count, lane, wr, wc;
     // panel > 1: the block owns `panel` consecutive N tiles of its M panel and runs them as ONE flattened
     // pipeline (A comes from HBM once, from L2 afterwards; the fill/drain latency is paid once per panel).
-    __device__ __forceinline__ Coord(int n_tiles_n, int panel = 1)
+    // group_m > 1: L2-aware order.  Walking all N tiles of one M tile before the next M tile makes the blocks that are
+    // co-resident on an XCD (64 of them) touch ~3 A tiles and EVERY W tile: for fc1 (24 W tiles = 4.7 MB) that alone exceeds
+    // the 4 MB L2 and the PMC pass shows each launch fetching 10x its operands from beyond L2.  In groups of `group_m` M tiles
+    // walked M-fastest, 64 consecutive blocks cover group_m A tiles x 64/group_m W tiles (8 + 8 tiles = 3 MB at group_m = 8).
+    __device__ __forceinline__ Coord(int n_tiles_n, int panel = 1, int group_m = 1, int m_tiles = 0)
     {
         const int wg = xcd_remap(blockIdx.x, gridDim.x);
         const int groups = (n_tiles_n + panel - 1) / panel;
-        m0 = (wg / groups) * S::BM;
-        nt = (wg % groups) * panel;
+        if (group_m > 1) {
+            const int per_group = group_m * groups;
+            const int g = wg / per_group, within = wg - g * per_group;
+            const int rows = min(group_m, m_tiles - g * group_m);  // the last group may be short
+            m0 = (g * group_m + within % rows) * S::BM;
+            nt = (within / rows) * panel;
+        } else {
+            m0 = (wg / groups) * S::BM;
+            nt = (wg % groups) * panel;
+        }
         count = min(panel, n_tiles_n - nt);
         lane = threadIdx.x & 63;
         const int wave = threadIdx.x >> 6;
@@ -62,7 +75,7 @@ template <class S, int ACT, bool EXTRAS>
 __global__ __launch_bounds__(S::THREADS, S::WAVES_PER_SIMD) void gemm_std_kernel(GlobalTile A, GlobalTile W, StdParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    const Coord<S> c((p.N + S::BN - 1) / S::BN, p.panel);
+    const Coord<S> c((p.N + S::BN - 1) / S::BN, p.panel, p.group_m, (p.M + S::BM - 1) / S::BM);
     const int kt_per = (p.K / BK + p.split_k - 1) / p.split_k;
     const int kt_begin = blockIdx.y * kt_per;
     const int kt_count = min(kt_per, p.K / BK - kt_begin);
@@ -125,7 +138,7 @@ __global__ __launch_bounds__(S::THREADS, S::WAVES_PER_SIMD) void gemm_std_kernel
 // and are stored transposed into [B,H,64,Tp] so the attention kernel reads keys contiguously.
 // ------------------------------------------------------------------------------------------------
 struct QkvParams {
-    int M, T, Tp, C, H;
+    int M, T, Tp, C, H, group_m;
     const float* bias;
     bf16_t *q, *k, *vt;
 };
@@ -134,7 +147,7 @@ template <class S>
 __global__ __launch_bounds__(S::THREADS, S::WAVES_PER_SIMD) void gemm_qkv_kernel(GlobalTile A, GlobalTile W, QkvParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    const Coord<S> c((3 * p.C) / S::BN);
+    const Coord<S> c((3 * p.C) / S::BN, 1, p.group_m, (p.M + S::BM - 1) / S::BM);
     const int which = (c.nt * S::BN) / p.C;  // 0 q, 1 k, 2 v : block-uniform because C % BN == 0
 
     if (which < 2) {
@@ -403,6 +416,14 @@ int launch(Kern kernel, dim3 grid, int lds, hipStream_t s, Args... args)
 // HBM latency of each block's few K-steps, not by bandwidth or MFMA rate; walking the whole N panel in one block
 // pays that latency once and re-reads A from L2.  CMDIAD_GEMM_PANEL_MIN = smallest M-tile count that switches
 // it on (default 2048; 1 in the parity tests so small shapes cover the path; a huge value disables it).
+// M tiles per L2 group of the block order (Coord); CMDIAD_GEMM_GROUPM=1 restores the row-major order (A/B runs)
+int group_m_tiles()
+{
+    const char* e = getenv("CMDIAD_GEMM_GROUPM");
+    const int g = e ? atoi(e) : 8;
+    return g < 1 ? 1 : g;
+}
+
 template <class S>
 int panel_tiles(long M, long N, long K, int split)
 {
@@ -480,7 +501,7 @@ extern "C" int cmdiad_gemm_bf16(const cmdiad_gemm_args* a, cmdiad_stream_t strea
                    CMDIAD_ERR_ARG, "cmdiad_gemm_bf16: out_pre_bf16 / dact_of alignment");
     GlobalTile A{(const bf16_t*)a->A, a->lda, a->M}, W{(const bf16_t*)a->W, a->ldw, a->N};
     StdParams p{a->M, a->N, a->K, a->bias, a->group_bias, a->group_rows, a->act, a->residual, a->ldr,
-                a->out_f32, a->ldo32, (bf16_t*)a->out_bf16, a->ldo16, (bf16_t*)a->out_pre_bf16, (const bf16_t*)a->dact_of, split, 1};
+                a->out_f32, a->ldo32, (bf16_t*)a->out_bf16, a->ldo16, (bf16_t*)a->out_pre_bf16, (const bf16_t*)a->dact_of, split, 1, 1};
     hipStream_t s = (hipStream_t)stream;
     const bool extras = a->out_pre_bf16 || a->dact_of;
     int rc;
@@ -496,6 +517,7 @@ extern "C" int cmdiad_gemm_bf16(const cmdiad_gemm_args* a, cmdiad_stream_t strea
     }
 #define CMDIAD_STD(SH, ACT, EX) launch<SH>(gemm_std_kernel<SH, ACT, EX>, grid_for<SH>(a->M, a->N, split, p.panel), SH::LDS_BYTES, s, A, W, p)
     p.panel = panel_tiles<S128>(a->M, a->N, a->K, split);
+    p.group_m = p.panel == 1 && split == 1 ? group_m_tiles() : 1;
     if (extras) rc = a->act == CMDIAD_ACT_GELU ? CMDIAD_STD(S128, CMDIAD_ACT_GELU, true)
                    : a->act == CMDIAD_ACT_RELU ? CMDIAD_STD(S128, CMDIAD_ACT_RELU, true) : CMDIAD_STD(S128, CMDIAD_ACT_NONE, true);
     else rc = a->act == CMDIAD_ACT_GELU ? CMDIAD_STD(S128, CMDIAD_ACT_GELU, false)
@@ -515,7 +537,7 @@ extern "C" int cmdiad_gemm_qkv(const uint16_t* A, const uint16_t* W, const float
                    CMDIAD_ERR_ARG, "cmdiad_gemm_qkv: 16-byte alignment");
     const int M = B * T;
     GlobalTile At{(const bf16_t*)A, C, M}, Wt{(const bf16_t*)W, C, 3 * C};
-    QkvParams p{M, T, (T + 63) / 64 * 64, C, C / 64, bias, (bf16_t*)q_out, (bf16_t*)k_out, (bf16_t*)vt_out};
+    QkvParams p{M, T, (T + 63) / 64 * 64, C, C / 64, group_m_tiles(), bias, (bf16_t*)q_out, (bf16_t*)k_out, (bf16_t*)vt_out};
     hipStream_t s = (hipStream_t)stream;
     const int rc = launch<S128>(gemm_qkv_kernel<S128>, grid_for<S128>(M, 3 * C), S128::LDS_BYTES, s, At, Wt, p);
     if (rc) return rc;
