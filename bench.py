@@ -397,9 +397,17 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_images)
-        print(json.dumps(out), flush=True)
     if group is not None:
         td.destroy_process_group()
+    if rank == 0:
+        # RCCL writes its version banner to C stdout, which is flushed at exit -- i.e. AFTER a Python print: push it out
+        # first so that the JSON line is the last line of stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
