@@ -207,20 +207,18 @@ struct GroupMaxParams {
     bf16_t* max_bf16;
 };
 
-template <class S, class ALoader>
-__device__ __forceinline__ void groupmax_body(const ALoader& A, const GlobalTile& W, const GroupMaxParams& p, char* lds)
+// epilogue of one finished BM x BN tile: + bias, optional full store, per-group column maxima (see above)
+template <class S, class Acc>
+__device__ __forceinline__ void groupmax_epilogue(Acc& acc, int ntile, const Coord<S>& c, const GroupMaxParams& p,
+                                                  float (*s_max)[S::BN], int tid, const f32x4* pre_bias = nullptr)
 {
-    float(*s_max)[S::BN] = reinterpret_cast<float(*)[S::BN]>(lds + S::LDS_BYTES);
-    const Coord<S> c((p.N + S::BN - 1) / S::BN, p.panel);
-    const int tid = threadIdx.x;
-
-    run<S, true>(A, W, c.m0, c.nt, c.count, p.K / BK, lds, [&](auto& acc, int ntile, char*) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int nl = c.wc * 64 + j * 16 + (c.lane >> 4) * 4;  // column within the tile
             const int n = ntile * S::BN + nl;
             float4 b = {0.f, 0.f, 0.f, 0.f};
-            if (p.bias && n < p.N) b = *reinterpret_cast<const float4*>(p.bias + n);
+            if (pre_bias) b = float4{pre_bias[j][0], pre_bias[j][1], pre_bias[j][2], pre_bias[j][3]};  // fetched by the caller
+            else if (p.bias && n < p.N) b = *reinterpret_cast<const float4*>(p.bias + n);
             f32x4 mx[S::MI / 2];
 #pragma unroll
             for (int i = 0; i < S::MI; ++i) {
@@ -264,7 +262,16 @@ __device__ __forceinline__ void groupmax_body(const ALoader& A, const GlobalTile
                 }
             }
         }
-    });
+}
+
+template <class S, class ALoader>
+__device__ __forceinline__ void groupmax_body(const ALoader& A, const GlobalTile& W, const GroupMaxParams& p, char* lds)
+{
+    float(*s_max)[S::BN] = reinterpret_cast<float(*)[S::BN]>(lds + S::LDS_BYTES);
+    const Coord<S> c((p.N + S::BN - 1) / S::BN, p.panel);
+    const int tid = threadIdx.x;
+
+    run<S, true>(A, W, c.m0, c.nt, c.count, p.K / BK, lds, [&](auto& acc, int ntile, char*) { groupmax_epilogue<S>(acc, ntile, c, p, s_max, tid); });
 }
 
 template <class S>
@@ -279,6 +286,60 @@ __global__ __launch_bounds__(S::THREADS, S::WAVES_PER_SIMD) void encoder_stage1_
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     groupmax_body<S>(A, W, p, lds);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Encoder first stage, dedicated form: a block's 128 x 128 conv1 activations are computed ONCE into LDS (both K tiles)
+// and the four 128 x 64 weight tiles of conv2 stream past them -- the generic pipeline above re-stages (re-computes) the A
+// tile for every (N tile, K tile) step, i.e. conv1 runs twice per block with a dependent round trip for its weights and
+// coordinates in front of every step.  Same arithmetic in the same order (conv1 formula, K order, epilogue): identical
+// h2 / group maxima.  LDS: A 32 KiB + 2 weight stages 32 KiB + max table 2 KiB.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void encoder_stage1_once_kernel(Conv1Tile A, GlobalTile W, GroupMaxParams p)
+{
+    using S = S128;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr int KT_BYTES = S::BM * BK * 2;  // one [128][64] bf16 tile: 16 KiB
+    char* a_lds = lds;                        // [2 K tiles]
+    char* w_lds = lds + 2 * KT_BYTES;         // [2 stages]
+    float(*s_max)[S::BN] = reinterpret_cast<float(*)[S::BN]>(lds + 4 * KT_BYTES);
+    const Coord<S> c(1);                      // block = one M tile; both N tiles are walked here
+    const int tid = threadIdx.x;
+
+    // conv2's bias for both N tiles, by inline asm before anything else: loaded by the compiler where the epilogue uses it, it
+    // is hoisted above the MFMA steps and guarded with s_waitcnt vmcnt(0) in front of their fragment reads (tools/isa_lint.py)
+    f32x4 bias[2][4];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bias[nt][j]) : "v"(p.bias + nt * S::BN + c.wc * 64 + j * 16 + (c.lane >> 4) * 4) : "memory");
+    W.stage<S::BN, S::WAVES>(w_lds, 0, 0, tid);  // step 0's weights fly while conv1 runs on the VALU
+    A.stage<S::BM, S::WAVES>(a_lds, c.m0, 0, tid);
+    A.stage<S::BM, S::WAVES>(a_lds + KT_BYTES, c.m0, BK, tid);
+    wait_vmcnt<0>();
+    block_barrier();
+
+    f32x4 acc[S::MI][4];
+#pragma unroll
+    for (int i = 0; i < S::MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int step = 0; step < 4; ++step) {  // (N tile, K tile) = (0,0) (0,1) (1,0) (1,1)
+        const int nt = step >> 1, kt = step & 1;
+        if (step < 3) W.stage<S::BN, S::WAVES>(w_lds + ((step + 1) & 1) * KT_BYTES, ((step + 1) >> 1) * S::BN, ((step + 1) & 1) * BK, tid);
+        compute_stage<S, true, false>(acc, a_lds + kt * KT_BYTES, w_lds + (step & 1) * KT_BYTES, c.wr, c.wc, c.lane);
+        if (kt == 1) {
+            groupmax_epilogue<S>(acc, nt, c, p, s_max, tid, bias[nt]);
+#pragma unroll
+            for (int i = 0; i < S::MI; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        wait_vmcnt<0>();
+        block_barrier();
+    }
 }
 
 template <class S> constexpr int group_max_lds() { return S::LDS_BYTES + (S::BM / 32) * S::BN * (int)sizeof(float); }
@@ -587,7 +648,14 @@ extern "C" int cmdiad_encoder_stage1(const float* neigh, const float* w1, const 
     GroupMaxParams p{M, 256, 128, Mg, 1, b2, (bf16_t*)h2_out, 256, gmax_out, (bf16_t*)gmax_bf16_out};
     hipStream_t s = (hipStream_t)stream;
     p.panel = panel_tiles<S128>(M, 256, 128, 1);
-    const int rc = launch<S128>(encoder_stage1_kernel<S128>, grid_for<S128>(M, 256, 1, p.panel), group_max_lds<S128>(), s, At, Wt, p);
+    // CMDIAD_STAGE1_ONCE=0 selects the generic pipeline (A/B runs; read per call)
+    const char* e1 = getenv("CMDIAD_STAGE1_ONCE");
+    int rc;
+    if (!(e1 && e1[0] == '0') && b2) {
+        p.panel = 1;
+        rc = launch<S128>(encoder_stage1_once_kernel, dim3((unsigned)((M + 127) / 128)), group_max_lds<S128>(), s, At, Wt, p);
+    } else
+        rc = launch<S128>(encoder_stage1_kernel<S128>, grid_for<S128>(M, 256, 1, p.panel), group_max_lds<S128>(), s, At, Wt, p);
     if (rc) return rc;
     CMDIAD_CHECK_LAUNCH();
     return CMDIAD_OK;

@@ -49,6 +49,10 @@ def hot_blocks(asm_path):
                 events.append("SCRATCH")
             if op.startswith("v_mfma"):
                 n_mfma += 1
+            elif n_mfma == 0 and op.startswith("global_load_lds") and "READ" not in events:
+                # only waits BETWEEN the DMA issue and the fragment reads matter (a fully unrolled kernel carries the previous
+                # step's end-of-step wait in the same basic block)
+                events = [e for e in events if e == "SCRATCH"]
             elif n_mfma == 0:
                 if op == "s_waitcnt":
                     events.append(" ".join(t[1:]))
