@@ -317,6 +317,29 @@ def test_l2_min_and_rescore(Q, Nb, D, tile, monkeypatch):
     assert torch.equal(merged, keys)
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("tile", ["0", "2", "3", "4"])
+def test_l2_min_all_tiles_identical_keys(tile, dt, monkeypatch):
+    """Both operand types of every distance-GEMM variant (the engine defaults to fp16): all variants must return
+    IDENTICAL keys on the same operands (same products, same fp32 accumulation order per 64-deep K tile, same
+    first-occurrence rule), and agree with the fp64 argmin up to bf16 near-ties.  Shapes with several bank tiles per block, a
+    partial last tile (handled by the 128x128 kernel in variants 3 and 4) and a ragged query tile."""
+    Q, Nb, D = 1100, 2900, 256
+    g = torch.Generator().manual_seed(77)
+    bank = torch.randn(Nb, D, generator=g)
+    q = bank[torch.randint(0, Nb, (Q,), generator=g)] + 0.3 * torch.randn(Q, D, generator=g)
+    b16, b32, bsq = ops.normalize_cast(bank.to(DEV), want_f32=True, dtype=dt)
+    q16, q32, qsq = ops.normalize_cast(q.to(DEV), want_f32=True, dtype=dt)
+    monkeypatch.setenv("CMDIAD_L2_TILE", "0")
+    base = ops.l2_min_keys(q16, qsq, b16, bsq, ops.new_keys(Q, DEV)).clone()
+    monkeypatch.setenv("CMDIAD_L2_TILE", tile)
+    keys = ops.l2_min_keys(q16, qsq, b16, bsq, ops.new_keys(Q, DEV))
+    assert torch.equal(keys, base)
+    _, mi = ops.l2_rescore(q32, b32, keys)
+    ref_i = torch.cdist(q.double(), bank.double()).argmin(1)
+    assert (mi.cpu() == ref_i).float().mean() > 0.97
+
+
 def test_reweight_scan_top3():
     g = torch.Generator().manual_seed(3)
     bank = torch.randn(4000, 768, generator=g)
