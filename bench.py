@@ -130,9 +130,29 @@ class Pipeline:
             xyz_q = eng.normalize(xyz_raw, s["xyz_mean"], s["xyz_std"])         # a11
             rgb_q = eng.normalize(hall, s["rgb_mean"], s["rgb_std"])
         else:
-            ex = e.extract(st["rgb"], st["pcs"], n_max=N_POINTS, side_stream=self.side)
+            early = {}
+
+            def rgb_branch(ex):
+                # everything the rgb library needs depends on the ViT only: normalise, cast and SEARCH it here, beside the
+                # rest of the point-cloud branch (the Point-MAE transformer leaves half of the chip's issue slots idle)
+                rq = eng.normalize(e.rgb_patch(ex).contiguous(), s["rgb_mean"], s["rgb_std"])
+                B, Q, D = rq.shape
+                q16, _, qsq = ops.normalize_cast(rq.reshape(B * Q, D))
+                early["rgb"] = (rq, q16, qsq)
+                if self.group is None:
+                    bank = st["bank_rgb"]
+                    k = torch.full((B * Q,), -1, dtype=torch.int64, device=rq.device)
+                    ops.l2_min_keys(q16, qsq, bank.bf16, bank.sqnorm, k, bank.row_offset)
+                    early["rgb_keys"] = k
+
+            ex = e.extract(st["rgb"], st["pcs"], n_max=N_POINTS, side_stream=self.side, rgb_hook=rgb_branch)
             xyz_q = e.xyz_patch(ex, 56, s["xyz_mean"], 1.0 / s["xyz_std"])        # a9 + a11 fused
-            rgb_q = eng.normalize(e.rgb_patch(ex).contiguous(), s["rgb_mean"], s["rgb_std"])
+            B, Q, D = xyz_q.shape
+            q16, _, qsq = ops.normalize_cast(xyz_q.reshape(B * Q, D))
+            out = {"xyz": (xyz_q, q16, qsq), "rgb": early["rgb"]}
+            if "rgb_keys" in early:
+                out["rgb_keys"] = early["rgb_keys"]
+            return out
         out = {}
         for name, q in (("xyz", xyz_q), ("rgb", rgb_q)):
             B, Q, D = q.shape
@@ -146,6 +166,9 @@ class Pipeline:
         from cmdiad_amd import ops
         keys = {}
         for name, bank in (("xyz", self.st["bank_xyz"]), ("rgb", self.st["bank_rgb"])):
+            if name == "rgb" and "rgb_keys" in qs:  # searched inside stage 1 already (beside the point-cloud branch)
+                keys[name] = qs["rgb_keys"]
+                continue
             q, q16, qsq = qs[name]
             B, Q, D = q.shape
             q_all, s_all = eng.gather_queries(q16, qsq, self.group)
