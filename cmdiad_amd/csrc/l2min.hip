@@ -395,6 +395,265 @@ __global__ __launch_bounds__(512, 1) void l2_min_pp_kernel(GlobalTile A, GlobalT
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The two-group pipeline with MORE BANK BYTES IN FLIGHT (the ablations above put the remaining time in the latency of the
+// streamed bank tiles against one K-tile of prefetch): three bank buffers (96 KiB) + three query HALF slots (48 KiB: a
+// query tile's lo rows are read in phase 0 and its hi rows in phase 2, so halves rotate through three slots) = 144 KiB.
+// The two operands are issued by DIFFERENT waves -- waves 0-3 (the earlier group) feed the bank stream, waves 4-7 the query
+// stream -- because s_waitcnt vmcnt retires in order per wave: in one queue the short-lead query pieces would force the
+// long-lead bank pieces out early.  Each stream is a plain sequence of half-units (8 pieces) [lo h0, lo h1, hi h0, hi h1] per
+// K-tile, one per phase:   bank half-unit (P + 10) and query half-unit (P + 5) are issued in phase P.
+//   bank:  lo(T') in phases 4T'-10, -9 (its buffer held tile T'-3, whose lo rows were last read in phase 4T'-12: an
+//          earlier-group issuer needs two phases of distance), hi(T') in 4T'-8, -7 (last read 4T'-11); read in 4T', 4T'+1:
+//          every half-unit has >= 7 phases, so vmcnt(14) (the 7 newest half-units) is the counted wait of the bank waves;
+//   query: lo(T') in 4T'-5, -4 (slot of hi(T'-2), last read 4T'-6: a later-group issuer needs one phase), hi(T') in
+//          4T'-3, -2 (slot of lo(T'-1), last read 4T'-4); the earlier group reads half a phase before the issuing group's
+//          wait, so a half-unit issued in phase P is readable from P + 3: vmcnt(6) for the query waves.
+// ------------------------------------------------------------------------------------------------
+struct SPingPong3 {
+    static constexpr int BM = 256, BN = 256, THREADS = 512;
+    static constexpr int BUF = 32768, HALF = 16384;
+    static constexpr int A_OFF = 3 * BUF, BN_OFF = A_OFF + 3 * HALF;
+    static constexpr int LDS_BYTES = BN_OFF + 2 * 256 * 4;
+};
+
+template <bool F16>
+__global__ __launch_bounds__(512, 1) void l2_min_pp3_kernel(GlobalTile A, GlobalTile W, L2Params p)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    using S = SPingPong3;
+    using frag = typename std::conditional<F16, f16x8, bf16x8>::type;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int gsz = p.qgroup * p.splits;
+    const int within = wg % gsz;
+    const int split = within / p.qgroup, qt = (wg / gsz) * p.qgroup + within % p.qgroup;
+    if (qt >= p.nq_tiles) return;
+    const int per = (p.n_bank_tiles + p.splits - 1) / p.splits;
+    const int nt0 = split * per;
+    const int ntc = min(per, p.n_bank_tiles - nt0);
+    if (ntc <= 0) return;
+    const int m0 = qt * S::BM;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int KT = p.D / BK, T_total = ntc * KT;
+    // LDS byte address of the [2][256] bank-norm area (the inline-asm accesses take raw LDS addresses)
+    const unsigned bn_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(lds + S::BN_OFF);
+
+    float best[8], qn[8];
+    int besti[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        best[i] = __builtin_inff();
+        besti[i] = 0;
+        const int m = m0 + wr * 128 + i * 16 + (lane & 15);
+        qn[i] = m < p.Q ? p.q_sqnorm[m] : 0.0f;
+    }
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // Everything below is instantiated twice, once per stream: a wave only ever executes its own (lean) issue path.
+    auto body = [&](auto BANK) {
+    constexpr bool bank_wave = decltype(BANK)::value;
+    // ---- staging: waves 0-3 feed the BANK stream, waves 4-7 the QUERY stream; each stream is a sequence of half-units
+    // (8 pieces = 4 waves x 2): [lo h0, lo h1, hi h0, hi h1] per K-tile, one half-unit per phase.  The issue path is kept to a
+    // handful of instructions (it has to fit beside the other group's 16 MFMAs): one per-lane pointer per wave that walks the
+    // K-tiles, compile-time row offsets per (part, piece), rotating slot counters instead of modulo arithmetic.
+    const int sw = wave & 3;
+    const int src_chunk = ((lane & 7) ^ (lane >> 3)) * 8;  // element offset of the 16-byte chunk this lane fetches (rule 21)
+    const int row_w = bank_wave ? (sw >> 1) * 64 + (sw & 1) * 16 : sw * 16;  // this wave's share of every half-unit
+    const size_t ld2 = (size_t)(bank_wave ? W.ld : A.ld) * 2;                  // row pitch in bytes
+    // per-lane pointer to (first row of the current tile + row_w + lane / 8, k-tile column + chunk); query rows past Q clamp
+    const bool a_full = m0 + S::BM <= A.rows;
+    const char* ptr = bank_wave ? reinterpret_cast<const char*>(W.base + (size_t)(nt0 * S::BN + row_w + (lane >> 3)) * W.ld + src_chunk)
+                                : reinterpret_cast<const char*>(A.base + (size_t)(m0 + row_w + (lane >> 3)) * A.ld + src_chunk);
+    int hT = 0, hK = 0;           // stream cursor: tile index, k tile
+    int slot_lo = 0, slot_hi = 1;  // bank: both = buffer of tile hT;  query: half slots of (lo, hi) of tile hT
+    if (bank_wave) slot_hi = 0;
+    auto issue_part = [&](auto PART) {  // -> true when the half-unit was issued
+        constexpr int part = decltype(PART)::value, hi = part >> 1, hsel = part & 1;
+        if (hT >= T_total) return false;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const char* src;
+            char* dst;
+            if (bank_wave) {
+                constexpr int rows = hsel * 128 + hi * 32;
+                src = ptr + (size_t)(rows + e * 8) * ld2;
+                dst = lds + slot_lo * S::BUF + (row_w + rows + e * 8) * 128;
+            } else {
+                constexpr int rows = hsel * 128 + hi * 64;
+                if (a_full) src = ptr + (size_t)(rows + e * 8) * ld2;
+                else src = reinterpret_cast<const char*>(A.base + (size_t)min(m0 + row_w + rows + e * 8 + (lane >> 3), A.rows - 1) * A.ld + hK * BK + src_chunk);
+                dst = lds + S::A_OFF + (hi ? slot_hi : slot_lo) * S::HALF + (row_w + hsel * 64 + e * 8) * 128;
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+        if constexpr (part == 3) {  // next K-tile of this stream
+            ++hT;
+            if (++hK == KT) {
+                hK = 0;
+                ptr += bank_wave ? (size_t)S::BN * ld2 - (size_t)(KT - 1) * BK * 2 : (size_t)0 - (size_t)(KT - 1) * BK * 2;
+            } else ptr += BK * 2;
+            if (bank_wave) { slot_lo = slot_lo == 2 ? 0 : slot_lo + 1; slot_hi = slot_lo; }
+            else { slot_lo = slot_lo == 0 ? 2 : slot_lo - 1; slot_hi = slot_hi == 0 ? 2 : slot_hi - 1; }  // (x + 2) mod 3
+        }
+        return true;
+    };
+    // phase j issues bank part (j + 2) % 4 and query part (j + 1) % 4 (bank half-unit P + 10, query half-unit P + 5)
+    auto issue_phase = [&](auto J) {
+        constexpr int j = decltype(J)::value;
+        return bank_wave ? issue_part(std::integral_constant<int, (j + 2) % 4>{}) : issue_part(std::integral_constant<int, (j + 1) % 4>{});
+    };
+    // counted wait of a phase: the bank stream keeps 7 half-units in flight, the query stream 3 (see the header comment)
+    auto phase_wait = [&](bool issued) {
+        if (!issued) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (bank_wave) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    };
+    // prologue: bank half-units 0..9 (tiles 0, 1 and the lo unit of tile 2), query half-units 0..4 (tile 0 and lo h0 of tile 1)
+    {
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+        issue_part(I0{}); issue_part(I1{}); issue_part(I2{}); issue_part(I3{}); issue_part(I0{});  // half-units 0..4
+        if (bank_wave) { issue_part(I1{}); issue_part(I2{}); issue_part(I3{}); issue_part(I0{}); issue_part(I1{}); }  // 5..9
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    pp_barrier();
+    if (wr == 1) pp_barrier();  // the second group runs one barrier (half a phase) behind the first
+
+    // ---- fragment addresses: row*128 + ((chunk ^ (row & 7)) << 4), chunk = kk*4 + (lane >> 4); kk = 1 flips bit 6.
+    // Query rows of a half slot: wr*64 + i*16 + (lane & 15); bank rows of a buffer: wc*64 + j*16 + (lane & 15).
+    const int swz = (((lane >> 4)) ^ (lane & 7)) << 4;
+    const int a_off = (wr * 64 + (lane & 15)) * 128 + swz, b_off = (wc * 64 + (lane & 15)) * 128 + swz;
+    int a_lo = 0, a_hi = 0, b_base = 0;
+    auto lda = [&](int i, int kk) { return *reinterpret_cast<const frag*>(lds + (((i < 4 ? a_lo : a_hi) + (i & 3) * 2048) ^ (kk << 6))); };
+    auto ldb = [&](int j, int kk) { return *reinterpret_cast<const frag*>(lds + ((b_base + j * 2048) ^ (kk << 6))); };
+
+    frag af[4][2], wlo[2][2], whi[2][2];
+    int nt_c = nt0, kt_c = 0;
+    for (int T = 0; T < T_total; ++T) {
+        a_lo = S::A_OFF + ((2 * T) % 3) * S::HALF + a_off;
+        a_hi = S::A_OFF + ((2 * T + 1) % 3) * S::HALF + a_off;
+        b_base = (T % 3) * S::BUF + b_off;
+        f32x4 bnv;  // wave 0: this bank tile's squared norms on their way to LDS
+        // ================= phase 0: B lo + A lo
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) wlo[j][kk] = ldb(j, kk);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) af[i][kk] = lda(i, kk);
+        const bool bn_fetch = wave == 0 && kt_c == 0;  // wave-uniform
+        if (bn_fetch) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bnv) : "v"(p.b_sqnorm + (size_t)nt_c * S::BN + lane * 4) : "memory");
+        phase_wait(issue_phase(std::integral_constant<int, 0>{}));
+        pp_barrier();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(wlo[j][kk], af[i][kk], acc[i][j]);
+        __builtin_amdgcn_s_setprio(0);
+        pp_barrier();
+        // ================= phase 1: B hi
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) whi[j][kk] = ldb(2 + j, kk);
+        phase_wait(issue_phase(std::integral_constant<int, 1>{}));
+        pp_barrier();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][2 + j] = mfma16(whi[j][kk], af[i][kk], acc[i][2 + j]);
+        __builtin_amdgcn_s_setprio(0);
+        pp_barrier();
+        // ================= phase 2: A hi
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) af[i][kk] = lda(4 + i, kk);
+        phase_wait(issue_phase(std::integral_constant<int, 2>{}));
+        pp_barrier();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[4 + i][2 + j] = mfma16(whi[j][kk], af[i][kk], acc[4 + i][2 + j]);
+        __builtin_amdgcn_s_setprio(0);
+        pp_barrier();
+        // ================= phase 3: no reads (B lo is still in registers)
+        if (bn_fetch)  // 6 DMA pieces were issued after the fetch (phases 0-2): a counted wait, then park the norms in LDS
+            asm volatile("s_waitcnt vmcnt(6)\n\tds_write_b128 %0, %1" ::"v"(bn_lds + (unsigned)((nt_c & 1) * 1024 + lane * 16)), "v"(bnv) : "memory");
+        phase_wait(issue_phase(std::integral_constant<int, 3>{}));
+        pp_barrier();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[4 + i][j] = mfma16(wlo[j][kk], af[i][kk], acc[4 + i][j]);
+        __builtin_amdgcn_s_setprio(0);
+        if (kt_c == KT - 1) {  // bank tile finished: d2 = |q|^2 + |b|^2 - 2 q.b, running (min, first index) per lane
+            const int nbase = nt_c * S::BN + wc * 64 + (lane >> 4) * 4;
+            f32x4 b4[4];
+            {
+                const unsigned ra = bn_lds + (unsigned)((nt_c & 1) * 1024 + (wc * 64 + (lane >> 4) * 4) * 4);
+                asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:64\n\tds_read_b128 %2, %4 offset:128\n\t"
+                             "ds_read_b128 %3, %4 offset:192\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(b4[0]), "=&v"(b4[1]), "=&v"(b4[2]), "=&v"(b4[3]) : "v"(ra) : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float d2 = (qn[i] + b4[j][r]) - 2.0f * acc[i][j][r];
+                        if (d2 < best[i]) { best[i] = d2; besti[i] = nbase + j * 16 + r; }
+                    }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        pp_barrier();
+        if (++kt_c == KT) { kt_c = 0; ++nt_c; }
+    }
+    if (wr == 0) pp_barrier();  // both groups execute the same number of barriers
+
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        unsigned long long key = pack_key(fmaxf(best[i], 0.0f), p.row_offset + (unsigned)besti[i]);
+        if (!(best[i] < __builtin_inff())) key = ~0ull;
+        unsigned long long o = shfl_xor_u64(key, 16);
+        key = o < key ? o : key;
+        o = shfl_xor_u64(key, 32);
+        key = o < key ? o : key;
+        const int m = m0 + wr * 128 + i * 16 + (lane & 15);
+        if (lane < 16 && m < p.Q) atomicMin(p.keys + m, key);
+    }
+    };
+    if (wave < 4) body(std::true_type{});
+    else body(std::false_type{});
+}
+
 // Exact fp32 distance to the winning row: one wave per query.
 __global__ __launch_bounds__(256) void l2_rescore_kernel(const float* __restrict__ q, const float* __restrict__ bank,
                                                          const unsigned long long* __restrict__ keys, int Q, int Nb,
@@ -656,6 +915,7 @@ bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 template <class S, bool F16> struct L2Kernel { static constexpr auto fn = l2_min_kernel<S, F16>; };
 template <bool F16> struct L2Kernel<SWide, F16> { static constexpr auto fn = l2_min_wide_kernel<F16>; };
 template <bool F16> struct L2Kernel<SPingPong, F16> { static constexpr auto fn = l2_min_pp_kernel<F16>; };
+template <bool F16> struct L2Kernel<SPingPong3, F16> { static constexpr auto fn = l2_min_pp3_kernel<F16>; };
 
 template <class S, bool F16>
 int launch_l2(const uint16_t* q, const float* q_sqnorm, const uint16_t* bank, const float* bank_sqnorm, int Q, int Nb,
@@ -677,7 +937,7 @@ int launch_l2(const uint16_t* q, const float* q_sqnorm, const uint16_t* bank, co
     // measured on the bagel xyz library (profiles/r1_notes.md): 8 bank ranges for the 8-wave shapes; the 4-wave wide
     // shape gains another 5 % from 16-32 (shorter ranges, better tail balance), as long as a range keeps >= 4 tiles
     int splits = env_splits > 0 ? env_splits : 8;
-    if (env_splits <= 0 && (std::is_same<S, SWide>::value || std::is_same<S, SPingPong>::value)) splits = nbt / 4 < 1 ? 1 : (nbt / 4 > 32 ? 32 : nbt / 4);
+    if (env_splits <= 0 && (std::is_same<S, SWide>::value || std::is_same<S, SPingPong>::value || std::is_same<S, SPingPong3>::value)) splits = nbt / 4 < 1 ? 1 : (nbt / 4 > 32 ? 32 : nbt / 4);
     splits = splits > nbt ? nbt : splits;
     int qgroup = env_qgroup > 0 ? env_qgroup : 4;
     qgroup = qgroup > nq ? nq : qgroup;
@@ -701,15 +961,17 @@ extern "C" int cmdiad_l2_min_keys(const uint16_t* q, const float* q_sqnorm, cons
     const int force = env_tile ? atoi(env_tile) : -1;
     // 0 S128, 2 S2x2 (256x256, 8 waves), 3 SWide (256x256, 4 waves of 128x128), 4 SPingPong (256x256, 2 groups of 4 waves)
     int tile = force >= 0 ? force : (Q >= 256 * 64 ? 3 : 0);
-    if (tile == 4 && D < 192) tile = 3;  // the ping-pong schedule assumes >= 3 K-tiles per bank tile
+    if ((tile == 4 || tile == 5) && D < 192) tile = 3;  // the ping-pong schedule assumes >= 3 K-tiles per bank tile
     hipStream_t s = (hipStream_t)stream;
     const bool h = dtype == CMDIAD_DT_F16;
     int rc;
 #define L2_ARGS q, q_sqnorm, bank, bank_sqnorm, Q, Nb, D, row_offset, keys, s
-    if (tile == 4) {
+    if (tile == 4 || tile == 5) {
         const int full = Nb / 256 * 256, rest = Nb - full;
         rc = CMDIAD_OK;
-        if (full > 0) rc = h ? launch_l2<SPingPong, true>(q, q_sqnorm, bank, bank_sqnorm, Q, full, D, row_offset, keys, s)
+        if (full > 0 && tile == 5) rc = h ? launch_l2<SPingPong3, true>(q, q_sqnorm, bank, bank_sqnorm, Q, full, D, row_offset, keys, s)
+                                          : launch_l2<SPingPong3, false>(q, q_sqnorm, bank, bank_sqnorm, Q, full, D, row_offset, keys, s);
+        else if (full > 0) rc = h ? launch_l2<SPingPong, true>(q, q_sqnorm, bank, bank_sqnorm, Q, full, D, row_offset, keys, s)
                              : launch_l2<SPingPong, false>(q, q_sqnorm, bank, bank_sqnorm, Q, full, D, row_offset, keys, s);
         if (rc == CMDIAD_OK && rest > 0) {
             const uint16_t* b2 = bank + (size_t)full * D;

@@ -289,9 +289,11 @@ def test_pointmae_encoder_stages(Mg, panel_min, wide, monkeypatch):
 @pytest.mark.parametrize("Q,Nb,D,tile", [(784, 1500, 768, None), (3136, 5000, 128, None), (100, 77, 64, None),
                                           (784, 1500, 768, "3"), (3136, 5000, 128, "3"), (100, 77, 64, "3"), (1000, 2100, 256, "2"),
                                           (784, 1500, 768, "4"), (3136, 5000, 192, "4"), (100, 77, 64, "4"), (1000, 2100, 256, "4"),
-                                          (700, 512, 768, "4"), (515, 9000, 320, "4")])
+                                          (700, 512, 768, "4"), (515, 9000, 320, "4"),
+                                          (784, 1500, 768, "5"), (3136, 5000, 192, "5"), (1000, 2100, 256, "5"), (700, 512, 768, "5"),
+                                          (515, 9000, 320, "5"), (300, 256, 192, "5"), (260, 1024, 1024, "5")])
 def test_l2_min_and_rescore(Q, Nb, D, tile, monkeypatch):
-    if tile:  # 3 = 4-wave 128x128-per-wave shape; 2 = 8-wave 256x256 shape; 4 = the two-group (ping-pong) 256x256 pipeline
+    if tile:  # 3 = 4-wave 128x128-per-wave shape; 2 = 8-wave 256x256 shape; 4 / 5 = the two-group (ping-pong) 256x256 pipelines (5: three bank buffers, split issuers)
         # (whole bank tiles only: the remainder rows go through the 128x128 kernel; D < 192 falls back to 3)
         monkeypatch.setenv("CMDIAD_L2_TILE", tile)
     g = torch.Generator().manual_seed(Q + Nb)
@@ -318,7 +320,7 @@ def test_l2_min_and_rescore(Q, Nb, D, tile, monkeypatch):
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
-@pytest.mark.parametrize("tile", ["0", "2", "3", "4"])
+@pytest.mark.parametrize("tile", ["0", "2", "3", "4", "5"])
 def test_l2_min_all_tiles_identical_keys(tile, dt, monkeypatch):
     """Both operand types of every distance-GEMM variant (the engine defaults to fp16): all variants must return
     IDENTICAL keys on the same operands (same products, same fp32 accumulation order per 64-deep K tile, same
