@@ -312,7 +312,7 @@ def measured_traffic(world, sharded):
     grid = 0
     best = None
     for row in json.load(open(path)):
-        if row["kernel"].startswith("l2_min_wide_kernel") and row["grid_threads"] > grid and "fetch_bytes" in row:
+        if row["kernel"].startswith("l2_min_") and row["grid_threads"] > grid and "fetch_bytes" in row:
             grid, best = row["grid_threads"], row
     return None if best is None else int(best["fetch_bytes"] + best.get("write_bytes", 0.0))
 
@@ -410,7 +410,7 @@ def main():
                        "batch_per_gpu": BATCH, "bank": "row-sharded search + RCCL min-reduce" if sharded else ("replicated per rank, images sharded, no data-path collective" if world > 1 else "single"),
                        "hip_graphs": bool(pipe.use_graph), "search_operands": "fp16 (fp32 accumulate, exact fp32 re-score)",
                        "weights": "seeded random init (no checkpoints offline)"},
-            "roofline": {"kernel": "l2_min_wide_kernel (xyz library distance GEMM + running min/argmin)", "bound": "mfma",
+            "roofline": {"kernel": "l2_min_pp3_kernel (xyz library distance GEMM + running min/argmin)", "bound": "mfma",
                          "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": measured_traffic(world, sharded),
                          "launch_ms": round(l2_ms, 3), "flops_per_launch": flops,

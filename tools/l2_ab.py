@@ -22,3 +22,13 @@ for v in variants:
     print(f"tile {v}: median {statistics.median(r):.3f} ms  min {min(r):.3f} ms  -> {2.0 * Q * Nb * 768 / statistics.median(r) / 1e9:.0f} TFLOP/s", flush=True)
 a, b = keys[variants[0]], keys[variants[-1]]
 print("argmin agreement between variants:", (a & 0xFFFFFFFF == b & 0xFFFFFFFF).float().mean().item(), " identical keys:", (a == b).float().mean().item())
+n_stress = int(os.environ.get("L2_STRESS", "0"))
+if n_stress:
+    os.environ["CMDIAD_L2_TILE"] = variants[0]
+    ref = ops.l2_min_keys(q16, qsq, b16, bsq, ops.new_keys(Q, "cuda")).clone()
+    os.environ["CMDIAD_L2_TILE"] = variants[-1]
+    bad = 0
+    for i in range(n_stress):
+        k = ops.l2_min_keys(q16, qsq, b16, bsq, ops.new_keys(Q, "cuda"))
+        bad += int(not torch.equal(k, ref))
+    print(f"stress: {n_stress} launches of tile {variants[-1]} against tile {variants[0]}: {bad} mismatching launches", flush=True)
