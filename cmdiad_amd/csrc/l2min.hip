@@ -8,7 +8,7 @@
 // the four 16-lane groups are merged by shuffles and every query gets ONE 64-bit atomicMin per block on its packed key
 // (value bits << 32 | global row: integer order = (distance, row) order).  Blocks are dealt to the XCDs in groups of
 // `qgroup` query tiles x `splits` bank ranges, so a streamed bank tile is shared through that XCD's L2.
-// Shapes: l2_min_pp3_kernel (256 x 256, 8 waves in two groups, per-stream issuer waves) from Q >= 16 384; l2_min_kernel<S128>
+// Shapes: l2_min_pp3_kernel (256 x 256, 8 waves in two groups, per-stream issuer waves) from Q >= 512; l2_min_kernel<S128>
 // below that and for the last Nb % 256 bank rows; l2_min_wide_kernel (gemm_wide.h: 4 waves of 128 x 128), l2_min_pp_kernel and
 // l2_min_kernel<S2x2> kept as A/B references (CMDIAD_L2_TILE); every variant returns the same keys.
 #include <stdlib.h>
@@ -961,8 +961,9 @@ extern "C" int cmdiad_l2_min_keys(const uint16_t* q, const float* q_sqnorm, cons
     const char* env_tile = getenv("CMDIAD_L2_TILE");  // read per call: the parity tests force each shape on small inputs
     const int force = env_tile ? atoi(env_tile) : -1;
     // 0 S128, 2 S2x2 (256x256, 8 waves), 3 SWide (256x256, 4 waves of 128x128), 4 SPingPong (256x256, 2 groups of 4 waves),
-    // 5 SPingPong3 (the same with three bank buffers and per-stream issuer waves: production from Q >= 16384)
-    int tile = force >= 0 ? force : (Q >= 256 * 64 ? 5 : 0);
+    // 5 SPingPong3 (the same with three bank buffers and per-stream issuer waves: production from Q >= 512)
+    // measured at the B = 1 shapes too (Q = 3136 / 784 against the bagel libraries): 0.68 -> 0.43 ms and 0.17 -> 0.11 ms
+    int tile = force >= 0 ? force : (Q >= 512 ? 5 : 0);
     if ((tile == 4 || tile == 5) && D < 192) tile = 3;  // the two-group schedules assume >= 3 K-tiles per bank tile  // the ping-pong schedule assumes >= 3 K-tiles per bank tile
     hipStream_t s = (hipStream_t)stream;
     const bool h = dtype == CMDIAD_DT_F16;
