@@ -43,9 +43,13 @@ def shard_range(n, rank, world):
     return min(rank * per, n), min((rank + 1) * per, n)
 
 
+KEY_EMPTY = ops.KEY_EMPTY
+
+
 def merge_shard_keys(keys, group=None):
-    """Combine per-shard packed keys: key = (fp32 bits of d2 >= 0) << 32 | global row.  The keys are
-    non-negative as int64, so signed MIN == unsigned MIN == (smallest distance, lowest global row)."""
+    """Combine per-shard packed keys: key = (fp32 bits of d2 >= 0) << 32 | global row.  The keys -- and the "no
+    candidate" sentinel ops.KEY_EMPTY a rank with an EMPTY shard leaves behind -- are non-negative as int64, so
+    signed MIN == unsigned MIN == (smallest distance, lowest global row)."""
     if group is not None:
         import torch.distributed as td
         td.all_reduce(keys, op=td.ReduceOp.MIN, group=group)
@@ -94,8 +98,9 @@ def score_patches_from_keys(patch32, keys, bank, dims, gt_size=224):
     B, Q, D = patch32.shape
     dev = patch32.device
     flat = patch32.reshape(B * Q, D)
-    min_val = torch.empty((B * Q,), dtype=torch.float32, device=dev)
-    min_idx = torch.empty((B * Q,), dtype=torch.int64, device=dev)
+    # a key that names no row of the library (only possible when EVERY shard was empty) leaves (0, -1) behind, not garbage
+    min_val = torch.zeros((B * Q,), dtype=torch.float32, device=dev)
+    min_idx = torch.full((B * Q,), -1, dtype=torch.int64, device=dev)
     ops.l2_rescore(flat, bank.f32, keys, min_val, min_idx, 0)
     s_star = torch.empty((B,), dtype=torch.float32, device=dev)
     s_idx = torch.empty((B,), dtype=torch.int32, device=dev)
@@ -198,6 +203,13 @@ class Engine:
         B, T, C = p.shape
         s = int(math.isqrt(T))
         return p.reshape(B, s, 1, s, 1, C).expand(B, s, 2, s, 2, C).reshape(B, 4 * T, C)
+
+
+def predict_batch(engine, rgb, pcs, bank_xyz, bank_second, stats, det, seg, **kw):
+    """Batched `predict` (image scores [B] f64, pixel maps [B,gt,gt] f64): see cmdiad_amd.predictor.BatchPredictor, which
+    also keeps the HIP graphs and buffer sets between calls."""
+    from . import predictor
+    return predictor.predict_batch(engine, rgb, pcs, bank_xyz, bank_second, stats, det, seg, **kw)
 
 
 def normalize(x, mean, std):

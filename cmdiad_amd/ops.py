@@ -9,7 +9,10 @@ import torch
 from . import _native as nat
 
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_RELU_POST = 0, 1, 2, 3
-U64_MAX = -1  # as int64 bit pattern
+# "no candidate yet" key: the largest NON-NEGATIVE int64.  Every real key is (fp32 bits of d2 >= +0) << 32 | row, i.e. has bit 63
+# clear, so this sentinel is >= every real key under the kernels' unsigned atomicMin AND under the signed MIN all-reduce of the
+# row-sharded search (a rank whose shard is empty contributes only sentinels and can never win the reduce).
+KEY_EMPTY = 0x7FFFFFFFFFFFFFFF
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
@@ -303,7 +306,7 @@ def normalize_cast(x, mean=0.0, inv_std=1.0, want_f32=False, want_sq=True, dtype
 
 
 def new_keys(Q, device):
-    return torch.full((Q,), -1, dtype=torch.int64, device=device)  # 0xFFFF... = UINT64_MAX
+    return torch.full((Q,), KEY_EMPTY, dtype=torch.int64, device=device)
 
 
 def l2_min_keys(q16, q_sq, bank16, bank_sq, keys, row_offset=0):

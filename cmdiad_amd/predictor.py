@@ -1,0 +1,292 @@
+"""Batched `predict` of the two-library method classes, device-resident end to end (`engine.predict_batch`).
+
+What `DoubleRGBPointFeatures.predict` (multiple_features.py:929-1015) and `RGBorXYZWithOneHallucination.predict`
+with main modality xyz (multiple_features.py:486-573) do for ONE sample -- extract, patch, normalise with the
+(cross-wired) scalar statistics, nearest neighbour in both libraries, re-weighting, bilinear maps, 8-bit
+Gaussian blur, lambda weights, the two linear one-class SVMs -- done for a batch of B samples per call, every
+sample's result being what the B = 1 drop-in returns (tests/test_gpu_predictor.py).
+
+One step = stage 1 (extraction + 16-bit queries; a HIP graph) -> search (distance GEMMs, eager so that the
+collectives of the row-sharded mode and the HIP-event bracket of bench.py's `roofline` can sit there) -> stage 2
+(exact re-score, re-weighting, maps, blur, SVM scores; a HIP graph) -> D2H of the final image scores and pixel maps
+into a ring of pinned buffers.  Two complete buffer sets alternate: the scoring tail of step i runs on a second
+stream beside the extraction of step i+1, and the inputs of step i+1 are copied (H2D from pinned host memory, or
+D2D from resident batches) into the other set's static input buffers on a copy stream while step i computes.
+"""
+import sys
+
+import numpy as np
+import torch
+
+from . import engine as eng
+from . import ops
+
+
+class EventTimer:
+    """HIP-event bracket on torch's current stream (the stream every cmdiad kernel is launched on)."""
+
+    def __init__(self):
+        self.pairs = []
+
+    def __enter__(self):
+        self.e0 = torch.cuda.Event(enable_timing=True)
+        self.e1 = torch.cuda.Event(enable_timing=True)
+        self.e0.record()
+        return self
+
+    def __exit__(self, *a):
+        self.e1.record()
+        self.pairs.append((self.e0, self.e1))
+
+    def mean_ms(self, skip=0):
+        v = [a.elapsed_time(b) for a, b in self.pairs[skip:]]
+        return sum(v) / max(len(v), 1)
+
+
+class _NoTimer:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+class Ticket:
+    """One submitted batch: wait() -> (image scores [B] f64, pixel maps [B, gt, gt] f64) as numpy arrays."""
+
+    def __init__(self, host_s, host_m, event, gt):
+        self._s, self._m, self._ev, self._gt = host_s, host_m, event, gt
+
+    def wait(self):
+        self._ev.synchronize()
+        B = self._s.shape[0]
+        return self._s.numpy().reshape(B).copy(), self._m.numpy().reshape(B, self._gt, self._gt).copy()
+
+
+class BatchPredictor:
+    """engine: eng.Engine.  bank_xyz / bank_second: eng.Bank (the main-modality library and the rgb -- or, for the
+    'mtfi' workload, the hallucinated-feature -- library).  stats: dict(xyz_mean, xyz_std, rgb_mean, rgb_std) with the
+    second library's statistics under the rgb_* keys.  det / seg: fitted sklearn SGDOneClassSVM (only coef_ / offset_
+    are read; the fit stays on the host).  lambdas = (xyz_s, xyz_smap, second_s, second_smap)
+    (main.py:114-125).  workload: 'dino_pointmae' (both modalities extracted) or 'mtfi' (Point-MAE extraction +
+    `halluc`: runtime.PackedHallucination generating the second modality's features from the xyz patches).
+    group: torch.distributed process group -> row-sharded library search (all-gather of the queries, per-shard
+    distance GEMM, one integer-MIN all-reduce of packed keys); None -> every rank searches its own copy."""
+
+    def __init__(self, engine, bank_xyz, bank_second, stats, det, seg, lambdas=(1.0, 1.0, 0.1, 0.1), batch=32, n_max=None,
+                 workload="dino_pointmae", halluc=None, group=None, use_graph=True, timers=None, ring=3, size=224,
+                 gt_size=224, blur_radius=4.0):
+        if workload not in ("dino_pointmae", "mtfi"):
+            raise ValueError(f"unknown workload {workload!r}")
+        if workload == "mtfi" and halluc is None:
+            raise ValueError("workload 'mtfi' needs the packed hallucination network")
+        self.e, self.bank_xyz, self.bank_second, self.stats = engine, bank_xyz, bank_second, stats
+        self.det, self.seg, self.lambdas = det, seg, tuple(float(v) for v in lambdas)
+        self.B, self.n_max, self.workload, self.halluc, self.group = batch, n_max, workload, halluc, group
+        self.size, self.gt, self.blur_radius = size, gt_size, float(blur_radius)
+        self.timers = timers or {}
+        self.use_graph = use_graph
+        dev = bank_xyz.f32.device
+        self.dev = dev
+        self.side, self.post, self.copy = torch.cuda.Stream(dev), torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+        # host ring: the step's FINAL outputs (image score, pixel map), f64 as sklearn's score_samples returns them
+        self.ring = [(torch.empty((batch, 1), dtype=torch.float64, pin_memory=True),
+                      torch.empty((batch, gt_size * gt_size), dtype=torch.float64, pin_memory=True)) for _ in range(ring)]
+        self.slot = 0
+        self.step_no = 0
+        self.sets = None
+        self.static = {}
+        self.inputs = [self._new_inputs() for _ in range(2 if use_graph else 1)]
+
+    def _new_inputs(self):
+        want_rgb = self.workload == "dino_pointmae"
+        return dict(rgb=torch.zeros((self.B, 3, self.size, self.size), dtype=torch.float32, device=self.dev) if want_rgb else None,
+                    pcs=torch.zeros((self.B, 3, self.size, self.size), dtype=torch.float32, device=self.dev),
+                    ready=None, free=None)
+
+    # ---- stage 1: everything up to the 16-bit queries of both libraries
+    def stage1(self, inp):
+        e, s = self.e, self.stats
+        if self.workload == "mtfi":
+            ex = e.extract(None, inp["pcs"], want_rgb=False, n_max=self.n_max)
+            xyz_raw = e.xyz_patch(ex, 56)                                       # a9
+            hall = self.halluc.generate(xyz_raw, "xyz")                         # a15: hallucinated rgb features [B,3136,768]
+            xyz_q = eng.normalize(xyz_raw, s["xyz_mean"], s["xyz_std"])         # a11
+            sec_q = eng.normalize(hall, s["rgb_mean"], s["rgb_std"])
+            out = {}
+            for name, q in (("xyz", xyz_q), ("rgb", sec_q)):
+                B, Q, D = q.shape
+                q16, _, qsq = ops.normalize_cast(q.reshape(B * Q, D))
+                out[name] = (q, q16, qsq)
+            return out
+        early = {}
+
+        def rgb_branch(ex):
+            # everything the rgb library needs depends on the ViT only: normalise, cast and SEARCH it here, beside the
+            # rest of the point-cloud branch (the Point-MAE transformer leaves half of the chip's issue slots idle)
+            rq = eng.normalize(e.rgb_patch(ex).contiguous(), s["rgb_mean"], s["rgb_std"])
+            B, Q, D = rq.shape
+            q16, _, qsq = ops.normalize_cast(rq.reshape(B * Q, D))
+            early["rgb"] = (rq, q16, qsq)
+            if self.group is None:
+                bank = self.bank_second
+                k = ops.new_keys(B * Q, rq.device)
+                ops.l2_min_keys(q16, qsq, bank.bf16, bank.sqnorm, k, bank.row_offset)
+                early["rgb_keys"] = k
+
+        ex = e.extract(inp["rgb"], inp["pcs"], n_max=self.n_max, side_stream=self.side, rgb_hook=rgb_branch)
+        xyz_q = e.xyz_patch(ex, 56, s["xyz_mean"], 1.0 / s["xyz_std"])        # a9 + a11 fused
+        B, Q, D = xyz_q.shape
+        q16, _, qsq = ops.normalize_cast(xyz_q.reshape(B * Q, D))
+        out = {"xyz": (xyz_q, q16, qsq), "rgb": early["rgb"]}
+        if "rgb_keys" in early:
+            out["rgb_keys"] = early["rgb_keys"]
+        return out
+
+    # ---- search: eager (HIP events around the distance GEMM; RCCL collectives when sharded)
+    def search(self, qs, buf=0):
+        keys = {}
+        for name, bank in (("xyz", self.bank_xyz), ("rgb", self.bank_second)):
+            if name == "rgb" and "rgb_keys" in qs:  # searched inside stage 1 already (beside the point-cloud branch)
+                keys[name] = qs["rgb_keys"]
+                continue
+            q, q16, qsq = qs[name]
+            B, Q, D = q.shape
+            q_all, s_all = eng.gather_queries(q16, qsq, self.group)
+            k = self.static.get(f"keys_{name}_{buf}")
+            if k is None or k.shape[0] != q_all.shape[0]:
+                k = self.static[f"keys_{name}_{buf}"] = torch.empty((q_all.shape[0],), dtype=torch.int64, device=q.device)
+            k.fill_(eng.KEY_EMPTY)
+            with self.timers.get(name, _NoTimer()):
+                ops.l2_min_keys(q_all, s_all, bank.bf16, bank.sqnorm, k, bank.row_offset)
+            k = eng.merge_shard_keys(k, self.group)
+            keys[name] = k[bank.rank * B * Q:(bank.rank + 1) * B * Q] if self.group is not None else k
+        return keys
+
+    # ---- stage 2: exact re-score, re-weighting, bilinear maps, 8-bit blur (a14), lambda weights + one-class SVMs (a19)
+    def stage2(self, qs, keys):
+        lam = self.lambdas
+        gt = self.gt
+        rx = eng.score_patches_from_keys(qs["xyz"][0], keys["xyz"].contiguous(), self.bank_xyz, (56, 56), gt)
+        side = (56, 56) if self.workload == "mtfi" else (28, 28)
+        rr = eng.score_patches_from_keys(qs["rgb"][0], keys["rgb"].contiguous(), self.bank_second, side, gt)
+        s = torch.stack([rx["s"], rr["s"]], 1)                                   # [B,2]
+        maps = torch.stack([rx["s_map_pre"], rr["s_map_pre"]], 1).contiguous()   # [B,2,gt,gt]
+        B = maps.shape[0]
+        blurred = ops.blur8_maps(maps.view(B * 2, gt, gt), self.blur_radius).view(B, 2, gt * gt)
+        pix = ops.ocsvm_score_maps(blurred, (lam[1], lam[3]), self.seg.coef_, self.seg.offset_)
+        img = ops.ocsvm_score_maps(s.view(B, 2, 1).contiguous(), (lam[0], lam[2]), self.det.coef_, self.det.offset_)
+        return img, pix
+
+    def _capture(self):
+        qs = self.stage1(self.inputs[0])  # one eager pass first: module loading / attribute setting must not happen in capture
+        self.stage2(qs, self.search(qs, 0))
+        torch.cuda.synchronize()
+        try:
+            sets = []
+            for s in range(2):  # two complete buffer sets: step i+1's extraction overlaps step i's scoring tail
+                g1 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g1):
+                    qs = self.stage1(self.inputs[s])
+                g1.replay()
+                keys = self.search(qs, s)
+                k = {n: v.contiguous() for n, v in keys.items()}
+                g2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g2):
+                    out = self.stage2(qs, k)
+                torch.cuda.synchronize()
+                sets.append(dict(g1=g1, g2=g2, qs=qs, k=k, out=out, done=None))
+            self.sets = sets
+        except Exception as exc:  # capture is an optimisation, never a requirement
+            print(f"[cmdiad_amd.predictor] HIP graph capture unavailable ({type(exc).__name__}: {exc}); running eagerly",
+                  file=sys.stderr)
+            self.sets = None
+            self.use_graph = False
+            torch.cuda.synchronize()
+
+    def _load_inputs(self, inp, rgb, pcs):
+        """Copies one batch into a set's static input buffers on the copy stream (H2D when the source is pinned host memory,
+        D2D when it is already resident); the compute stream waits for the copy, the copy waits until the previous user
+        of these buffers (stage 1 of two steps ago) has finished with them."""
+        cur = torch.cuda.current_stream()
+        if inp["free"] is not None:
+            self.copy.wait_event(inp["free"])
+        else:
+            self.copy.wait_stream(cur)
+        with torch.cuda.stream(self.copy):
+            if inp["rgb"] is not None:
+                inp["rgb"].copy_(rgb, non_blocking=True)
+            inp["pcs"].copy_(pcs, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        for t in (rgb, pcs):
+            if t is not None and t.is_cuda:
+                t.record_stream(self.copy)
+        cur.wait_event(ev)
+
+    def submit(self, rgb, pcs):
+        """rgb [B,3,S,S] f32 (None for 'mtfi'), pcs [B,3,S,S] f32 organised clouds; on the GPU or in (pinned) host memory.
+        Returns a Ticket; at most len(ring) - 1 tickets may be outstanding."""
+        if pcs.shape[0] != self.B:
+            raise ValueError(f"batch of {pcs.shape[0]} given to a predictor built for {self.B}")
+        if self.use_graph and self.sets is None:
+            for inp in self.inputs:  # capture (and its eager rehearsal) must see real clouds, not the zero-filled buffers
+                if inp["rgb"] is not None:
+                    inp["rgb"].copy_(rgb)
+                inp["pcs"].copy_(pcs)
+            torch.cuda.synchronize()
+            self._capture()
+        host_s, host_m = self.ring[self.slot]
+        self.slot = (self.slot + 1) % len(self.ring)
+        cur = torch.cuda.current_stream()
+        if self.use_graph:
+            # Software pipeline across batches: the scoring tail of step i (re-score, re-weighting scans, maps, blur, one-class
+            # SVMs, D2H: ~2 ms of small bandwidth-bound kernels) runs on a second stream beside the extraction of step i+1,
+            # which leaves most of the chip idle while farthest-point sampling walks its chain.  Two buffer sets alternate; a
+            # set is reused only after its own tail has finished (event wait below).
+            which = self.step_no & 1
+            st, inp = self.sets[which], self.inputs[which]
+            self.step_no += 1
+            self._load_inputs(inp, rgb, pcs)
+            if st["done"] is not None:
+                cur.wait_event(st["done"])
+            st["g1"].replay()
+            inp["free"] = torch.cuda.Event()
+            inp["free"].record()
+            keys = self.search(st["qs"], which)
+            for n, k in keys.items():
+                if k.data_ptr() != st["k"][n].data_ptr():
+                    st["k"][n].copy_(k)
+            self.post.wait_stream(cur)
+            with torch.cuda.stream(self.post):
+                st["g2"].replay()
+                s_dev, maps_dev = st["out"]
+                host_s.copy_(s_dev, non_blocking=True)
+                host_m.copy_(maps_dev, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+            st["done"] = ev
+            return Ticket(host_s, host_m, ev, self.gt)
+        inp = self.inputs[0]
+        self.step_no += 1
+        self._load_inputs(inp, rgb, pcs)
+        qs = self.stage1(inp)
+        inp["free"] = torch.cuda.Event()
+        inp["free"].record()
+        s_dev, maps_dev = self.stage2(qs, self.search(qs, 0))
+        host_s.copy_(s_dev, non_blocking=True)
+        host_m.copy_(maps_dev, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return Ticket(host_s, host_m, ev, self.gt)
+
+    def predict_batch(self, rgb, pcs):
+        """-> (image scores [B] f64, pixel maps [B,gt,gt] f64): detect_fuser / seg_fuser.score_samples of every sample."""
+        return self.submit(rgb, pcs).wait()
+
+
+def predict_batch(engine, rgb, pcs, bank_xyz, bank_second, stats, det, seg, **kw):
+    """One-shot convenience form (no graphs are kept): builds a BatchPredictor for this batch size and runs it once."""
+    kw.setdefault("use_graph", False)
+    p = BatchPredictor(engine, bank_xyz, bank_second, stats, det, seg, batch=pcs.shape[0], **kw)
+    return p.predict_batch(rgb, pcs)

@@ -217,3 +217,21 @@ def synth_state_dict(kind, seed, prefix="", **kw):
         if name.endswith("running_var"):
             sd[name.replace("running_var", "num_batches_tracked")] = torch.tensor(0)
     return sd
+
+
+def sharpen_pointmae(sd, conv_gain=400.0, qk_gain=36.0):
+    """Synthetic Point-MAE weights whose features DISCRIMINATE between patches.  With the O(1)-activation weights of
+    synth_state_dict the 8 mm neighbourhood coordinates vanish against the biases and random-init attention is uniform
+    (every token receives the mean of V), so all 3136 xyz patch features of a sample are near-duplicates: their
+    nearest-neighbour distances (~0.02 of |f| ~ 25) sit below the bf16 error of ANY 16-bit feature extractor and only an
+    absolute tolerance is meaningful.  A first-convolution gain (coordinates become O(1)) and sharper attention logits
+    (q and k scaled) lift the patch-to-patch distances to ~4, ten times the bf16 error, so the xyz modality can be
+    checked relatively end to end."""
+    sd = dict(sd)
+    sd["encoder.first_conv.0.weight"] = sd["encoder.first_conv.0.weight"] * conv_gain
+    for k in list(sd):
+        if k.endswith("attn.qkv.weight"):
+            w = sd[k].clone()
+            w[: 2 * w.shape[0] // 3] *= qk_gain ** 0.5   # q and k rows: logits scale by qk_gain
+            sd[k] = w
+    return sd

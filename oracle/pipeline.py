@@ -4,7 +4,11 @@ scoring exactly as feature_extractors/features.py and multiple_features.py call 
 for FPS / kNN grouping (the reference has no CPU implementation of those: models/models.py:5-6
 hard-imports the CUDA packages).
 
-Protocol mirrored: DoubleRGBPointFeatures (multiple_features.py:800-1015) = "DINO+Point_MAE".
+Protocols mirrored: DoubleRGBPointFeatures (multiple_features.py:800-1015) = "DINO+Point_MAE"; RGBFeatures (:28-121) and
+PointFeatures (:207-309), the single-library classes with their OWN (correctly wired) statistics; and
+RGBorXYZWithOneHallucination (:312-573), the MTFI feature-to-feature class (main modality + hallucinated other modality,
+statistics cross-wired as SURVEY F5).  Pinned by tests/golden/g6_protocol.npz and g11_methods.npz (the reference's own
+classes driven over the same backbone restatements).
 """
 import math
 import time
@@ -97,3 +101,92 @@ class CpuDoubleRGBPoint:
     def predict(self, rgb, organized_pc, blur=True):
         rp, xp = self.ex(rgb, organized_pc)
         return self.score(rp, xp, blur=blur)
+
+
+def _coreset(lib, f_coreset, eps, random_state, override=None):
+    """features.py:360-425 as the method classes call it (`n = int(f_coreset * rows)`); returns (rows kept, own selection)."""
+    if f_coreset >= 1:
+        return lib, None
+    idx = scoring.coreset_idx_randomp(lib, int(f_coreset * lib.shape[0]), eps, random_state)
+    return lib[idx if override is None else torch.as_tensor(override).long()], idx
+
+
+class CpuSingleModality:
+    """RGBFeatures (multiple_features.py:28-121) / PointFeatures (:207-309): one library, statistics from that library
+    (:38-41, :221-223), one (s, s_map) column."""
+
+    def __init__(self, extractor, modality, lambdas=(1.0, 1.0), f_coreset=1.0, coreset_eps=0.9, random_state=None):
+        assert modality in ("rgb", "xyz")
+        self.ex, self.modality = extractor, modality
+        self.s_l, self.m_l = lambdas
+        self.f_coreset, self.coreset_eps, self.random_state = f_coreset, coreset_eps, random_state
+
+    def _patch(self, rgb, organized_pc):
+        rp, xp = self.ex(rgb, organized_pc)
+        return rp if self.modality == "rgb" else xp
+
+    def fit(self, samples, coreset_override=None):
+        feats = [self._patch(r, p) for r, p in samples]
+        lib = torch.cat(feats, 0)
+        self.mean, self.std = torch.mean(lib), torch.std(lib)
+        self.lib, self.coreset_idx = _coreset((lib - self.mean) / self.std, self.f_coreset, self.coreset_eps, self.random_state,
+                                              coreset_override)
+        return feats
+
+    def score(self, patch, blur=True):
+        r = scoring.score_modality(patch, self.lib, self.mean, self.std, blur=blur)
+        s = torch.tensor([[self.s_l * r["s"]]])
+        s_map = (self.m_l * r["s_map"]).reshape(1, -1).permute(1, 0)
+        return s, s_map, r
+
+    def predict(self, rgb, organized_pc, blur=True):
+        return self.score(self._patch(rgb, organized_pc), blur=blur)
+
+
+class CpuOneHallucination:
+    """RGBorXYZWithOneHallucination with --use_hn (multiple_features.py:312-573): the main modality's real patches plus the
+    OTHER modality's features hallucinated from them by the distilled MLP (hallucination_network.py:34-45); libraries
+    `main` and `fusion`; every mean from the xyz library and every std from the rgb library (:372-377, SURVEY F5);
+    s = [main, fusion] columns (:459-470)."""
+
+    def __init__(self, extractor, sd_halluc, main_modality, lambdas=(1.0, 1.0, 1.0, 1.0), f_coreset=1.0, coreset_eps=0.9,
+                 random_state=None):
+        assert main_modality in ("rgb", "xyz")
+        self.ex, self.sd_h, self.main = extractor, sd_halluc, main_modality
+        self.main_s_l, self.main_m_l, self.fus_s_l, self.fus_m_l = lambdas
+        self.f_coreset, self.coreset_eps, self.random_state = f_coreset, coreset_eps, random_state
+
+    def patches(self, rgb, organized_pc):
+        """-> (main patch, hallucinated patch [3136,768]).  main rgb: rgb_patch [784,768] scored on 28 x 28, the
+        hallucination is generated from rgb_patch2 (56 x 56 replication, :345); main xyz: from the xyz patch (:360)."""
+        rp, xp = self.ex(rgb, organized_pc)
+        with torch.no_grad():
+            if self.main == "rgb":
+                C = rp.shape[1]
+                _, rp2 = scoring.get_rgb_patch(rp.T.reshape(1, C, 28, 28))
+                hall = nets.halluc_generate(self.sd_h, rp2.unsqueeze(0), "rgb2xyz")
+                return rp, xp, hall[0]
+            hall = nets.halluc_generate(self.sd_h, xp.unsqueeze(0), "xyz2rgb")
+            return rp, xp, hall[0]
+
+    def fit(self, samples, coreset_override=None):
+        trip = [self.patches(r, p) for r, p in samples]
+        rgb_lib, xyz_lib, fus_lib = (torch.cat([t[k] for t in trip], 0) for k in range(3))
+        self.mean, self.std = torch.mean(xyz_lib), torch.std(rgb_lib)      # :372-377, all three pairs
+        main_lib = rgb_lib if self.main == "rgb" else xyz_lib
+        ov = coreset_override or (None, None)
+        self.main_lib, self.main_coreset = _coreset((main_lib - self.mean) / self.std, self.f_coreset, self.coreset_eps,
+                                                    self.random_state, ov[0])
+        self.fus_lib, self.fus_coreset = _coreset((fus_lib - self.mean) / self.std, self.f_coreset, self.coreset_eps,
+                                                  self.random_state, ov[1])
+        return trip
+
+    def score(self, rp, xp, hall, blur=True):
+        rf = scoring.score_modality(hall, self.fus_lib, self.mean, self.std, blur=blur)
+        rm = scoring.score_modality(rp if self.main == "rgb" else xp, self.main_lib, self.mean, self.std, blur=blur)
+        s = torch.tensor([[self.main_s_l * rm["s"], self.fus_s_l * rf["s"]]])
+        s_map = torch.cat([self.main_m_l * rm["s_map"], self.fus_m_l * rf["s_map"]], 0).reshape(2, -1).permute(1, 0)
+        return s, s_map, rm, rf
+
+    def predict(self, rgb, organized_pc, blur=True):
+        return self.score(*self.patches(rgb, organized_pc), blur=blur)

@@ -141,11 +141,134 @@ def golden_heads():
     print("g10_heads.npz", os.path.getsize(os.path.join(HERE, "g10_heads.npz")) // 1024, "KB")
 
 
+class _CpuRedirect:
+    """The reference hard-codes CUDA placement (features.py:96,103,106,397-399; multiple_features.py:327,334,344,350):
+    inside this context `.cuda()` and `.to("cuda")` are no-ops so that its own arithmetic runs on the CPU (generator-only
+    patch; nothing of it is shipped)."""
+
+    def __enter__(self):
+        self.to, self.tcuda, self.mcuda = torch.Tensor.to, torch.Tensor.cuda, torch.nn.Module.cuda
+        orig_to = self.to
+        torch.Tensor.to = lambda t, *a, **k: orig_to(t, *[("cpu" if (isinstance(x, str) and x == "cuda") else x) for x in a], **k)
+        torch.Tensor.cuda = lambda t, *a, **k: t
+        torch.nn.Module.cuda = lambda m, *a, **k: m
+        return self
+
+    def __exit__(self, *a):
+        torch.Tensor.to, torch.Tensor.cuda, torch.nn.Module.cuda = self.to, self.tcuda, self.mcuda
+        return False
+
+
+def method_args(**kw):
+    a = dict(rgb_backbone_name="vit_base_patch8_224_dino", xyz_backbone_name="Point_MAE", group_size=128, num_group=1024,
+             rgb_size=224, xyz_size=224, gt_size=224, f_coreset=0.25, coreset_eps=0.9, coreset_dtype="FP16",
+             random_state=0, dist_method_s="l2", dist_method_coreset="l2", main_modality="", use_hn=False,
+             use_hn_conv=False, use_hn_from_rgb_mlp=False, use_hn_from_rgb_conv=False, use_hrnet=False, use_uff=False,
+             use_depth=False, fusion_module_path="", ocsvm_nu=0.5, ocsvm_maxiter=1000, xyz_s_lambda=1.0,
+             xyz_smap_lambda=1.0, rgb_s_lambda=0.1, rgb_smap_lambda=0.1, fusion_s_lambda=1.0, fusion_smap_lambda=1.0,
+             save_feature_for_fusion=False, save_frgb_xyz=False, save_rgb_fxyz=False, save_seg_results=False,
+             save_raw_results=False, save_path="", save_path_frgb_xyz="", save_path_rgb_fxyz="", experiment_note="", c_hrnet=0)
+    a.update(kw)
+    return _ns(**a)
+
+
+def golden_methods():
+    """G11: the five-call protocol (cmdiad_runner.py:44-92) of the reference's OWN RGBFeatures (multiple_features.py:28-121),
+    PointFeatures (:207-309) and RGBorXYZWithOneHallucination (:312-573; --use_hn, main modality xyz and rgb) over this
+    repo's CPU backbone restatements (timm / pointnet2_ops / knn_cuda are absent) -- as G6 does for DoubleRGBPointFeatures.
+    Point-MAE runs with the 'sharpened' synthetic weights (oracle.nets.sharpen_pointmae) so the xyz nearest-neighbour
+    distances are genuine numbers, not fp32 cancellation noise.  Pins oracle/pipeline.py's CpuSingleModality /
+    CpuOneHallucination."""
+    from feature_extractors import features as rfeat
+    from feature_extractors import multiple_features as rmf
+    from cmdiad_amd.synth import synth_rgb
+    sd_vit = onets.synth_state_dict("vit", 31)
+    sd_pm = onets.sharpen_pointmae(onets.synth_state_dict("pointmae", 21))
+    sd_h = onets.synth_state_dict("halluc", 51)
+    cache = {}
+
+    class FakeModel(torch.nn.Module):
+        def __init__(self, device, rgb_backbone_name, xyz_backbone_name, group_size, num_group):
+            super().__init__()
+            self.G, self.M = num_group, group_size
+
+        def forward(self, rgb, xyz, out_type="rgb+xyz"):
+            key = (float(rgb.double().sum()), float(xyz.double().sum()), tuple(xyz.shape))
+            if key not in cache:
+                with torch.no_grad():
+                    fmap = onets.vit_forward(sd_vit, rgb)
+                    pts = np.ascontiguousarray(xyz[0].T.numpy())[None]
+                    cidx, cen = ok.fps(pts, self.G)
+                    idx, nb = ok.knn_group(pts, cen, self.M)
+                    center = torch.from_numpy(cen)
+                    tok = onets.pointmae_encoder(sd_pm, torch.from_numpy(nb))
+                    feats = onets.pointmae_transformer(sd_pm, tok, center)
+                cache[key] = (fmap, feats, center, torch.from_numpy(idx), torch.from_numpy(cidx))
+            return cache[key]
+
+    rfeat.Model = FakeModel
+    TRAIN, TEST = (301, 302, 303), (311, 312)
+    FRAC, TEX = 0.45, 0.004
+
+    def sample(sd, anomalous=False):
+        pc = synth_cloud(sd, FRAC, texture=TEX)
+        rgb = synth_rgb(sd)
+        if anomalous:
+            pc[0, 2, 100:120, 100:120] -= 0.005 * (pc[0, 2, 100:120, 100:120] != 0)
+            rgb[0, :, 100:120, 100:120] += 2.0
+        return (rgb, pc, pc.clone())
+
+    out = dict(train_seeds=np.array(TRAIN), test_seeds=np.array(TEST), test_anomalous=np.array([0, 1]), frac=FRAC, texture=TEX,
+               f_coreset=0.25, random_state=0, pm_conv_gain=400.0, pm_qk_gain=36.0)
+    runs = {"rgb": (rmf.RGBFeatures, {}), "xyz": (rmf.PointFeatures, {}),
+            "mtfi_xyz": (rmf.RGBorXYZWithOneHallucination, dict(use_hn=True, main_modality="xyz")),
+            "mtfi_rgb": (rmf.RGBorXYZWithOneHallucination, dict(use_hn=True, main_modality="rgb"))}
+    for tag, (cls, kw) in runs.items():
+        with _CpuRedirect():
+            m = cls(method_args(**kw))
+            if kw.get("use_hn"):
+                print(tag, m.fusion.load_state_dict(sd_h))
+            for sd in TRAIN:
+                m.add_sample_to_mem_bank(sample(sd), class_name="synthetic")
+            picked = []
+            inner = m.get_coreset_idx_randomp
+            m.get_coreset_idx_randomp = lambda *a, **k: (picked.append(inner(*a, **k)), picked[-1])[1]
+            m.run_coreset()
+            for sd in TRAIN:
+                m.add_sample_to_late_fusion_mem_bank(sample(sd))
+            s_lib, s_map_lib = torch.cat(m.s_lib, 0).clone(), torch.cat(m.s_map_lib, 0).clone()
+            m.run_late_fusion()
+            for sd, an in zip(TEST, (False, True)):
+                m.predict(sample(sd, an), torch.zeros(1, 224, 224), 0, ["x.png"])
+        g = {"s_lib": s_lib.numpy(), "s_map_lib_sub": s_map_lib[::53].numpy(),
+             "detect_coef": m.detect_fuser.coef_, "detect_offset": m.detect_fuser.offset_,
+             "seg_coef": m.seg_fuser.coef_, "seg_offset": m.seg_fuser.offset_,
+             "image_preds": np.array(m.image_preds).reshape(-1), "pred_maps_sub": np.array(m.predictions)[:, ::4, ::4]}
+        for k, idx in enumerate(picked):
+            g[f"coreset_idx{k}"] = idx.numpy().astype(np.int32)
+        if tag == "rgb":
+            g.update(mean=float(m.rgb_mean), std=float(m.rgb_std), lib_rows=m.patch_rgb_lib.shape[0], lib_sub=m.patch_rgb_lib[::31, ::16].numpy())
+        elif tag == "xyz":
+            g.update(mean=float(m.xyz_mean), std=float(m.xyz_std), lib_rows=m.patch_xyz_lib.shape[0], lib_sub=m.patch_xyz_lib[::97, ::16].numpy())
+        else:
+            main = m.patch_xyz_lib if tag == "mtfi_xyz" else m.patch_rgb_lib
+            g.update(mean=float(m.fusion_mean), std=float(m.fusion_std), xyz_mean=float(m.xyz_mean), xyz_std=float(m.xyz_std),
+                     rgb_mean=float(m.rgb_mean), rgb_std=float(m.rgb_std), lib_rows=main.shape[0],
+                     lib_sub=main[::97 if tag == "mtfi_xyz" else 31, ::16].numpy(), fusion_rows=m.patch_fusion_lib.shape[0],
+                     fusion_sub=m.patch_fusion_lib[::97, ::16].numpy())
+        out.update({f"{tag}/{k}": v for k, v in g.items()})
+        print(tag, "image_preds", g["image_preds"], "s_lib", g["s_lib"][:2])
+    np.savez_compressed(os.path.join(HERE, "g11_methods.npz"), **out)
+    print("g11_methods.npz", os.path.getsize(os.path.join(HERE, "g11_methods.npz")) // 1024, "KB")
+
+
 def main():
     _install_stubs()
     sys.path.insert(0, REF)
     if len(sys.argv) > 1 and sys.argv[1] == "g10":  # only the distillation-head fixture
         return golden_heads()
+    if len(sys.argv) > 1 and sys.argv[1] == "g11":  # only the method-class fixture
+        return golden_methods()
     from models import models as rmodels
     from models import pointnet2_utils as rp2
     from models.hallucination_network import HallucinationCrossModalityNetwork
@@ -409,6 +532,7 @@ def main():
                         idx=sel.numpy().astype(np.int64))
 
     golden_heads()
+    golden_methods()
 
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
