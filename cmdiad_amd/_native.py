@@ -67,7 +67,9 @@ SIGNATURES = {
     "cmdiad_gemm_groupmax": [P, P, P, I, I, I, I, P, P, P],
     "cmdiad_l2_min_keys": [P, P, P, P, I, I, I, U32, P, I, P],
     "cmdiad_l2_rescore": [P, P, P, I, I, I, U32, P, P, P],
-    "cmdiad_reweight_scan": [P, P, I, I, I, U32, P, P, SZ, P],
+    "cmdiad_reweight_scan": [P, P, P, I, I, I, U32, P, P, SZ, P],
+    "cmdiad_bank_block16": [P, I, I, P, P],
+    "cmdiad_l2_dist_matrix": [P, P, I, I, I, P, P],
     "cmdiad_score_head": [P, P, P, P, I, I, I, I, U32, P, P, P, P, P],
     "cmdiad_score_tail": [P, P, P, P, I, I, I, U32, P, P],
     "cmdiad_score_final": [P, P, I, I, P, P],
@@ -87,6 +89,7 @@ SIGNATURES = {
 SIZE_QUERIES = {
     "cmdiad_fps_workspace_bytes": [I, I],
     "cmdiad_reweight_workspace_bytes": [I, I],
+    "cmdiad_bank_block16_floats": [I, I],
     "cmdiad_coreset_workspace_bytes": [I, I, I],
     "cmdiad_blur8_lds_bytes": [I, I],
     "cmdiad_transformer_block_workspace_bytes": [I, I, I],

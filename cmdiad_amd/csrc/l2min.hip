@@ -683,120 +683,6 @@ __global__ __launch_bounds__(256) void l2_rescore_kernel(const float* __restrict
     }
 }
 
-// Re-weighting scan: R probe rows against every bank row, exact fp32 ||a-b||^2, 3 smallest per probe.
-// One wave per bank row at a time (coalesced 16-byte loads of the row), probes re-read from L1/L2.
-// Per-wave top-3 in registers of lane 0 semantics (all lanes carry the same values after the
-// reduction), merged through LDS per block and then by atomic min-insertion into top3[R][3].
-
-__device__ __forceinline__ void top3_insert(unsigned long long (&t)[3], unsigned long long k)
-{
-    if (k < t[2]) {
-        if (k < t[1]) {
-            t[2] = t[1];
-            if (k < t[0]) { t[1] = t[0]; t[0] = k; }
-            else t[1] = k;
-        } else t[2] = k;
-    }
-}
-
-// All R probes are evaluated against a bank row while it sits in registers, so the library is streamed
-// ONCE (Nb*D*4 bytes) whatever R is.  Block = 8 waves; probes live in LDS (R*D*4 <= 96 KiB for R = 32,
-// D = 768); each wave walks rows r0+wave, r0+wave+8, ...; per (row, probe) a 64-lane butterfly reduction
-// gives every lane the squared distance; lane p keeps probe p's current 3rd-best key as the insertion
-// threshold (R <= 64), the per-wave top-3 lists live in LDS and are touched only on an insertion.
-constexpr int kScanWaves = 8;
-constexpr int kMaxProbes = 64;
-
-template <int D4>  // D4 = float4 chunks per lane = D / 256
-__global__ __launch_bounds__(kScanWaves * 64) void reweight_scan_kernel(const float* __restrict__ probes,
-                                                                        const float* __restrict__ bank, int R, int Nb,
-                                                                        unsigned row_offset,
-                                                                        unsigned long long* __restrict__ partial,
-                                                                        int rows_per_block)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int D = D4 * 256;
-    float* s_probe = reinterpret_cast<float*>(smem);                                            // [R][D]
-    unsigned long long* s_top = reinterpret_cast<unsigned long long*>(smem + (size_t)R * D * 4);  // [waves][R][3]
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int i = threadIdx.x * 4; i < R * D; i += kScanWaves * 64 * 4)
-        *reinterpret_cast<float4*>(s_probe + i) = *reinterpret_cast<const float4*>(probes + i);
-    for (int i = threadIdx.x; i < kScanWaves * R * 3; i += kScanWaves * 64) s_top[i] = ~0ull;
-    __syncthreads();
-    unsigned long long thr = ~0ull;  // lane p: 3rd-best key of probe p in THIS wave
-    unsigned long long* my_top = s_top + (size_t)wave * R * 3;
-    const int r0 = blockIdx.x * rows_per_block;
-    const int r1 = min(r0 + rows_per_block, Nb);
-    for (int row = r0 + wave; row < r1; row += kScanWaves) {
-        float4 b[D4];
-#pragma unroll
-        for (int c = 0; c < D4; ++c) b[c] = *reinterpret_cast<const float4*>(bank + (size_t)row * D + c * 256 + lane * 4);
-        for (int p0 = 0; p0 < R; p0 += 4) {  // 4 probes per pass: four independent reduction chains hide the shuffle latency
-            float s[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float* a = s_probe + min(p0 + u, R - 1) * D;
-#pragma unroll
-                for (int c = 0; c < D4; ++c) {
-                    const float4 x = *reinterpret_cast<const float4*>(a + c * 256 + lane * 4);
-                    const float d0 = x.x - b[c].x, d1 = x.y - b[c].y, d2 = x.z - b[c].z, d3 = x.w - b[c].w;
-                    s[u] += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
-                }
-            }
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) s[u] += __shfl_xor(s[u], m, 64);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int p = p0 + u;
-                if (p >= R) break;
-                const unsigned long long key = pack_key(s[u], row_offset + (unsigned)row);
-                const unsigned long long tp = ((unsigned long long)__shfl((unsigned)(thr >> 32), p, 64) << 32) | __shfl((unsigned)thr, p, 64);
-                if (key < tp) {  // wave-uniform: rare after the first rows
-                    unsigned long long t3[3] = {my_top[p * 3], my_top[p * 3 + 1], my_top[p * 3 + 2]};
-                    top3_insert(t3, key);
-                    if (lane == 0) { my_top[p * 3] = t3[0]; my_top[p * 3 + 1] = t3[1]; my_top[p * 3 + 2] = t3[2]; }
-                    if (lane == p) thr = t3[2];
-                }
-            }
-        }
-    }
-    __syncthreads();
-    for (int p = threadIdx.x; p < R; p += kScanWaves * 64) {
-        unsigned long long m[3] = {~0ull, ~0ull, ~0ull};
-        for (int w = 0; w < kScanWaves; ++w)
-            for (int k = 0; k < 3; ++k) top3_insert(m, s_top[((size_t)w * R + p) * 3 + k]);
-        unsigned long long* o = partial + ((size_t)p * gridDim.x + blockIdx.x) * 3;
-        o[0] = m[0]; o[1] = m[1]; o[2] = m[2];
-    }
-}
-
-// One wave per probe: lanes take the partial keys round-robin into a private top-3, then the three global minima are
-// extracted by wave-wide min + pop (keys are unique: they carry the bank row).
-__global__ __launch_bounds__(64) void reweight_merge_kernel(const unsigned long long* __restrict__ partial, int R, int nblocks,
-                                                            unsigned long long* __restrict__ top3)
-{
-    const int pr = blockIdx.x, lane = threadIdx.x;
-    if (pr >= R) return;
-    unsigned long long m[3] = {~0ull, ~0ull, ~0ull};
-    if (lane < 3) m[0] = top3[pr * 3 + lane];  // the running list (earlier shards / calls) joins the candidates
-    const unsigned long long* src = partial + (size_t)pr * nblocks * 3;
-    for (int i = lane; i < nblocks * 3; i += 64) top3_insert(m, src[i]);
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        unsigned long long best = m[0];
-#pragma unroll
-        for (int sft = 32; sft >= 1; sft >>= 1) {
-            const unsigned long long o = shfl_xor_u64(best, sft);
-            best = o < best ? o : best;
-        }
-        if (m[0] == best && best != ~0ull) { m[0] = m[1]; m[1] = m[2]; m[2] = ~0ull; }  // the owner pops it
-        if (lane == 0) top3[pr * 3 + r] = best;
-    }
-}
-
 // (x - mean) * inv_std -> bf16 (+ optional f32 copy, + optional |row|^2 of the ROUNDED values).
 // One wave per row.
 template <bool F16>
@@ -1008,69 +894,6 @@ extern "C" int cmdiad_l2_rescore(const float* q, const float* bank, const unsign
     if (Q == 0) return CMDIAD_OK;
     hipLaunchKernelGGL(l2_rescore_kernel, dim3((Q + 3) / 4), dim3(256), 0, (hipStream_t)stream, q, bank, keys, Q, Nb, D,
                        row_offset, min_val, min_idx);
-    CMDIAD_CHECK_LAUNCH();
-    return CMDIAD_OK;
-}
-
-// rows per block: ~3 blocks of work per CU whatever the library size (each block re-loads the probes into LDS)
-static int scan_rows_per_block(int Nb)
-{
-    int r = (Nb + 767) / 768;
-    r = (r + 7) / 8 * 8;
-    return r < 16 ? 16 : r;
-}
-
-extern "C" size_t cmdiad_reweight_workspace_bytes(int R, int Nb)
-{
-    const int kScanRowsPerBlock = scan_rows_per_block(Nb);
-    const int nblocks = (Nb + kScanRowsPerBlock - 1) / kScanRowsPerBlock;
-    return (size_t)R * nblocks * 3 * sizeof(unsigned long long);
-}
-
-template <int D4>
-int launch_scan(const float* probes, const float* bank, int R, int Nb, uint32_t row_offset, unsigned long long* ws,
-                int nblocks, hipStream_t s)
-{
-    const int kScanRowsPerBlock = scan_rows_per_block(Nb);
-    const size_t lds = (size_t)R * D4 * 256 * 4 + (size_t)kScanWaves * R * 3 * 8;
-    static size_t attr = 0;
-    if (lds > attr) {
-        if (hipFuncSetAttribute((const void*)reweight_scan_kernel<D4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-            cmdiad_set_error("cmdiad_reweight_scan: %zu bytes of LDS exceed the device limit (R too large for D)", lds);
-            return CMDIAD_ERR_ARG;
-        }
-        attr = lds;
-    }
-    hipLaunchKernelGGL(reweight_scan_kernel<D4>, dim3(nblocks), dim3(kScanWaves * 64), lds, s, probes, bank, R, Nb, row_offset, ws,
-                       kScanRowsPerBlock);
-    return CMDIAD_OK;
-}
-
-extern "C" int cmdiad_reweight_scan(const float* probes, const float* bank, int R, int Nb, int D, uint32_t row_offset,
-                                    unsigned long long* top3, void* workspace, size_t workspace_bytes,
-                                    cmdiad_stream_t stream)
-{
-    CMDIAD_REQUIRE(probes && bank && top3, CMDIAD_ERR_ARG, "cmdiad_reweight_scan: null pointer");
-    CMDIAD_REQUIRE(R > 0 && R <= kMaxProbes && D % 256 == 0 && D <= 1024 && aligned16(probes) && aligned16(bank), CMDIAD_ERR_ARG,
-                   "cmdiad_reweight_scan: 0<R<=64, D%%256==0, D<=1024, 16-byte alignment (R=%d D=%d)", R, D);
-    CMDIAD_REQUIRE((size_t)R * D * 4 + (size_t)kScanWaves * R * 24 <= 160 * 1024, CMDIAD_ERR_ARG,
-                   "cmdiad_reweight_scan: R*D too large for LDS; split the probes (R=%d D=%d)", R, D);
-    if (Nb == 0) return CMDIAD_OK;
-    CMDIAD_REQUIRE(workspace && workspace_bytes >= cmdiad_reweight_workspace_bytes(R, Nb), CMDIAD_ERR_WORKSPACE,
-                   "cmdiad_reweight_scan: workspace too small");
-    const int nblocks = (Nb + scan_rows_per_block(Nb) - 1) / scan_rows_per_block(Nb);
-    hipStream_t s = (hipStream_t)stream;
-    unsigned long long* ws = (unsigned long long*)workspace;
-    int rc;
-    switch (D / 256) {
-        case 1: rc = launch_scan<1>(probes, bank, R, Nb, row_offset, ws, nblocks, s); break;
-        case 2: rc = launch_scan<2>(probes, bank, R, Nb, row_offset, ws, nblocks, s); break;
-        case 3: rc = launch_scan<3>(probes, bank, R, Nb, row_offset, ws, nblocks, s); break;
-        default: rc = launch_scan<4>(probes, bank, R, Nb, row_offset, ws, nblocks, s); break;
-    }
-    if (rc) return rc;
-    CMDIAD_CHECK_LAUNCH();
-    hipLaunchKernelGGL(reweight_merge_kernel, dim3(R), dim3(64), 0, s, (const unsigned long long*)workspace, R, nblocks, top3);
     CMDIAD_CHECK_LAUNCH();
     return CMDIAD_OK;
 }

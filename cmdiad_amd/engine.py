@@ -17,8 +17,9 @@ from . import ops
 class Bank:
     """One patch library resident in HBM.
 
-    * ``f32``  [Nb,D]  the reference's normalised library (exact re-score, re-weighting scan): replicated on
-      every GPU (<= 350 MB for the largest MVTec-3D class);
+    * ``f32``  [Nb,D]  the reference's normalised library (exact re-score, re-weighting): replicated on every GPU
+      (<= 350 MB for the largest MVTec-3D class); ``blk16`` is the same data in the MFMA-operand layout the
+      re-weighting scan streams (one more copy: 288 GB of HBM);
     * ``bf16`` [rows,D] + ``sqnorm`` [rows]: the operand of the distance GEMM.  On a multi-GPU node this is the
       rank's ROW SHARD of the search (``row_offset`` = first global row): every rank searches its
       shard for the queries of ALL ranks and the per-shard minima are combined with one integer-MIN
@@ -31,6 +32,14 @@ class Bank:
         lo, hi = shard_range(n, rank, world)
         self.row_offset, self.rank, self.world = lo, rank, world
         self.bf16, _, self.sqnorm = ops.normalize_cast(self.f32[lo:hi])
+        self._blk16 = None
+
+    @property
+    def blk16(self):
+        """fp32 copy in the MFMA-operand layout of the re-weighting scan (cmdiad_bank_block16), built on first use."""
+        if self._blk16 is None:
+            self._blk16 = ops.bank_block16(self.f32)
+        return self._blk16
 
     @property
     def rows(self):
@@ -109,7 +118,7 @@ def score_patches_from_keys(patch32, keys, bank, dims, gt_size=224):
     st = ops._stream()
     _call("cmdiad_score_head", ops._p(min_val), ops._p(min_idx), ops._p(flat), ops._p(bank.f32), B, Q, D, bank.rows,
           0, ops._p(s_star), ops._p(s_idx), ops._p(m_test), ops._p(m_star), st)
-    top3 = ops.reweight_scan(m_star, bank.f32)
+    top3 = ops.reweight_scan(m_star, bank.f32, bank.blk16)
     knn_d = torch.empty((B, 2), dtype=torch.float32, device=dev)
     _call("cmdiad_score_tail", ops._p(s_star), ops._p(m_test), ops._p(top3), ops._p(bank.f32), B, D, bank.rows, 0,
           ops._p(knn_d), st)

@@ -7,7 +7,8 @@ Differences a caller can observe (also listed in INTEGRATION.md):
     (the reference moves everything to the CPU, features.py:137-140, and then runs cdist there);
   * ``interpolated_feature_maps`` is a lazy handle (``LazyInterpolated``): the 154 MB [1,768,N] tensor
     is only materialised when ``.materialize()`` / ``.to()`` is called; get_xyz_patch consumes the handle;
-  * ``calculate_dist`` returns a ``DistHandle`` (the Q x N matrix is never built; ``.materialize()`` builds it);
+  * ``calculate_dist`` returns a ``DistHandle`` (the Q x N matrix is never built; ``.materialize()`` builds it exactly,
+    ``.min(1)`` gives torch.min(dist, 1) without it);
   * the feature extractor runs in eval mode, dist_method_s must be 'l2' (the reference's
     l1 / cos branches are broken).
 """
@@ -54,11 +55,22 @@ class DistHandle:
     def shape(self):
         return torch.Size((self.patch.shape[0], self.lib.shape[0]))
 
-    def materialize(self, chunk=4096):
-        """Exact fp32 matrix, built block-wise by the re-weighting scan's distance kernel (debug / API
-        compatibility only)."""
-        raise NotImplementedError("the Q x N distance matrix is not materialised by cmdiad_amd; use "
-                                  "compute_single_s_s_map(patch, dist_handle, ...) or engine.score_patches")
+    def materialize(self):
+        """The reference's Q x N matrix (features.py:190), exact fp32 (sum of squared differences, cmdiad_l2_dist_matrix):
+        960 MB at the reference's sizes -- API compatibility and debugging only, the scoring path never builds it."""
+        dev = self.lib.device if self.lib.is_cuda else "cuda"
+        return ops.l2_dist_matrix(self.patch.to(dev).float().contiguous(), self.lib.to(dev).float().contiguous())
+
+    def min(self, dim=1):
+        """torch.min(dist, dim=1) of the reference (features.py:227) without the matrix: (values, indices)."""
+        if dim != 1:
+            raise NotImplementedError("DistHandle.min: dim=1 only")
+        dev = self.lib.device if self.lib.is_cuda else "cuda"
+        bank = eng.Bank(self.lib.to(dev).float())
+        q = self.patch.to(dev).float().contiguous()
+        q16, _, qsq = ops.normalize_cast(q)
+        keys = ops.l2_min_keys(q16, qsq, bank.bf16, bank.sqnorm, ops.new_keys(q.shape[0], q.device))
+        return ops.l2_rescore(q, bank.f32, keys)
 
 
 class PixelList:
@@ -105,7 +117,8 @@ class Features(torch.nn.Module):
         self.device = "cuda" if torch.cuda.is_available() else "cpu"
         self.deep_feature_extractor = Model(
             device=self.device, rgb_backbone_name=args.rgb_backbone_name, xyz_backbone_name=args.xyz_backbone_name,
-            group_size=args.group_size, num_group=args.num_group)
+            group_size=args.group_size, num_group=args.num_group,
+            checkpoint_path=getattr(args, "rgb_checkpoint_path", "") or "")   # offline stand-in for timm's hub download
         self.deep_feature_extractor.to(self.device)
         self.deep_feature_extractor.eval()
 
@@ -279,6 +292,14 @@ class Features(torch.nn.Module):
         """features.py:225-297 -> (s scalar tensor, s_map [1,gt,gt]) on the CPU (the blur is host PIL)."""
         lib = {"xyz": self.patch_xyz_lib, "rgb": self.patch_rgb_lib, "fusion": self.patch_fusion_lib,
                "share": self.patch_share_lib, "non_share": self.patch_non_share_lib}[modal]
+        if isinstance(dist, DistHandle):
+            # the nearest neighbours are searched in the modal library (as the reference's own call sites pair them); a
+            # handle onto ANOTHER library would silently give scores that do not belong to `dist`
+            if dist.lib is not lib and not (dist.lib.shape == lib.shape and dist.lib.data_ptr() == lib.data_ptr()):
+                raise ValueError(f"compute_single_s_s_map(modal={modal!r}): `dist` was computed against a different library")
+        elif dist is not None:
+            raise TypeError("compute_single_s_s_map expects the DistHandle returned by calculate_dist (the Q x N matrix is "
+                            "never built on this path); a materialised matrix cannot be re-used")
         r = eng.score_patches(patch.to(self.device).float().unsqueeze(0).contiguous(), self._bank(lib),
                               feature_map_dims, self.gt_size)
         s_map = self.blur(r["s_map_pre"].unsqueeze(0))  # [1,1,H,W] -> [1,H,W], 8-bit PIL blur (utils.py:71-83)

@@ -92,24 +92,69 @@ def _param_version(module):
     return tuple((p.data_ptr(), p._version) for p in cache[0])
 
 
+def allow_random_init():
+    """CMDIAD_ALLOW_RANDOM_INIT=1: explicit opt-in to backbones without pretrained weights (tests, benchmarks on synthetic
+    weights).  Without it a missing checkpoint is an error, as in the reference (timm pretrained=True models/models.py:23;
+    torch.load of checkpoints/pointmae_pretrain.pth :30,285) -- silently random features would still produce
+    plausible-looking, meaningless AUROC numbers."""
+    return os.environ.get("CMDIAD_ALLOW_RANDOM_INIT", "0") == "1"
+
+
+def unwrap_checkpoint(ckpt, prefixes=("module.", "backbone.")):
+    """The forms timm's `checkpoint_path` accepts: a bare state_dict or one wrapped under 'state_dict' / 'model' / 'teacher'
+    (DINO releases), with DataParallel / wrapper prefixes on the keys."""
+    for key in ("state_dict", "model", "teacher", "state_dict_ema", "model_ema"):
+        if isinstance(ckpt, dict) and key in ckpt and isinstance(ckpt[key], dict):
+            ckpt = ckpt[key]
+            break
+    out = {}
+    for k, v in ckpt.items():
+        for p in prefixes:
+            while k.startswith(p):
+                k = k[len(p):]
+        out[k] = v
+    return out
+
+
+def load_backbone_weights(module, state_dict, what, ignore_unexpected=("head.", "fc_norm.", "pre_logits.")):
+    """load_state_dict that FAILS when a backbone parameter is missing (strict=False hid empty loads) and reports keys the
+    checkpoint has but the backbone does not (classifier heads are expected extras)."""
+    res = module.load_state_dict(state_dict, strict=False)
+    if res.missing_keys:
+        raise RuntimeError(f"{what}: checkpoint lacks {len(res.missing_keys)} backbone tensors, e.g. {res.missing_keys[:4]} "
+                           f"(keys in the file look like {list(state_dict)[:3]})")
+    extra = [k for k in res.unexpected_keys if not k.startswith(tuple(ignore_unexpected))]
+    if extra:
+        warnings.warn(f"{what}: {len(extra)} checkpoint tensors have no counterpart in the backbone, e.g. {extra[:4]}")
+    return res
+
+
 class Model(torch.nn.Module):
     def __init__(self, device, rgb_backbone_name='vit_base_patch8_224_dino', out_indices=None, checkpoint_path='',
-                 pool_last=False, xyz_backbone_name='Point_MAE', group_size=128, num_group=1024):
+                 pool_last=False, xyz_backbone_name='Point_MAE', group_size=128, num_group=1024,
+                 xyz_checkpoint_path="checkpoints/pointmae_pretrain.pth"):
         super().__init__()
         self.device = device
         self.rgb_backbone_name = rgb_backbone_name
         if rgb_backbone_name not in ('vit_base_patch8_224_dino', 'vit_base_patch8_224', 'vit_base_patch8_224_in21k'):
             raise NotImplementedError(f"cmdiad_amd implements the ViT-B/8 backbones only (got {rgb_backbone_name})")
         self.rgb_backbone = VisionTransformer()
+        # timm downloads `pretrained=True` weights from the hub (models/models.py:23); offline the same state_dict comes from
+        # a file: the `checkpoint_path` argument (timm's own name for it) or CMDIAD_VIT_CHECKPOINT
+        checkpoint_path = checkpoint_path or os.environ.get("CMDIAD_VIT_CHECKPOINT", "")
         if checkpoint_path:
-            self.rgb_backbone.load_state_dict(torch.load(checkpoint_path, map_location='cpu'), strict=False)
-        else:
-            warnings.warn("no pretrained ViT weights offline: rgb_backbone keeps its seeded random init "
+            load_backbone_weights(self.rgb_backbone, unwrap_checkpoint(torch.load(checkpoint_path, map_location='cpu')),
+                                  f"ViT checkpoint {checkpoint_path}")
+        elif allow_random_init():
+            warnings.warn("CMDIAD_ALLOW_RANDOM_INIT=1: rgb_backbone keeps its seeded random init "
                           "(load a timm state_dict with rgb_backbone.load_state_dict)")
+        else:
+            raise RuntimeError("no ViT-B/8 weights: pass checkpoint_path= / set CMDIAD_VIT_CHECKPOINT to a timm "
+                               f"{rgb_backbone_name} state_dict, or opt in to random weights with CMDIAD_ALLOW_RANDOM_INIT=1")
         if xyz_backbone_name != 'Point_MAE':
             raise NotImplementedError("cmdiad_amd implements the Point_MAE xyz backbone only")
         self.xyz_backbone = PointTransformer(group_size=group_size, num_group=num_group)
-        self.xyz_backbone.load_model_from_ckpt("checkpoints/pointmae_pretrain.pth")
+        self.xyz_backbone.load_model_from_ckpt(os.environ.get("CMDIAD_POINTMAE_CHECKPOINT", xyz_checkpoint_path))
         self._vit_packed = None
 
     def _vit(self):
@@ -198,7 +243,10 @@ class PointTransformer(torch.nn.Module):
         if bert_ckpt_path is None:
             return
         if not os.path.exists(bert_ckpt_path):
-            warnings.warn(f"{bert_ckpt_path} not found: Point-MAE keeps its seeded random init")
+            if not allow_random_init():  # the reference fails here too (torch.load, models/models.py:285)
+                raise FileNotFoundError(f"{bert_ckpt_path} not found: place the Point-MAE pretrain checkpoint there, set "
+                                        "CMDIAD_POINTMAE_CHECKPOINT, or opt in to random weights with CMDIAD_ALLOW_RANDOM_INIT=1")
+            warnings.warn(f"{bert_ckpt_path} not found and CMDIAD_ALLOW_RANDOM_INIT=1: Point-MAE keeps its seeded random init")
             return
         ckpt = torch.load(bert_ckpt_path, map_location='cpu')
         base = {k.replace("module.", ""): v for k, v in ckpt['base_model'].items()}
@@ -207,7 +255,9 @@ class PointTransformer(torch.nn.Module):
                 base[k[len('MAE_encoder.'):]] = base.pop(k)
             elif k.startswith('base_model'):
                 base[k[len('base_model.'):]] = base.pop(k)
-        self.load_state_dict(base, strict=False)
+        # the pretrain checkpoint also carries the MAE decoder / mask token, which the extractor does not have
+        load_backbone_weights(self, base, f"Point-MAE checkpoint {bert_ckpt_path}",
+                              ignore_unexpected=("MAE_decoder", "mask_token", "decoder_pos_embed", "increase_dim", "cls_"))
 
     def packed(self):
         ver = _param_version(self)

@@ -328,19 +328,41 @@ def l2_rescore(q32, bank32, keys, min_val=None, min_idx=None, row_offset=0):
     return min_val, min_idx
 
 
-def reweight_scan(probes, bank32, top3=None, row_offset=0):
-    """probes [R,D] f32 -> top3 [R,3] packed keys (int64 view of u64).  One pass over the bank per 32 probes."""
+def bank_block16(bank32):
+    """[Nb,D] f32 -> the library copy laid out for the fp32 matrix cores (cmdiad_bank_block16), a flat f32 tensor."""
+    _chk(bank32, torch.float32, "bank_block16.bank")
+    Nb, D = bank32.shape
+    out = torch.empty((int(nat.lib().cmdiad_bank_block16_floats(Nb, D)),), dtype=torch.float32, device=bank32.device)
+    _call("cmdiad_bank_block16", _p(bank32), Nb, D, _p(out), _stream())
+    return out
+
+
+def reweight_scan(probes, bank32, blk16=None, top3=None, row_offset=0):
+    """probes [R,D] f32 -> top3 [R,3] packed keys (int64 view of u64; exact fp32 d2).  One pass over the library per 32
+    probes.  blk16: ops.bank_block16(bank32) (built on the fly when absent -- engine.Bank keeps one)."""
+    _chk(probes, torch.float32, "reweight.probes"); _chk(bank32, torch.float32, "reweight.bank")
     R, D = probes.shape
     Nb = bank32.shape[0]
+    if blk16 is None:
+        blk16 = bank_block16(bank32)
     if top3 is None:
-        top3 = torch.full((R, 3), -1, dtype=torch.int64, device=probes.device)
+        top3 = torch.full((R, 3), KEY_EMPTY, dtype=torch.int64, device=probes.device)
     for lo in range(0, R, 32):
         r = min(32, R - lo)
         wsb = nat.lib().cmdiad_reweight_workspace_bytes(r, Nb)
         ws = torch.empty(max(wsb // 8, 1), dtype=torch.int64, device=probes.device)
-        _call("cmdiad_reweight_scan", _p(probes[lo:lo + r]), _p(bank32), r, Nb, D, row_offset, _p(top3[lo:lo + r]), _p(ws),
-              wsb, _stream())
+        _call("cmdiad_reweight_scan", _p(probes[lo:lo + r]), _p(bank32), _p(blk16), r, Nb, D, row_offset, _p(top3[lo:lo + r]),
+              _p(ws), wsb, _stream())
     return top3
+
+
+def l2_dist_matrix(q32, bank32):
+    """Exact fp32 [Q,Nb] matrix of L2 distances (features.py:186-190 materialised; API compatibility only)."""
+    _chk(q32, torch.float32, "dist_matrix.q"); _chk(bank32, torch.float32, "dist_matrix.bank")
+    Q, D = q32.shape
+    out = torch.empty((Q, bank32.shape[0]), dtype=torch.float32, device=q32.device)
+    _call("cmdiad_l2_dist_matrix", _p(q32), _p(bank32), Q, bank32.shape[0], D, _p(out), _stream())
+    return out
 
 
 def unpack_keys(keys):

@@ -56,9 +56,37 @@ def trapezoid(x, y, x_max=None):
     return float(np.sum(0.5 * (y[1:] + y[:-1]) * (x[1:] - x[:-1])))
 
 
+def _pro_curve_sampled(gts, predictions, num_thresholds):
+    """The reference's sampling of the curve (utils/au_pro_util.py:156-201): ``num_thresholds`` thresholds taken at
+    equidistant RANKS of the sorted defect-free scores; at threshold s a pixel is flagged when its score is > s, so
+    FPR = 1 - (rank + 1) / n_ok and a component's overlap = the fraction of its scores > s; the point (1, 1) closes the
+    curve.  Vectorised with searchsorted instead of the reference's per-component cursor."""
+    structure = np.ones((3, 3), dtype=int)
+    ok, comps = [], []
+    for gt, pred in zip(gts, predictions):
+        gt = np.asarray(gt)
+        pred = np.asarray(pred, dtype=np.float64)
+        labeled, n = label(gt, structure)
+        ok.append(pred[labeled == 0])
+        comps.extend(np.sort(pred[labeled == c]) for c in range(1, n + 1))
+    ok = np.sort(np.concatenate(ok))
+    pos = np.linspace(0, len(ok) - 1, num=num_thresholds, dtype=int)
+    thr = ok[pos]
+    fpr = 1.0 - (pos + 1) / len(ok)
+    pro = np.zeros(len(thr))
+    for sc in comps:
+        pro += 1.0 - np.searchsorted(sc, thr, side="right") / len(sc)
+    pro /= max(len(comps), 1)
+    return np.concatenate([fpr[::-1], [1.0]]), np.concatenate([pro[::-1], [1.0]])
+
+
 def calculate_au_pro(gts, predictions, integration_limit=0.3, num_thresholds=100):
-    """-> (au_pro normalised to [0,1], (fpr, pro) curve).  ``num_thresholds`` is accepted for signature
-    compatibility; the curve is exact (one point per distinct score) rather than sampled."""
-    fpr, pro = _pro_curve(gts, predictions)
+    """-> (au_pro normalised to [0,1], (fpr, pro) curve).  With ``num_thresholds`` (default 100, as the reference calls it,
+    features.py:323-324) the curve is sampled exactly as the reference samples it, so AU-PRO / AU-PRO@1% are directly
+    comparable with reference numbers; ``num_thresholds=None`` integrates the exact curve (one point per distinct score)."""
+    if num_thresholds is None:
+        fpr, pro = _pro_curve(gts, predictions)
+    else:
+        fpr, pro = _pro_curve_sampled(gts, predictions, int(num_thresholds))
     au = trapezoid(fpr, pro, x_max=integration_limit) / integration_limit
     return au, (fpr, pro)

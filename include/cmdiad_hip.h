@@ -247,14 +247,28 @@ int cmdiad_l2_min_keys(const uint16_t* q, const float* q_sqnorm, const uint16_t*
 int cmdiad_l2_rescore(const float* q, const float* bank, const unsigned long long* keys, int Q, int Nb,
                       int D, uint32_t row_offset, float* min_val, int64_t* min_idx, cmdiad_stream_t stream);
 
-/* Re-weighting scan (features.py:235-254): for each of R probe rows (m_star), exact fp32 squared L2
- * distance to every bank row; the 3 smallest as packed keys (d2 bits << 32 | global row) are merged
- * into top3 [R,3] u64, which the caller initialises to UINT64_MAX (shards call it in turn or
- * all-gather their top3).  probes [R,D] f32, bank [Nb,D] f32. */
+/* Library copy laid out for the fp32 matrix cores ("block16"): groups of 16 rows,
+ * out[(((g * D/16 + t) * 4 + kq) * 16 + j) * 4 + e] = bank[16 g + j][16 t + 4 kq + e] (zero beyond Nb),
+ * cmdiad_bank_block16_floats(Nb, D) = ceil(Nb/16) * 16 * D floats.  Built once per library; the re-weighting scan
+ * streams it with fully coalesced 1 KiB loads straight into MFMA B operands. */
+size_t cmdiad_bank_block16_floats(int Nb, int D);
+int cmdiad_bank_block16(const float* bank, int Nb, int D, float* out, cmdiad_stream_t stream);
+
+/* Re-weighting scan (features.py:235-254: torch.cdist(m_star, bank) + topk(3, largest=False)): for each of R <= 32
+ * probe rows (m_star) the 3 nearest library rows as packed keys (EXACT fp32 squared distance bits << 32 | global row),
+ * merged into top3 [R,3] u64, which the caller initialises to UINT64_MAX or 0x7FFF...F (shards call it in turn or
+ * all-gather their top3).  One pass over bank_block16 for all probes (v_mfma_f32_16x16x4_f32 cross term, 4 approximate
+ * candidates per probe), then the candidates are re-evaluated exactly on the row-major library.
+ * probes [R,D] f32, bank [Nb,D] f32 row-major, bank_block16 from cmdiad_bank_block16; D % 128 == 0. */
 size_t cmdiad_reweight_workspace_bytes(int R, int Nb);
-int cmdiad_reweight_scan(const float* probes, const float* bank, int R, int Nb, int D, uint32_t row_offset,
-                         unsigned long long* top3, void* workspace, size_t workspace_bytes,
+int cmdiad_reweight_scan(const float* probes, const float* bank, const float* bank_block16, int R, int Nb, int D,
+                         uint32_t row_offset, unsigned long long* top3, void* workspace, size_t workspace_bytes,
                          cmdiad_stream_t stream);
+
+/* calculate_dist (features.py:186-190) as a MATERIALISED matrix, exact fp32 (sum of squared differences):
+ * out[q][n] = || Q[q] - bank[n] ||_2, [Q, Nb] row-major.  API compatibility of DistHandle.materialize() only: the
+ * scoring path never builds the Q x Nb matrix (960 MB per image at the reference's sizes). */
+int cmdiad_l2_dist_matrix(const float* q, const float* bank, int Q, int Nb, int D, float* out, cmdiad_stream_t stream);
 
 /* compute_single_s_s_map head / tail (features.py:227-290), batched over B images.
  * head: s_idx[b] = argmax_q min_val[b][q] (first occurrence), s_star[b] = the max; copies

@@ -7,6 +7,8 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 GOLDEN = os.path.join(REPO, "tests", "golden")
+# every test loads seeded synthetic weights after construction (no checkpoints offline): explicit opt-in, see models.Model
+os.environ.setdefault("CMDIAD_ALLOW_RANDOM_INIT", "1")
 
 
 def pytest_configure(config):

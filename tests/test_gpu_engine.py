@@ -283,3 +283,108 @@ def test_other_method_classes_run_the_protocol(weights):
         m.calculate_metrics()
         assert np.isfinite([m.image_rocauc, m.pixel_rocauc, m.au_pro]).all(), cls.__name__
         assert m.predictions[0].shape == (224, 224)
+
+
+def test_public_features_contract(weights):
+    """the PUBLIC surface the reference's callers use -- Features.__call__(rgb, xyz_unorganized) for all
+    three out_types (features.py:123-158), get_xyz_patch with CALLER-supplied nonzero_indices (:169-184),
+    LazyInterpolated.materialize() against interpolating_points (pointnet2_utils.py:45-75), Model.forward
+    (models.py:55-67), calculate_dist -> DistHandle.materialize() / .min(1) (features.py:186-190, 227)."""
+    import warnings
+    from cmdiad_amd.feature_extractors.features import DistHandle, LazyInterpolated
+    from cmdiad_amd.feature_extractors.multiple_features import DoubleRGBPointFeatures, organized_pc_to_unorganized_pc_no_zeros
+    from oracle import scoring
+    sd_vit, sd_pm = weights
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = DoubleRGBPointFeatures(make_args())
+    m.deep_feature_extractor.rgb_backbone.load_state_dict(sd_vit)
+    m.deep_feature_extractor.xyz_backbone.load_state_dict(sd_pm)
+    rgb, pc = synth_sample(60)
+    sample = (rgb, pc, pc)
+    xyz, nz = organized_pc_to_unorganized_pc_no_zeros(sample)
+    ref_pc, ref_nz = scoring.unorganize_no_zeros(pc)
+    assert torch.equal(xyz, ref_pc) and np.array_equal(nz, ref_nz)
+    cpu = CpuExtractor(sd_vit, sd_pm)
+    ref_rgb_patch, ref_xyz_patch = cpu(rgb, pc)
+
+    # ---- out_type = "rgb+xyz": the reference's 6-tuple, feature maps on the CPU
+    rgb_maps, xyz_maps, center, ori_idx, center_idx, interp = m(rgb, xyz.contiguous())
+    assert isinstance(rgb_maps, list) and rgb_maps[0].device.type == "cpu" and tuple(rgb_maps[0].shape) == (1, 768, 28, 28)
+    assert isinstance(xyz_maps, list) and xyz_maps[0].device.type == "cpu" and tuple(xyz_maps[0].shape) == (1, 768, 1024)
+    assert tuple(center.shape) == (1, 1024, 3) and tuple(ori_idx.shape) == (1, 1024, 128) and tuple(center_idx.shape) == (1, 1024)
+    assert isinstance(interp, LazyInterpolated) and tuple(interp.shape) == (1, 768, xyz.shape[2])
+    # FPS / kNN indices are bit-exact against the oracle
+    from oracle import kernels as ok
+    pts = np.ascontiguousarray(xyz[0].T.numpy())[None]
+    ridx, rcen = ok.fps(pts, 1024)
+    assert np.array_equal(center_idx.cpu().numpy(), ridx) and np.array_equal(center.cpu().numpy(), rcen)
+    rk, _ = ok.knn_group(pts, rcen, 128)
+    assert np.array_equal(ori_idx.cpu().numpy(), rk)
+    # feature maps vs the fp32 oracle (bf16 network tolerance)
+    mr, xr = _rel(rgb_maps[0].reshape(768, -1).T, ref_rgb_patch)
+    assert mr < 0.02 and xr < 0.2, (mr, xr)
+    # LazyInterpolated.materialize() == interpolating_points on the SAME (GPU) centre features
+    full = interp.materialize().cpu()
+    want = scoring.interpolating_points(xyz, center.cpu().permute(0, 2, 1), xyz_maps[0])
+    err = (full - want).abs()
+    # (-2ab + a^2 + b^2 cancels for the ~4 % of points that ARE centres: their weights depend on the summation order)
+    assert err.mean() < 2e-3 * want.abs().mean() + 1e-4 and (err > 0.05 * want.abs().mean()).float().mean() < 0.06
+    assert torch.equal(interp.to("cpu"), full)
+    # get_xyz_patch with the caller's nonzero_indices (no pix2pt from a device-side unorganise on this path)
+    assert interp.ex.pix2pt is None
+    xp = m.get_xyz_patch(xyz_maps, interp, nz)
+    assert tuple(xp.shape) == (3136, 768)
+    mx, xx = _rel(xp.cpu(), ref_xyz_patch)
+    assert mx < 0.03 and xx < 0.3, (mx, xx)
+    xp28 = m.get_xyz_patch(xyz_maps, interp, nz, get_2828=True)
+    ref28 = scoring.get_xyz_patch(want, nz, out=28)
+    assert tuple(xp28.shape) == (784, 768)
+    assert _rel(xp28.cpu(), ref28)[0] < 0.03
+    # the method classes' private device path gives the same patches
+    ex = m._extract_device(rgb, pc)
+    torch.testing.assert_close(m._engine.xyz_patch(ex)[0], xp, rtol=1e-5, atol=1e-5)
+    rp, rp2 = m.get_rgb_patch(rgb_maps)
+    assert tuple(rp.shape) == (784, 768) and tuple(rp2.shape) == (3136, 768)
+    torch.testing.assert_close(rp, m._engine.rgb_patch(ex)[0], rtol=1e-5, atol=1e-5)
+    # get_rgb_patch on a plain CPU tensor list (no device handle attached), as a caller that re-built the list would pass
+    rp_plain, rp2_plain = m.get_rgb_patch([rgb_maps[0].clone()])
+    torch.testing.assert_close(rp_plain, rp, rtol=0, atol=0)
+    ref_p, ref_p2 = scoring.get_rgb_patch(rgb_maps[0])
+    torch.testing.assert_close(rp2_plain.cpu(), ref_p2, rtol=0, atol=0)
+
+    # ---- out_type = "rgb" and "xyz"
+    only_rgb = m(rgb=rgb, out_type="rgb")
+    assert isinstance(only_rgb, list) and torch.equal(only_rgb[0], rgb_maps[0])
+    xyz_maps2, center2, ori2, cidx2, interp2 = m(xyz=xyz.contiguous(), out_type="xyz")
+    assert torch.equal(xyz_maps2[0], xyz_maps[0]) and torch.equal(center2, center) and torch.equal(ori2, ori_idx)
+    assert torch.equal(cidx2, center_idx) and isinstance(interp2, LazyInterpolated)
+
+    # ---- Model.forward (models.py:55-67): device tensors in the reference's layouts
+    dfe = m.deep_feature_extractor
+    f_rgb, f_xyz, c3, o3, ci3 = dfe(rgb.cuda(), xyz.cuda().contiguous())
+    assert tuple(f_rgb.shape) == (1, 768, 28, 28) and tuple(f_xyz.shape) == (1, 768, 1024)
+    assert torch.equal(f_rgb.cpu(), rgb_maps[0]) and torch.equal(f_xyz.cpu(), xyz_maps[0]) and torch.equal(ci3, center_idx)
+    assert torch.equal(dfe(rgb=rgb.cuda(), out_type="rgb").cpu(), rgb_maps[0])
+    assert torch.equal(dfe(xyz=xyz.cuda().contiguous(), out_type="xyz")[0].cpu(), xyz_maps[0])
+
+    # ---- calculate_dist: handle, exact materialisation, min without the matrix, and the library guard
+    lib = torch.randn(1500, 768, generator=torch.Generator().manual_seed(3)).cuda()
+    q = (rp - rp.mean()) / rp.std()
+    h = m.calculate_dist(q, lib)
+    assert isinstance(h, DistHandle) and tuple(h.shape) == (784, 1500)
+    dm = h.materialize()
+    ref_d = torch.cdist(q.double().cpu(), lib.double().cpu())
+    np.testing.assert_allclose(dm.cpu().numpy(), ref_d.numpy(), rtol=2e-6, atol=1e-5)
+    mv, mi = h.min(1)
+    rmv, rmi = ref_d.min(1)
+    assert (mi.cpu() == rmi).float().mean() > 0.995
+    np.testing.assert_allclose(mv.cpu().numpy(), rmv.numpy(), rtol=2e-3)
+    m.patch_rgb_lib = lib
+    s, s_map = m.compute_single_s_s_map(q, h, (28, 28), modal="rgb")
+    ref = scoring.single_s_s_map(q.cpu(), ref_d.float(), lib.cpu(), (28, 28))
+    np.testing.assert_allclose(float(s), float(ref["s"]), rtol=1e-3)
+    assert tuple(s_map.shape) == (1, 224, 224) and np.abs(s_map.numpy() - ref["s_map"].numpy()).max() <= float(ref["s_map"].max()) / 255 * 1.01
+    m.patch_xyz_lib = torch.randn(10, 768).cuda()
+    with pytest.raises(ValueError, match="different library"):
+        m.compute_single_s_s_map(q, h, (28, 28), modal="xyz")

@@ -342,16 +342,82 @@ def test_l2_min_all_tiles_identical_keys(tile, dt, monkeypatch):
     assert (mi.cpu() == ref_i).float().mean() > 0.97
 
 
+def _exact_top3(probes, bank):
+    d = torch.cdist(probes.double(), bank.double())
+    return torch.topk(d, min(3, bank.shape[0]), largest=False)
+
+
 def test_reweight_scan_top3():
     g = torch.Generator().manual_seed(3)
     bank = torch.randn(4000, 768, generator=g)
     probes = bank[[5, 1234, 3999]].clone()
     top3 = ops.reweight_scan(probes.to(DEV), bank.to(DEV))
     val, idx = ops.unpack_keys(top3)
-    d = torch.cdist(probes.double(), bank.double())
-    rv, ri = torch.topk(d, 3, largest=False)
+    rv, ri = _exact_top3(probes, bank)
     np.testing.assert_array_equal(idx.cpu().numpy(), ri.numpy())
     np.testing.assert_allclose(val.sqrt().cpu().numpy(), rv.numpy(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("Nb,D,R", [(4001, 768, 32), (16, 768, 1), (37, 256, 5), (20000, 768, 32), (5, 128, 2)])
+def test_reweight_scan_shapes_and_block16_layout(Nb, D, R):
+    """cmdiad_reweight_scan (fp32 MFMA scan over the block16 copy + exact re-evaluation of 4 candidates) against an exact
+    float64 top-3: ragged library sizes (Nb % 16 != 0, Nb < 16), every probe count class, several feature widths; probes
+    are library rows (distance 0 to themselves, as m_star always is, features.py:233) and unseen rows."""
+    g = torch.Generator().manual_seed(Nb + R)
+    bank = torch.randn(Nb, D, generator=g)
+    probes = torch.cat([bank[torch.randint(0, Nb, (R - R // 2,), generator=g)], torch.randn(R // 2, D, generator=g)])
+    blk = ops.bank_block16(bank.to(DEV))
+    # layout: [group][t][kq][row j][4] with k = 16 t + 4 kq + e
+    T, G = D // 16, (Nb + 15) // 16
+    padded = torch.zeros(G * 16, D)
+    padded[:Nb] = bank
+    want = padded.view(G, 16, T, 4, 4).permute(0, 2, 3, 1, 4).reshape(-1)
+    assert torch.equal(blk.cpu(), want)
+    top3 = ops.reweight_scan(probes.to(DEV), bank.to(DEV), blk)
+    val, idx = ops.unpack_keys(top3)
+    rv, ri = _exact_top3(probes, bank)
+    k = ri.shape[1]
+    np.testing.assert_array_equal(idx[:, :k].cpu().numpy(), ri.numpy())
+    np.testing.assert_allclose(val[:, :k].sqrt().cpu().numpy(), rv.numpy(), rtol=1e-5, atol=1e-5)
+    if k < 3:
+        assert (top3[:, k:] == ops.KEY_EMPTY).all()
+
+
+def test_reweight_scan_duplicates_near_ties_and_shards():
+    """Exact duplicates of the probe row (all-zero background patches are exact duplicates in real libraries) resolve to
+    the LOWEST rows like torch.topk on the exact matrix; rows closer together than the scan's approximation error are
+    still ordered by their exact distances; two row shards called in turn give the single-call result."""
+    g = torch.Generator().manual_seed(11)
+    bank = torch.randn(6000, 768, generator=g)
+    bank[[100, 2500, 2501, 5999, 17]] = bank[4000]              # six copies of one row
+    near = bank[3000].clone()
+    bank[3001] = near + 3e-4 * torch.randn(768, generator=g)     # d2 ~ 7e-5, far below the fp32 expansion's error on |b|^2 ~ 768
+    bank[3002] = near + 6e-4 * torch.randn(768, generator=g)
+    bank[3003] = near + 9e-4 * torch.randn(768, generator=g)
+    probes = torch.stack([bank[4000], bank[3000], torch.zeros(768)])
+    bank[50:60] = 0.0                                             # duplicate all-zero rows, probe 2 equals them
+    top3 = ops.reweight_scan(probes.to(DEV), bank.to(DEV))
+    val, idx = ops.unpack_keys(top3)
+    assert idx[0].tolist() == [17, 100, 2500] and float(val[0].max()) == 0.0
+    assert idx[1].tolist() == [3000, 3001, 3002]
+    assert idx[2].tolist() == [50, 51, 52] and float(val[2].max()) == 0.0
+    rv, _ = _exact_top3(probes, bank)
+    np.testing.assert_allclose(val.sqrt().cpu().numpy(), rv.numpy(), rtol=1e-4, atol=1e-6)
+    # shards in turn (SURVEY 8e): rows [0, 2560) then [2560, 6000)
+    b = bank.to(DEV)
+    t2 = ops.reweight_scan(probes.to(DEV), b[:2560].contiguous())
+    t2 = ops.reweight_scan(probes.to(DEV), b[2560:].contiguous(), top3=t2, row_offset=2560)
+    assert torch.equal(t2, top3)
+
+
+def test_l2_dist_matrix_exact():
+    g = torch.Generator().manual_seed(12)
+    q, bank = torch.randn(130, 768, generator=g), torch.randn(333, 768, generator=g)
+    q[7] = bank[21]
+    d = ops.l2_dist_matrix(q.to(DEV), bank.to(DEV)).cpu()
+    ref = torch.cdist(q.double(), bank.double())
+    assert float(d[7, 21]) == 0.0
+    np.testing.assert_allclose(d.numpy(), ref.numpy(), rtol=2e-6, atol=1e-6)
 
 
 # ------------------------------------------------------------------------------------------ small ops

@@ -1,0 +1,254 @@
+"""GPU: the batched predict of the package (cmdiad_amd.predictor.BatchPredictor = engine.predict_batch, what bench.py times)
+and the single-library / MTFI drop-in classes, end to end against the CPU oracle pipelines (oracle/pipeline.py, pinned to
+the reference's own classes by goldens G6 / G11) and against the reference's outputs themselves (G11).
+
+The synthetic class uses oracle.nets.sharpen_pointmae weights: with them the xyz patch-to-patch distances are ~4 (ten
+times the bf16 feature error), so BOTH modalities are checked relatively -- round 1's smooth-surface class left the xyz
+column inside the bf16 noise."""
+import types
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from cmdiad_amd import engine as eng  # noqa: E402
+from cmdiad_amd import runtime  # noqa: E402
+from cmdiad_amd.predictor import BatchPredictor  # noqa: E402
+from cmdiad_amd.synth import synth_cloud, synth_rgb  # noqa: E402
+from oracle import nets, pipeline  # noqa: E402
+
+DEV = "cuda"
+
+
+def make_args(**kw):
+    a = dict(rgb_backbone_name='vit_base_patch8_224_dino', xyz_backbone_name='Point_MAE', group_size=128, num_group=1024,
+             rgb_size=224, xyz_size=224, gt_size=224, f_coreset=1.0, coreset_eps=0.9, coreset_dtype='FP16',
+             random_state=None, dist_method_s='l2', dist_method_coreset='l2', main_modality='', use_hn=False,
+             fusion_module_path='', ocsvm_nu=0.5, ocsvm_maxiter=1000, xyz_s_lambda=1.0, xyz_smap_lambda=1.0,
+             rgb_s_lambda=0.1, rgb_smap_lambda=0.1, fusion_s_lambda=1.0, fusion_smap_lambda=1.0,
+             save_feature_for_fusion=False, save_seg_results=False, use_depth=False)
+    a.update(kw)
+    return types.SimpleNamespace(**a)
+
+
+def synth_sample(i, anomalous=False, frac=None):
+    pc = synth_cloud(500 + i, frac or (0.40 + 0.03 * (i % 4)), texture=0.004)
+    rgb = synth_rgb(500 + i)
+    mask = torch.zeros(1, 224, 224)
+    if anomalous:
+        y0, x0 = 70 + 9 * (i % 7), 80 + 7 * (i % 5)
+        pc[0, 2, y0:y0 + 20, x0:x0 + 20] -= 0.005 * (pc[0, 2, y0:y0 + 20, x0:x0 + 20] != 0)  # 5 mm dent
+        rgb[0, :, y0:y0 + 20, x0:x0 + 20] += 2.0
+        mask[0, y0:y0 + 20, x0:x0 + 20] = 1
+    return rgb, pc, mask
+
+
+@pytest.fixture(scope="module")
+def weights():
+    return (nets.synth_state_dict("vit", 31), nets.sharpen_pointmae(nets.synth_state_dict("pointmae", 21)),
+            nets.synth_state_dict("halluc", 51))
+
+
+@pytest.fixture(scope="module")
+def cpu_ex(weights):
+    return pipeline.CpuExtractor(weights[0], weights[1])
+
+
+@pytest.fixture(scope="module")
+def gpu_engine(weights):
+    return eng.Engine(runtime.PackedViT(weights[0], device=DEV), runtime.PackedPointMAE(weights[1], device=DEV))
+
+
+def _fit_svms(rows_s, rows_map):
+    from sklearn import linear_model
+    det = linear_model.SGDOneClassSVM(random_state=42, nu=0.5, max_iter=1000).fit(torch.cat(rows_s, 0).numpy())
+    seg = linear_model.SGDOneClassSVM(random_state=42, nu=0.5, max_iter=1000).fit(torch.cat(rows_map, 0)[::7].numpy())
+    return det, seg
+
+
+def _auroc_pair(labels, got, ref):
+    from sklearn.metrics import roc_auc_score
+    return roc_auc_score(labels, got), roc_auc_score(labels, ref)
+
+
+def test_feature_error_is_far_below_the_patch_distances(weights, cpu_ex, gpu_engine):
+    """The premise of this file: on the sharpened synthetic class the GPU (bf16) xyz patch features differ from the fp32
+    oracle's by much less than the distance between different patches."""
+    rgb, pc, _ = synth_sample(0)
+    rp, xp = cpu_ex(rgb, pc)
+    ex = gpu_engine.extract(rgb.to(DEV), pc.to(DEV))
+    gx = gpu_engine.xyz_patch(ex)[0].cpu()
+    gr = gpu_engine.rgb_patch(ex)[0].cpu()
+    fg = xp.abs().sum(1) > 0
+    err_x = (gx - xp)[fg].norm(dim=1)
+    err_r = (gr - rp).norm(dim=1)
+    nn_x = torch.cdist(xp[fg][::4], xp[fg]).topk(2, largest=False).values[:, 1]
+    nn_r = torch.cdist(rp, rp).topk(2, largest=False).values[:, 1]
+    print(f"xyz: |err| mean {err_x.mean():.3f} max {err_x.max():.3f}; nn dist mean {nn_x.mean():.3f}; "
+          f"rgb: |err| mean {err_r.mean():.3f}; nn dist mean {nn_r.mean():.3f}")
+    assert err_x.mean() < 0.15 * nn_x.mean() and err_r.mean() < 0.15 * nn_r.mean()
+
+
+def test_predict_batch_b32_vs_oracle(weights, cpu_ex, gpu_engine):
+    """B = 32 through BatchPredictor (HIP graphs, both buffer sets, and the eager path) against
+    oracle.pipeline.CpuDoubleRGBPoint.predict sample by sample: image score, blurred pixel map, and I-/P-AUROC over the 32
+    samples (10 anomalous)."""
+    cpu = pipeline.CpuDoubleRGBPoint(cpu_ex)
+    train = [synth_sample(100 + i)[:2] for i in range(4)]
+    cpu.fit(train)
+    # late-fusion models from the oracle's scores of 3 further normal samples (shared by both sides: only coef_/offset_ matter)
+    rows = [cpu.predict(*synth_sample(200 + i)[:2])[:2] for i in range(3)]
+    det, seg = _fit_svms([r[0] for r in rows], [r[1] for r in rows])
+    B = 32
+    samples = [synth_sample(i, anomalous=(i % 3 == 0 and i < 30)) for i in range(B)]
+    labels = np.array([int(s[2].any()) for s in samples])
+    assert labels.sum() == 10
+    ref_img, ref_pix = [], []
+    for rgb, pc, _ in samples:
+        s, s_map, _, _ = cpu.predict(rgb, pc)
+        ref_img.append(float(det.score_samples(s.numpy())[0]))
+        ref_pix.append(seg.score_samples(s_map.numpy()).reshape(224, 224))
+    ref_img, ref_pix = np.array(ref_img), np.stack(ref_pix)
+
+    bank_xyz, bank_rgb = eng.Bank(cpu.xyz_lib.to(DEV)), eng.Bank(cpu.rgb_lib.to(DEV))
+    stats = dict(xyz_mean=float(cpu.xyz_mean), xyz_std=float(cpu.xyz_std), rgb_mean=float(cpu.rgb_mean), rgb_std=float(cpu.rgb_std))
+    rgb = torch.cat([s[0] for s in samples]).to(DEV)
+    pcs = torch.cat([s[1] for s in samples]).to(DEV)
+    outs = {}
+    for mode in ("graph", "eager"):
+        p = BatchPredictor(gpu_engine, bank_xyz, bank_rgb, stats, det, seg, lambdas=(1.0, 1.0, 0.1, 0.1), batch=B,
+                           use_graph=(mode == "graph"))
+        first = p.predict_batch(rgb, pcs)
+        second = p.predict_batch(rgb.cpu().pin_memory(), pcs.cpu().pin_memory())   # other buffer set, host-fed
+        assert mode != "graph" or p.use_graph, "HIP graph capture failed"
+        assert np.array_equal(first[0], second[0]) and np.array_equal(first[1], second[1])
+        outs[mode] = first
+    assert np.array_equal(outs["graph"][0], outs["eager"][0]) and np.array_equal(outs["graph"][1], outs["eager"][1])
+    img, pix = outs["graph"]
+    assert img.shape == (B,) and pix.shape == (B, 224, 224) and img.dtype == np.float64
+
+    spread = float(ref_img.max() - ref_img.min())
+    d_img = np.abs(img - ref_img)
+    d_pix = np.abs(pix - ref_pix).reshape(B, -1)
+    print(f"image score: max |d| {d_img.max():.4f} of spread {spread:.4f}; pixel map: max |d| {d_pix.max():.5f}, "
+          f"mean {d_pix.mean():.6f}, map range {np.ptp(ref_pix):.4f}")
+    assert d_img.max() <= 0.03 * spread + 1e-6, (d_img.max(), spread)
+    assert d_pix.mean() <= 0.01 * np.ptp(ref_pix) and d_pix.max() <= 0.08 * np.ptp(ref_pix), (d_pix.mean(), d_pix.max(), np.ptp(ref_pix))
+    for b in range(B):
+        assert np.corrcoef(pix[b].ravel(), ref_pix[b].ravel())[0, 1] > 0.995, b
+    i_got, i_ref = _auroc_pair(labels, img, ref_img)
+    masks = np.stack([s[2].numpy().reshape(224, 224) for s in samples]).astype(int)
+    p_got, p_ref = _auroc_pair(masks.ravel(), pix.ravel(), ref_pix.ravel())
+    print(f"I-AUROC {i_got:.4f} (oracle {i_ref:.4f}); P-AUROC {p_got:.4f} (oracle {p_ref:.4f})")
+    assert abs(i_got - i_ref) <= 1e-2 and abs(p_got - p_ref) <= 1e-2
+
+    # per-sample result does not depend on the batch: the B = 1 drop-in composition gives the batch's numbers
+    p1 = BatchPredictor(gpu_engine, bank_xyz, bank_rgb, stats, det, seg, lambdas=(1.0, 1.0, 0.1, 0.1), batch=1, use_graph=False)
+    for b in (0, 13, 31):
+        i1, m1 = p1.predict_batch(rgb[b:b + 1], pcs[b:b + 1])
+        np.testing.assert_allclose(i1[0], img[b], rtol=1e-4, atol=1e-6)
+        assert np.abs(m1[0] - pix[b]).max() <= 2.5 * np.ptp(pix[b]) / 255.0 + 1e-9   # at most one 8-bit blur level per column
+
+
+def test_mtfi_batch_vs_oracle(weights, cpu_ex, gpu_engine):
+    """`--workload mtfi` (configs[4] per-GPU work): BatchPredictor with the hallucination network against
+    oracle.pipeline.CpuOneHallucination(main xyz).predict -- [xyz, hallucinated-rgb] columns, cross-wired statistics."""
+    cpu = pipeline.CpuOneHallucination(cpu_ex, weights[2], "xyz", lambdas=(1.0, 1.0, 1.0, 1.0))
+    cpu.fit([synth_sample(100 + i)[:2] for i in range(4)])
+    rows = [cpu.predict(*synth_sample(200 + i)[:2])[:2] for i in range(2)]
+    det, seg = _fit_svms([r[0] for r in rows], [r[1] for r in rows])
+    B = 8
+    samples = [synth_sample(i, anomalous=(i % 2 == 0)) for i in range(B)]
+    ref_img, ref_pix = [], []
+    for rgb, pc, _ in samples:
+        s, s_map = cpu.predict(rgb, pc)[:2]
+        ref_img.append(float(det.score_samples(s.numpy())[0]))
+        ref_pix.append(seg.score_samples(s_map.numpy()).reshape(224, 224))
+    ref_img, ref_pix = np.array(ref_img), np.stack(ref_pix)
+    stats = dict(xyz_mean=float(cpu.mean), xyz_std=float(cpu.std), rgb_mean=float(cpu.mean), rgb_std=float(cpu.std))
+    p = BatchPredictor(gpu_engine, eng.Bank(cpu.main_lib.to(DEV)), eng.Bank(cpu.fus_lib.to(DEV)), stats, det, seg,
+                       lambdas=(1.0, 1.0, 1.0, 1.0), batch=B, workload="mtfi",
+                       halluc=runtime.PackedHallucination(weights[2], device=DEV))
+    pcs = torch.cat([s[1] for s in samples]).to(DEV)
+    img, pix = p.predict_batch(None, pcs)
+    img2, pix2 = p.predict_batch(None, pcs)
+    assert p.use_graph and np.array_equal(img, img2) and np.array_equal(pix, pix2)
+    spread = float(ref_img.max() - ref_img.min())
+    d_pix = np.abs(pix - ref_pix)
+    print(f"mtfi image score max |d| {np.abs(img - ref_img).max():.4f} of spread {spread:.4f}; pixel max |d| {d_pix.max():.5f} "
+          f"mean {d_pix.mean():.6f} of range {np.ptp(ref_pix):.4f}")
+    assert np.abs(img - ref_img).max() <= 0.05 * spread + 1e-6
+    assert d_pix.mean() <= 0.015 * np.ptp(ref_pix) and d_pix.max() <= 0.10 * np.ptp(ref_pix)
+
+
+@pytest.mark.parametrize("tag", ["rgb", "xyz", "mtfi_xyz", "mtfi_rgb"])
+def test_method_classes_vs_reference_golden(tag, golden, weights):
+    """The drop-in RGBFeatures / PointFeatures / RGBorXYZWithOneHallucination(main xyz | rgb) through the five-call protocol
+    against the outputs of the REFERENCE's own classes (golden G11, tests/golden/make_golden.py): statistics, normalised
+    libraries (with the reference's coreset picks injected -- the greedy selection itself is pinned by G9), late-fusion rows,
+    and the final image / pixel predictions under the reference's fitted one-class SVMs."""
+    from cmdiad_amd.feature_extractors import multiple_features as mf
+    from test_oracle_golden import g11_sample
+    g = golden("g11_methods.npz")
+    G = lambda k: g[f"{tag}/{k}"]  # noqa: E731
+    cls, kw = {"rgb": (mf.RGBFeatures, {}), "xyz": (mf.PointFeatures, {}),
+               "mtfi_xyz": (mf.RGBorXYZWithOneHallucination, dict(use_hn=True, main_modality="xyz")),
+               "mtfi_rgb": (mf.RGBorXYZWithOneHallucination, dict(use_hn=True, main_modality="rgb"))}[tag]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = cls(make_args(f_coreset=float(g["f_coreset"]), random_state=int(g["random_state"]), **kw))
+    m.deep_feature_extractor.rgb_backbone.load_state_dict(weights[0])
+    m.deep_feature_extractor.xyz_backbone.load_state_dict(weights[1])
+    if kw.get("use_hn"):
+        m.fusion.load_state_dict(weights[2])
+    sample = lambda sd, an=False: (lambda r, p: (r, p, p.clone()))(*g11_sample(g, sd, an))  # noqa: E731
+    for sd in g["train_seeds"]:
+        m.add_sample_to_mem_bank(sample(sd), class_name="synthetic")
+    picks = [torch.from_numpy(G(f"coreset_idx{k}").astype(np.int64)) for k in range(2) if f"{tag}/coreset_idx{k}" in g.files]
+    own = []
+    inner = m.get_coreset_idx_randomp
+    m.get_coreset_idx_randomp = lambda *a, **k: (own.append(inner(*a, **k)), picks[len(own) - 1])[1]
+    m.run_coreset()
+    for o, pk in zip(own, picks):  # the drop-in's own greedy selection on ITS (bf16) features: large overlap, chaotic in the last bit
+        assert len(set(o.tolist()) & set(pk.tolist())) > 0.6 * len(pk), tag
+    single = tag in ("rgb", "xyz")
+    main_mod = tag if single else tag.split("_")[1]
+    mean, std = getattr(m, f"{main_mod}_mean"), getattr(m, f"{main_mod}_std")
+    np.testing.assert_allclose([float(mean), float(std)], [G("mean"), G("std")], rtol=5e-3, atol=1e-4)
+    if not single:
+        assert float(m.xyz_mean) == float(m.rgb_mean) == float(m.fusion_mean) and float(m.xyz_std) == float(m.rgb_std) == float(m.fusion_std)
+    lib = getattr(m, f"patch_{main_mod}_lib")
+    step = 31 if main_mod == "rgb" else 97
+    assert lib.shape[0] == int(G("lib_rows"))
+    ref_sub = G("lib_sub")
+    err = np.abs(lib[::step, ::16].cpu().numpy() - ref_sub)
+    assert err.mean() < 0.02 * np.abs(ref_sub).mean() and err.max() < 0.25 * np.abs(ref_sub).mean() + 0.05, (tag, err.mean(), err.max())
+    if not single:
+        assert m.patch_fusion_lib.shape[0] == int(G("fusion_rows"))
+        ref_f = G("fusion_sub")
+        err = np.abs(m.patch_fusion_lib[::97, ::16].cpu().numpy() - ref_f)
+        assert err.mean() < 0.03 * np.abs(ref_f).mean() + 1e-3, (tag, err.mean())
+    for sd in g["train_seeds"]:
+        m.add_sample_to_late_fusion_mem_bank(sample(sd))
+    s_lib = torch.cat(m.s_lib, 0).numpy()
+    ref_s = G("s_lib")
+    print(tag, "s_lib", s_lib.tolist(), "ref", ref_s.tolist())
+    np.testing.assert_allclose(s_lib, ref_s, rtol=0.06, atol=0.02 * np.abs(ref_s).max())
+    m.run_late_fusion()
+    assert m.detect_fuser.coef_.shape == G("detect_coef").shape
+    # predictions under the REFERENCE's fitted models (an SGD fit on three rows flips with 1e-3 input changes)
+    m.detect_fuser.coef_, m.detect_fuser.offset_ = G("detect_coef"), G("detect_offset")
+    m.seg_fuser.coef_, m.seg_fuser.offset_ = G("seg_coef"), G("seg_offset")
+    for sd, an in zip(g["test_seeds"], g["test_anomalous"]):
+        m.predict(sample(sd, bool(an)), torch.zeros(1, 224, 224), np.array([int(an)]), ["x.png"])
+    got = np.concatenate(m.image_preds).ravel()
+    ref = G("image_preds")
+    maps = np.stack(m.predictions)[:, ::4, ::4]
+    ref_maps = G("pred_maps_sub")
+    print(tag, "image_preds", got, "ref", ref, "map max |d|", np.abs(maps - ref_maps).max(), "range", np.ptp(ref_maps))
+    np.testing.assert_allclose(got, ref, rtol=0.05, atol=0.02 * np.abs(ref).max())
+    assert np.abs(maps - ref_maps).mean() <= 0.015 * np.ptp(ref_maps) and np.abs(maps - ref_maps).max() <= 0.10 * np.ptp(ref_maps)
+    assert (got[1] > got[0]) == (ref[1] > ref[0])

@@ -10,6 +10,8 @@ import warnings
 
 import torch
 
+os.environ.setdefault("CMDIAD_ALLOW_RANDOM_INIT", "1")  # synthetic weights: no checkpoints offline
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cmdiad_amd.feature_extractors.multiple_features import DoubleRGBPointFeatures  # noqa: E402
 from cmdiad_amd.synth import synth_bank, synth_cloud_fixed_n, synth_rgb  # noqa: E402

@@ -86,7 +86,8 @@ def main():
         ms = timeit(lambda: ops.l2_rescore(q32, b32, keys))
         line(f"l2_rescore {nm}", ms, None, Q * 768 * 8.0)
         probes = bank[:B].contiguous()
-        ms = timeit(lambda: ops.reweight_scan(probes, b32), iters=3, warm=1)
+        blk = ops.bank_block16(b32)
+        ms = timeit(lambda: ops.reweight_scan(probes, b32, blk), iters=10, warm=2)
         line(f"reweight_scan {nm} R={B}", ms, None, B * Nb * 768 * 4.0)
     # ---- point-cloud front end
     pcs = torch.cat([synth_cloud_fixed_n(100 + i, 24576) for i in range(B)], 0).to(DEV)
