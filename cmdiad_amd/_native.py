@@ -69,6 +69,8 @@ SIGNATURES = {
     "cmdiad_l2_rescore": [P, P, P, I, I, I, U32, P, P, P],
     "cmdiad_reweight_scan": [P, P, P, I, I, I, U32, P, P, SZ, P],
     "cmdiad_bank_block16": [P, I, I, P, P],
+    "cmdiad_col_moments": [P, SZ, I, I, P, P, P],
+    "cmdiad_moments3": [P, SZ, P, P],
     "cmdiad_l2_dist_matrix": [P, P, I, I, I, P, P],
     "cmdiad_score_head": [P, P, P, P, I, I, I, I, U32, P, P, P, P, P],
     "cmdiad_score_tail": [P, P, P, P, I, I, I, U32, P, P],

@@ -132,6 +132,52 @@ __global__ __launch_bounds__(S::THREADS, S::WAVES_PER_SIMD) void gemm_std_kernel
     }, kt_begin);
 }
 
+// The same product as a PERSISTENT kernel on the 256 x 256 shape (8 waves of 128 x 64; gemm_core.h run_jobs): one block per
+// CU walks a contiguous range of the (M tile, N tile) list.  For the wide transformer products (qkv, fc1: N >= 1536) -- the
+// 128 x 128 shape moves 32 KiB through the L1 -> LDS path per 512 MFMA cycles, which IS that path's 64 B/clk: two co-resident
+// blocks can never exceed half the MFMA rate; 256 x 256 halves the bytes per FLOP.  Epilogue terms: bias, activation,
+// residual, f32 and/or bf16 output (no group bias, no training extras, no split-K).
+template <class S, int ACT>
+__global__ __launch_bounds__(S::THREADS, S::WAVES_PER_SIMD) void gemm_std_persist_kernel(GlobalTile A, GlobalTile W, StdParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int NT = p.N / S::BN, MT = (p.M + S::BM - 1) / S::BM;
+    const int jobs = MT * NT;
+    const int vb = xcd_remap(blockIdx.x, gridDim.x);   // an XCD's blocks take CONSECUTIVE job ranges (shared W tiles in its L2)
+    const int j0 = (int)((long)jobs * vb / gridDim.x), j1 = (int)((long)jobs * (vb + 1) / gridDim.x);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave / S::WN, wc = wave % S::WN;
+    run_jobs<S, true>(A, W, j0, j1, NT, p.K / BK, lds, [&](auto& acc, int mt, int ntile) {
+#pragma unroll
+        for (int i = 0; i < S::MI; ++i) {
+            const int m = mt * S::BM + wr * (S::MI * 16) + i * 16 + (lane & 15);
+            if (m >= p.M) continue;
+            const float* res = p.residual ? p.residual + (size_t)m * p.ldr : nullptr;
+            float* o32 = p.out_f32 ? p.out_f32 + (size_t)m * p.ldo32 : nullptr;
+            bf16_t* o16 = p.out_bf16 ? p.out_bf16 + (size_t)m * p.ldo16 : nullptr;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = ntile * S::BN + wc * 64 + j * 16 + (lane >> 4) * 4;
+                f32x4 v = acc[i][j];
+                if (p.bias) { const float4 b = *reinterpret_cast<const float4*>(p.bias + n); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+                if constexpr (ACT == CMDIAD_ACT_GELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                } else if constexpr (ACT == CMDIAD_ACT_RELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
+                }
+                if (res) { const float4 b = *reinterpret_cast<const float4*>(res + n); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+                if (o32) *reinterpret_cast<f32x4*>(o32 + n) = v;
+                if (o16) {
+                    bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+                    *reinterpret_cast<bf16x4*>(o16 + n) = o;
+                }
+            }
+        }
+    });
+}
+
 // ------------------------------------------------------------------------------------------------
 // QKV projection, head-split stores (head_dim 64).  Q and K tiles run swapped (4 consecutive d per
 // lane -> 8-byte stores into [B,H,Tp,64]); V tiles run un-swapped (4 consecutive tokens per lane)
@@ -510,6 +556,23 @@ int wide_choice(long M, long N, long K, bool plain_epilogue, int split)
     return 0;
 }
 
+// Persistent 256 x 256 kernel: products with whole 256-column tiles and enough of them that 256 blocks each get >= 2 tiles
+// (qkv, fc1 of both transformers at batch 32).  CMDIAD_GEMM_PERSIST=0 / 1 forces it off / on wherever it is legal (A/B runs,
+// parity tests on small shapes; read per call).
+constexpr int kPersistCUs = 256;
+unsigned persist_blocks(long M, long N)
+{
+    const long jobs = ((M + 255) / 256) * (N / 256);
+    return (unsigned)(jobs < kPersistCUs ? jobs : kPersistCUs);
+}
+bool persist_choice(long M, long N, long K, bool legal_epilogue)
+{
+    if (!legal_epilogue || N % 256 != 0 || K % 64 != 0) return false;
+    const char* e = getenv("CMDIAD_GEMM_PERSIST");
+    if (e) return e[0] != '0';
+    return N >= 1536 && ((M + 255) / 256) * (N / 256) >= 2 * kPersistCUs;
+}
+
 template <class SW, class Kern, class P>
 int launch_wide(Kern kernel, long M, long N, long K, P& p, const GlobalTile& A, const GlobalTile& W, hipStream_t s)
 {
@@ -572,6 +635,14 @@ extern "C" int cmdiad_gemm_bf16(const cmdiad_gemm_args* a, cmdiad_stream_t strea
         if (wide == 8) rc = a->act == CMDIAD_ACT_GELU ? CMDIAD_WIDE(8, CMDIAD_ACT_GELU) : a->act == CMDIAD_ACT_RELU ? CMDIAD_WIDE(8, CMDIAD_ACT_RELU) : CMDIAD_WIDE(8, CMDIAD_ACT_NONE);
         else rc = a->act == CMDIAD_ACT_GELU ? CMDIAD_WIDE(4, CMDIAD_ACT_GELU) : a->act == CMDIAD_ACT_RELU ? CMDIAD_WIDE(4, CMDIAD_ACT_RELU) : CMDIAD_WIDE(4, CMDIAD_ACT_NONE);
 #undef CMDIAD_WIDE
+        if (rc) return rc;
+        CMDIAD_CHECK_LAUNCH();
+        return CMDIAD_OK;
+    }
+    if (persist_choice(a->M, a->N, a->K, !extras && !a->group_bias && split == 1)) {
+#define CMDIAD_PERSIST(ACT) launch<S2x2>(gemm_std_persist_kernel<S2x2, ACT>, dim3(persist_blocks(a->M, a->N)), S2x2::LDS_BYTES, s, A, W, p)
+        rc = a->act == CMDIAD_ACT_GELU ? CMDIAD_PERSIST(CMDIAD_ACT_GELU) : a->act == CMDIAD_ACT_RELU ? CMDIAD_PERSIST(CMDIAD_ACT_RELU) : CMDIAD_PERSIST(CMDIAD_ACT_NONE);
+#undef CMDIAD_PERSIST
         if (rc) return rc;
         CMDIAD_CHECK_LAUNCH();
         return CMDIAD_OK;

@@ -169,6 +169,51 @@ unsigned blocks_for(size_t n) { return (unsigned)((n + 255) / 256); }
 
 }  // namespace
 
+
+// ------------------------------------------------------------------------------------------------
+// Batch-statistics BatchNorm support (the reference never calls .eval() on the extractor, models/models.py:189,195 run
+// in training mode under no_grad: SURVEY F1).  Per-column first / second moments in double precision:
+//   col_moments:  x [rows, C] f32 (row pitch ld)  ->  sum[c] += x[r][c],  sumsq[c] += x[r][c]^2
+//   moments3:     x [rows, 3] f32                 ->  out[0..2] += (x, y, z), out[3..8] += (xx, xy, xz, yy, yz, zz)
+// (conv1 is linear in the three coordinates, so the mean / variance of each of its 128 outputs follow from these nine sums.)
+// ------------------------------------------------------------------------------------------------
+static __global__ __launch_bounds__(256) void col_moments_kernel(const float* __restrict__ x, size_t rows, int C, int ld,
+                                                          int rows_per_block, double* __restrict__ sum, double* __restrict__ sumsq)
+{
+    const size_t r0 = (size_t)blockIdx.y * rows_per_block;
+    const size_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (size_t r = r0; r < r1; ++r) {
+        const double v = (double)x[r * ld + c];
+        s += v;
+        q += v * v;
+    }
+    atomicAdd(sum + c, s);
+    atomicAdd(sumsq + c, q);
+}
+
+static __global__ __launch_bounds__(256) void moments3_kernel(const float* __restrict__ x, size_t rows, double* __restrict__ out)
+{
+    double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (size_t r = (size_t)blockIdx.x * 256 + threadIdx.x; r < rows; r += (size_t)gridDim.x * 256) {
+        const double px = x[r * 3], py = x[r * 3 + 1], pz = x[r * 3 + 2];
+        a[0] += px; a[1] += py; a[2] += pz;
+        a[3] += px * px; a[4] += px * py; a[5] += px * pz; a[6] += py * py; a[7] += py * pz; a[8] += pz * pz;
+    }
+    __shared__ double sh[4][9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        double v = a[k];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 9) atomicAdd(out + threadIdx.x, sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+}
+
 extern "C" int cmdiad_layernorm(float* x, const float* add, const float* gamma, const float* beta, float eps, int M,
                                 int C, uint16_t* out_bf16, float* out_f32, int ldo32, float* mean_out, float* rstd_out,
                                 cmdiad_stream_t stream)
@@ -250,6 +295,27 @@ extern "C" int cmdiad_transpose_bf16(const uint16_t* in, int rows, int cols, uin
     CMDIAD_REQUIRE(in && out && rows > 0 && cols > 0, CMDIAD_ERR_ARG, "cmdiad_transpose_bf16: bad args");
     hipLaunchKernelGGL(transpose_bf16_kernel, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)in, rows, cols, (bf16_t*)out);
+    CMDIAD_CHECK_LAUNCH();
+    return CMDIAD_OK;
+}
+
+extern "C" int cmdiad_col_moments(const float* x, size_t rows, int C, int ld, double* sum, double* sumsq, cmdiad_stream_t stream)
+{
+    CMDIAD_REQUIRE(x && sum && sumsq && C > 0 && ld >= C, CMDIAD_ERR_ARG, "cmdiad_col_moments: null pointer / C / ld");
+    if (rows == 0) return CMDIAD_OK;
+    const int per = 256;
+    hipLaunchKernelGGL(col_moments_kernel, dim3((C + 255) / 256, (unsigned)((rows + per - 1) / per)), dim3(256), 0, (hipStream_t)stream,
+                       x, rows, C, ld, per, sum, sumsq);
+    CMDIAD_CHECK_LAUNCH();
+    return CMDIAD_OK;
+}
+
+extern "C" int cmdiad_moments3(const float* xyz, size_t rows, double* out9, cmdiad_stream_t stream)
+{
+    CMDIAD_REQUIRE(xyz && out9, CMDIAD_ERR_ARG, "cmdiad_moments3: null pointer");
+    if (rows == 0) return CMDIAD_OK;
+    const unsigned blocks = (unsigned)((rows + 255) / 256 < 1024 ? (rows + 255) / 256 : 1024);
+    hipLaunchKernelGGL(moments3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, xyz, rows, out9);
     CMDIAD_CHECK_LAUNCH();
     return CMDIAD_OK;
 }

@@ -260,7 +260,9 @@ class PointTransformer(torch.nn.Module):
                               ignore_unexpected=("MAE_decoder", "mask_token", "decoder_pos_embed", "increase_dim", "cls_"))
 
     def packed(self):
-        ver = _param_version(self)
+        # BatchNorm mode: module.training selects nothing by itself (the contract of record is eval mode whatever the flag,
+        # SURVEY F1 / DESIGN.md); CMDIAD_BN_BATCH_STATS=1 opts in to the reference's as-shipped batch-statistics behaviour
+        ver = (_param_version(self), os.environ.get("CMDIAD_BN_BATCH_STATS", "0"))
         if self._packed is None or self._packed[0] != ver:
             dev = next(self.parameters()).device
             self._packed = (ver, runtime.PackedPointMAE(self.state_dict(), device=dev, group_size=self.group_size,

@@ -269,6 +269,27 @@ def layernorm(x, gamma, beta, eps, add=None, out_bf16=None, out_f32=None, want_b
     return out_bf16
 
 
+def col_moments(x):
+    """x [rows, C] f32 -> (mean [C], biased variance [C]) in float64 (cmdiad_col_moments)."""
+    _chk(x, torch.float32, "col_moments.x")
+    rows, C = x.shape
+    acc = torch.zeros((2, C), dtype=torch.float64, device=x.device)
+    _call("cmdiad_col_moments", _p(x), rows, C, x.stride(0), _p(acc[0]), _p(acc[1]), _stream())
+    mean = acc[0] / rows
+    return mean, acc[1] / rows - mean * mean
+
+
+def moments3(xyz):
+    """xyz [rows, 3] f32 -> (mean [3], covariance [3,3]) in float64, biased (cmdiad_moments3)."""
+    _chk(xyz, torch.float32, "moments3.xyz")
+    rows = xyz.shape[0]
+    acc = torch.zeros((9,), dtype=torch.float64, device=xyz.device)
+    _call("cmdiad_moments3", _p(xyz), rows, _p(acc), _stream())
+    mean = acc[:3] / rows
+    m2 = torch.stack([acc[[3, 4, 5]], acc[[4, 6, 7]], acc[[5, 7, 8]]]) / rows
+    return mean, m2 - torch.outer(mean, mean)
+
+
 def encoder_stage1(neigh, w1b1, W2, b2, groups, Mg):
     """-> (h2 [groups*Mg,256] bf16, gmax [groups,256] f32, gmax_bf16)."""
     dev = neigh.device

@@ -140,11 +140,28 @@ def fold_pointmae_encoder(sd, prefix, device):
         W4=_bf(w4.reshape(w4.shape[0], 512), device), b4=_dev(sd[prefix + "second_conv.3.bias"], device))
 
 
+def raw_pointmae_encoder(sd, prefix, device):
+    """The encoder's parameters UNFOLDED (fp32, on the device) for the batch-statistics BatchNorm mode: the normalisation
+    constants then depend on the sample (models/models.py:189,195 in training mode)."""
+    g = lambda k: _dev(sd[prefix + k], device)  # noqa: E731
+    return dict(w1=g("first_conv.0.weight").reshape(128, 3), b1=g("first_conv.0.bias"),
+                g1=g("first_conv.1.weight"), be1=g("first_conv.1.bias"),
+                w3=g("second_conv.0.weight").reshape(512, 512), b3=g("second_conv.0.bias"),
+                g2=g("second_conv.1.weight"), be2=g("second_conv.1.bias"))
+
+
 class PackedPointMAE:
-    def __init__(self, sd, prefix="", device="cuda", depth=12, num_heads=6, taps=(3, 11), group_size=128, num_group=1024):
+    def __init__(self, sd, prefix="", device="cuda", depth=12, num_heads=6, taps=(3, 11), group_size=128, num_group=1024,
+                 bn_batch_stats=None):
+        """bn_batch_stats: True reproduces the reference AS SHIPPED -- its extractor is never put in .eval(), so the two
+        BatchNorm1d layers of the encoder normalise with the statistics of the sample at hand (DropPath, also
+        active there, is RNG-dependent and stays off).  Default (None): the CMDIAD_BN_BATCH_STATS=1 environment switch, else
+        the eval-mode contract of record (running statistics folded into the convolutions)."""
         self.device, self.depth, self.heads, self.taps = device, depth, num_heads, taps
         self.group_size, self.num_group = group_size, num_group
+        self.bn_batch_stats = (os.environ.get("CMDIAD_BN_BATCH_STATS", "0") == "1") if bn_batch_stats is None else bool(bn_batch_stats)
         self.enc = fold_pointmae_encoder(sd, prefix + "encoder.", device)
+        self.enc_raw = raw_pointmae_encoder(sd, prefix + "encoder.", device) if self.bn_batch_stats else None
         self.dim = self.enc["W4"].shape[0]
         self.pos0 = _dev(torch.cat([sd[prefix + "pos_embed.0.weight"], sd[prefix + "pos_embed.0.bias"][:, None]], 1), device)
         self.pos2_w = _bf(sd[prefix + "pos_embed.2.weight"], device)
@@ -153,10 +170,45 @@ class PackedPointMAE:
         self.norm_w, self.norm_b = _dev(sd[prefix + "norm.weight"], device), _dev(sd[prefix + "norm.bias"], device)
         self.bufs = _QkvBuffers()
 
+    def encode_batch_stats(self, neighborhood, eps=1e-5):
+        """models/models.py:200-215 with BOTH BatchNorm1d layers in training mode: every sample is normalised with its own
+        (biased) batch statistics -- the reference drives the extractor at batch size 1, so 'the batch' is the sample's
+        G x Mg points.  Same kernels as the eval path; the folded constants are rebuilt per sample:
+          BN1: conv1 is linear in the coordinates, so mean / variance of its 128 outputs follow from the mean vector and
+               covariance matrix of the sample's points (cmdiad_moments3): mean_c = w_c . mu + b_c, var_c = w_c^T S w_c;
+          BN2: a statistics pass evaluates conv3's pre-activation z = W3b . h2 + (W3a . gmax + b3) in fp32 and reduces its
+               column moments (cmdiad_col_moments); then scale = gamma / sqrt(var + eps) goes into W3b and the group bias."""
+        B, G, Mg, _ = neighborhood.shape
+        e, r = self.enc, self.enc_raw
+        toks = []
+        for b in range(B):
+            pts = neighborhood[b].reshape(-1, 3).contiguous()
+            mu, cov = ops.moments3(pts)
+            w1 = r["w1"].double()
+            mean1 = w1 @ mu + r["b1"].double()
+            var1 = ((w1 @ cov) * w1).sum(1).clamp_min(0.0)
+            s1 = r["g1"].double() / torch.sqrt(var1 + eps)
+            w1b1 = torch.cat([w1 * s1[:, None], ((r["b1"].double() - mean1) * s1 + r["be1"].double())[:, None]], 1).float().contiguous()
+            h2, _, g16 = ops.encoder_stage1(pts, w1b1, e["W2"], e["b2"], G, Mg)
+            gb_raw, _ = ops.gemm(g16, e["W3a_raw"], bias=r["b3"], want_f32=True, want_bf16=False)
+            z, _ = ops.gemm(h2, e["W3b_raw"], group_bias=gb_raw, group_rows=Mg, want_f32=True, want_bf16=False)
+            mean2, var2 = ops.col_moments(z)
+            del z
+            s2 = r["g2"].double() / torch.sqrt(var2.clamp_min(0.0) + eps)
+            w3b = ops.cast_bf16((r["w3"][:, 256:].double() * s2[:, None]).float().contiguous())
+            gb = ((gb_raw.double() - mean2) * s2 + r["be2"].double()).float().contiguous()
+            toks.append(ops.encoder_tail(h2, gb, w3b, e["W4"], e["b4"], G, Mg))
+        return torch.cat(toks, 0)
+
     def encode(self, neighborhood):
         """neighborhood [B,G,Mg,3] f32 -> tokens [B*G, 384] f32 (models/models.py:200-215)."""
         B, G, Mg, _ = neighborhood.shape
         e = self.enc
+        if self.bn_batch_stats:
+            if "W3a_raw" not in e:
+                e["W3a_raw"] = ops.cast_bf16(self.enc_raw["w3"][:, :256].contiguous())
+                e["W3b_raw"] = ops.cast_bf16(self.enc_raw["w3"][:, 256:].contiguous())
+            return self.encode_batch_stats(neighborhood)
         h2, _, g16 = ops.encoder_stage1(neighborhood.reshape(-1, 3), e["w1b1"], e["W2"], e["b2"], B * G, Mg)
         gb, _ = ops.gemm(g16, e["W3a"], bias=e["b3"], want_f32=True, want_bf16=False)
         if os.environ.get("CMDIAD_ENCODER_TAIL", "1") == "1":

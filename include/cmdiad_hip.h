@@ -247,6 +247,13 @@ int cmdiad_l2_min_keys(const uint16_t* q, const float* q_sqnorm, const uint16_t*
 int cmdiad_l2_rescore(const float* q, const float* bank, const unsigned long long* keys, int Q, int Nb,
                       int D, uint32_t row_offset, float* min_val, int64_t* min_idx, cmdiad_stream_t stream);
 
+/* Batch-statistics BatchNorm support (the reference runs Point-MAE's BatchNorm1d layers, models/models.py:189,195,
+ * in training mode because the extractor is never put in .eval()).  Double-precision moment sums, ACCUMULATED into
+ * caller-zeroed buffers:  col_moments: x [rows,C] f32 (row pitch ld) -> sum[C], sumsq[C];
+ * moments3: xyz [rows,3] f32 -> out9 = (x, y, z, xx, xy, xz, yy, yz, zz) sums. */
+int cmdiad_col_moments(const float* x, size_t rows, int C, int ld, double* sum, double* sumsq, cmdiad_stream_t stream);
+int cmdiad_moments3(const float* xyz, size_t rows, double* out9, cmdiad_stream_t stream);
+
 /* Library copy laid out for the fp32 matrix cores ("block16"): groups of 16 rows,
  * out[(((g * D/16 + t) * 4 + kq) * 16 + j) * 4 + e] = bank[16 g + j][16 t + 4 kq + e] (zero beyond Nb),
  * cmdiad_bank_block16_floats(Nb, D) = ceil(Nb/16) * 16 * D floats.  Built once per library; the re-weighting scan

@@ -188,6 +188,32 @@ def test_gemm_epilogues(M, N, K, panel_min, wide, monkeypatch):
     np.testing.assert_allclose(x.cpu().numpy(), (ref + bias.double() + res.double()).numpy(), rtol=1e-4, atol=1e-4)
 
 
+def test_gemm_persistent_256_tile_matches_128_tile(monkeypatch):
+    """cmdiad_gemm_bf16 on the persistent 256 x 256 kernel (gemm_std_persist_kernel: one block per CU walks a job list;
+    production choice for qkv / fc1 at batch 32) gives bit for bit what the 128 x 128 kernel gives -- same K order, same
+    epilogue arithmetic -- on shapes with ragged M, more and fewer jobs than blocks, every epilogue it supports."""
+    g = torch.Generator().manual_seed(77)
+    for M, N, K in ((1000, 512, 192), (70000, 256, 64), (3 * 785, 1536, 768)):
+        A = _bf(torch.randn(M, K, generator=g))
+        W = _bf(torch.randn(N, K, generator=g) / K ** 0.5)
+        bias, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+        dA, dW = A.to(DEV).bfloat16(), W.to(DEV).bfloat16()
+        got = {}
+        for mode in ("0", "1"):
+            monkeypatch.setenv("CMDIAD_GEMM_PERSIST", mode)
+            o32, o16 = ops.gemm(dA, dW, bias=bias.to(DEV), act=ops.ACT_GELU, want_f32=True, want_bf16=True)
+            x = res.clone().to(DEV)
+            ops.gemm(dA, dW, bias=bias.to(DEV), residual=x, out_f32=x, want_bf16=False)
+            _, r16 = ops.gemm(dA, dW, act=ops.ACT_RELU)
+            got[mode] = (o32.clone(), o16.clone(), x, r16.clone())
+        for a, b in zip(got["0"], got["1"]):
+            assert torch.equal(a, b)
+        ref = A.double() @ W.double().T
+        want = torch.nn.functional.gelu(ref + bias.double())
+        np.testing.assert_allclose(got["1"][0].cpu().numpy(), want.numpy(), rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(got["1"][2].cpu().numpy(), (ref + bias.double() + res.double()).numpy(), rtol=1e-4, atol=1e-4)
+
+
 def test_gemm_identity_asymmetric_layout():
     # A = I against an asymmetric W catches any row/column swap in the accumulator mapping
     K = 128
@@ -389,7 +415,7 @@ def test_reweight_scan_duplicates_near_ties_and_shards():
     still ordered by their exact distances; two row shards called in turn give the single-call result."""
     g = torch.Generator().manual_seed(11)
     bank = torch.randn(6000, 768, generator=g)
-    bank[[100, 2500, 2501, 5999, 17]] = bank[4000]              # six copies of one row
+    bank[[100, 2500, 2501, 5999, 17]] = bank[4000].clone()      # six copies of one row
     near = bank[3000].clone()
     bank[3001] = near + 3e-4 * torch.randn(768, generator=g)     # d2 ~ 7e-5, far below the fp32 expansion's error on |b|^2 ~ 768
     bank[3002] = near + 6e-4 * torch.randn(768, generator=g)

@@ -109,3 +109,43 @@ def test_transformer_block_entry_point_equals_its_seven_launches():
         transformer_block(xa, blk, B, T, H, eps, _QkvBuffers(), pos=pos)
         transformer_block_unfused(xb, blk, B, T, H, eps, _QkvBuffers(), pos=pos)
         assert torch.equal(xa, xb) and not torch.equal(xa, x0)
+
+
+def test_pointmae_batch_statistics_bn_vs_reference_golden(golden):
+    """the reference as shipped never calls .eval() on the extractor, so Point-MAE's two BatchNorm1d layers
+    (models/models.py:189,195) normalise with the statistics of the sample.  bn_batch_stats=True reproduces that mode on
+    the GPU; golden G2 `tokens_train` / `feats_train` are the REFERENCE's own PointTransformer in .train() (DropPath
+    stubbed to identity).  Also: per-sample statistics (a batch of two gives each sample's B = 1 result) and the moment
+    kernels against torch."""
+    g = golden("g2_pointmae.npz")
+    sd = nets.synth_state_dict("pointmae", 21)
+    pm = runtime.PackedPointMAE(sd, device=DEV, group_size=32, num_group=64, bn_batch_stats=True)
+    xyz = torch.from_numpy(np.ascontiguousarray(g["pc"][0].T)[None]).to(DEV)
+    feats, center, ori_idx, center_idx = pm.forward(xyz)
+    np.testing.assert_array_equal(center_idx.cpu().numpy(), g["center_idx"])
+    ref = torch.from_numpy(g["feats_train"])
+    mean_rel, max_rel = _rel(feats.transpose(1, 2).cpu(), ref)
+    assert mean_rel < 0.015 and max_rel < 0.12, (mean_rel, max_rel)
+    # encoder tokens alone (models.py:200-215)
+    _, nb = ops.knn_group(xyz, center, 32)
+    tok = pm.encode(nb).cpu()
+    ref_tok = torch.from_numpy(g["tokens_train"]).reshape(-1, 384)
+    mt, xt = _rel(tok, ref_tok)
+    assert mt < 0.01 and xt < 0.08, (mt, xt)
+    # ... and it IS a different function from the eval-mode contract
+    ev = runtime.PackedPointMAE(sd, device=DEV, group_size=32, num_group=64, bn_batch_stats=False).encode(nb).cpu()
+    assert _rel(ev, ref_tok)[0] > 5 * mt
+    assert _rel(ev, torch.from_numpy(g["tokens_eval"]).reshape(-1, 384))[0] < 0.01
+    # per-sample statistics: sample 0 of a batch of two == the B = 1 result
+    two = torch.cat([nb, nb.flip(1) * 1.3], 0).contiguous()
+    tok2 = pm.encode(two).cpu()
+    torch.testing.assert_close(tok2[:64], tok, rtol=0, atol=0)
+    # moment kernels
+    x = torch.randn(5000, 37, generator=torch.Generator().manual_seed(2)).to(DEV)
+    m, v = ops.col_moments(x)
+    np.testing.assert_allclose(m.cpu().numpy(), x.double().mean(0).cpu().numpy(), atol=1e-12)
+    np.testing.assert_allclose(v.cpu().numpy(), x.double().var(0, unbiased=False).cpu().numpy(), rtol=1e-10)
+    p3 = torch.randn(7001, 3, generator=torch.Generator().manual_seed(3)).to(DEV) * 0.01 + 0.5
+    mu, cov = ops.moments3(p3)
+    np.testing.assert_allclose(mu.cpu().numpy(), p3.double().mean(0).cpu().numpy(), atol=1e-12)
+    np.testing.assert_allclose(cov.cpu().numpy(), torch.cov(p3.double().T, correction=0).cpu().numpy(), rtol=1e-7, atol=1e-14)
