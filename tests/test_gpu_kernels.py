@@ -369,7 +369,8 @@ def test_l2_min_all_tiles_identical_keys(tile, dt, monkeypatch):
 
 
 def _exact_top3(probes, bank):
-    d = torch.cdist(probes.double(), bank.double())
+    # explicit differences in float64 (torch.cdist's |a|^2 + |b|^2 - 2ab form reports 1e-6 for identical rows even in double)
+    d = torch.stack([(bank.double() - p.double()).pow(2).sum(1).sqrt() for p in probes])
     return torch.topk(d, min(3, bank.shape[0]), largest=False)
 
 

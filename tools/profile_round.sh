@@ -11,14 +11,14 @@ ROOT=$PWD
 OUT=$ROOT/gpurun_out/prof_$R
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/trace.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras > "$OUT/trace.log" 2>&1
 tail -1 "$OUT/trace.log" | cut -c1-400
 for pass in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "l2:TCC_HIT_sum TCC_MISS_sum" \
             "sq:SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES" \
             "lds:SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
     name=${pass%%:*}
     ctrs=${pass#*:}
-    rocprofv3 --pmc $ctrs --output-format csv -d "$OUT/pmc/$name" -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/pmc_$name.log" 2>&1
+    rocprofv3 --pmc $ctrs --output-format csv -d "$OUT/pmc/$name" -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > "$OUT/pmc_$name.log" 2>&1
     echo "pass $name rc=$?"
 done
 du -sh "$OUT"
