@@ -35,18 +35,116 @@ def _side(patch):
     return (s, s)
 
 
-class _MethodBase(Features):
-    """Shared plumbing of the method classes (not part of the reference's public surface)."""
+def _lazy_result(name, kind):
+    """Result attribute of the reference (a plain list there) that FLUSHES the deferred micro-batch of its phase before it is
+    read, so an observer sees exactly what the reference's eager loop would have appended by then."""
+    key = "_lz_" + name
 
-    def _extract(self, sample, want_rgb=True, want_xyz=True):
-        """(rgb_maps, xyz_maps, interpolated, nonzero_indices) as the reference's methods name them.  The two map lists
-        are handles onto the device-resident extraction (the public Features.__call__ still returns the CPU copies the
-        reference returns; the method classes themselves never need them)."""
-        from .features import LazyInterpolated
-        ex = self._extract_device(sample[0], sample[1], want_rgb, want_xyz)
-        handle = torch.empty(0)
-        handle._cmdiad = ex
-        return [handle], [handle], LazyInterpolated(ex), None
+    def get(self):
+        if not self.__dict__.get("_flushing", False):
+            self._flush(kind)
+        return self.__dict__[key]
+
+    def set_(self, value):
+        self.__dict__[key] = value
+
+    return property(get, set_)
+
+
+class _MethodBase(Features):
+    """Shared plumbing of the method classes (not part of the reference's public surface).
+
+    The five protocol calls keep the reference's signatures and order of effects, but the per-sample calls
+    (add_sample_to_mem_bank / add_sample_to_late_fusion_mem_bank / predict) only QUEUE the sample: the queue is run through
+    the batched engine every CMDIAD_PREDICT_BATCH samples (default 8), at the next phase call (run_coreset /
+    run_late_fusion / calculate_metrics) and whenever a result attribute is read.  The reference itself reads those results
+    only at the phase boundaries (cmdiad_runner.py:44-92), every sample is independent of the others, and a
+    sample's numbers do not depend on the batch it rode in (tests/test_gpu_engine.py::test_batch_invariance,
+    test_gpu_predictor.py::test_dropin_micro_batching_is_invisible); at B = 1 the GPU is bound by a 2 ms single-CU FPS
+    chain and ~200 tiny launches per image, in a micro-batch of 8 those run side by side."""
+
+    patch_xyz_lib = _lazy_result("patch_xyz_lib", "fit")
+    patch_rgb_lib = _lazy_result("patch_rgb_lib", "fit")
+    patch_fusion_lib = _lazy_result("patch_fusion_lib", "fit")
+    s_lib = _lazy_result("s_lib", "late")
+    s_map_lib = _lazy_result("s_map_lib", "late")
+    image_preds = _lazy_result("image_preds", "predict")
+    image_labels = _lazy_result("image_labels", "predict")
+    pixel_preds = _lazy_result("pixel_preds", "predict")
+    pixel_labels = _lazy_result("pixel_labels", "predict")
+    predictions = _lazy_result("predictions", "predict")
+    gts = _lazy_result("gts", "predict")
+    img_name = _lazy_result("img_name", "predict")
+
+    # ------------------------------------------------------------------ deferred micro-batches
+    def _micro_batch(self):
+        return max(1, int(os.environ.get("CMDIAD_PREDICT_BATCH", "8")))
+
+    def _defer(self, kind, item):
+        q = self.__dict__.setdefault("_pending", {"fit": [], "late": [], "predict": []})
+        q[kind].append(item)
+        if len(q[kind]) >= self._micro_batch():
+            self._flush(kind)
+
+    def _flush(self, kind):
+        q = self.__dict__.get("_pending")
+        if not q or not q[kind]:
+            return
+        items, q[kind] = q[kind], []
+        self.__dict__["_flushing"] = True
+        try:
+            if kind == "fit":
+                self._fit_batch(items)
+            elif kind == "late":
+                for s, s_map in self._score_batch(items, test=False):
+                    self.s_lib.append(s)
+                    self.s_map_lib.append(s_map)
+            else:
+                scores = self._score_batch([it[0] for it in items], test=True)
+                for (s, s_map), (_, mask, label, rgb_path) in zip(scores, items):
+                    self._record(s, s_map, mask, label, rgb_path)
+        finally:
+            self.__dict__["_flushing"] = False
+
+    def add_sample_to_mem_bank(self, sample, class_name=None):
+        self.class_name = class_name
+        self._defer("fit", sample)
+
+    def add_sample_to_late_fusion_mem_bank(self, sample):
+        self._defer("late", sample)
+
+    def predict(self, sample, mask, label, rgb_path):
+        self._defer("predict", (sample, mask, label, rgb_path))
+
+    def run_late_fusion(self):
+        self._flush("late")
+        super().run_late_fusion()
+
+    def calculate_metrics(self):
+        self._flush("predict")
+        super().calculate_metrics()
+
+    # ------------------------------------------------------------------ batched extraction
+    def _extract_batch(self, samples, want_rgb=True, want_xyz=True):
+        """Device-resident extraction of a micro-batch (engine.Engine.extract; the zero-pixel compaction of
+        organized_pc_to_unorganized_pc_no_zeros runs in cmdiad_unorganize, bit-identical order)."""
+        dev = self.device
+        rgb = torch.cat([s[0] for s in samples]).to(dev, torch.float32) if want_rgb else None
+        if not want_xyz:
+            with torch.no_grad():
+                return self._engine.extract(rgb, want_xyz=False)
+        pcs = torch.cat([s[1] for s in samples])
+        flat = pcs.numpy().reshape(len(samples), 3, -1)   # numpy: no 150 k-element op through torch's CPU thread pool
+        counts = np.count_nonzero(np.all(flat != 0, axis=1), axis=1)
+        if counts.min() < self.args.group_size:
+            raise ValueError(f"point cloud has {int(counts.min())} valid points; the {self.args.group_size}-nearest-neighbour "
+                             f"grouping (models/models.py:88-113) needs at least {self.args.group_size}")
+        side = self.__dict__.get("_side_stream")
+        if side is None:
+            side = self.__dict__["_side_stream"] = torch.cuda.Stream()
+        with torch.no_grad():
+            return self._engine.extract(rgb, pcs.to(dev, torch.float32), want_rgb=want_rgb, n_max=int(counts.max()),
+                                        side_stream=side if want_rgb else None)
 
     def _coreset(self, lib, name):
         if self.f_coreset < 1:
@@ -56,37 +154,32 @@ class _MethodBase(Features):
             return lib[idx.to(lib.device)]
         return lib
 
-    def _score(self, patch, mean, std, modal):
-        patch = eng.normalize(patch.to(self.device).float(), mean, std)  # a11: fused HIP kernel
-        dist = self.calculate_dist(patch, getattr(self, f"patch_{modal}_lib"))
-        return self.compute_single_s_s_map(patch, dist, _side(patch), modal=modal)
-
-    def _score_many(self, items):
-        """[(patch, mean, std, modal)] -> [(s, s_map)], each pair as _score returns it.  The device work of every modality
-        is queued first, then ONE blur launch (a block per map) and ONE device->host copy: at B = 1 the per-modality
-        blur + copy of compute_single_s_s_map left the GPU idle while the host queued the next modality."""
+    def _score_columns(self, columns):
+        """columns: [(patch [B,Q,D] raw, mean, std, modal, lambda_s, lambda_map)] in the reference's column order ->
+        per sample (s [1,k], s_map [gt*gt, k]) exactly as the reference stacks them (e.g. multiple_features.py:985-992).
+        The device work of every column is queued first, then ONE blur launch (a block per map) and ONE device->host copy."""
         from .. import ops
         gt = self.gt_size
         rs = []
-        for patch, mean, std, modal in items:
-            patch = eng.normalize(patch.to(self.device).float(), mean, std)
-            rs.append(eng.score_patches(patch.unsqueeze(0).contiguous(), self._bank(getattr(self, f"patch_{modal}_lib")),
-                                        _side(patch), gt))
-        k = len(rs)
-        maps = ops.blur8_maps(torch.cat([r["s_map_pre"].reshape(1, gt, gt) for r in rs]).contiguous(), float(self.blur.radius))
-        host = torch.cat([maps.reshape(-1)] + [r["s"][:1].float() for r in rs]).cpu()
-        return [(host[k * gt * gt + i], host[i * gt * gt:(i + 1) * gt * gt].view(1, gt, gt)) for i in range(k)]
-
-    def _fuse_inputs(self, pairs):
-        """pairs: [(lambda_s, s, lambda_map, s_map)] -> (s [1,k], s_map [gt*gt, k]) as the reference stacks them."""
-        s = torch.tensor([[float(ls * sv) for ls, sv, _, _ in pairs]])
-        # numpy for the two host-side products: torch's CPU intra-op pool (one thread per core by default) stalls for
-        # 80 ms every few calls on 50 176-element tensors on a 128-core host; same float32 arithmetic either way
-        s_map = torch.from_numpy(np.stack([(np.float32(lm) * m.numpy()).reshape(-1) for _, _, lm, m in pairs], axis=1))
-        return s, s_map
+        for patch, mean, std, modal, _, _ in columns:
+            q = eng.normalize(patch.to(self.device).float().contiguous(), mean, std)        # a11: fused HIP kernel
+            side = int(math.sqrt(q.shape[1]))
+            rs.append(eng.score_patches(q, self._bank(getattr(self, f"patch_{modal}_lib")), (side, side), gt))
+        B, k = columns[0][0].shape[0], len(columns)
+        maps = ops.blur8_maps(torch.stack([r["s_map_pre"] for r in rs], 1).reshape(B * k, gt, gt).contiguous(),
+                              float(self.blur.radius))
+        host = torch.cat([maps.reshape(-1), torch.stack([r["s"] for r in rs], 1).reshape(-1).float()]).cpu().numpy()
+        out = []
+        for b in range(B):
+            s = torch.tensor([[float(columns[i][4] * host[B * k * gt * gt + b * k + i]) for i in range(k)]])
+            # numpy for the host-side products: torch's CPU intra-op pool (one thread per core by default) stalls for
+            # 80 ms every few calls on 50 176-element tensors on a 128-core host; same float32 arithmetic either way
+            cols = [np.float32(columns[i][5]) * host[(b * k + i) * gt * gt:(b * k + i + 1) * gt * gt] for i in range(k)]
+            out.append((s, torch.from_numpy(np.stack(cols, axis=1))))
+        return out
 
     def _record(self, s, s_map, mask, label, rgb_path):
-        # from_numpy, not torch.tensor(): no 50 176-element copy through torch's CPU thread pool (see _fuse_inputs)
+        # from_numpy, not torch.tensor(): no 50 176-element copy through torch's CPU thread pool (see _score_columns)
         s = torch.from_numpy(np.ascontiguousarray(self.detect_fuser.score_samples(s.numpy())))
         s_map = torch.from_numpy(np.ascontiguousarray(self.seg_fuser.score_samples(s_map.numpy()))).view(1, self.gt_size, self.gt_size)
         self.image_preds.append(s.numpy())
@@ -103,74 +196,64 @@ class _MethodBase(Features):
 
 
 class RGBFeatures(_MethodBase):
-    def add_sample_to_mem_bank(self, sample, class_name=None):
-        self.class_name = class_name
-        rgb_maps, _, _, _ = self._extract(sample, want_xyz=False)
-        self.patch_rgb_lib.append(self.get_rgb_patch(rgb_maps)[0])
+    def _fit_batch(self, samples):
+        ex = self._extract_batch(samples, want_xyz=False)
+        self.patch_rgb_lib.extend(eng.Engine.rgb_patch(ex).unbind(0))
 
     def run_coreset(self):
+        self._flush("fit")
         self.patch_rgb_lib = torch.cat(self.patch_rgb_lib, 0)
         self.rgb_mean, self.rgb_std = torch.mean(self.patch_rgb_lib), torch.std(self.patch_rgb_lib)
         self.patch_rgb_lib = self._coreset(eng.normalize(self.patch_rgb_lib, self.rgb_mean, self.rgb_std), 'patch_rgb_lib')
 
-    def _s(self, sample):
-        rgb_maps, _, _, _ = self._extract(sample, want_xyz=False)
-        s_rgb, m_rgb = self._score(self.get_rgb_patch(rgb_maps)[0], self.rgb_mean, self.rgb_std, 'rgb')
-        return self._fuse_inputs([(self.args.rgb_s_lambda, s_rgb, self.args.rgb_smap_lambda, m_rgb)])
-
-    def add_sample_to_late_fusion_mem_bank(self, sample):
-        s, s_map = self._s(sample)
-        self.s_lib.append(s)
-        self.s_map_lib.append(s_map)
-
-    def predict(self, sample, mask, label, rgb_path):
-        s, s_map = self._s(sample)
-        self._record(s, s_map, mask, label, rgb_path)
+    def _score_batch(self, samples, test=False):
+        ex = self._extract_batch(samples, want_xyz=False)
+        return self._score_columns([(eng.Engine.rgb_patch(ex), self.rgb_mean, self.rgb_std, 'rgb',
+                                     self.args.rgb_s_lambda, self.args.rgb_smap_lambda)])
 
 
 class PointFeatures(_MethodBase):
-    def add_sample_to_mem_bank(self, sample, class_name=None):
-        self.class_name = class_name
-        _, xyz_maps, interp, nz = self._extract(sample, want_rgb=False)
-        self.patch_xyz_lib.append(self.get_xyz_patch(xyz_maps, interp, nz))
+    def _fit_batch(self, samples):
+        ex = self._extract_batch(samples, want_rgb=False)
+        self.patch_xyz_lib.extend(self._engine.xyz_patch(ex, P=56).unbind(0))
 
     def run_coreset(self):
+        self._flush("fit")
         self.patch_xyz_lib = torch.cat(self.patch_xyz_lib, 0)
         self.xyz_mean, self.xyz_std = torch.mean(self.patch_xyz_lib), torch.std(self.patch_xyz_lib)
         self.patch_xyz_lib = self._coreset(eng.normalize(self.patch_xyz_lib, self.xyz_mean, self.xyz_std), 'patch_xyz_lib')
 
-    def _s(self, sample):
-        _, xyz_maps, interp, nz = self._extract(sample, want_rgb=False)
-        s_xyz, m_xyz = self._score(self.get_xyz_patch(xyz_maps, interp, nz), self.xyz_mean, self.xyz_std, 'xyz')
-        return self._fuse_inputs([(self.args.xyz_s_lambda, s_xyz, self.args.xyz_smap_lambda, m_xyz)])
-
-    def add_sample_to_late_fusion_mem_bank(self, sample):
-        s, s_map = self._s(sample)
-        self.s_lib.append(s)
-        self.s_map_lib.append(s_map)
-
-    def predict(self, sample, mask, label, rgb_path):
-        s, s_map = self._s(sample)
-        self._record(s, s_map, mask, label, rgb_path)
+    def _score_batch(self, samples, test=False):
+        ex = self._extract_batch(samples, want_rgb=False)
+        return self._score_columns([(self._engine.xyz_patch(ex, P=56), self.xyz_mean, self.xyz_std, 'xyz',
+                                     self.args.xyz_s_lambda, self.args.xyz_smap_lambda)])
 
 
 class DoubleRGBPointFeatures(_MethodBase):
-    def add_sample_to_mem_bank(self, sample, class_name=None):
-        self.class_name = class_name
-        rgb_maps, xyz_maps, interp, nz = self._extract(sample)
-        xyz_patch = self.get_xyz_patch(xyz_maps, interp, nz)
-        rgb_patch, rgb_patch2 = self.get_rgb_patch(rgb_maps)
-        if getattr(self.args, "save_feature_for_fusion", False):
-            # the trainer's on-disk format: [3136, 768 xyz | 768 rgb] f32 per sample (multiple_features.py:815-825)
-            for sub in ("", "train", "test"):
-                os.makedirs(os.path.join(self.args.save_path, sub), exist_ok=True)
-            torch.save(torch.cat([xyz_patch, rgb_patch2], dim=1).cpu(),
-                       os.path.join(self.args.save_path, 'train', class_name + str(self.ins_id) + '.pt'))
+    def _save_features(self, xyz_patch, rgb_patch2, split):
+        # the trainer's on-disk format: [3136, 768 xyz | 768 rgb] f32 per sample (multiple_features.py:815-825, 942-945)
+        for sub in ("", "train", "test"):
+            os.makedirs(os.path.join(self.args.save_path, sub), exist_ok=True)
+        for x, r in zip(xyz_patch, rgb_patch2):
+            torch.save(torch.cat([x, r], dim=1).cpu(), os.path.join(self.args.save_path, split, self.class_name + str(self.ins_id) + '.pt'))
             self.ins_id += 1
-        self.patch_xyz_lib.append(xyz_patch)
-        self.patch_rgb_lib.append(rgb_patch)
+
+    def _patches(self, samples):
+        if getattr(self.args, "use_depth", False):
+            samples = [(s[1], s[1], *s[2:]) for s in samples]   # multiple_features.py:931-932: the point map stands in for the image
+        ex = self._extract_batch(samples)
+        return self._engine.xyz_patch(ex, P=56), eng.Engine.rgb_patch(ex), eng.Engine.rgb_patch56(ex)
+
+    def _fit_batch(self, samples):
+        ex = self._extract_batch(samples)
+        xyz_patch, rgb_patch, rgb_patch2 = self._engine.xyz_patch(ex, P=56), eng.Engine.rgb_patch(ex), eng.Engine.rgb_patch56(ex)
+        if getattr(self.args, "save_feature_for_fusion", False):
+            self._save_features(xyz_patch, rgb_patch2, 'train')
+        self.patch_xyz_lib.extend(xyz_patch.unbind(0))
+        self.patch_rgb_lib.extend(rgb_patch.unbind(0))
 
     def run_coreset(self):
+        self._flush("fit")
         self.patch_xyz_lib = torch.cat(self.patch_xyz_lib, 0)
         self.patch_rgb_lib = torch.cat(self.patch_rgb_lib, 0)
         # cross-wired exactly as the reference (multiple_features.py:877-880)
@@ -181,29 +264,13 @@ class DoubleRGBPointFeatures(_MethodBase):
         self.patch_xyz_lib = self._coreset(eng.normalize(self.patch_xyz_lib, self.xyz_mean, self.xyz_std), 'patch_xyz_lib')
         self.patch_rgb_lib = self._coreset(eng.normalize(self.patch_rgb_lib, self.rgb_mean, self.rgb_std), 'patch_rgb_lib')
 
-    def _s(self, sample, test=False):
-        if getattr(self.args, "use_depth", False):
-            sample[0] = sample[1]
-        rgb_maps, xyz_maps, interp, nz = self._extract(sample)
-        xyz_patch = self.get_xyz_patch(xyz_maps, interp, nz)
-        rgb_patch, rgb_patch2 = self.get_rgb_patch(rgb_maps)
+    def _score_batch(self, samples, test=False):
+        xyz_patch, rgb_patch, rgb_patch2 = self._patches(samples)
         if test and getattr(self.args, "save_feature_for_fusion", False):
-            torch.save(torch.cat([xyz_patch, rgb_patch2], dim=1).cpu(),
-                       os.path.join(self.args.save_path, 'test', self.class_name + str(self.ins_id) + '.pt'))
-            self.ins_id += 1
-        (s_xyz, m_xyz), (s_rgb, m_rgb) = self._score_many([(xyz_patch, self.xyz_mean, self.xyz_std, 'xyz'),
-                                                            (rgb_patch, self.rgb_mean, self.rgb_std, 'rgb')])
-        return self._fuse_inputs([(self.args.xyz_s_lambda, s_xyz, self.args.xyz_smap_lambda, m_xyz),
-                                  (self.args.rgb_s_lambda, s_rgb, self.args.rgb_smap_lambda, m_rgb)])
-
-    def add_sample_to_late_fusion_mem_bank(self, sample):
-        s, s_map = self._s(sample)
-        self.s_lib.append(s)
-        self.s_map_lib.append(s_map)
-
-    def predict(self, sample, mask, label, rgb_path):
-        s, s_map = self._s(sample, test=True)
-        self._record(s, s_map, mask, label, rgb_path)
+            self._save_features(xyz_patch, rgb_patch2, 'test')
+        a = self.args
+        return self._score_columns([(xyz_patch, self.xyz_mean, self.xyz_std, 'xyz', a.xyz_s_lambda, a.xyz_smap_lambda),
+                                    (rgb_patch, self.rgb_mean, self.rgb_std, 'rgb', a.rgb_s_lambda, a.rgb_smap_lambda)])
 
 
 class RGBorXYZWithOneHallucination(_MethodBase):
@@ -211,36 +278,37 @@ class RGBorXYZWithOneHallucination(_MethodBase):
     plus the other modality's features hallucinated either from the main modality's FEATURES (``--use_hn``: the FtoF MLP, or
     the FtoF conv head when ``--use_hn_conv`` is given as well) or from the main modality's INPUT (``--use_hrnet``, ItoF)."""
 
-    def _hallucinate(self, sample, xyz_patch, rgb_patch2):
+    def _hallucinate(self, samples, xyz_patch, rgb_patch2):
+        """-> [B, 3136, 768] hallucinated features of the OTHER modality."""
         a = self.args
         if a.main_modality not in ('rgb', 'xyz'):
             raise Exception('Unknown modality')
         with torch.no_grad():
             if getattr(a, "use_hrnet", False):  # multiple_features.py:326-331, 343-348: from the raw image / point map
-                src = sample[0] if a.main_modality == 'rgb' else sample[1]
+                src = torch.cat([s[0] if a.main_modality == 'rgb' else s[1] for s in samples])
                 h = self.fusion.hallucination_tokens(src.to(self.device))
                 assert tuple(h.shape[1:]) == (3136, 768)
             elif a.main_modality == 'rgb':
-                h = self.fusion.hallucination_generation(rgb_feature=rgb_patch2.unsqueeze(0), out_type='xyz')
+                h = self.fusion.hallucination_generation(rgb_feature=rgb_patch2, out_type='xyz')
             else:
-                h = self.fusion.hallucination_generation(xyz_feature=xyz_patch.unsqueeze(0), out_type='rgb')
+                h = self.fusion.hallucination_generation(xyz_feature=xyz_patch, out_type='rgb')
         assert len(h.shape) == 3
-        return h.reshape(-1, h.shape[2]).detach()
+        return h.detach()
 
-    def _patches(self, sample, fit=False):
-        rgb_maps, xyz_maps, interp, nz = self._extract(sample)
-        xyz_patch = self.get_xyz_patch(xyz_maps, interp, nz)
-        rgb_patch, rgb_patch2 = self.get_rgb_patch(rgb_maps)
-        return xyz_patch, rgb_patch, self._hallucinate(sample, xyz_patch, rgb_patch2)
+    def _patches(self, samples, fit=False):
+        """-> (xyz_patch [B,3136,768] | None, rgb_patch [B,784,768] | None, hallucination [B,3136,768])."""
+        ex = self._extract_batch(samples)
+        xyz_patch = self._engine.xyz_patch(ex, P=56)
+        return xyz_patch, eng.Engine.rgb_patch(ex), self._hallucinate(samples, xyz_patch, eng.Engine.rgb_patch56(ex))
 
-    def add_sample_to_mem_bank(self, sample, class_name=None):
-        self.class_name = class_name
-        xyz_patch, rgb_patch, hall = self._patches(sample, fit=True)
-        self.patch_rgb_lib.append(rgb_patch)
-        self.patch_xyz_lib.append(xyz_patch)
-        self.patch_fusion_lib.append(hall)
+    def _fit_batch(self, samples):
+        xyz_patch, rgb_patch, hall = self._patches(samples, fit=True)
+        self.patch_rgb_lib.extend(rgb_patch.unbind(0))
+        self.patch_xyz_lib.extend(xyz_patch.unbind(0))
+        self.patch_fusion_lib.extend(hall.unbind(0))
 
     def run_coreset(self):
+        self._flush("fit")
         self.patch_xyz_lib = torch.cat(self.patch_xyz_lib, 0)
         self.patch_rgb_lib = torch.cat(self.patch_rgb_lib, 0)
         self.patch_fusion_lib = torch.cat(self.patch_fusion_lib, 0)
@@ -254,26 +322,16 @@ class RGBorXYZWithOneHallucination(_MethodBase):
         self.patch_fusion_lib = self._coreset(eng.normalize(self.patch_fusion_lib, self.fusion_mean, self.fusion_std),
                                               'patch_fusion_lib')
 
-    def _s(self, sample):
-        xyz_patch, rgb_patch, hall = self._patches(sample)
+    def _score_batch(self, samples, test=False):
+        xyz_patch, rgb_patch, hall = self._patches(samples)
         a = self.args
-        main_item = ((rgb_patch, self.rgb_mean, self.rgb_std, 'rgb') if a.main_modality == 'rgb'
-                     else (xyz_patch, self.xyz_mean, self.xyz_std, 'xyz'))
-        (s_f, m_f), (s_m, m_m) = self._score_many([(hall, self.fusion_mean, self.fusion_std, 'fusion'), main_item])
         if a.main_modality == 'rgb':
-            main = (a.rgb_s_lambda, s_m, a.rgb_smap_lambda, m_m)
+            main = (rgb_patch, self.rgb_mean, self.rgb_std, 'rgb', a.rgb_s_lambda, a.rgb_smap_lambda)
         else:
-            main = (a.xyz_s_lambda, s_m, a.xyz_smap_lambda, m_m)
-        return self._fuse_inputs([main, (a.fusion_s_lambda, s_f, a.fusion_smap_lambda, m_f)])
-
-    def add_sample_to_late_fusion_mem_bank(self, sample):
-        s, s_map = self._s(sample)
-        self.s_lib.append(s)
-        self.s_map_lib.append(s_map)
-
-    def predict(self, sample, mask, label, rgb_path):
-        s, s_map = self._s(sample)
-        self._record(s, s_map, mask, label, rgb_path)
+            main = (xyz_patch, self.xyz_mean, self.xyz_std, 'xyz', a.xyz_s_lambda, a.xyz_smap_lambda)
+        # the reference scores the hallucinated library first (:514-518) and stacks [main, fusion] (:525,533)
+        fus = (hall, self.fusion_mean, self.fusion_std, 'fusion', a.fusion_s_lambda, a.fusion_smap_lambda)
+        return self._score_columns([main, fus])
 
 
 class RGBorXYZWithOneHallucinationFromFeature(RGBorXYZWithOneHallucination):
@@ -287,25 +345,28 @@ class RGBorXYZWithOneHallucinationFromFeature(RGBorXYZWithOneHallucination):
     (its patches feed the cross-wired statistics, :582,605,612-618); late fusion and predict never touch it (:651-663,
     :701-719), so the 3-D branch of the extractor is skipped there."""
 
-    def _patches(self, sample, fit=False):
+    def _patches(self, samples, fit=False):
         a = self.args
+        B = len(samples)
         if a.main_modality == 'rgb':
-            ex = self._extract_device(sample[0], sample[1], want_rgb=True, want_xyz=fit)
-            rgb_patch, rgb_patch2 = eng.Engine.rgb_patch(ex)[0], eng.Engine.rgb_patch56(ex)[0]
-            xyz_patch = self._engine.xyz_patch(ex, P=56)[0] if fit else None
+            ex = self._extract_batch(samples, want_rgb=True, want_xyz=fit)
+            rgb_patch, rgb_patch2 = eng.Engine.rgb_patch(ex), eng.Engine.rgb_patch56(ex)
+            xyz_patch = self._engine.xyz_patch(ex, P=56) if fit else None
             with torch.no_grad():
-                pc = self.fusion.hallucination_generation(rgb_patch2.unsqueeze(0))  # [1,3,224,224] hallucinated point map
-            assert tuple(pc.shape) == (1, 3, self.xyz_size, self.xyz_size), tuple(pc.shape)
-            hx = self._extract_device(None, pc, want_rgb=False, want_xyz=True)   # zero-coordinate pixels dropped as :592-594
-            hall = self._engine.xyz_patch(hx, P=56)[0]
+                pc = self.fusion.hallucination_generation(rgb_patch2)  # [B,3,224,224] hallucinated point maps
+            assert tuple(pc.shape) == (B, 3, self.xyz_size, self.xyz_size), tuple(pc.shape)
+            # zero-coordinate pixels dropped as :592-594; hallucinated maps have their own point counts: one by one
+            hall = torch.cat([self._engine.xyz_patch(self._extract_device(None, pc[b:b + 1], want_rgb=False, want_xyz=True), P=56)
+                              for b in range(B)])
         elif a.main_modality == 'xyz':
-            ex = self._extract_device(sample[0], sample[1], want_rgb=fit, want_xyz=True)
-            xyz_patch = self._engine.xyz_patch(ex, P=56)[0]
-            rgb_patch = eng.Engine.rgb_patch(ex)[0] if fit else None
+            ex = self._extract_batch(samples, want_rgb=fit, want_xyz=True)
+            xyz_patch = self._engine.xyz_patch(ex, P=56)
+            rgb_patch = eng.Engine.rgb_patch(ex) if fit else None
             with torch.no_grad():
-                img = self.fusion.hallucination_generation(xyz_patch.unsqueeze(0))
-            assert tuple(img.shape) == tuple(sample[0].shape), (tuple(img.shape), tuple(sample[0].shape))
-            hall = eng.Engine.rgb_patch(self._extract_device(img, None, want_rgb=True, want_xyz=False))[0]
+                img = self.fusion.hallucination_generation(xyz_patch)
+            assert tuple(img.shape) == (B, *samples[0][0].shape[1:]), (tuple(img.shape), tuple(samples[0][0].shape))
+            with torch.no_grad():
+                hall = eng.Engine.rgb_patch(self._engine.extract(img.to(self.device, torch.float32), want_xyz=False))
         else:
             raise NotImplementedError
         return xyz_patch, rgb_patch, hall

@@ -87,7 +87,7 @@ def test_predict_scores_match_oracle(fitted):
     for i, anomalous in ((10, False), (11, True)):
         rgb, pc = synth_sample(i, anomalous)
         s_ref, map_ref, rx, rr = cpu.predict(rgb, pc)
-        s_got, map_got = m._s((rgb, pc, pc))
+        s_got, map_got = m._score_batch([(rgb, pc, pc)])[0]
         # image-level pre-OCSVM scores: w * s_star of each modality (2-3 % from the bf16 feature error)
         # (with random-init weights on a smooth synthetic surface the xyz features of neighbouring patches
         # are nearly identical, so s_xyz = w * s_star is a small difference of near-equal numbers: absolute

@@ -442,7 +442,7 @@ def test_l2_dist_matrix_exact():
     q, bank = torch.randn(130, 768, generator=g), torch.randn(333, 768, generator=g)
     q[7] = bank[21]
     d = ops.l2_dist_matrix(q.to(DEV), bank.to(DEV)).cpu()
-    ref = torch.cdist(q.double(), bank.double())
+    ref = torch.stack([(bank.double() - r.double()).pow(2).sum(1).sqrt() for r in q])   # (cdist's expansion is not exact at 0)
     assert float(d[7, 21]) == 0.0
     np.testing.assert_allclose(d.numpy(), ref.numpy(), rtol=2e-6, atol=1e-6)
 

@@ -44,11 +44,13 @@ def main(n=40, warm=5):
     for i in range(warm):
         rgb, pc = samples[i % 8]
         m.predict((rgb, pc, pc), mask, 0, ["x.png"])
+    m._flush("predict")
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(n):
         rgb, pc = samples[i % 8]
         m.predict((rgb, pc, pc), mask, 0, ["x.png"])
+    m._flush("predict")
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     print(f'{{"dropin_B1_images_per_s": {n / dt:.2f}, "ms_per_image": {dt / n * 1e3:.2f}}}')
