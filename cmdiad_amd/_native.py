@@ -98,10 +98,14 @@ SIZE_QUERIES = {
 }
 
 
-def build(force=False, verbose=False):
-    """Compile cmdiad_amd/csrc into libcmdiad_hip.so with hipcc --offload-arch=gfx950."""
+AB_SO_PATH = os.path.join(_HERE, "libcmdiad_hip_ab.so")   # test-only build with the superseded kernel formulations
+
+
+def build(force=False, verbose=False, ab=False):
+    """Compile cmdiad_amd/csrc into libcmdiad_hip.so with hipcc --offload-arch=gfx950 (ab=True: also the test-only
+    libcmdiad_hip_ab.so, -DCMDIAD_AB_VARIANTS, that the variant parity tests and the A/B tools load via CMDIAD_HIP_LIB)."""
     csrc = os.path.join(_HERE, "csrc")
-    cmd = ["make", "-C", csrc, "-j8"] + (["-B"] if force else [])
+    cmd = ["make", "-C", csrc, "-j8"] + (["-B"] if force else []) + (["all", "ab"] if ab else [])
     res = subprocess.run(cmd, capture_output=True, text=True)
     if verbose or res.returncode != 0:
         print(res.stdout[-4000:], res.stderr[-4000:])
@@ -128,6 +132,7 @@ def lib():
             fn.restype = c_size_t
         L.cmdiad_last_error.restype = c_char_p
         L.cmdiad_abi_version.restype = c_int
+        L.cmdiad_has_ab_variants.restype = c_int
         _lib = L
     return _lib
 

@@ -39,6 +39,7 @@ __device__ __forceinline__ unsigned long long fps_key(float v, int idx)
     return v < 0.0f ? 0ull : (((unsigned long long)__float_as_uint(v) << 32) | (0xFFFFFFFFu - (unsigned)idx));
 }
 
+#ifdef CMDIAD_AB_VARIANTS  // first formulation of the round: test-only build (make ab), A/B reference for fps_pk_kernel
 template <int kThreads, int PPT>
 __global__ __launch_bounds__(kThreads) void fps_reg_kernel(const float* __restrict__ xyz,
                                                            const int32_t* __restrict__ n_valid, int N, int G,
@@ -104,6 +105,7 @@ __global__ __launch_bounds__(kThreads) void fps_reg_kernel(const float* __restri
         }
     }
 }
+#endif  // CMDIAD_AB_VARIANTS
 
 // Second formulation of the same round, built for VALU throughput: one CU retires 64 lanes x 4 SIMDs / 4 cycles, and the
 // round above spends 12 VALU operations per point (48 points per lane: ~4 600 cycles, most of the 2.6 us round).  Here
@@ -298,7 +300,8 @@ extern "C" int cmdiad_fps(const float* xyz, const int32_t* n_valid, int B, int N
     CMDIAD_REQUIRE(B >= 0 && N > 0 && G >= 0, CMDIAD_ERR_ARG, "cmdiad_fps: bad sizes B=%d N=%d G=%d", B, N, G);
     if (B == 0 || G == 0) return CMDIAD_OK;
     hipStream_t s = (hipStream_t)stream;
-    // CMDIAD_FPS_PK=0 selects the first formulation (A/B runs and the parity tests; read per call)
+#ifdef CMDIAD_AB_VARIANTS
+    // test-only build: CMDIAD_FPS_PK=0 selects the first formulation (A/B runs and the parity tests; read per call)
     const char* e = getenv("CMDIAD_FPS_PK");
     const bool pk = !(e && e[0] == '0');
 #define FPS_LAUNCH(T, P)                                                                                                      \
@@ -306,6 +309,9 @@ extern "C" int cmdiad_fps(const float* xyz, const int32_t* n_valid, int B, int N
         if (pk) hipLaunchKernelGGL((fps_pk_kernel<T, P>), dim3(B), dim3(T), 0, s, xyz, n_valid, N, G, idx_out, center_out);   \
         else hipLaunchKernelGGL((fps_reg_kernel<T, P>), dim3(B), dim3(T), 0, s, xyz, n_valid, N, G, idx_out, center_out);     \
     } while (0)
+#else
+#define FPS_LAUNCH(T, P) hipLaunchKernelGGL((fps_pk_kernel<T, P>), dim3(B), dim3(T), 0, s, xyz, n_valid, N, G, idx_out, center_out)
+#endif
     // 1024 threads (4 waves/SIMD, 128 VGPRs) hold 16 points per lane; larger clouds use 512 threads
     // (2 waves/SIMD, 256 VGPRs): the register file of ONE CU bounds the resident cloud at ~28k points.
     if (N <= 1024 * 4) FPS_LAUNCH(1024, 4);

@@ -5,7 +5,11 @@
 #include <mutex>
 #include <set>
 
-#include "gemm_wide.h"
+#ifdef CMDIAD_AB_VARIANTS
+#include "gemm_wide.h"  // 4-wave 256-row shapes: A/B references, test-only build (make ab)
+#else
+#include "gemm_core.h"
+#endif
 
 namespace {
 
@@ -327,12 +331,14 @@ __global__ __launch_bounds__(S::THREADS, S::WAVES_PER_SIMD) void gemm_groupmax_k
     groupmax_body<S>(A, W, p, lds);
 }
 
+#ifdef CMDIAD_AB_VARIANTS  // generic-pipeline form of the encoder's first stage (conv1 re-staged per step): A/B reference
 template <class S>
 __global__ __launch_bounds__(S::THREADS, S::WAVES_PER_SIMD) void encoder_stage1_kernel(Conv1Tile A, GlobalTile W, GroupMaxParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     groupmax_body<S>(A, W, p, lds);
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // Encoder first stage, dedicated form: a block's 128 x 128 conv1 activations are computed ONCE into LDS (both K tiles)
@@ -390,6 +396,7 @@ __global__ __launch_bounds__(256, 2) void encoder_stage1_once_kernel(Conv1Tile A
 
 template <class S> constexpr int group_max_lds() { return S::LDS_BYTES + (S::BM / 32) * S::BN * (int)sizeof(float); }
 
+#ifdef CMDIAD_AB_VARIANTS
 // ------------------------------------------------------------------------------------------------
 // The same two products on the 4-wave 256-row shapes of gemm_wide.h (256 x 256 or 256 x 128 blocks): half / three
 // quarters of the operand bytes per FLOP through the L1 / LDS-DMA path, which is what bounds the 128 x 128 shape on
@@ -494,6 +501,7 @@ __global__ __launch_bounds__(256, 1) void gemm_groupmax_wide_kernel(GlobalTile A
         }
     });
 }
+#endif  // CMDIAD_AB_VARIANTS
 
 bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
@@ -541,21 +549,6 @@ int panel_tiles(long M, long N, long K, int split)
     return (int)(ntl < 8 ? ntl : 8);
 }
 
-// Wide-shape choice for a product: 0 = keep 128 x 128, 8 = 256 x 256, 4 = 256 x 128.  Measured on MI355X
-// (profiles/r1_notes.md): the 4-wave shapes pay for issuing all LDS-DMA pieces from the MFMA-issuing wave; the only shape
-// they win as a bare product (4.2M x 512 x 256: 2.34 vs 2.57 ms) they lose again inside the encoder, where that GEMM
-// carries the group-bias + ReLU epilogue (encoder 8.6-8.9 vs 7.9 ms).  So no network GEMM selects them; the distance GEMM
-// does (l2min.hip).  CMDIAD_GEMM_WIDE=4 / =8 force a shape (A/B runs and the parity tests; read per call).
-int wide_choice(long M, long N, long K, bool plain_epilogue, int split)
-{
-    const char* e = getenv("CMDIAD_GEMM_WIDE");
-    const int force = e ? atoi(e) : -1;
-    if (!plain_epilogue || split > 1 || force == 0) return 0;
-    if (force == 4 || force == 8) return force;
-    (void)M; (void)N; (void)K;
-    return 0;
-}
-
 // Persistent 256 x 256 kernel: products with whole 256-column tiles and enough of them that 256 blocks each get >= 2 tiles
 // (qkv, fc1 of both transformers at batch 32).  CMDIAD_GEMM_PERSIST=0 / 1 forces it off / on wherever it is legal (A/B runs,
 // parity tests on small shapes; read per call).
@@ -571,6 +564,22 @@ bool persist_choice(long M, long N, long K, bool legal_epilogue)
     const char* e = getenv("CMDIAD_GEMM_PERSIST");
     if (e) return e[0] != '0';
     return N >= 1536 && ((M + 255) / 256) * (N / 256) >= 2 * kPersistCUs;
+}
+
+#ifdef CMDIAD_AB_VARIANTS
+// Wide-shape choice for a product: 0 = keep 128 x 128, 8 = 256 x 256, 4 = 256 x 128.  Measured on MI355X
+// (profiles/r1_notes.md): the 4-wave shapes pay for issuing all LDS-DMA pieces from the MFMA-issuing wave; the only shape
+// they win as a bare product (4.2M x 512 x 256: 2.34 vs 2.57 ms) they lose again inside the encoder, where that GEMM
+// carries the group-bias + ReLU epilogue (encoder 8.6-8.9 vs 7.9 ms).  So no network GEMM selects them; the distance GEMM
+// does (l2min.hip).  CMDIAD_GEMM_WIDE=4 / =8 force a shape (A/B runs and the parity tests; read per call).
+int wide_choice(long M, long N, long K, bool plain_epilogue, int split)
+{
+    const char* e = getenv("CMDIAD_GEMM_WIDE");
+    const int force = e ? atoi(e) : -1;
+    if (!plain_epilogue || split > 1 || force == 0) return 0;
+    if (force == 4 || force == 8) return force;
+    (void)M; (void)N; (void)K;
+    return 0;
 }
 
 template <class SW, class Kern, class P>
@@ -594,6 +603,7 @@ int launch_wide(Kern kernel, long M, long N, long K, P& p, const GlobalTile& A, 
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(256), SW::LDS_BYTES, s, A, W, p);
     return CMDIAD_OK;
 }
+#endif  // CMDIAD_AB_VARIANTS
 
 template <class S>
 dim3 grid_for(long M, long N, int y = 1, int panel = 1)
@@ -629,6 +639,7 @@ extern "C" int cmdiad_gemm_bf16(const cmdiad_gemm_args* a, cmdiad_stream_t strea
     hipStream_t s = (hipStream_t)stream;
     const bool extras = a->out_pre_bf16 || a->dact_of;
     int rc;
+#ifdef CMDIAD_AB_VARIANTS
     const int wide = wide_choice(a->M, a->N, a->K, !extras && !a->residual && a->ldo16 % 4 == 0, split);
     if (wide) {
 #define CMDIAD_WIDE(NJ, ACT) launch_wide<WideShape<NJ>>(gemm_std_wide_kernel<NJ, ACT>, a->M, a->N, a->K, p, A, W, s)
@@ -639,6 +650,7 @@ extern "C" int cmdiad_gemm_bf16(const cmdiad_gemm_args* a, cmdiad_stream_t strea
         CMDIAD_CHECK_LAUNCH();
         return CMDIAD_OK;
     }
+#endif
     if (persist_choice(a->M, a->N, a->K, !extras && !a->group_bias && split == 1)) {
 #define CMDIAD_PERSIST(ACT) launch<S2x2>(gemm_std_persist_kernel<S2x2, ACT>, dim3(persist_blocks(a->M, a->N)), S2x2::LDS_BYTES, s, A, W, p)
         rc = a->act == CMDIAD_ACT_GELU ? CMDIAD_PERSIST(CMDIAD_ACT_GELU) : a->act == CMDIAD_ACT_RELU ? CMDIAD_PERSIST(CMDIAD_ACT_RELU) : CMDIAD_PERSIST(CMDIAD_ACT_NONE);
@@ -689,6 +701,7 @@ extern "C" int cmdiad_gemm_groupmax(const uint16_t* A, const uint16_t* W, const 
     GlobalTile At{(const bf16_t*)A, K, M}, Wt{(const bf16_t*)W, K, N};
     GroupMaxParams p{M, N, K, Mg, 1, bias, nullptr, 0, out_f32, (bf16_t*)out_bf16};
     hipStream_t s = (hipStream_t)stream;
+#ifdef CMDIAD_AB_VARIANTS
     const int wide = wide_choice(M, N, K, true, 1);
     if (wide) {
         const int rcw = wide == 8 ? launch_wide<WideShape<8>>(gemm_groupmax_wide_kernel<8>, M, N, K, p, At, Wt, s)
@@ -697,6 +710,7 @@ extern "C" int cmdiad_gemm_groupmax(const uint16_t* A, const uint16_t* W, const 
         CMDIAD_CHECK_LAUNCH();
         return CMDIAD_OK;
     }
+#endif
     p.panel = panel_tiles<S128>(M, N, K, 1);
     const int rc = launch<S128>(gemm_groupmax_kernel<S128>, grid_for<S128>(M, N, 1, p.panel), group_max_lds<S128>(), s, At, Wt, p);
     if (rc) return rc;
@@ -718,15 +732,20 @@ extern "C" int cmdiad_encoder_stage1(const float* neigh, const float* w1, const 
     GlobalTile Wt{(const bf16_t*)W2, 128, 256};
     GroupMaxParams p{M, 256, 128, Mg, 1, b2, (bf16_t*)h2_out, 256, gmax_out, (bf16_t*)gmax_bf16_out};
     hipStream_t s = (hipStream_t)stream;
-    p.panel = panel_tiles<S128>(M, 256, 128, 1);
-    // CMDIAD_STAGE1_ONCE=0 selects the generic pipeline (A/B runs; read per call)
-    const char* e1 = getenv("CMDIAD_STAGE1_ONCE");
+    CMDIAD_REQUIRE(b2, CMDIAD_ERR_ARG, "cmdiad_encoder_stage1: the second convolution's bias is required");
     int rc;
-    if (!(e1 && e1[0] == '0') && b2) {
+#ifdef CMDIAD_AB_VARIANTS
+    // test-only build: CMDIAD_STAGE1_ONCE=0 selects the generic pipeline (A/B runs; read per call)
+    const char* e1 = getenv("CMDIAD_STAGE1_ONCE");
+    if (e1 && e1[0] == '0') {
+        p.panel = panel_tiles<S128>(M, 256, 128, 1);
+        rc = launch<S128>(encoder_stage1_kernel<S128>, grid_for<S128>(M, 256, 1, p.panel), group_max_lds<S128>(), s, At, Wt, p);
+    } else
+#endif
+    {
         p.panel = 1;
         rc = launch<S128>(encoder_stage1_once_kernel, dim3((unsigned)((M + 127) / 128)), group_max_lds<S128>(), s, At, Wt, p);
-    } else
-        rc = launch<S128>(encoder_stage1_kernel<S128>, grid_for<S128>(M, 256, 1, p.panel), group_max_lds<S128>(), s, At, Wt, p);
+    }
     if (rc) return rc;
     CMDIAD_CHECK_LAUNCH();
     return CMDIAD_OK;

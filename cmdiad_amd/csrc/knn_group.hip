@@ -28,6 +28,7 @@ constexpr int kCap = 1024;     // keys per centre buffer (power of two, bitonic)
 constexpr int kChunk = 512;    // points per streaming step; prune when cnt > kCap - kChunk
 constexpr unsigned long long kInf = ~0ull;
 
+#ifdef CMDIAD_AB_VARIANTS  // block-wide formulation (1024-key LDS bitonic sort): test-only build (make ab), A/B reference
 __device__ __forceinline__ void bitonic_sort_1024(unsigned long long* s, int tid)
 {
     for (int k = 2; k <= kCap; k <<= 1) {
@@ -155,6 +156,8 @@ __global__ __launch_bounds__(kThreads) void knn_group_kernel(const float* __rest
         __syncthreads();
     }
 }
+#endif  // CMDIAD_AB_VARIANTS
+
 
 // ------------------------------------------------------------------------------------------------
 // Second formulation: a WAVE owns its centres end to end -- no workgroup barriers, no LDS atomics, no 1024-key LDS sort.
@@ -339,9 +342,14 @@ extern "C" int cmdiad_knn_group(const float* xyz, const int32_t* n_valid, const 
     CMDIAD_REQUIRE(B >= 0 && N > 0 && G >= 0 && K > 0 && K <= 128, CMDIAD_ERR_ARG,
                    "cmdiad_knn_group: bad sizes B=%d N=%d G=%d K=%d (K<=128)", B, N, G, K);
     if (B == 0 || G == 0) return CMDIAD_OK;
-    // CMDIAD_KNN_WAVE=0 selects the block-wide formulation (A/B runs and the parity tests; read per call)
+#ifdef CMDIAD_AB_VARIANTS
+    // test-only build: CMDIAD_KNN_WAVE=0 selects the block-wide formulation (A/B runs and the parity tests; read per call)
     const char* e = getenv("CMDIAD_KNN_WAVE");
-    if (!(e && e[0] == '0')) {
+    const bool wave_form = !(e && e[0] == '0');
+#else
+    const bool wave_form = true;
+#endif
+    if (wave_form) {
         if ((long)B * ((G + 15) / 16) >= 512) {
             hipLaunchKernelGGL((knn_wave_kernel<4, 4>), dim3((G + 15) / 16, B), dim3(256), 0, (hipStream_t)stream, xyz, n_valid, center, N, G, K,
                                idx_out, neigh_out);
@@ -352,11 +360,14 @@ extern "C" int cmdiad_knn_group(const float* xyz, const int32_t* n_valid, const 
             hipLaunchKernelGGL((knn_wave_kernel<1, 1>), dim3(G, B), dim3(64), 0, (hipStream_t)stream, xyz, n_valid, center, N, G, K, idx_out,
                                neigh_out);
         }
-    } else {
+    }
+#ifdef CMDIAD_AB_VARIANTS
+    else {
         dim3 grid((G + kCPB - 1) / kCPB, B);
         hipLaunchKernelGGL(knn_group_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, xyz, n_valid, center, N, G,
                            K, idx_out, neigh_out);
     }
+#endif
     CMDIAD_CHECK_LAUNCH();
     return CMDIAD_OK;
 }

@@ -9,11 +9,16 @@
 // (value bits << 32 | global row: integer order = (distance, row) order).  Blocks are dealt to the XCDs in groups of
 // `qgroup` query tiles x `splits` bank ranges, so a streamed bank tile is shared through that XCD's L2.
 // Shapes: l2_min_pp3_kernel (256 x 256, 8 waves in two groups, per-stream issuer waves) from Q >= 512; l2_min_kernel<S128>
-// below that and for the last Nb % 256 bank rows; l2_min_wide_kernel (gemm_wide.h: 4 waves of 128 x 128), l2_min_pp_kernel and
-// l2_min_kernel<S2x2> kept as A/B references (CMDIAD_L2_TILE); every variant returns the same keys.
+// below that and for the last Nb % 256 bank rows.  The superseded formulations -- l2_min_wide_kernel (gemm_wide.h: 4 waves of
+// 128 x 128), l2_min_pp_kernel, l2_min_kernel<S2x2> -- are compiled into the test-only build alone (make ab,
+// -DCMDIAD_AB_VARIANTS; selected with CMDIAD_L2_TILE); every variant returns the same keys.
 #include <stdlib.h>
 
+#ifdef CMDIAD_AB_VARIANTS
 #include "gemm_wide.h"
+#else
+#include "gemm_core.h"
+#endif
 
 namespace {
 
@@ -91,6 +96,9 @@ __global__ __launch_bounds__(S::THREADS, S::WAVES_PER_SIMD) void l2_min_kernel(G
     }
 }
 
+__device__ __forceinline__ void pp_barrier() { asm volatile("s_barrier" ::: "memory"); }
+
+#ifdef CMDIAD_AB_VARIANTS  // superseded formulations of the 256 x 256 distance GEMM: test-only build (make ab), A/B references
 // The same contraction on the 4-wave 128 x 128-per-wave shape (gemm_wide.h).
 template <bool F16>
 __global__ __launch_bounds__(256, 1) void l2_min_wide_kernel(GlobalTile A, GlobalTile W, L2Params p)
@@ -186,7 +194,6 @@ struct SPingPong {
     static constexpr int LDS_BYTES = 4 * BUF + 2 * 256 * 4;  // [A buf0][A buf1][B buf0][B buf1][bank norms x 2]
 };
 
-__device__ __forceinline__ void pp_barrier() { asm volatile("s_barrier" ::: "memory"); }
 
 template <bool F16>
 __global__ __launch_bounds__(512, 1) void l2_min_pp_kernel(GlobalTile A, GlobalTile W, L2Params p)
@@ -395,6 +402,7 @@ __global__ __launch_bounds__(512, 1) void l2_min_pp_kernel(GlobalTile A, GlobalT
         if (lane < 16 && m < p.Q) atomicMin(p.keys + m, key);
     }
 }
+#endif  // CMDIAD_AB_VARIANTS
 
 // ------------------------------------------------------------------------------------------------
 // The two-group pipeline with MORE BANK BYTES IN FLIGHT (the ablations above put the remaining time in the latency of the
@@ -800,8 +808,10 @@ bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 }  // namespace
 
 template <class S, bool F16> struct L2Kernel { static constexpr auto fn = l2_min_kernel<S, F16>; };
+#ifdef CMDIAD_AB_VARIANTS
 template <bool F16> struct L2Kernel<SWide, F16> { static constexpr auto fn = l2_min_wide_kernel<F16>; };
 template <bool F16> struct L2Kernel<SPingPong, F16> { static constexpr auto fn = l2_min_pp_kernel<F16>; };
+#endif
 template <bool F16> struct L2Kernel<SPingPong3, F16> { static constexpr auto fn = l2_min_pp3_kernel<F16>; };
 
 template <class S, bool F16>
@@ -824,7 +834,7 @@ int launch_l2(const uint16_t* q, const float* q_sqnorm, const uint16_t* bank, co
     // measured on the bagel xyz library (profiles/r1_notes.md): 8 bank ranges for the 8-wave shapes; the 4-wave wide
     // shape gains another 5 % from 16-32 (shorter ranges, better tail balance), as long as a range keeps >= 4 tiles
     int splits = env_splits > 0 ? env_splits : 8;
-    if (env_splits <= 0 && (std::is_same<S, SWide>::value || std::is_same<S, SPingPong>::value || std::is_same<S, SPingPong3>::value)) splits = nbt / 4 < 1 ? 1 : (nbt / 4 > 32 ? 32 : nbt / 4);
+    if (env_splits <= 0 && S::BM == 256 && !std::is_same<S, S2x2>::value) splits = nbt / 4 < 1 ? 1 : (nbt / 4 > 32 ? 32 : nbt / 4);
     splits = splits > nbt ? nbt : splits;
     int qgroup = env_qgroup > 0 ? env_qgroup : 4;
     qgroup = qgroup > nq ? nq : qgroup;
@@ -844,13 +854,22 @@ extern "C" int cmdiad_l2_min_keys(const uint16_t* q, const float* q_sqnorm, cons
     CMDIAD_REQUIRE(aligned16(q) && aligned16(bank), CMDIAD_ERR_ARG, "cmdiad_l2_min_keys: 16-byte alignment");
     CMDIAD_REQUIRE(dtype == CMDIAD_DT_BF16 || dtype == CMDIAD_DT_F16, CMDIAD_ERR_ARG, "cmdiad_l2_min_keys: dtype");
     if (Q == 0 || Nb == 0) return CMDIAD_OK;
-    const char* env_tile = getenv("CMDIAD_L2_TILE");  // read per call: the parity tests force each shape on small inputs
+    // production: the two-group 256 x 256 pipeline (l2_min_pp3_kernel) from Q >= 512, the 128 x 128 kernel below that, for the
+    // last Nb % 256 library rows and for D < 192 (the two-group schedule assumes >= 3 K-tiles per library tile).
+    // CMDIAD_L2_TILE (read per call: the parity tests force each shape on small inputs) = 0 / 5 for those two; the test-only
+    // build (make ab) also knows 2 = 256 x 256 lock-step, 3 = 4 waves of 128 x 128, 4 = two groups with two buffers.
+    const char* env_tile = getenv("CMDIAD_L2_TILE");
     const int force = env_tile ? atoi(env_tile) : -1;
-    // 0 S128, 2 S2x2 (256x256, 8 waves), 3 SWide (256x256, 4 waves of 128x128), 4 SPingPong (256x256, 2 groups of 4 waves),
-    // 5 SPingPong3 (the same with three bank buffers and per-stream issuer waves: production from Q >= 512)
-    // measured at the B = 1 shapes too (Q = 3136 / 784 against the bagel libraries): 0.68 -> 0.43 ms and 0.17 -> 0.11 ms
     int tile = force >= 0 ? force : (Q >= 512 ? 5 : 0);
-    if ((tile == 4 || tile == 5) && D < 192) tile = 3;  // the two-group schedules assume >= 3 K-tiles per bank tile  // the ping-pong schedule assumes >= 3 K-tiles per bank tile
+#ifndef CMDIAD_AB_VARIANTS
+    if (tile != 0 && tile != 5) {
+        cmdiad_set_error("cmdiad_l2_min_keys: CMDIAD_L2_TILE=%d names an A/B variant that only the test build (make ab) contains", tile);
+        return CMDIAD_ERR_ARG;
+    }
+    if (tile == 5 && D < 192) tile = 0;
+#else
+    if ((tile == 4 || tile == 5) && D < 192) tile = 3;
+#endif
     hipStream_t s = (hipStream_t)stream;
     const bool h = dtype == CMDIAD_DT_F16;
     int rc;
@@ -860,14 +879,18 @@ extern "C" int cmdiad_l2_min_keys(const uint16_t* q, const float* q_sqnorm, cons
         rc = CMDIAD_OK;
         if (full > 0 && tile == 5) rc = h ? launch_l2<SPingPong3, true>(q, q_sqnorm, bank, bank_sqnorm, Q, full, D, row_offset, keys, s)
                                           : launch_l2<SPingPong3, false>(q, q_sqnorm, bank, bank_sqnorm, Q, full, D, row_offset, keys, s);
+#ifdef CMDIAD_AB_VARIANTS
         else if (full > 0) rc = h ? launch_l2<SPingPong, true>(q, q_sqnorm, bank, bank_sqnorm, Q, full, D, row_offset, keys, s)
                              : launch_l2<SPingPong, false>(q, q_sqnorm, bank, bank_sqnorm, Q, full, D, row_offset, keys, s);
+#endif
         if (rc == CMDIAD_OK && rest > 0) {
             const uint16_t* b2 = bank + (size_t)full * D;
             rc = h ? launch_l2<S128, true>(q, q_sqnorm, b2, bank_sqnorm + full, Q, rest, D, row_offset + full, keys, s)
                    : launch_l2<S128, false>(q, q_sqnorm, b2, bank_sqnorm + full, Q, rest, D, row_offset + full, keys, s);
         }
-    } else if (tile == 3) {
+    }
+#ifdef CMDIAD_AB_VARIANTS
+    else if (tile == 3) {
         const int full = Nb / 256 * 256, rest = Nb - full;
         rc = CMDIAD_OK;
         if (full > 0) rc = h ? launch_l2<SWide, true>(q, q_sqnorm, bank, bank_sqnorm, Q, full, D, row_offset, keys, s)
@@ -879,6 +902,7 @@ extern "C" int cmdiad_l2_min_keys(const uint16_t* q, const float* q_sqnorm, cons
         }
     }
     else if (tile == 2) rc = h ? launch_l2<S2x2, true>(L2_ARGS) : launch_l2<S2x2, false>(L2_ARGS);
+#endif
     else rc = h ? launch_l2<S128, true>(L2_ARGS) : launch_l2<S128, false>(L2_ARGS);
 #undef L2_ARGS
     if (rc) return rc;

@@ -34,6 +34,8 @@ typedef enum {
 
 const char* cmdiad_last_error(void);
 int cmdiad_abi_version(void);
+/* 1 when the library is the test-only build that also contains the superseded kernel formulations (A/B references). */
+int cmdiad_has_ab_variants(void);
 
 /* ---------------------------------------------------------------------------------------------
  * Point-cloud front end

@@ -9,6 +9,11 @@ if REPO not in sys.path:
 GOLDEN = os.path.join(REPO, "tests", "golden")
 # every test loads seeded synthetic weights after construction (no checkpoints offline): explicit opt-in, see models.Model
 os.environ.setdefault("CMDIAD_ALLOW_RANDOM_INIT", "1")
+# CMDIAD_TEST_AB=1: load the test-only build (make -C cmdiad_amd/csrc ab) that also contains the superseded kernel
+# formulations, so the variant parity tests run instead of skipping.  Must be set before cmdiad_amd is imported.
+_AB = os.path.join(REPO, "cmdiad_amd", "libcmdiad_hip_ab.so")
+if os.environ.get("CMDIAD_TEST_AB") == "1" and os.path.exists(_AB):
+    os.environ["CMDIAD_HIP_LIB"] = _AB
 
 
 def pytest_configure(config):
@@ -22,3 +27,10 @@ def golden():
     def load(name):
         return np.load(os.path.join(GOLDEN, name))
     return load
+
+
+def need_ab_variants(what):
+    """Skip unless the loaded library is the test-only build with the A/B kernel variants (CMDIAD_TEST_AB=1)."""
+    from cmdiad_amd import _native as nat
+    if not nat.lib().cmdiad_has_ab_variants():
+        pytest.skip(f"{what}: A/B variant, only in the test build (make -C cmdiad_amd/csrc ab; CMDIAD_TEST_AB=1)")

@@ -7,6 +7,8 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+from conftest import need_ab_variants  # noqa: E402
+
 from cmdiad_amd import ops  # noqa: E402
 from cmdiad_amd.synth import synth_cloud, synth_cloud_fixed_n  # noqa: E402
 from oracle import kernels as ok  # noqa: E402
@@ -28,6 +30,8 @@ def _bf(x):
 @pytest.fixture(params=["1", "0"], ids=["pk", "reg"])
 def fps_variant(request, monkeypatch):
     """Both formulations of the FPS round (fps.hip: packed-math + deferred argmax, and the per-slot (value, slot) one)."""
+    if request.param == "0":
+        need_ab_variants("fps_reg_kernel")
     monkeypatch.setenv("CMDIAD_FPS_PK", request.param)
 
 
@@ -83,6 +87,8 @@ def test_fps_mostly_skipped_and_all_skipped_clouds(fps_variant):
 def knn_variant(request, monkeypatch):
     """Both formulations of the kNN grouping (knn_group.hip: a wave owns its centres with an in-register sorting network, and
     the block-wide LDS bitonic sort)."""
+    if request.param == "0":
+        need_ab_variants("knn_group_kernel")
     monkeypatch.setenv("CMDIAD_KNN_WAVE", request.param)
 
 
@@ -163,6 +169,7 @@ def test_gemm_epilogues(M, N, K, panel_min, wide, monkeypatch):
     if panel_min:  # panel mode: one block walks up to 8 N tiles (K <= 512 products)
         monkeypatch.setenv("CMDIAD_GEMM_PANEL_MIN", panel_min)
     if wide:  # the 4-wave 256-row shapes (gemm_wide.h): 8 = 256x256, 4 = 256x128; ragged M and N tiles included
+        need_ab_variants("gemm_std_wide_kernel")
         monkeypatch.setenv("CMDIAD_GEMM_WIDE", wide)
     g = torch.Generator().manual_seed(M + N + K)
     A = _bf(torch.randn(M, K, generator=g))
@@ -320,7 +327,10 @@ def test_pointmae_encoder_stages(Mg, panel_min, wide, monkeypatch):
                                           (515, 9000, 320, "5"), (300, 256, 192, "5"), (260, 1024, 1024, "5")])
 def test_l2_min_and_rescore(Q, Nb, D, tile, monkeypatch):
     if tile:  # 3 = 4-wave 128x128-per-wave shape; 2 = 8-wave 256x256 shape; 4 / 5 = the two-group (ping-pong) 256x256 pipelines (5: three bank buffers, split issuers)
-        # (whole bank tiles only: the remainder rows go through the 128x128 kernel; D < 192 falls back to 3)
+        # (whole bank tiles only: the remainder rows go through the 128x128 kernel; D < 192 falls back to the 128x128 kernel,
+        #  to variant 3 in the test build)
+        if tile not in ("0", "5"):
+            need_ab_variants(f"CMDIAD_L2_TILE={tile}")
         monkeypatch.setenv("CMDIAD_L2_TILE", tile)
     g = torch.Generator().manual_seed(Q + Nb)
     bank = torch.randn(Nb, D, generator=g)
@@ -352,6 +362,8 @@ def test_l2_min_all_tiles_identical_keys(tile, dt, monkeypatch):
     IDENTICAL keys on the same operands (same products, same fp32 accumulation order per 64-deep K tile, same
     first-occurrence rule), and agree with the fp64 argmin up to bf16 near-ties.  Shapes with several bank tiles per block, a
     partial last tile (handled by the 128x128 kernel in variants 3 and 4) and a ragged query tile."""
+    if tile not in ("0", "5"):
+        need_ab_variants(f"CMDIAD_L2_TILE={tile}")
     Q, Nb, D = 1100, 2900, 256
     g = torch.Generator().manual_seed(77)
     bank = torch.randn(Nb, D, generator=g)

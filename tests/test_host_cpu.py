@@ -20,7 +20,8 @@ def test_cabi_library_loads_and_exports_every_declared_symbol():
     assert L.cmdiad_abi_version() == 1
     hdr = open(os.path.join(REPO, "include", "cmdiad_hip.h")).read()
     declared = set(re.findall(r"\b(cmdiad_[a-z0-9_]+)\s*\(", hdr))
-    bound = set(nat.SIGNATURES) | set(nat.SIZE_QUERIES) | {"cmdiad_last_error", "cmdiad_abi_version"}
+    bound = set(nat.SIGNATURES) | set(nat.SIZE_QUERIES) | {"cmdiad_last_error", "cmdiad_abi_version", "cmdiad_has_ab_variants"}
+    assert L.cmdiad_has_ab_variants() == 0   # the production library carries ONE formulation of every kernel
     assert declared == bound, (declared - bound, bound - declared)
     for name in declared:
         assert hasattr(L, name), name

@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """Randomised parity sweep of the kernels against the CPU oracle / float64 references (development QA, not part of the
 pytest suites): random shapes including ragged tiles, tiny and odd sizes.  `python tools/fuzz_gpu.py [seconds] [seed]`."""
+import os as _os
+# A/B tool: needs the test-only build with the superseded kernel formulations (make -C cmdiad_amd/csrc ab)
+_os.environ.setdefault("CMDIAD_HIP_LIB", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "cmdiad_amd", "libcmdiad_hip_ab.so"))
 import os
 import sys
 import time

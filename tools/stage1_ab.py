@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
 """Timing of cmdiad_encoder_stage1 at the bench shape (32 x 1024 groups x 128 points)."""
+import os as _os
+# A/B tool: needs the test-only build with the superseded kernel formulations (make -C cmdiad_amd/csrc ab)
+_os.environ.setdefault("CMDIAD_HIP_LIB", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "cmdiad_amd", "libcmdiad_hip_ab.so"))
 import os, sys, torch
 sys.path.insert(0, os.getcwd())
 from cmdiad_amd import ops
