@@ -10,47 +10,73 @@
 //
 // One launch per iteration, no host synchronisation: round r publishes its winner with a 64-bit
 // atomicMax of (value bits << 32 | ~index) into best[r]; round r+1 reads best[r].  The scan is
-// HBM/L2-bound: n*d*2 bytes per round (511 MB for the xyz bank of 'bagel').
+// HBM-bound: n*d*2 bytes per round (511 MB for the xyz bank of 'bagel': twice the Infinity Cache).
+//
+// Layout: besides the row-major fp16 copy (the pivot row is fetched from it) the rows are kept TRANSPOSED in pairs of
+// dimensions, zT[c][row] = (z[row][2c], z[row][2c+1]) as half2 -- a thread owns four consecutive rows and walks c, so every
+// load instruction of a wave is one contiguous 1 KiB piece and a row's sum of squares lives in ONE lane: no cross-lane
+// reduction per row (round 1's wave-per-row form spent a 6-step butterfly per 668 bytes and reached 2.3 TB/s).
 #include <hip/hip_fp16.h>
 
 #include "common.h"
 
 namespace {
 
-__global__ __launch_bounds__(256) void coreset_round_kernel(const __half* __restrict__ z, int n, int d,
-                                                            __half* __restrict__ min_d,
+typedef __attribute__((ext_vector_type(2))) _Float16 h2_t;
+
+__device__ __forceinline__ float sq_diff_acc(unsigned a, unsigned b, float acc)
+{
+    const h2_t df = __builtin_bit_cast(h2_t, a) - __builtin_bit_cast(h2_t, b);   // rounded to fp16 like z_lib - last_item (v_pk_add_f16)
+    const float x = (float)df[0], y = (float)df[1];
+    return acc + (x * x + y * y);
+}
+
+__global__ __launch_bounds__(256) void coreset_round_kernel(const __half* __restrict__ z, const uint4* __restrict__ zT, int n, int n4,
+                                                            int d2, __half* __restrict__ min_d,
                                                             const unsigned long long* __restrict__ best_prev,
                                                             unsigned long long* __restrict__ best_cur, int first_idx)
 {
+    __shared__ unsigned s_piv[512];
     __shared__ unsigned long long s_key[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int last = best_prev ? (int)(0xFFFFFFFFu - (unsigned)(*best_prev & 0xFFFFFFFFull)) : first_idx;
-    const __half* zl = z + (size_t)last * d;
+    const unsigned* zl = reinterpret_cast<const unsigned*>(z + (size_t)last * (2 * d2));
+    for (int c = threadIdx.x; c < d2; c += 256) s_piv[c] = zl[c];
+    __syncthreads();
     unsigned long long best = 0ull;
-    for (int row = blockIdx.x * 4 + wave; row < n; row += gridDim.x * 4) {
-        const __half* zr = z + (size_t)row * d;
-        float s = 0.0f;
-        for (int c = lane * 2; c < d; c += 128) {
-            const __half2 a = *reinterpret_cast<const __half2*>(zr + c);
-            const __half2 b = *reinterpret_cast<const __half2*>(zl + c);
-            const __half2 df = __hsub2(a, b);  // rounded to fp16 like the reference's z_lib - last_item
-            const float2 f = __half22float2(df);
-            s += f.x * f.x + f.y * f.y;
+    const int q = blockIdx.x * 256 + threadIdx.x;        // this thread's group of four rows
+    if (q < n4) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        const uint4* src = zT + q;
+#pragma unroll 8
+        for (int c = 0; c < d2; ++c) {
+            const uint4 v = src[(size_t)c * n4];
+            const unsigned pv = s_piv[c];
+            s0 = sq_diff_acc(v.x, pv, s0);
+            s1 = sq_diff_acc(v.y, pv, s1);
+            s2 = sq_diff_acc(v.z, pv, s2);
+            s3 = sq_diff_acc(v.w, pv, s3);
         }
-        if ((d & 1) && lane == 0) {
-            const float f = __half2float(__hsub(zr[d - 1], zl[d - 1]));
-            s += f * f;
-        }
+        const float ss[4] = {s0, s1, s2, s3};
+        __half md[4];
+        *reinterpret_cast<uint2*>(md) = *reinterpret_cast<const uint2*>(min_d + (size_t)q * 4);
 #pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
-        if (lane == 0) {
-            const __half dist = __float2half(sqrtf(s));
-            const __half cur = min_d[row];
-            const __half nm = __hlt(dist, cur) ? dist : cur;
-            min_d[row] = nm;
-            const unsigned long long k = ((unsigned long long)__float_as_uint(__half2float(nm)) << 32) | (0xFFFFFFFFu - (unsigned)row);
-            best = k > best ? k : best;
+        for (int r = 0; r < 4; ++r) {
+            const int row = q * 4 + r;
+            const __half dist = __float2half(sqrtf(ss[r]));
+            const __half nm = __hlt(dist, md[r]) ? dist : md[r];
+            md[r] = nm;
+            if (row < n) {
+                const unsigned long long k = ((unsigned long long)__float_as_uint(__half2float(nm)) << 32) | (0xFFFFFFFFu - (unsigned)row);
+                best = k > best ? k : best;
+            }
         }
+        *reinterpret_cast<uint2*>(min_d + (size_t)q * 4) = *reinterpret_cast<const uint2*>(md);
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const unsigned long long o = shfl_xor_u64(best, m);
+        best = o > best ? o : best;
     }
     if (lane == 0) s_key[wave] = best;
     __syncthreads();
@@ -62,19 +88,28 @@ __global__ __launch_bounds__(256) void coreset_round_kernel(const __half* __rest
 }
 
 // initial min distances in fp32 from fp32 z (features.py:378 runs before the .half() of :389-391)
-__global__ __launch_bounds__(256) void coreset_init_kernel(const float* __restrict__ z32, int n, int d, int first_idx,
-                                                           __half* __restrict__ z16, __half* __restrict__ min_d)
+__global__ __launch_bounds__(256) void coreset_init_kernel(const float* __restrict__ z32, int n, int n4, int d, int first_idx,
+                                                           __half* __restrict__ z16, __half* __restrict__ zT,
+                                                           __half* __restrict__ min_d)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float* zl = z32 + (size_t)first_idx * d;
-    for (int row = blockIdx.x * 4 + wave; row < n; row += gridDim.x * 4) {
+    const size_t tstride = (size_t)n4 * 8;   // halves between consecutive dimension pairs of zT: n4 groups x (4 rows x 2)
+    for (int row = blockIdx.x * 4 + wave; row < n4 * 4; row += gridDim.x * 4) {
+        if (row >= n) {  // padding rows of the last group: zeros, distance 0 (never the arg-max)
+            for (int c = lane; c < d; c += 64) zT[(size_t)(c >> 1) * tstride + (size_t)row * 2 + (c & 1)] = __float2half(0.f);
+            if (lane == 0) min_d[row] = __float2half(0.f);
+            continue;
+        }
         const float* zr = z32 + (size_t)row * d;
         float s = 0.0f;
         for (int c = lane; c < d; c += 64) {
             const float v = zr[c];
             const float df = v - zl[c];
             s += df * df;
-            z16[(size_t)row * d + c] = __float2half(v);
+            const __half h = __float2half(v);
+            z16[(size_t)row * d + c] = h;
+            zT[(size_t)(c >> 1) * tstride + (size_t)row * 2 + (c & 1)] = h;
         }
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
@@ -92,34 +127,36 @@ __global__ void coreset_decode_kernel(const unsigned long long* __restrict__ bes
 
 }  // namespace
 
+static size_t up256(size_t b) { return (b + 255) / 256 * 256; }
+
 extern "C" size_t cmdiad_coreset_workspace_bytes(int n, int d, int n_select)
 {
-    size_t z16 = ((size_t)n * d * 2 + 255) / 256 * 256;
-    size_t md = ((size_t)n * 2 + 255) / 256 * 256;
-    return z16 + md + (size_t)(n_select > 0 ? n_select : 1) * 8;
+    const size_t n4 = ((size_t)n + 3) / 4;
+    return up256((size_t)n * d * 2) + up256(n4 * 4 * (size_t)d * 2) + up256(n4 * 4 * 2) + (size_t)(n_select > 0 ? n_select : 1) * 8;
 }
 
 extern "C" int cmdiad_coreset_greedy(const float* z32, int n, int d, int n_select, int first_idx, int64_t* idx_out,
                                      void* workspace, size_t workspace_bytes, cmdiad_stream_t stream)
 {
-    CMDIAD_REQUIRE(z32 && idx_out && n > 0 && d > 0 && n_select > 0 && n_select <= n && d % 2 == 0, CMDIAD_ERR_ARG,
-                   "cmdiad_coreset_greedy: bad args (need d even)");
+    CMDIAD_REQUIRE(z32 && idx_out && n > 0 && d > 0 && n_select > 0 && n_select <= n && d % 2 == 0 && d <= 1024, CMDIAD_ERR_ARG,
+                   "cmdiad_coreset_greedy: bad args (need d even, d <= 1024)");
     CMDIAD_REQUIRE(workspace && workspace_bytes >= cmdiad_coreset_workspace_bytes(n, d, n_select), CMDIAD_ERR_WORKSPACE,
                    "cmdiad_coreset_greedy: workspace too small");
     hipStream_t s = (hipStream_t)stream;
     char* ws = (char*)workspace;
+    const int n4 = (n + 3) / 4;
     __half* z16 = (__half*)ws;
-    const size_t z16b = ((size_t)n * d * 2 + 255) / 256 * 256;
-    __half* min_d = (__half*)(ws + z16b);
-    unsigned long long* best = (unsigned long long*)(ws + z16b + ((size_t)n * 2 + 255) / 256 * 256);
+    __half* zT = (__half*)(ws + up256((size_t)n * d * 2));
+    __half* min_d = (__half*)((char*)zT + up256((size_t)n4 * 4 * d * 2));
+    unsigned long long* best = (unsigned long long*)((char*)min_d + up256((size_t)n4 * 4 * 2));
     if (hipMemsetAsync(best, 0, (size_t)n_select * 8, s) != hipSuccess) {
         cmdiad_set_error("cmdiad_coreset_greedy: memset failed");
         return CMDIAD_ERR_LAUNCH;
     }
-    const int grid = 2048;
-    hipLaunchKernelGGL(coreset_init_kernel, dim3(grid), dim3(256), 0, s, z32, n, d, first_idx, z16, min_d);
+    hipLaunchKernelGGL(coreset_init_kernel, dim3(2048), dim3(256), 0, s, z32, n, n4, d, first_idx, z16, zT, min_d);
+    const int grid = (n4 + 255) / 256;
     for (int r = 0; r + 1 < n_select; ++r)
-        hipLaunchKernelGGL(coreset_round_kernel, dim3(grid), dim3(256), 0, s, z16, n, d, min_d,
+        hipLaunchKernelGGL(coreset_round_kernel, dim3(grid), dim3(256), 0, s, z16, (const uint4*)zT, n, n4, d / 2, min_d,
                            r == 0 ? nullptr : best + (r - 1), best + r, first_idx);
     hipLaunchKernelGGL(coreset_decode_kernel, dim3((n_select + 255) / 256), dim3(256), 0, s, best, n_select, first_idx,
                        idx_out);
