@@ -10,6 +10,7 @@
 #else
 #include "gemm_core.h"
 #endif
+#include "gemm_pp3.h"
 
 namespace {
 
@@ -179,6 +180,86 @@ __global__ __launch_bounds__(S::THREADS, S::WAVES_PER_SIMD) void gemm_std_persis
                 }
             }
         }
+    });
+}
+
+// The same persistent job walk on the two-group pipeline of the distance GEMM (gemm_pp3.h): three W buffers + three A half
+// slots, per-stream issuer waves, counted waits that are never drained -- 7 phases of W lead instead of one K-step.
+// The epilogue is fully specialised (no run-time branch around a load: a branchy epilogue compiles to load -> s_waitcnt
+// vmcnt(0) -> use per term, 64 dependent L2 round trips per tile with all eight waves of the CU waiting at the next
+// barrier) and issues its loads in two batches of four rows before touching them:
+//   RES = false:  out_bf16 = act(acc + bias)                        (qkv-like products, fc1 + GELU)
+//   RES = true:   out_f32  = acc + bias + residual   (may alias)    (proj / fc2 on the fp32 residual stream)
+template <int ACT, bool RES>
+__global__ __launch_bounds__(512, 1) void gemm_std_pp3_kernel(GlobalTile A, GlobalTile W, StdParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int NT = p.N / SPP3::BN, MT = (p.M + SPP3::BM - 1) / SPP3::BM;
+    const int jobs = MT * NT;
+    const int vb = xcd_remap(blockIdx.x, gridDim.x);
+    const int j0 = (int)((long)jobs * vb / gridDim.x), j1 = (int)((long)jobs * (vb + 1) / gridDim.x);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave >> 2, wc = wave & 3;
+    run_pp3_jobs<false>(A, W, j0, j1, NT, p.K / BK, lds, [&](auto& acc, int mt, int ntile) {
+        const int n0 = ntile * SPP3::BN + wc * 64 + (lane >> 4) * 4;
+        const int mbase = mt * SPP3::BM + wr * 128 + (lane & 15);
+        f32x4 bias[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bias[j] = *reinterpret_cast<const f32x4*>(p.bias + n0 + j * 16);
+        // FULL tiles (all but the last M tile) store without a per-row test: a branch per row makes every group of stores
+        // its own basic block, and the compiler then guards each with s_waitcnt vmcnt(0) -- stores count in vmcnt on gfx9,
+        // so every group would wait for the previous group's stores to complete
+        auto emit = [&](auto FULL) {
+            constexpr bool full = decltype(FULL)::value;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                f32x4 res[4][4];
+                if constexpr (RES) {
+#pragma unroll
+                    for (int ii = 0; ii < 4; ++ii) {
+                        const int mr = mbase + (half * 4 + ii) * 16;
+                        const int mc = full ? mr : min(mr, p.M - 1);   // rows past M: any valid row, never stored
+                        const float* rp = p.residual + (size_t)mc * p.ldr + n0;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) res[ii][j] = *reinterpret_cast<const f32x4*>(rp + j * 16);
+                    }
+                }
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) {
+                    const int i = half * 4 + ii;
+                    const int m = mbase + i * 16;
+                    f32x4 v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        v[j] = acc[i][j] + bias[j];
+                        if constexpr (ACT == CMDIAD_ACT_GELU) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[j][r] = gelu_erf(v[j][r]);
+                        } else if constexpr (ACT == CMDIAD_ACT_RELU) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[j][r] = fmaxf(v[j][r], 0.0f);
+                        }
+                        if constexpr (RES) v[j] += res[ii][j];
+                    }
+                    if (full || m < p.M) {
+                        if constexpr (RES) {
+                            float* o = p.out_f32 + (size_t)m * p.ldo32 + n0;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(o + j * 16) = v[j];
+                        } else {
+                            bf16_t* o = p.out_bf16 + (size_t)m * p.ldo16 + n0;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                bf16x4 h = {f2bf(v[j][0]), f2bf(v[j][1]), f2bf(v[j][2]), f2bf(v[j][3])};
+                                *reinterpret_cast<bf16x4*>(o + j * 16) = h;
+                            }
+                        }
+                    }
+                }
+            }
+        };
+        if (mt * SPP3::BM + SPP3::BM <= p.M) emit(std::true_type{});
+        else emit(std::false_type{});
     });
 }
 
@@ -651,6 +732,38 @@ extern "C" int cmdiad_gemm_bf16(const cmdiad_gemm_args* a, cmdiad_stream_t strea
         return CMDIAD_OK;
     }
 #endif
+    {
+        // CMDIAD_GEMM_PP3=1 / 0 forces the two-group persistent kernel on / off wherever it is legal (read per call)
+        const char* e3 = getenv("CMDIAD_GEMM_PP3");
+        const bool shape3 = !extras && !a->group_bias && split == 1 && a->N % 256 == 0 && a->K % 64 == 0 && a->K >= 192 && a->bias;
+        const bool res3 = shape3 && a->residual && a->out_f32 && !a->out_bf16 && a->act == CMDIAD_ACT_NONE;
+        const bool plain3 = shape3 && !a->residual && !a->out_f32 && a->out_bf16;
+        const bool want3 = e3 ? e3[0] != '0' : false;
+        if ((res3 || plain3) && want3) {
+            static std::mutex mu3;
+            static std::set<const void*> done3;
+            auto go = [&](auto kernel) -> int {
+                {
+                    std::lock_guard<std::mutex> lock(mu3);
+                    if (!done3.count((const void*)kernel)) {
+                        if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SPP3::LDS_BYTES) != hipSuccess) {
+                            cmdiad_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d) failed", SPP3::LDS_BYTES);
+                            return CMDIAD_ERR_LAUNCH;
+                        }
+                        done3.insert((const void*)kernel);
+                    }
+                }
+                hipLaunchKernelGGL(kernel, dim3(persist_blocks(a->M, a->N)), dim3(512), SPP3::LDS_BYTES, s, A, W, p);
+                return CMDIAD_OK;
+            };
+            rc = res3 ? go(gemm_std_pp3_kernel<CMDIAD_ACT_NONE, true>)
+               : a->act == CMDIAD_ACT_GELU ? go(gemm_std_pp3_kernel<CMDIAD_ACT_GELU, false>)
+               : a->act == CMDIAD_ACT_RELU ? go(gemm_std_pp3_kernel<CMDIAD_ACT_RELU, false>) : go(gemm_std_pp3_kernel<CMDIAD_ACT_NONE, false>);
+            if (rc) return rc;
+            CMDIAD_CHECK_LAUNCH();
+            return CMDIAD_OK;
+        }
+    }
     if (persist_choice(a->M, a->N, a->K, !extras && !a->group_bias && split == 1)) {
 #define CMDIAD_PERSIST(ACT) launch<S2x2>(gemm_std_persist_kernel<S2x2, ACT>, dim3(persist_blocks(a->M, a->N)), S2x2::LDS_BYTES, s, A, W, p)
         rc = a->act == CMDIAD_ACT_GELU ? CMDIAD_PERSIST(CMDIAD_ACT_GELU) : a->act == CMDIAD_ACT_RELU ? CMDIAD_PERSIST(CMDIAD_ACT_RELU) : CMDIAD_PERSIST(CMDIAD_ACT_NONE);

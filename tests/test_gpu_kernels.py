@@ -200,21 +200,26 @@ def test_gemm_persistent_256_tile_matches_128_tile(monkeypatch):
     production choice for qkv / fc1 at batch 32) gives bit for bit what the 128 x 128 kernel gives -- same K order, same
     epilogue arithmetic -- on shapes with ragged M, more and fewer jobs than blocks, every epilogue it supports."""
     g = torch.Generator().manual_seed(77)
-    for M, N, K in ((1000, 512, 192), (70000, 256, 64), (3 * 785, 1536, 768)):
+    for M, N, K in ((1000, 512, 192), (70000, 256, 192), (3 * 785, 1536, 768), (40000, 512, 256)):
         A = _bf(torch.randn(M, K, generator=g))
         W = _bf(torch.randn(N, K, generator=g) / K ** 0.5)
         bias, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
         dA, dW = A.to(DEV).bfloat16(), W.to(DEV).bfloat16()
         got = {}
-        for mode in ("0", "1"):
-            monkeypatch.setenv("CMDIAD_GEMM_PERSIST", mode)
+        for mode in ("0", "1", "pp3"):
+            monkeypatch.setenv("CMDIAD_GEMM_PERSIST", "0" if mode == "pp3" else mode)
+            monkeypatch.setenv("CMDIAD_GEMM_PP3", "1" if mode == "pp3" else "0")   # two-group persistent kernel (gemm_pp3.h)
             o32, o16 = ops.gemm(dA, dW, bias=bias.to(DEV), act=ops.ACT_GELU, want_f32=True, want_bf16=True)
+            _, g16 = ops.gemm(dA, dW, bias=bias.to(DEV), act=ops.ACT_GELU)     # bf16-only output: the form the pp3 kernel takes
             x = res.clone().to(DEV)
             ops.gemm(dA, dW, bias=bias.to(DEV), residual=x, out_f32=x, want_bf16=False)
-            _, r16 = ops.gemm(dA, dW, act=ops.ACT_RELU)
-            got[mode] = (o32.clone(), o16.clone(), x, r16.clone())
-        for a, b in zip(got["0"], got["1"]):
-            assert torch.equal(a, b)
+            _, r16 = ops.gemm(dA, dW, bias=bias.to(DEV), act=ops.ACT_RELU)
+            _, n16 = ops.gemm(dA, dW, bias=bias.to(DEV))
+            got[mode] = (o32.clone(), o16.clone(), x, r16.clone(), g16.clone(), n16.clone())
+        for mode in ("1", "pp3"):
+            for a, b in zip(got["0"], got[mode]):
+                assert torch.equal(a, b), mode
+        assert torch.equal(got["0"][1], got["0"][4])
         ref = A.double() @ W.double().T
         want = torch.nn.functional.gelu(ref + bias.double())
         np.testing.assert_allclose(got["1"][0].cpu().numpy(), want.numpy(), rtol=1e-4, atol=1e-4)
