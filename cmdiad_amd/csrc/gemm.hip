@@ -120,8 +120,7 @@ __global__ __launch_bounds__(S::THREADS, S::WAVES_PER_SIMD) void gemm_std_kernel
                     }
                 }
                 if constexpr (ACT == CMDIAD_ACT_GELU) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+v = gelu_erf4(v);
                 } else if constexpr (ACT == CMDIAD_ACT_RELU) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
@@ -137,60 +136,25 @@ __global__ __launch_bounds__(S::THREADS, S::WAVES_PER_SIMD) void gemm_std_kernel
     }, kt_begin);
 }
 
-// The same product as a PERSISTENT kernel on the 256 x 256 shape (8 waves of 128 x 64; gemm_core.h run_jobs): one block per
-// CU walks a contiguous range of the (M tile, N tile) list.  For the wide transformer products (qkv, fc1: N >= 1536) -- the
+// Persistent form for the wide transformer products (fc1-like: whole 256-column tiles, bias, bf16 output): one block per CU
+// walks a contiguous range of the (M tile, N tile) list on the two-group pipeline of the distance GEMM (gemm_pp3.h).  The
 // 128 x 128 shape moves 32 KiB through the L1 -> LDS path per 512 MFMA cycles, which IS that path's 64 B/clk: two co-resident
-// blocks can never exceed half the MFMA rate; 256 x 256 halves the bytes per FLOP.  Epilogue terms: bias, activation,
-// residual, f32 and/or bf16 output (no group bias, no training extras, no split-K).
-template <class S, int ACT>
-__global__ __launch_bounds__(S::THREADS, S::WAVES_PER_SIMD) void gemm_std_persist_kernel(GlobalTile A, GlobalTile W, StdParams p)
-{
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int NT = p.N / S::BN, MT = (p.M + S::BM - 1) / S::BM;
-    const int jobs = MT * NT;
-    const int vb = xcd_remap(blockIdx.x, gridDim.x);   // an XCD's blocks take CONSECUTIVE job ranges (shared W tiles in its L2)
-    const int j0 = (int)((long)jobs * vb / gridDim.x), j1 = (int)((long)jobs * (vb + 1) / gridDim.x);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wr = wave / S::WN, wc = wave % S::WN;
-    run_jobs<S, true>(A, W, j0, j1, NT, p.K / BK, lds, [&](auto& acc, int mt, int ntile) {
-#pragma unroll
-        for (int i = 0; i < S::MI; ++i) {
-            const int m = mt * S::BM + wr * (S::MI * 16) + i * 16 + (lane & 15);
-            if (m >= p.M) continue;
-            const float* res = p.residual ? p.residual + (size_t)m * p.ldr : nullptr;
-            float* o32 = p.out_f32 ? p.out_f32 + (size_t)m * p.ldo32 : nullptr;
-            bf16_t* o16 = p.out_bf16 ? p.out_bf16 + (size_t)m * p.ldo16 : nullptr;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int n = ntile * S::BN + wc * 64 + j * 16 + (lane >> 4) * 4;
-                f32x4 v = acc[i][j];
-                if (p.bias) { const float4 b = *reinterpret_cast<const float4*>(p.bias + n); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
-                if constexpr (ACT == CMDIAD_ACT_GELU) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
-                } else if constexpr (ACT == CMDIAD_ACT_RELU) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
-                }
-                if (res) { const float4 b = *reinterpret_cast<const float4*>(res + n); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
-                if (o32) *reinterpret_cast<f32x4*>(o32 + n) = v;
-                if (o16) {
-                    bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-                    *reinterpret_cast<bf16x4*>(o16 + n) = o;
-                }
-            }
-        }
-    });
-}
+// blocks can never exceed half the MFMA rate; 256 x 256 halves the bytes per FLOP, the job walk removes the per-tile
+// fill / drain and the partial last round (a lock-step 256 x 256 persistent kernel without the two-group schedule gained
+// 12 % on fc1 and nothing on qkv, profiles/r2_notes.md; this one gains 18-40 %).
+// Three W buffers + three A half slots, per-stream issuer waves, counted waits that are never drained: 7 phases of W lead.
+//   out_bf16 = act(acc + bias)      (qkv-like products, fc1 + GELU; the N = 768 residual products stay on 128 x 128:
+//                                    3 x 99 tiles on 256 CUs are two rounds for a 256 x 256 tile)
+// Epilogue.  In the MFMA accumulator layout a lane holds 4 columns of ONE row, so a store instruction touches 16 rows x 32
+// bytes: 64 separate line accesses for the texture-addresser, ~2 000 cycles of store issue per wave and tile -- measured:
+// the stores, not the arithmetic (GELU included), cost 30 % of fc1 (profiles/r2_notes.md).  Every wave therefore
+// transposes its 16-row blocks through a private 2 KiB LDS scratch (XOR-swizzled 16-byte units: conflict-free both ways)
+// and stores 8 rows x 128 contiguous bytes per instruction.  The scratch is read back by inline asm: a compiler-visible
+// LDS read after LDS-DMA gets an s_waitcnt vmcnt(0), i.e. a drain of the whole prefetch queue per tile.  The bias arrives
+// by inline-asm loads issued in phase 0 of the tile's last K-tile (gemm_pp3.h `pre`), with a counted wait.
+constexpr int kPp3Scratch = 2048;   // per wave
 
-// The same persistent job walk on the two-group pipeline of the distance GEMM (gemm_pp3.h): three W buffers + three A half
-// slots, per-stream issuer waves, counted waits that are never drained -- 7 phases of W lead instead of one K-step.
-// The epilogue is fully specialised (no run-time branch around a load: a branchy epilogue compiles to load -> s_waitcnt
-// vmcnt(0) -> use per term, 64 dependent L2 round trips per tile with all eight waves of the CU waiting at the next
-// barrier) and issues its loads in two batches of four rows before touching them:
-//   RES = false:  out_bf16 = act(acc + bias)                        (qkv-like products, fc1 + GELU)
-//   RES = true:   out_f32  = acc + bias + residual   (may alias)    (proj / fc2 on the fp32 residual stream)
-template <int ACT, bool RES>
+template <int ACT>
 __global__ __launch_bounds__(512, 1) void gemm_std_pp3_kernel(GlobalTile A, GlobalTile W, StdParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -200,67 +164,77 @@ __global__ __launch_bounds__(512, 1) void gemm_std_pp3_kernel(GlobalTile A, Glob
     const int j0 = (int)((long)jobs * vb / gridDim.x), j1 = (int)((long)jobs * (vb + 1) / gridDim.x);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave >> 2, wc = wave & 3;
-    run_pp3_jobs<false>(A, W, j0, j1, NT, p.K / BK, lds, [&](auto& acc, int mt, int ntile) {
-        const int n0 = ntile * SPP3::BN + wc * 64 + (lane >> 4) * 4;
-        const int mbase = mt * SPP3::BM + wr * 128 + (lane & 15);
-        f32x4 bias[4];
+    char* scratch = lds + SPP3::LDS_BYTES + wave * kPp3Scratch;
+    // MFMA layout: row r = lane & 15 of the 16-row block, column group g = lane >> 4 (4 columns per j)
+    const int r = lane & 15, g = lane >> 4;
+    // transposed layout: rows R and R + 8 of the block, 16-byte unit u of the row's 128 bytes
+    const int R = lane >> 3, u = lane & 7;
+    const unsigned rd0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(scratch + R * 128 + ((u ^ (R >> 1)) << 4));
+    const unsigned rd1 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(scratch + (R + 8) * 128 + ((u ^ ((R + 8) >> 1)) << 4));
+    // vector-memory operations of a FULL-tile epilogue per wave (the four bias loads come earlier and are not counted)
+    constexpr int kEpiOps = 16;
+    f32x4 bias[4];
+    run_pp3_jobs<false, kEpiOps>(A, W, j0, j1, NT, p.K / BK, lds, [&](int mt, int ntile) {
+        const float* bp = p.bias + ntile * SPP3::BN + wc * 64 + g * 4;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bias[j] = *reinterpret_cast<const f32x4*>(p.bias + n0 + j * 16);
+        for (int j = 0; j < 4; ++j) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bias[j]) : "v"(bp + j * 16) : "memory");
+    }, [&](auto& acc, int mt, int ntile) -> int {
+        const int nw = ntile * SPP3::BN + wc * 64;                  // first column of this wave's 64
+        const int mw = mt * SPP3::BM + wr * 128;                    // first row of this wave's 128
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");            // the bias fetched in phase 0
+        __builtin_amdgcn_sched_barrier(0);
         // FULL tiles (all but the last M tile) store without a per-row test: a branch per row makes every group of stores
         // its own basic block, and the compiler then guards each with s_waitcnt vmcnt(0) -- stores count in vmcnt on gfx9,
         // so every group would wait for the previous group's stores to complete
         auto emit = [&](auto FULL) {
             constexpr bool full = decltype(FULL)::value;
+            bf16_t* o0 = p.out_bf16 + (size_t)(mw + R) * p.ldo16 + nw + u * 8;
+            // act(acc + bias) of 16-row block i as bf16, in the MFMA layout
+            auto compute = [&](int i, bf16x4 (&h)[4]) {
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                f32x4 res[4][4];
-                if constexpr (RES) {
+                for (int j = 0; j < 4; ++j) {
+                    f32x4 v = acc[i][j] + bias[j];
+                    if constexpr (ACT == CMDIAD_ACT_GELU) v = gelu_erf4(v);
+                    else if constexpr (ACT == CMDIAD_ACT_RELU) {
 #pragma unroll
-                    for (int ii = 0; ii < 4; ++ii) {
-                        const int mr = mbase + (half * 4 + ii) * 16;
-                        const int mc = full ? mr : min(mr, p.M - 1);   // rows past M: any valid row, never stored
-                        const float* rp = p.residual + (size_t)mc * p.ldr + n0;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) res[ii][j] = *reinterpret_cast<const f32x4*>(rp + j * 16);
+                        for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.0f);
                     }
+                    h[j] = bf16x4{f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
                 }
+            };
+            // 16 rows x 64 bf16 = 2 KiB: 8-byte slot s = 4 j + g of row r lives in unit (s >> 1) ^ (r >> 1), half s & 1
+            auto park = [&](const bf16x4 (&h)[4]) {
 #pragma unroll
-                for (int ii = 0; ii < 4; ++ii) {
-                    const int i = half * 4 + ii;
-                    const int m = mbase + i * 16;
-                    f32x4 v[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        v[j] = acc[i][j] + bias[j];
-                        if constexpr (ACT == CMDIAD_ACT_GELU) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) v[j][r] = gelu_erf(v[j][r]);
-                        } else if constexpr (ACT == CMDIAD_ACT_RELU) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) v[j][r] = fmaxf(v[j][r], 0.0f);
-                        }
-                        if constexpr (RES) v[j] += res[ii][j];
-                    }
-                    if (full || m < p.M) {
-                        if constexpr (RES) {
-                            float* o = p.out_f32 + (size_t)m * p.ldo32 + n0;
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(o + j * 16) = v[j];
-                        } else {
-                            bf16_t* o = p.out_bf16 + (size_t)m * p.ldo16 + n0;
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                bf16x4 h = {f2bf(v[j][0]), f2bf(v[j][1]), f2bf(v[j][2]), f2bf(v[j][3])};
-                                *reinterpret_cast<bf16x4*>(o + j * 16) = h;
-                            }
-                        }
-                    }
+                for (int j = 0; j < 4; ++j) {
+                    const int s8 = 4 * j + g;
+                    *reinterpret_cast<bf16x4*>(scratch + r * 128 + (((s8 >> 1) ^ (r >> 1)) << 4) + ((s8 & 1) << 3)) = h[j];
                 }
+            };
+            // software pipeline over the eight blocks: the arithmetic of block i + 1 (the GELU is ~20 VALU operations per
+            // element) runs while block i makes its round trip through the scratch
+            bf16x4 h[4];
+            compute(0, h);
+            park(h);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                uint4 t0, t1;
+                asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %0, %2\n\tds_read_b128 %1, %3"
+                             : "=&v"(t0), "=&v"(t1) : "v"(rd0), "v"(rd1) : "memory");
+                if (i < 7) compute(i + 1, h);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // t0 / t1 are only ever STORED below: memory operations do not cross this
+                const int m = mw + i * 16 + R;
+                if (full || m < p.M) *reinterpret_cast<uint4*>(o0 + (size_t)(i * 16) * p.ldo16) = t0;
+                if (full || m + 8 < p.M) *reinterpret_cast<uint4*>(o0 + (size_t)(i * 16 + 8) * p.ldo16) = t1;
+                if (i < 7) park(h);
             }
         };
-        if (mt * SPP3::BM + SPP3::BM <= p.M) emit(std::true_type{});
-        else emit(std::false_type{});
-    });
+        if (mt * SPP3::BM + SPP3::BM <= p.M) {
+            emit(std::true_type{});
+            return kEpiOps;
+        }
+        emit(std::false_type{});
+        return 0;
+    }, p.group_m, MT);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -511,8 +485,7 @@ __global__ __launch_bounds__(256, 1) void gemm_std_wide_kernel(GlobalTile A, Glo
             if (p.bias) { const float4 b = *reinterpret_cast<const float4*>(p.bias + n); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
             if (gb) { const float4 b = *reinterpret_cast<const float4*>(gb + n); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
             if constexpr (ACT == CMDIAD_ACT_GELU) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+v = gelu_erf4(v);
             } else if constexpr (ACT == CMDIAD_ACT_RELU) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
@@ -630,21 +603,11 @@ int panel_tiles(long M, long N, long K, int split)
     return (int)(ntl < 8 ? ntl : 8);
 }
 
-// Persistent 256 x 256 kernel: products with whole 256-column tiles and enough of them that 256 blocks each get >= 2 tiles
-// (qkv, fc1 of both transformers at batch 32).  CMDIAD_GEMM_PERSIST=0 / 1 forces it off / on wherever it is legal (A/B runs,
-// parity tests on small shapes; read per call).
-constexpr int kPersistCUs = 256;
+constexpr int kPersistCUs = 256;   // one persistent block per CU (MI355X)
 unsigned persist_blocks(long M, long N)
 {
     const long jobs = ((M + 255) / 256) * (N / 256);
     return (unsigned)(jobs < kPersistCUs ? jobs : kPersistCUs);
-}
-bool persist_choice(long M, long N, long K, bool legal_epilogue)
-{
-    if (!legal_epilogue || N % 256 != 0 || K % 64 != 0) return false;
-    const char* e = getenv("CMDIAD_GEMM_PERSIST");
-    if (e) return e[0] != '0';
-    return N >= 1536 && ((M + 255) / 256) * (N / 256) >= 2 * kPersistCUs;
 }
 
 #ifdef CMDIAD_AB_VARIANTS
@@ -733,44 +696,37 @@ extern "C" int cmdiad_gemm_bf16(const cmdiad_gemm_args* a, cmdiad_stream_t strea
     }
 #endif
     {
-        // CMDIAD_GEMM_PP3=1 / 0 forces the two-group persistent kernel on / off wherever it is legal (read per call)
+        // two-group persistent kernel: whole 256-column tiles, bias, bf16-only output; chosen when every CU gets >= 2 tiles of
+        // a wide product.  CMDIAD_GEMM_PP3=1 / 0 forces it on / off wherever it is legal (A/B runs, parity tests; read per call)
         const char* e3 = getenv("CMDIAD_GEMM_PP3");
-        const bool shape3 = !extras && !a->group_bias && split == 1 && a->N % 256 == 0 && a->K % 64 == 0 && a->K >= 192 && a->bias;
-        const bool res3 = shape3 && a->residual && a->out_f32 && !a->out_bf16 && a->act == CMDIAD_ACT_NONE;
-        const bool plain3 = shape3 && !a->residual && !a->out_f32 && a->out_bf16;
-        const bool want3 = e3 ? e3[0] != '0' : false;
-        if ((res3 || plain3) && want3) {
+        const bool plain3 = !extras && !a->group_bias && split == 1 && a->N % 256 == 0 && a->K % 64 == 0 && a->K >= 192 && a->bias &&
+                            !a->residual && !a->out_f32 && a->out_bf16 && a->ldo16 % 8 == 0 && aligned16(a->out_bf16);
+        const bool want3 = e3 ? e3[0] != '0' : (a->N >= 1536 && ((long)(a->M + 255) / 256) * (a->N / 256) >= 2 * kPersistCUs);
+        if (plain3 && want3) {
             static std::mutex mu3;
             static std::set<const void*> done3;
+            constexpr int kLds3 = SPP3::LDS_BYTES + 8 * kPp3Scratch;
             auto go = [&](auto kernel) -> int {
                 {
                     std::lock_guard<std::mutex> lock(mu3);
                     if (!done3.count((const void*)kernel)) {
-                        if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SPP3::LDS_BYTES) != hipSuccess) {
-                            cmdiad_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d) failed", SPP3::LDS_BYTES);
+                        if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLds3) != hipSuccess) {
+                            cmdiad_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d) failed", kLds3);
                             return CMDIAD_ERR_LAUNCH;
                         }
                         done3.insert((const void*)kernel);
                     }
                 }
-                hipLaunchKernelGGL(kernel, dim3(persist_blocks(a->M, a->N)), dim3(512), SPP3::LDS_BYTES, s, A, W, p);
+                hipLaunchKernelGGL(kernel, dim3(persist_blocks(a->M, a->N)), dim3(512), kLds3, s, A, W, p);
                 return CMDIAD_OK;
             };
-            rc = res3 ? go(gemm_std_pp3_kernel<CMDIAD_ACT_NONE, true>)
-               : a->act == CMDIAD_ACT_GELU ? go(gemm_std_pp3_kernel<CMDIAD_ACT_GELU, false>)
-               : a->act == CMDIAD_ACT_RELU ? go(gemm_std_pp3_kernel<CMDIAD_ACT_RELU, false>) : go(gemm_std_pp3_kernel<CMDIAD_ACT_NONE, false>);
+            p.group_m = 1;
+            rc = a->act == CMDIAD_ACT_GELU ? go(gemm_std_pp3_kernel<CMDIAD_ACT_GELU>)
+               : a->act == CMDIAD_ACT_RELU ? go(gemm_std_pp3_kernel<CMDIAD_ACT_RELU>) : go(gemm_std_pp3_kernel<CMDIAD_ACT_NONE>);
             if (rc) return rc;
             CMDIAD_CHECK_LAUNCH();
             return CMDIAD_OK;
         }
-    }
-    if (persist_choice(a->M, a->N, a->K, !extras && !a->group_bias && split == 1)) {
-#define CMDIAD_PERSIST(ACT) launch<S2x2>(gemm_std_persist_kernel<S2x2, ACT>, dim3(persist_blocks(a->M, a->N)), S2x2::LDS_BYTES, s, A, W, p)
-        rc = a->act == CMDIAD_ACT_GELU ? CMDIAD_PERSIST(CMDIAD_ACT_GELU) : a->act == CMDIAD_ACT_RELU ? CMDIAD_PERSIST(CMDIAD_ACT_RELU) : CMDIAD_PERSIST(CMDIAD_ACT_NONE);
-#undef CMDIAD_PERSIST
-        if (rc) return rc;
-        CMDIAD_CHECK_LAUNCH();
-        return CMDIAD_OK;
     }
 #define CMDIAD_STD(SH, ACT, EX) launch<SH>(gemm_std_kernel<SH, ACT, EX>, grid_for<SH>(a->M, a->N, split, p.panel), SH::LDS_BYTES, s, A, W, p)
     p.panel = panel_tiles<S128>(a->M, a->N, a->K, split);

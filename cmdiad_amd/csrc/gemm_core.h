@@ -242,64 +242,6 @@ __device__ __forceinline__ void run(const ALoader& A, const WLoader& W, int m0, 
     }
 }
 
-// Persistent form of run(): the block walks jobs [j0, j1) of the flattened (M tile, N tile) list (job = mt * NT + nt, N
-// fastest) as ONE pipeline -- the LDS-DMA of a job's first K-steps is issued under the previous job's last MFMAs and its
-// epilogue, so a tile no longer pays its own fill and drain, and a launch of #CU blocks has no partial last round
-// (a 99 x 12 tile grid on 256 CUs is 4.64 tiles per CU: 5 rounds of one-tile blocks run 93 % full at best, and each
-// round's tail waits for its slowest block).  epi(acc, mt, nt) is called once per finished tile.
-template <class S, bool SWAP, bool F16 = false, class ALoader, class WLoader, class Epi>
-__device__ __forceinline__ void run_jobs(const ALoader& A, const WLoader& W, int j0, int j1, int NT, int KT, char* lds, Epi&& epi)
-{
-    constexpr int BM = S::BM, BN = S::BN, ST = S::STAGES, AHEAD = ST - 1;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave / S::WN, wc = wave % S::WN;
-    f32x4 acc[S::MI][4];
-#pragma unroll
-    for (int i = 0; i < S::MI; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int total = (j1 - j0) * KT;
-    if (total <= 0) return;
-    int kt_s = 0, mt_s = j0 / NT, nt_s = j0 - mt_s * NT;  // coordinates of the next K-step to STAGE
-    auto stage_next = [&](int slot) {
-        char* buf = lds + slot * S::STAGE_BYTES;
-        A.template stage<BM, S::WAVES>(buf, mt_s * BM, kt_s * BK, tid);
-        W.template stage<BN, S::WAVES>(buf + BM * BK * 2, nt_s * BN, kt_s * BK, tid);
-        if (++kt_s == KT) {
-            kt_s = 0;
-            if (++nt_s == NT) { nt_s = 0; ++mt_s; }
-        }
-    };
-    stage_next(0);
-    if (AHEAD == 2 && total >= 2) {
-        stage_next(1);
-        wait_vmcnt<S::GL>();
-    } else wait_vmcnt<0>();
-    block_barrier();
-    int kt = 0, mt = j0 / NT, nt = j0 - mt * NT, slot = 0, slot_s = AHEAD % ST;
-    for (int it = 0; it < total; ++it) {
-        const char* cur = lds + slot * S::STAGE_BYTES;
-        const bool more = it + AHEAD < total;
-        if (more) stage_next(slot_s);
-        compute_stage<S, SWAP, F16>(acc, cur, cur + BM * BK * 2, wr, wc, lane);
-        if (kt == KT - 1) {
-            epi(acc, mt, nt);
-#pragma unroll
-            for (int i = 0; i < S::MI; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        if (AHEAD == 2 && more) wait_vmcnt<S::GL>(); else wait_vmcnt<0>();
-        block_barrier();
-        if (++kt == KT) {
-            kt = 0;
-            if (++nt == NT) { nt = 0; ++mt; }
-        }
-        slot = slot + 1 == ST ? 0 : slot + 1;
-        slot_s = slot_s + 1 == ST ? 0 : slot_s + 1;
-    }
-}
-
 // XCD-aware bijective remap of the linear workgroup id (guide T1): blocks b and b+8 share an XCD
 // (and its L2), so give every XCD a CONTIGUOUS chunk of the tile order.
 __device__ __forceinline__ int xcd_remap(int orig, int nwg)

@@ -9,8 +9,14 @@
 //     never drained inside a stream, and BOTH streams run on across tile boundaries: the next job's first K-tiles are
 //     in flight while the current tile's last MFMAs and its epilogue execute -- no per-tile fill or drain, and with one block
 //     per CU walking jobs [j0, j1) no partial last round.
-//   * epi(acc, mt, nt) runs after a tile's last phase.  Its loads and stores count in vmcnt as well: the first counted wait
-//     after an epilogue also retires most of its stores (one ~1 us stall per 17 us tile at K = 768).
+//   * epi(acc, mt, nt) runs after a tile's last phase and returns the number of vector-memory operations it is GUARANTEED to
+//     have issued (0 when unsure).  Loads and stores count in vmcnt like the DMA pieces and retire in order, so for the
+//     phases in which the epilogue's operations are younger than the piece a counted wait protects (7 phases for the W
+//     stream, 3 for the A stream) the wait's immediate is raised by that number: vmcnt(14) right after 32 stores would wait
+//     for 20 of them to reach L2 -- with all eight waves of the CU at the next barrier.
+//   * pre(mt, nt) runs in phase 0 of a tile's LAST K-tile: the place to fetch epilogue operands (bias) by inline asm; eight
+//     DMA pieces are issued between that point and the epilogue (or the stream has ended and drained), so the epilogue opens
+//     with s_waitcnt vmcnt(8) instead of a compiler-placed vmcnt(0) that would drain the prefetch queue.
 // Whole 256-column tiles only (N % 256 == 0); ragged M is clamped on the A stream and masked by the epilogue; K >= 192.
 #pragma once
 #include "gemm_core.h"
@@ -28,9 +34,42 @@ __device__ __forceinline__ void pp3_barrier() { asm volatile("s_barrier" ::: "me
 
 // acc[i][j][r]: row m = mt*256 + wr*128 + i*16 + (lane & 15), column n = nt*256 + wc*64 + j*16 + (lane >> 4)*4 + r
 // (swapped orientation: a lane holds four consecutive columns of one row).
-template <bool F16, class Epi>
+// Job order: M tiles in groups of GM; inside a group the M tile runs fastest, then the N tile (job -> (g, nt, m) with
+// g = job / (rows(g) * NT)); GM = 1 is plain N-fastest.  A block's consecutive jobs then share the W tile (kept hot in
+// L2) while the A tiles change; the blocks of an XCD (consecutive job ranges) work on few M groups at a time.
+struct JobCursor {
+    int g, nt, mi, rows, GM, NT, MT;
+    __device__ __forceinline__ void init(int job, int GM_, int NT_, int MT_)
+    {
+        GM = GM_; NT = NT_; MT = MT_;
+        const int per = GM * NT;             // jobs of a full group
+        g = job / per;
+        rows = min(GM, MT - g * GM);
+        const int rem = job - g * per;       // (the last, short group is only ever entered at its first job or walked into)
+        nt = rem / rows;
+        mi = rem - nt * rows;
+    }
+    __device__ __forceinline__ int mt() const { return g * GM + mi; }
+    __device__ __forceinline__ void next()
+    {
+        if (++mi == rows) {
+            mi = 0;
+            if (++nt == NT) { nt = 0; ++g; rows = min(GM, MT - g * GM); }
+        }
+    }
+};
+
+template <int N>
+__device__ __forceinline__ void pp3_wait_vmcnt()
+{
+    static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit field");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// EPI_OPS: the operation count a FULL-tile epilogue returns (compile time: it becomes an s_waitcnt immediate)
+template <bool F16, int EPI_OPS, class Pre, class Epi>
 __device__ __forceinline__ void run_pp3_jobs(const GlobalTile& A, const GlobalTile& W, int j0, int j1, int NT, int KT, char* lds,
-                                             Epi&& epi)
+                                             Pre&& pre, Epi&& epi, int GM = 1, int MT = 1 << 30)
 {
     using S = SPP3;
     using frag = typename std::conditional<F16, f16x8, bf16x8>::type;
@@ -52,9 +91,11 @@ __device__ __forceinline__ void run_pp3_jobs(const GlobalTile& A, const GlobalTi
     const int src_chunk = ((lane & 7) ^ (lane >> 3)) * 8;  // element offset of the 16-byte chunk this lane fetches
     const int row_w = bank_wave ? (sw >> 1) * 64 + (sw & 1) * 16 : sw * 16;  // this wave's share of every half-unit
     const size_t ld2 = (size_t)(bank_wave ? W.ld : A.ld) * 2;                  // row pitch in bytes
-    int s_mt = j0 / NT, s_nt = j0 - (j0 / NT) * NT;                            // the stream's current job
+    JobCursor sj;                                                              // the stream's current job
+    sj.init(j0, GM, NT, MT);
+    int s_mt = sj.mt();
     auto tile_ptr = [&]() {
-        return bank_wave ? reinterpret_cast<const char*>(W.base + (size_t)(s_nt * S::BN + row_w + (lane >> 3)) * W.ld + src_chunk)
+        return bank_wave ? reinterpret_cast<const char*>(W.base + (size_t)(sj.nt * S::BN + row_w + (lane >> 3)) * W.ld + src_chunk)
                          : reinterpret_cast<const char*>(A.base + (size_t)(s_mt * S::BM + row_w + (lane >> 3)) * A.ld + src_chunk);
     };
     const char* ptr = tile_ptr();
@@ -84,9 +125,10 @@ __device__ __forceinline__ void run_pp3_jobs(const GlobalTile& A, const GlobalTi
         }
         if constexpr (part == 3) {  // next K-tile of this stream
             ++hT;
-            if (++hK == KT) {       // next job: N fastest
+            if (++hK == KT) {       // next job
                 hK = 0;
-                if (++s_nt == NT) { s_nt = 0; ++s_mt; }
+                sj.next();
+                s_mt = sj.mt();
                 ptr = tile_ptr();
                 a_full = s_mt * S::BM + S::BM <= A.rows;
             } else ptr += BK * 2;
@@ -100,10 +142,14 @@ __device__ __forceinline__ void run_pp3_jobs(const GlobalTile& A, const GlobalTi
         constexpr int j = decltype(J)::value;
         return bank_wave ? issue_part(std::integral_constant<int, (j + 2) % 4>{}) : issue_part(std::integral_constant<int, (j + 1) % 4>{});
     };
+    int ep_age = 1 << 20;  // phases since an epilogue that issued EPI_OPS operations (wave-uniform)
     auto phase_wait = [&](bool issued) {
+        constexpr int lead = bank_wave ? 7 : 3, base = bank_wave ? 14 : 6;
+        constexpr int raised = base + EPI_OPS > 63 ? 63 : base + EPI_OPS;
         if (!issued) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (bank_wave) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (ep_age < lead) pp3_wait_vmcnt<raised>();
+        else pp3_wait_vmcnt<base>();
+        ++ep_age;
     };
     {
         using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
@@ -123,7 +169,9 @@ __device__ __forceinline__ void run_pp3_jobs(const GlobalTile& A, const GlobalTi
     auto ldb = [&](int j, int kk) { return *reinterpret_cast<const frag*>(lds + ((b_base + j * 2048) ^ (kk << 6))); };
 
     frag af[4][2], wlo[2][2], whi[2][2];
-    int mt_c = j0 / NT, nt_c = j0 - (j0 / NT) * NT, kt_c = 0;
+    JobCursor cj;
+    cj.init(j0, GM, NT, MT);
+    int kt_c = 0;
     for (int T = 0; T < T_total; ++T) {
         a_lo = S::A_OFF + ((2 * T) % 3) * S::HALF + a_off;
         a_hi = S::A_OFF + ((2 * T + 1) % 3) * S::HALF + a_off;
@@ -138,6 +186,7 @@ __device__ __forceinline__ void run_pp3_jobs(const GlobalTile& A, const GlobalTi
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) af[i][kk] = lda(i, kk);
+        if (kt_c == KT - 1) pre(cj.mt(), cj.nt);
         phase_wait(issue_phase(std::integral_constant<int, 0>{}));
         pp3_barrier();
         __builtin_amdgcn_s_setprio(1);
@@ -194,7 +243,8 @@ __device__ __forceinline__ void run_pp3_jobs(const GlobalTile& A, const GlobalTi
         __builtin_amdgcn_s_setprio(0);
         if (kt_c == KT - 1) {  // tile finished
             __builtin_amdgcn_sched_barrier(0);
-            epi(acc, mt_c, nt_c);
+            const int ops = epi(acc, cj.mt(), cj.nt);
+            ep_age = ops >= EPI_OPS ? 0 : 1 << 20;
 #pragma unroll
             for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -204,7 +254,7 @@ __device__ __forceinline__ void run_pp3_jobs(const GlobalTile& A, const GlobalTi
         pp3_barrier();
         if (++kt_c == KT) {
             kt_c = 0;
-            if (++nt_c == NT) { nt_c = 0; ++mt_c; }
+            cj.next();
         }
     }
     if (wr == 0) pp3_barrier();  // both groups execute the same number of barriers

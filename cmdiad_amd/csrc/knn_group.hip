@@ -22,13 +22,13 @@
 
 namespace {
 
+constexpr unsigned long long kInf = ~0ull;
+
+#ifdef CMDIAD_AB_VARIANTS  // block-wide formulation (1024-key LDS bitonic sort): test-only build (make ab), A/B reference
 constexpr int kThreads = 256;
 constexpr int kCPB = 4;        // centres per block
 constexpr int kCap = 1024;     // keys per centre buffer (power of two, bitonic)
 constexpr int kChunk = 512;    // points per streaming step; prune when cnt > kCap - kChunk
-constexpr unsigned long long kInf = ~0ull;
-
-#ifdef CMDIAD_AB_VARIANTS  // block-wide formulation (1024-key LDS bitonic sort): test-only build (make ab), A/B reference
 __device__ __forceinline__ void bitonic_sort_1024(unsigned long long* s, int tid)
 {
     for (int k = 2; k <= kCap; k <<= 1) {
