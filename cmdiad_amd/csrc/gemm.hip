@@ -152,7 +152,7 @@ v = gelu_erf4(v);
 // and stores 8 rows x 128 contiguous bytes per instruction.  The scratch is read back by inline asm: a compiler-visible
 // LDS read after LDS-DMA gets an s_waitcnt vmcnt(0), i.e. a drain of the whole prefetch queue per tile.  The bias arrives
 // by inline-asm loads issued in phase 0 of the tile's last K-tile (gemm_pp3.h `pre`), with a counted wait.
-constexpr int kPp3Scratch = 2048;   // per wave
+constexpr int kPp3Scratch = kRowStoreScratch;   // per wave
 
 template <int ACT>
 __global__ __launch_bounds__(512, 1) void gemm_std_pp3_kernel(GlobalTile A, GlobalTile W, StdParams p)
@@ -164,13 +164,9 @@ __global__ __launch_bounds__(512, 1) void gemm_std_pp3_kernel(GlobalTile A, Glob
     const int j0 = (int)((long)jobs * vb / gridDim.x), j1 = (int)((long)jobs * (vb + 1) / gridDim.x);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave >> 2, wc = wave & 3;
-    char* scratch = lds + SPP3::LDS_BYTES + wave * kPp3Scratch;
-    // MFMA layout: row r = lane & 15 of the 16-row block, column group g = lane >> 4 (4 columns per j)
-    const int r = lane & 15, g = lane >> 4;
-    // transposed layout: rows R and R + 8 of the block, 16-byte unit u of the row's 128 bytes
-    const int R = lane >> 3, u = lane & 7;
-    const unsigned rd0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(scratch + R * 128 + ((u ^ (R >> 1)) << 4));
-    const unsigned rd1 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(scratch + (R + 8) * 128 + ((u ^ ((R + 8) >> 1)) << 4));
+    RowStore16 rs;
+    rs.init(lds + SPP3::LDS_BYTES + wave * kPp3Scratch, lane);
+    const int g = rs.g, R = rs.R, u = rs.u;
     // vector-memory operations of a FULL-tile epilogue per wave (the four bias loads come earlier and are not counted)
     constexpr int kEpiOps = 16;
     f32x4 bias[4];
@@ -202,30 +198,21 @@ __global__ __launch_bounds__(512, 1) void gemm_std_pp3_kernel(GlobalTile A, Glob
                     h[j] = bf16x4{f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
                 }
             };
-            // 16 rows x 64 bf16 = 2 KiB: 8-byte slot s = 4 j + g of row r lives in unit (s >> 1) ^ (r >> 1), half s & 1
-            auto park = [&](const bf16x4 (&h)[4]) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int s8 = 4 * j + g;
-                    *reinterpret_cast<bf16x4*>(scratch + r * 128 + (((s8 >> 1) ^ (r >> 1)) << 4) + ((s8 & 1) << 3)) = h[j];
-                }
-            };
             // software pipeline over the eight blocks: the arithmetic of block i + 1 (the GELU is ~20 VALU operations per
             // element) runs while block i makes its round trip through the scratch
             bf16x4 h[4];
             compute(0, h);
-            park(h);
+            rs.park(h);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 uint4 t0, t1;
-                asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %0, %2\n\tds_read_b128 %1, %3"
-                             : "=&v"(t0), "=&v"(t1) : "v"(rd0), "v"(rd1) : "memory");
+                rs.fetch_issue(t0, t1);
                 if (i < 7) compute(i + 1, h);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // t0 / t1 are only ever STORED below: memory operations do not cross this
+                rs.fetch_wait();
                 const int m = mw + i * 16 + R;
                 if (full || m < p.M) *reinterpret_cast<uint4*>(o0 + (size_t)(i * 16) * p.ldo16) = t0;
                 if (full || m + 8 < p.M) *reinterpret_cast<uint4*>(o0 + (size_t)(i * 16 + 8) * p.ldo16) = t1;
-                if (i < 7) park(h);
+                if (i < 7) rs.park(h);
             }
         };
         if (mt * SPP3::BM + SPP3::BM <= p.M) {
@@ -259,21 +246,34 @@ __global__ __launch_bounds__(S::THREADS, S::WAVES_PER_SIMD) void gemm_qkv_kernel
         bf16_t* dst = which == 0 ? p.q : p.k;
         // q carries head_dim^-0.5 (models.py:153) AND log2(e), so the attention kernel's softmax is a bare exp2
         const float scale = which == 0 ? 0.125f * 1.4426950408889634f : 1.0f;
+        // a wave's 64 columns are ONE head: its 16-token blocks leave as 8 tokens x 128 contiguous bytes per store (RowStore16)
+        RowStore16 rs;
+        rs.init(lds + S::LDS_BYTES + (threadIdx.x >> 6) * kRowStoreScratch, c.lane);
         run<S, true>(A, W, c.m0, c.nt, 1, p.C / BK, lds, [&](auto& acc, int ntile, char*) {
+            const int n0 = ntile * S::BN + c.wc * 64;              // first column of the wave: a head boundary
+            const int hh = (n0 - which * p.C) >> 6;
+            f32x4 bj[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                bj[j] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n0 + j * 16 + (c.lane >> 4) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < S::MI; ++i) {
-                const int m = c.m(i);
-                if (m >= p.M) continue;
-                const int b = m / p.T, t = m - b * p.T;
+                bf16x4 h[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int n = c.n(ntile, j);
-                    const int cc = n - which * p.C;
-                    const int h = cc >> 6, d = cc & 63;
-                    f32x4 v = acc[i][j];
-                    if (p.bias) { const float4 bb = *reinterpret_cast<const float4*>(p.bias + n); v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w; }
-                    bf16x4 o = {f2bf(v[0] * scale), f2bf(v[1] * scale), f2bf(v[2] * scale), f2bf(v[3] * scale)};
-                    *reinterpret_cast<bf16x4*>(dst + (((size_t)b * p.H + h) * p.Tp + t) * 64 + d) = o;
+                    const f32x4 v = (acc[i][j] + bj[j]) * scale;
+                    h[j] = bf16x4{f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+                }
+                rs.park(h);
+                uint4 t0, t1;
+                rs.fetch_issue(t0, t1);
+                rs.fetch_wait();
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int m = c.m0 + c.wr * (S::MI * 16) + i * 16 + rs.R + 8 * half;
+                    if (m >= p.M) continue;
+                    const int b = m / p.T, t = m - b * p.T;
+                    *reinterpret_cast<uint4*>(dst + (((size_t)b * p.H + hh) * p.Tp + t) * 64 + rs.u * 8) = half ? t1 : t0;
                 }
             }
         });
@@ -315,8 +315,35 @@ struct GroupMaxParams {
 // epilogue of one finished BM x BN tile: + bias, optional full store, per-group column maxima (see above)
 template <class S, class Acc>
 __device__ __forceinline__ void groupmax_epilogue(Acc& acc, int ntile, const Coord<S>& c, const GroupMaxParams& p,
-                                                  float (*s_max)[S::BN], int tid, const f32x4* pre_bias = nullptr)
+                                                  float (*s_max)[S::BN], int tid, const f32x4* pre_bias = nullptr,
+                                                  const RowStore16* rs = nullptr)
 {
+        if (rs && p.full_bf16) {   // full activations, row-contiguous (8 rows x 128 bytes per store): see RowStore16
+            f32x4 bj[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = ntile * S::BN + c.wc * 64 + j * 16 + (c.lane >> 4) * 4;
+                bj[j] = pre_bias ? pre_bias[j] : (p.bias && n < p.N ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f});
+            }
+            const int mrow = c.m0 + c.wr * (S::MI * 16) + rs->R;
+            bf16_t* o0 = p.full_bf16 + (size_t)mrow * p.ldf + ntile * S::BN + c.wc * 64 + rs->u * 8;
+#pragma unroll
+            for (int i = 0; i < S::MI; ++i) {
+                bf16x4 h[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 v = acc[i][j] + bj[j];
+                    h[j] = bf16x4{f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+                }
+                rs->park(h);
+                uint4 t0, t1;
+                rs->fetch_issue(t0, t1);
+                rs->fetch_wait();
+                const int m = mrow + i * 16;
+                if (m < p.M) *reinterpret_cast<uint4*>(o0 + (size_t)(i * 16) * p.ldf) = t0;
+                if (m + 8 < p.M) *reinterpret_cast<uint4*>(o0 + (size_t)(i * 16 + 8) * p.ldf) = t1;
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int nl = c.wc * 64 + j * 16 + (c.lane >> 4) * 4;  // column within the tile
@@ -330,7 +357,7 @@ __device__ __forceinline__ void groupmax_epilogue(Acc& acc, int ntile, const Coo
                 f32x4 v = acc[i][j];
                 v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
                 const int m = c.m(i);
-                if (p.full_bf16 && m < p.M && n < p.N) {
+                if (!rs && p.full_bf16 && m < p.M && n < p.N) {
                     bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
                     *reinterpret_cast<bf16x4*>(p.full_bf16 + (size_t)m * p.ldf + n) = o;
                 }
@@ -412,6 +439,8 @@ __global__ __launch_bounds__(256, 2) void encoder_stage1_once_kernel(Conv1Tile A
     float(*s_max)[S::BN] = reinterpret_cast<float(*)[S::BN]>(lds + 4 * KT_BYTES);
     const Coord<S> c(1);                      // block = one M tile; both N tiles are walked here
     const int tid = threadIdx.x;
+    RowStore16 rs;                            // h2 (2.2 GB per batch of 32) leaves as 128-byte row pieces
+    rs.init(lds + 4 * KT_BYTES + (S::BM / 32) * S::BN * (int)sizeof(float) + (tid >> 6) * kRowStoreScratch, tid & 63);
 
     // conv2's bias for both N tiles, by inline asm before anything else: loaded by the compiler where the epilogue uses it, it
     // is hoisted above the MFMA steps and guarded with s_waitcnt vmcnt(0) in front of their fragment reads (tools/isa_lint.py)
@@ -438,7 +467,7 @@ __global__ __launch_bounds__(256, 2) void encoder_stage1_once_kernel(Conv1Tile A
         if (step < 3) W.stage<S::BN, S::WAVES>(w_lds + ((step + 1) & 1) * KT_BYTES, ((step + 1) >> 1) * S::BN, ((step + 1) & 1) * BK, tid);
         compute_stage<S, true, false>(acc, a_lds + kt * KT_BYTES, w_lds + (step & 1) * KT_BYTES, c.wr, c.wc, c.lane);
         if (kt == 1) {
-            groupmax_epilogue<S>(acc, nt, c, p, s_max, tid, bias[nt]);
+            groupmax_epilogue<S>(acc, nt, c, p, s_max, tid, bias[nt], &rs);
 #pragma unroll
             for (int i = 0; i < S::MI; ++i)
 #pragma unroll
@@ -752,7 +781,7 @@ extern "C" int cmdiad_gemm_qkv(const uint16_t* A, const uint16_t* W, const float
     GlobalTile At{(const bf16_t*)A, C, M}, Wt{(const bf16_t*)W, C, 3 * C};
     QkvParams p{M, T, (T + 63) / 64 * 64, C, C / 64, group_m_tiles(), bias, (bf16_t*)q_out, (bf16_t*)k_out, (bf16_t*)vt_out};
     hipStream_t s = (hipStream_t)stream;
-    const int rc = launch<S128>(gemm_qkv_kernel<S128>, grid_for<S128>(M, 3 * C), S128::LDS_BYTES, s, At, Wt, p);
+    const int rc = launch<S128>(gemm_qkv_kernel<S128>, grid_for<S128>(M, 3 * C), S128::LDS_BYTES + S128::WAVES * kRowStoreScratch, s, At, Wt, p);
     if (rc) return rc;
     CMDIAD_CHECK_LAUNCH();
     return CMDIAD_OK;
@@ -813,7 +842,7 @@ extern "C" int cmdiad_encoder_stage1(const float* neigh, const float* w1, const 
 #endif
     {
         p.panel = 1;
-        rc = launch<S128>(encoder_stage1_once_kernel, dim3((unsigned)((M + 127) / 128)), group_max_lds<S128>(), s, At, Wt, p);
+        rc = launch<S128>(encoder_stage1_once_kernel, dim3((unsigned)((M + 127) / 128)), group_max_lds<S128>() + 4 * kRowStoreScratch, s, At, Wt, p);
     }
     if (rc) return rc;
     CMDIAD_CHECK_LAUNCH();

@@ -242,6 +242,41 @@ __device__ __forceinline__ void run(const ALoader& A, const WLoader& W, int m0, 
     }
 }
 
+// Row-contiguous stores from the MFMA accumulator layout.  In the swapped orientation a lane holds 4 consecutive columns of
+// ONE row, so a store instruction of a wave's 16 x 64 block touches 16 rows x 32 bytes (bf16): 64 separate line accesses for
+// the texture addresser -- measured as 30 % of the fc1 GEMM (profiles/r2_notes.md).  A wave parks the block (as bf16) in a
+// private 2 KiB LDS scratch -- 8-byte slot s = 4 j + g of row r in 16-byte unit (s >> 1) ^ (r >> 1), half s & 1: conflict-free
+// for the writes and for the reads -- and takes it back as two 16-byte units per lane: rows R = lane >> 3 and R + 8, columns
+// 8 (lane & 7) .. + 7, i.e. 8 rows x 128 contiguous bytes per store instruction.  The read-back is inline asm: a
+// compiler-visible LDS read after LDS-DMA gets an s_waitcnt vmcnt(0) (a drain of the prefetch queue).
+struct RowStore16 {
+    char* scratch;
+    unsigned rd0, rd1;
+    int r, g, R, u;
+    __device__ __forceinline__ void init(char* wave_scratch, int lane)
+    {
+        scratch = wave_scratch;
+        r = lane & 15; g = lane >> 4; R = lane >> 3; u = lane & 7;
+        rd0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(scratch + R * 128 + ((u ^ (R >> 1)) << 4));
+        rd1 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(scratch + (R + 8) * 128 + ((u ^ ((R + 8) >> 1)) << 4));
+    }
+    __device__ __forceinline__ void park(const bf16x4 (&h)[4]) const
+    {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int s8 = 4 * j + g;
+            *reinterpret_cast<bf16x4*>(scratch + r * 128 + (((s8 >> 1) ^ (r >> 1)) << 4) + ((s8 & 1) << 3)) = h[j];
+        }
+    }
+    __device__ __forceinline__ void fetch_issue(uint4& t0, uint4& t1) const
+    {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %0, %2\n\tds_read_b128 %1, %3" : "=&v"(t0), "=&v"(t1) : "v"(rd0), "v"(rd1) : "memory");
+    }
+    // the fetched units may only be STORED after this (memory operations do not cross it)
+    __device__ __forceinline__ void fetch_wait() const { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+};
+constexpr int kRowStoreScratch = 2048;   // bytes per wave
+
 // XCD-aware bijective remap of the linear workgroup id (guide T1): blocks b and b+8 share an XCD
 // (and its L2), so give every XCD a CONTIGUOUS chunk of the tile order.
 __device__ __forceinline__ int xcd_remap(int orig, int nwg)

@@ -221,8 +221,9 @@ def test_gemm_persistent_256_tile_matches_128_tile(monkeypatch):
         assert torch.equal(got["0"][1], got["0"][4])
         ref = A.double() @ W.double().T
         want = torch.nn.functional.gelu(ref + bias.double())
-        np.testing.assert_allclose(got["1"][0].cpu().numpy(), want.numpy(), rtol=1e-4, atol=1e-4)
-        np.testing.assert_allclose(got["1"][2].cpu().numpy(), (ref + bias.double() + res.double()).numpy(), rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(got["pp3"][0].cpu().numpy(), want.numpy(), rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(got["pp3"][4].float().cpu().numpy(), want.numpy(), rtol=8e-3, atol=8e-3)   # the bf16 form pp3 takes
+        np.testing.assert_allclose(got["pp3"][2].cpu().numpy(), (ref + bias.double() + res.double()).numpy(), rtol=1e-4, atol=1e-4)
 
 
 def test_gemm_identity_asymmetric_layout():
