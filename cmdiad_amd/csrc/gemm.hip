@@ -87,7 +87,46 @@ __global__ __launch_bounds__(S::THREADS, S::WAVES_PER_SIMD) void gemm_std_kernel
     float* out32 = p.out_f32 ? p.out_f32 + (size_t)blockIdx.y * p.M * p.ldo32 : nullptr;
     if (kt_count <= 0) return;
 
+    // fp32 residual stream in place (proj / fc2 of every transformer block): out_f32 = acc + bias + residual.  In the
+    // accumulator layout its 16-byte loads and stores touch 16 rows x 64 bytes per instruction; on the short-K products the
+    // texture addresser, not the MFMAs, then bounds the block (proj 25120 x 768 x 768: 417 TFLOP/s against fc2's 710 on the
+    // same kernel).  RowStore32: 8 rows x 128 contiguous bytes per load / store.
+    const bool res_rows = !EXTRAS && ACT == CMDIAD_ACT_NONE && p.residual && p.out_f32 && !p.out_bf16 && !p.group_bias && p.bias &&
+                          p.split_k == 1 && p.N % 64 == 0 && p.panel == 1;
+    RowStore32 rs;
+    rs.init(lds + S::LDS_BYTES + (threadIdx.x >> 6) * kRowStoreScratch, c.lane);
+
     run<S, true>(A, W, c.m0, c.nt, c.count, kt_count, lds, [&](auto& acc, int ntile, char*) {
+        if (res_rows) {
+            const int n0 = ntile * S::BN + c.wc * 64;
+            f32x4 bj[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bj[j] = *reinterpret_cast<const f32x4*>(p.bias + n0 + j * 16 + (c.lane >> 4) * 4);
+            // full tiles run without a per-row test (a branch per row = a basic block per store group = s_waitcnt vmcnt(0)
+            // in front of each: stores count in vmcnt on gfx9)
+            auto emit = [&](auto FULL) {
+                constexpr bool full = decltype(FULL)::value;
+#pragma unroll
+                for (int i = 0; i < S::MI; ++i) {
+                    const int m0r = c.m0 + c.wr * (S::MI * 16) + i * 16 + rs.R;
+                    const int ma = full ? m0r : min(m0r, p.M - 1), mb = full ? m0r + 8 : min(m0r + 8, p.M - 1);
+#pragma unroll
+                    for (int ch = 0; ch < 2; ++ch) {
+                        const int col = n0 + ch * 32 + rs.u * 4;
+                        const f32x4 r0 = *reinterpret_cast<const f32x4*>(p.residual + (size_t)ma * p.ldr + col);
+                        const f32x4 r1 = *reinterpret_cast<const f32x4*>(p.residual + (size_t)mb * p.ldr + col);
+                        rs.park(acc[i][2 * ch] + bj[2 * ch], acc[i][2 * ch + 1] + bj[2 * ch + 1]);
+                        f32x4 t0, t1;
+                        rs.fetch(t0, t1);
+                        if (full || m0r < p.M) *reinterpret_cast<f32x4*>(out32 + (size_t)m0r * p.ldo32 + col) = t0 + r0;
+                        if (full || m0r + 8 < p.M) *reinterpret_cast<f32x4*>(out32 + (size_t)(m0r + 8) * p.ldo32 + col) = t1 + r1;
+                    }
+                }
+            };
+            if (c.m0 + S::BM <= p.M) emit(std::true_type{});
+            else emit(std::false_type{});
+            return;
+        }
         // (do NOT hoist the bias loads above the row loop: the compiler then speculates them into the K loop and
         //  guards the fragment reads with s_waitcnt vmcnt(0), which also waits for the LDS-DMA of the next stage --
         //  15 % slower on every shape; tools/isa_lint.py checks the main loops for that pattern)
@@ -757,7 +796,7 @@ extern "C" int cmdiad_gemm_bf16(const cmdiad_gemm_args* a, cmdiad_stream_t strea
             return CMDIAD_OK;
         }
     }
-#define CMDIAD_STD(SH, ACT, EX) launch<SH>(gemm_std_kernel<SH, ACT, EX>, grid_for<SH>(a->M, a->N, split, p.panel), SH::LDS_BYTES, s, A, W, p)
+#define CMDIAD_STD(SH, ACT, EX) launch<SH>(gemm_std_kernel<SH, ACT, EX>, grid_for<SH>(a->M, a->N, split, p.panel), SH::LDS_BYTES + SH::WAVES * kRowStoreScratch, s, A, W, p)
     p.panel = panel_tiles<S128>(a->M, a->N, a->K, split);
     p.group_m = p.panel == 1 && split == 1 ? group_m_tiles() : 1;
     if (extras) rc = a->act == CMDIAD_ACT_GELU ? CMDIAD_STD(S128, CMDIAD_ACT_GELU, true)

@@ -277,6 +277,31 @@ struct RowStore16 {
 };
 constexpr int kRowStoreScratch = 2048;   // bytes per wave
 
+// The same for fp32 values: a 16-row x 32-column half block (two j) is 2 KiB -- 16-byte unit 4 (j & 1) + g of row r at
+// (unit ^ (r >> 1)); read back as rows R / R + 8, columns 4 (lane & 7) .. + 3 of the half.
+struct RowStore32 {
+    char* scratch;
+    unsigned rd0, rd1;
+    int r, g, R, u;
+    __device__ __forceinline__ void init(char* wave_scratch, int lane)
+    {
+        scratch = wave_scratch;
+        r = lane & 15; g = lane >> 4; R = lane >> 3; u = lane & 7;
+        rd0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(scratch + R * 128 + ((u ^ (R >> 1)) << 4));
+        rd1 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(scratch + (R + 8) * 128 + ((u ^ ((R + 8) >> 1)) << 4));
+    }
+    __device__ __forceinline__ void park(const f32x4& v0, const f32x4& v1) const   // columns j = 2 ch and 2 ch + 1
+    {
+        *reinterpret_cast<f32x4*>(scratch + r * 128 + ((g ^ (r >> 1)) << 4)) = v0;
+        *reinterpret_cast<f32x4*>(scratch + r * 128 + (((4 + g) ^ (r >> 1)) << 4)) = v1;
+    }
+    __device__ __forceinline__ void fetch(f32x4& t0, f32x4& t1) const
+    {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(t0), "=&v"(t1) : "v"(rd0), "v"(rd1) : "memory");
+    }
+};
+
 // XCD-aware bijective remap of the linear workgroup id (guide T1): blocks b and b+8 share an XCD
 // (and its L2), so give every XCD a CONTIGUOUS chunk of the tile order.
 __device__ __forceinline__ int xcd_remap(int orig, int nwg)
