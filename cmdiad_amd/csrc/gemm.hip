@@ -517,6 +517,167 @@ __global__ __launch_bounds__(256, 2) void encoder_stage1_once_kernel(Conv1Tile A
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Encoder first stage, PERSISTENT form (M % 128 == 0): the once-per-block kernel above lives ~21 us per 128-row block for 1 us
+// of MFMA (coordinates -> conv1 -> four weight tiles, each behind a full wait, 32 768 blocks per batch of 32).  Here a block
+// of 8 waves (2 x 4 grid of 64 x 64 wave tiles = 128 rows x all 256 conv2 channels) stays on its CU and walks tiles
+// blockIdx, + gridDim, ...: conv2's weights never touch LDS -- every wave keeps its 64 x 128 slice as MFMA fragments in 64
+// VGPRs for the whole launch -- the conv1 activations of tile t+1 are computed into the other half of a double buffer
+// while nothing waits on memory, and the coordinates of tile t+2 are fetched a full iteration ahead (an inline-asm load
+// older than the iteration's eight stores per wave: s_waitcnt vmcnt(8) never waits for a store).  What is left per tile is
+// its 64 KiB of h2 stores: the kernel is bound by the HBM write stream (2.15 GB per batch of 32).
+// Same arithmetic in the same order as the kernels above (conv1 expression, K order, + bias, bf16, maxima): identical bits.
+// LDS: conv1 tiles 2 x 32 KiB | coordinates 2 x 1.5 KiB | max tables 2 x 4 KiB | 8 store scratches of 2 KiB | conv1 weights 2 KiB.
+// ------------------------------------------------------------------------------------------------
+struct Stage1Persist {
+    static constexpr int KT_BYTES = 128 * BK * 2;
+    static constexpr int C_OFF = 4 * KT_BYTES, MAX_OFF = C_OFF + 2 * 384 * 4, SCR_OFF = MAX_OFF + 2 * 4 * 256 * 4;
+    static constexpr int W1_OFF = SCR_OFF + 8 * kRowStoreScratch, LDS_BYTES = W1_OFF + 128 * 16;
+};
+
+__global__ __launch_bounds__(512, 1) void encoder_stage1_persist_kernel(const float* __restrict__ neigh, const float4* __restrict__ wb,
+                                                                        const bf16_t* __restrict__ W2, GroupMaxParams p, int n_tiles)
+{
+    using L = Stage1Persist;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    float* cbuf = reinterpret_cast<float*>(lds + L::C_OFF);
+    float(*s_max)[4][256] = reinterpret_cast<float(*)[4][256]>(lds + L::MAX_OFF);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    RowStore16 rs;
+    rs.init(lds + L::SCR_OFF + wave * kRowStoreScratch, lane);
+
+    // conv2 weights of this wave's 64 channels as MFMA fragments (row = channel, 8 consecutive k per lane), resident
+    bf16x8 wf[4][4];
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            wf[kc][j] = *reinterpret_cast<const bf16x8*>(W2 + (size_t)(wc * 64 + j * 16 + (lane & 15)) * 128 + kc * 32 + (lane >> 4) * 8);
+    f32x4 bias[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bias[j] = *reinterpret_cast<const f32x4*>(p.bias + wc * 64 + j * 16 + (lane >> 4) * 4);
+    // conv1: a thread owns 8 channels (16-byte chunk c16 of the 128) of rows (tid >> 4) + 32 i; the folded weights sit in LDS
+    const int c16 = tid & 15;
+    float4* wl = reinterpret_cast<float4*>(lds + L::W1_OFF);
+    if (tid < 128) wl[tid] = wb[tid];
+    char* const a_dst = lds + (c16 >> 3) * L::KT_BYTES;
+    auto conv1 = [&](int par) {
+        const float* cb = cbuf + par * 384 + (tid >> 4) * 3;
+        float xs[4], ys[4], zs[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { xs[i] = cb[i * 96]; ys[i] = cb[i * 96 + 1]; zs[i] = cb[i * 96 + 2]; }
+        bf16x8 h[4];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float4 w = wl[c16 * 8 + e];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) h[i][e] = f2bf(conv1_act(w, xs[i], ys[i], zs[i]));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<bf16x8*>(a_dst + par * 2 * L::KT_BYTES + lds_off((tid >> 4) + 32 * i, c16 & 7)) = h[i];
+    };
+    const int my = (n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // tiles blockIdx + t gridDim
+    const float4* n4 = reinterpret_cast<const float4*>(neigh);                           // a tile = 384 floats = 96 float4
+    f32x4 cnext = {0.f, 0.f, 0.f, 0.f};
+    if (tid < 96) {
+        *reinterpret_cast<float4*>(cbuf + tid * 4) = n4[(size_t)blockIdx.x * 96 + tid];
+        if (my > 1) *reinterpret_cast<float4*>(cbuf + 384 + tid * 4) = n4[(size_t)(blockIdx.x + gridDim.x) * 96 + tid];
+    }
+    __syncthreads();
+    conv1(0);
+    __syncthreads();
+
+    const int a_frag = (wr * 64 + (lane & 15)) * 128, swz = lane & 7, g4 = lane >> 4;
+    for (int t = 0; t < my; ++t) {
+        const int par = t & 1;
+        const size_t m0 = (size_t)(blockIdx.x + (size_t)t * gridDim.x) * 128;
+        const bool fetch = t + 2 < my;   // block-uniform
+        if (fetch && tid < 96)
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(cnext) : "v"(n4 + (size_t)(blockIdx.x + (size_t)(t + 2) * gridDim.x) * 96 + tid) : "memory");
+        if (t + 1 < my) conv1(par ^ 1);
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const char* at = lds + par * 2 * L::KT_BYTES + a_frag;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            bf16x8 af[2][4];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    af[kk][i] = *reinterpret_cast<const bf16x8*>(at + kt * L::KT_BYTES + i * 2048 + (((kk * 4 + g4) ^ swz) << 4));
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(wf[kt * 2 + kk][j], af[kk][i], acc[i][j]);
+        }
+        // ---- epilogue: + bias, h2 as 8 rows x 128 contiguous bytes per store, column maxima of the 32-row blocks
+        bf16_t* o0 = p.full_bf16 + (m0 + wr * 64 + rs.R) * 256 + wc * 64 + rs.u * 8;
+        f32x4 mx[2][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            bf16x4 h[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 v = acc[i][j] + bias[j];
+                h[j] = bf16x4{f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+                if ((i & 1) == 0) mx[i >> 1][j] = v;
+                else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) mx[i >> 1][j][r] = fmaxf(mx[i >> 1][j][r], v[r]);
+                }
+            }
+            rs.park(h);
+            uint4 t0, t1;
+            rs.fetch_issue(t0, t1);
+            rs.fetch_wait();
+            *reinterpret_cast<uint4*>(o0 + (size_t)(i * 16) * 256) = t0;
+            *reinterpret_cast<uint4*>(o0 + (size_t)(i * 16 + 8) * 256) = t1;
+        }
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = mx[hb][j][r];
+                    v = fmaxf(v, __shfl_xor(v, 1, 64));
+                    v = fmaxf(v, __shfl_xor(v, 2, 64));
+                    v = fmaxf(v, __shfl_xor(v, 4, 64));
+                    v = fmaxf(v, __shfl_xor(v, 8, 64));
+                    mx[hb][j][r] = v;
+                }
+        if ((lane & 15) == 0) {
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    *reinterpret_cast<f32x4*>(&s_max[par][wr * 2 + hb][wc * 64 + j * 16 + g4 * 4]) = mx[hb][j];
+        }
+        // coordinates of tile t+2: the load is older than this iteration's eight stores
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if (fetch && tid < 96) *reinterpret_cast<f32x4*>(cbuf + par * 384 + tid * 4) = cnext;
+        __syncthreads();
+        if (tid < 256) {
+            const int per = p.Mg >> 5;  // 32-row blocks per group: 1, 2 or 4
+            for (int g = 0; g < 4 / per; ++g) {
+                float v = s_max[par][g * per][tid];
+                for (int q = 1; q < per; ++q) v = fmaxf(v, s_max[par][g * per + q][tid]);
+                const size_t grp = (m0 + (size_t)g * p.Mg) / p.Mg;
+                if (p.max_f32) p.max_f32[grp * 256 + tid] = v;
+                if (p.max_bf16) p.max_bf16[grp * 256 + tid] = f2bf(v);
+            }
+        }
+    }
+}
+
 template <class S> constexpr int group_max_lds() { return S::LDS_BYTES + (S::BM / 32) * S::BN * (int)sizeof(float); }
 
 #ifdef CMDIAD_AB_VARIANTS
@@ -871,15 +1032,31 @@ extern "C" int cmdiad_encoder_stage1(const float* neigh, const float* w1, const 
     hipStream_t s = (hipStream_t)stream;
     CMDIAD_REQUIRE(b2, CMDIAD_ERR_ARG, "cmdiad_encoder_stage1: the second convolution's bias is required");
     int rc;
+    bool persist = M % 128 == 0;   // the once-per-block kernel keeps the ragged case (Mg = 32 / 64 with an odd group count)
 #ifdef CMDIAD_AB_VARIANTS
-    // test-only build: CMDIAD_STAGE1_ONCE=0 selects the generic pipeline (A/B runs; read per call)
+    // test-only build: CMDIAD_STAGE1_PERSIST=0 selects the once-per-block kernel, CMDIAD_STAGE1_ONCE=0 the generic pipeline
+    // (A/B runs; read per call)
     const char* e1 = getenv("CMDIAD_STAGE1_ONCE");
+    if (getenv("CMDIAD_STAGE1_PERSIST") && getenv("CMDIAD_STAGE1_PERSIST")[0] == '0') persist = false;
     if (e1 && e1[0] == '0') {
         p.panel = panel_tiles<S128>(M, 256, 128, 1);
         rc = launch<S128>(encoder_stage1_kernel<S128>, grid_for<S128>(M, 256, 1, p.panel), group_max_lds<S128>(), s, At, Wt, p);
     } else
 #endif
-    {
+    if (persist) {
+        static bool attr = false;
+        if (!attr) {
+            if (hipFuncSetAttribute((const void*)encoder_stage1_persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, Stage1Persist::LDS_BYTES) != hipSuccess) {
+                cmdiad_set_error("cmdiad_encoder_stage1: hipFuncSetAttribute failed");
+                return CMDIAD_ERR_LAUNCH;
+            }
+            attr = true;
+        }
+        const int n_tiles = M / 128;
+        hipLaunchKernelGGL(encoder_stage1_persist_kernel, dim3((unsigned)(n_tiles < kPersistCUs ? n_tiles : kPersistCUs)), dim3(512),
+                           Stage1Persist::LDS_BYTES, s, neigh, (const float4*)w1, (const bf16_t*)W2, p, n_tiles);
+        rc = CMDIAD_OK;
+    } else {
         p.panel = 1;
         rc = launch<S128>(encoder_stage1_once_kernel, dim3((unsigned)((M + 127) / 128)), group_max_lds<S128>() + 4 * kRowStoreScratch, s, At, Wt, p);
     }

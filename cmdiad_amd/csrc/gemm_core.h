@@ -74,7 +74,14 @@ struct GlobalTile {
     }
 };
 
-// Point-MAE first conv (3 -> 128, BN folded, ReLU) evaluated while staging: models/models.py:188-190.
+// One output of the Point-MAE first conv (3 -> 128, BatchNorm folded, ReLU), models/models.py:188-190.  The FMA chain is
+// spelled out so that every kernel evaluating it (and every compiler schedule) rounds the same way.
+__device__ __forceinline__ float conv1_act(const float4& w, float x, float y, float z)
+{
+    return fmaxf(__builtin_fmaf(w.z, z, __builtin_fmaf(w.y, y, __builtin_fmaf(w.x, x, w.w))), 0.0f);
+}
+
+// Point-MAE first conv evaluated while staging.
 // Computed values go through registers and ds_write_b128 (thread t: rows (t>>3) + (THREADS/8) i, chunk t&7).
 struct Conv1Tile {
     const float* neigh;  // [rows,3]
@@ -107,7 +114,7 @@ struct Conv1Tile {
             const float x = px[i], y = py[i], z = pz[i];
             bf16x8 h;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) h[e] = f2bf(fmaxf(w[e].x * x + w[e].y * y + w[e].z * z + w[e].w, 0.0f));
+            for (int e = 0; e < 8; ++e) h[e] = f2bf(conv1_act(w[e], x, y, z));
             *reinterpret_cast<bf16x8*>(tile + lds_off(r, tid & 7)) = h;
         }
     }

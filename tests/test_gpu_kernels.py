@@ -323,6 +323,31 @@ def test_pointmae_encoder_stages(Mg, panel_min, wide, monkeypatch):
     assert err.mean().item() < 0.01 * scale and err.max().item() < 0.08 * scale, (err.mean().item(), err.max().item(), scale)
 
 
+@pytest.mark.parametrize("groups,Mg", [(24, 128), (300, 128), (700, 128), (1030, 32), (514, 64), (7, 32), (9, 64)])
+def test_encoder_stage1_against_direct_reference(groups, Mg):
+    """cmdiad_encoder_stage1 (models/models.py:188-195: conv1 + BN + ReLU, conv2, per-group max) against the same arithmetic in
+    torch: persistent kernel when groups * Mg is a multiple of 128 (1, 2 and 3 tiles per block: the coordinate prefetch runs two
+    tiles ahead), the once-per-block kernel for ragged row counts."""
+    from oracle import nets
+    from cmdiad_amd.runtime import fold_pointmae_encoder
+    w = fold_pointmae_encoder(nets.synth_state_dict("pointmae", 21), "encoder.", DEV)
+    g = torch.Generator().manual_seed(groups * 1000 + Mg)
+    nb = (0.05 * torch.randn(groups * Mg, 3, generator=g)).to(DEV)
+    h2, g32, g16 = ops.encoder_stage1(nb, w["w1b1"], w["W2"], w["b2"], groups, Mg)
+    a1 = torch.relu(nb.double() @ w["w1b1"][:, :3].double().T + w["w1b1"][:, 3].double()).float().bfloat16()
+    ref = a1.double() @ w["W2"].double().T + w["b2"].double()
+    scale = ref.abs().mean().item()
+    # conv1 outputs that straddle a bf16 rounding boundary move one input by 2^-8 relative: tolerance in units of the output scale
+    err = (h2.double() - ref).abs()
+    assert err.max().item() < 0.03 * scale + 0.01 * ref.abs().max().item() and err.mean().item() < 0.004 * scale, (err.max().item(), err.mean().item(), scale)
+    gref = ref.reshape(groups, Mg, 256).amax(1)
+    gerr = (g32.double() - gref).abs()
+    assert gerr.max().item() < 0.02 * scale + 0.004 * gref.abs().max().item(), (gerr.max().item(), scale)
+    # the maxima are taken before the bf16 rounding of h2, and rounding is monotone: bf16(max) == max(bf16)
+    assert torch.equal(g32.bfloat16(), h2.reshape(groups, Mg, 256).amax(1))
+    assert torch.equal(g16, g32.bfloat16())
+
+
 # ------------------------------------------------------------------------------------------ scoring
 @pytest.mark.parametrize("Q,Nb,D,tile", [(784, 1500, 768, None), (3136, 5000, 128, None), (100, 77, 64, None),
                                           (784, 1500, 768, "3"), (3136, 5000, 128, "3"), (100, 77, 64, "3"), (1000, 2100, 256, "2"),
