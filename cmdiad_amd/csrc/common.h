@@ -9,6 +9,7 @@ typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 #define CMDIAD_WAVE 64
@@ -111,6 +112,42 @@ __device__ __forceinline__ float gelu_erf_grad(float x)
 __device__ __forceinline__ unsigned long long pack_key(float v, unsigned idx)
 {
     return ((unsigned long long)__float_as_uint(v) << 32) | idx;
+}
+
+// max over the 16 lanes of a DPP row (lanes 16 r .. 16 r + 15), result in all 16: quad xor 1, quad xor 2, half-row mirror,
+// row mirror -- VALU only (four __shfl_xor steps are four ds_bpermute round trips through the LDS pipeline).
+__device__ __forceinline__ float row16_max(float v)
+{
+    int i = __builtin_bit_cast(int, v);
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, 0xB1, 0xF, 0xF, false)));
+    i = __builtin_bit_cast(int, v);
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, 0x4E, 0xF, 0xF, false)));
+    i = __builtin_bit_cast(int, v);
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, 0x141, 0xF, 0xF, false)));
+    i = __builtin_bit_cast(int, v);
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, 0x140, 0xF, 0xF, false)));
+    return v;
+}
+
+// The same for N >= 4 values at once, ONE instruction per value and step (v_max_f32 with the DPP modifier on its first
+// source): the builtin form above costs a copy, the DPP move, a quieting v_max v, v, v and the max.  Inline asm is outside
+// the compiler's hazard tracking: a DPP read needs two wait states after the VALU write of its source -- the s_nop covers
+// the values' producers, and inside the batch consecutive steps of one value are N - 1 >= 3 instructions apart (the
+// statements are volatile: their order is kept).  No NaN inputs.
+template <int N>
+__device__ __forceinline__ void row16_max_batch(float (&v)[N])
+{
+    static_assert(N >= 4, "spacing between dependent DPP steps");
+    asm volatile("s_nop 1");
+#pragma unroll
+    for (int k = 0; k < N; ++k) asm volatile("v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(v[k]));
+#pragma unroll
+    for (int k = 0; k < N; ++k) asm volatile("v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "+v"(v[k]));
+#pragma unroll
+    for (int k = 0; k < N; ++k) asm volatile("v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf" : "+v"(v[k]));
+#pragma unroll
+    for (int k = 0; k < N; ++k) asm volatile("v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf" : "+v"(v[k]));
+    asm volatile("s_nop 1");   // nothing the compiler places next may read a lane-crossed result too early either
 }
 
 __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int m)

@@ -171,10 +171,7 @@ __global__ __launch_bounds__(TW * 64, 2) void encoder_tail_kernel(GlobalTile H2,
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float v = fmaxf(acco[o][0][j][r], acco[o][1][j][r]);
-                v = fmaxf(v, __shfl_xor(v, 1, 64));
-                v = fmaxf(v, __shfl_xor(v, 2, 64));
-                v = fmaxf(v, __shfl_xor(v, 4, 64));
-                v = fmaxf(v, __shfl_xor(v, 8, 64));
+                v = row16_max(v);
                 if ((lane & 15) == 0) s_part[wr * 384 + n + r] = v;
             }
         }

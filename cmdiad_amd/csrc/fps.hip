@@ -115,7 +115,6 @@ __global__ __launch_bounds__(kThreads) void fps_reg_kernel(const float* __restri
 //   * the winner's index is recovered AFTER that: one v_cmp_eq per slot against the wave maximum writes a lane mask to
 //     SGPRs, the scalar unit picks the lowest slot with a match and its lowest lane (= lowest point index, the tie rule).
 // 6.5 operations per point instead of 12.  Same (value, ~index) keys across the waves, so results are bit-identical.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ unsigned dpp_max_u32(unsigned v)
 {

@@ -411,10 +411,7 @@ __device__ __forceinline__ void groupmax_epilogue(Acc& acc, int ntile, const Coo
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float v = mx[hb][r];
-                    v = fmaxf(v, __shfl_xor(v, 1, 64));
-                    v = fmaxf(v, __shfl_xor(v, 2, 64));
-                    v = fmaxf(v, __shfl_xor(v, 4, 64));
-                    v = fmaxf(v, __shfl_xor(v, 8, 64));
+                    v = row16_max(v);
                     if ((c.lane & 15) == 0) s_max[c.wr * (S::MI / 2) + hb][nl + r] = v;
                 }
             }
@@ -535,6 +532,7 @@ struct Stage1Persist {
     static constexpr int W1_OFF = SCR_OFF + 8 * kRowStoreScratch, LDS_BYTES = W1_OFF + 128 * 16;
 };
 
+template <bool G64>   // G64: Mg is 64 or 128 -- a wave's 64 rows are one group, their maximum is taken in-lane first
 __global__ __launch_bounds__(512, 1) void encoder_stage1_persist_kernel(const float* __restrict__ neigh, const float4* __restrict__ wb,
                                                                         const bf16_t* __restrict__ W2, GroupMaxParams p, int n_tiles)
 {
@@ -569,10 +567,16 @@ __global__ __launch_bounds__(512, 1) void encoder_stage1_persist_kernel(const fl
         for (int i = 0; i < 4; ++i) { xs[i] = cb[i * 96]; ys[i] = cb[i * 96 + 1]; zs[i] = cb[i * 96 + 2]; }
         bf16x8 h[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
+        for (int e = 0; e < 8; ++e) {   // two rows per v_pk_fma_f32: the same FMA chain as conv1_act, element-wise
             const float4 w = wl[c16 * 8 + e];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) h[i][e] = f2bf(conv1_act(w, xs[i], ys[i], zs[i]));
+            for (int i = 0; i < 4; i += 2) {
+                f32x2 a = __builtin_elementwise_fma(f32x2{w.x, w.x}, f32x2{xs[i], xs[i + 1]}, f32x2{w.w, w.w});
+                a = __builtin_elementwise_fma(f32x2{w.y, w.y}, f32x2{ys[i], ys[i + 1]}, a);
+                a = __builtin_elementwise_fma(f32x2{w.z, w.z}, f32x2{zs[i], zs[i + 1]}, a);
+                h[i][e] = f2bf(fmaxf(a[0], 0.0f));
+                h[i + 1][e] = f2bf(fmaxf(a[1], 0.0f));
+            }
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -628,10 +632,11 @@ __global__ __launch_bounds__(512, 1) void encoder_stage1_persist_kernel(const fl
             for (int j = 0; j < 4; ++j) {
                 const f32x4 v = acc[i][j] + bias[j];
                 h[j] = bf16x4{f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-                if ((i & 1) == 0) mx[i >> 1][j] = v;
+                const int hb = G64 ? 0 : i >> 1;
+                if (i == 0 || (!G64 && i == 2)) mx[hb][j] = v;
                 else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) mx[i >> 1][j][r] = fmaxf(mx[i >> 1][j][r], v[r]);
+                    for (int r = 0; r < 4; ++r) mx[hb][j][r] = fmaxf(mx[hb][j][r], v[r]);
                 }
             }
             rs.park(h);
@@ -641,25 +646,21 @@ __global__ __launch_bounds__(512, 1) void encoder_stage1_persist_kernel(const fl
             *reinterpret_cast<uint4*>(o0 + (size_t)(i * 16) * 256) = t0;
             *reinterpret_cast<uint4*>(o0 + (size_t)(i * 16 + 8) * 256) = t1;
         }
+        {
+            constexpr int NV = (G64 ? 1 : 2) * 16;
+            float red[NV];
 #pragma unroll
-        for (int hb = 0; hb < 2; ++hb)
+            for (int q = 0; q < NV; ++q) red[q] = mx[q >> 4][(q >> 2) & 3][q & 3];
+            row16_max_batch(red);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = mx[hb][j][r];
-                    v = fmaxf(v, __shfl_xor(v, 1, 64));
-                    v = fmaxf(v, __shfl_xor(v, 2, 64));
-                    v = fmaxf(v, __shfl_xor(v, 4, 64));
-                    v = fmaxf(v, __shfl_xor(v, 8, 64));
-                    mx[hb][j][r] = v;
-                }
-        if ((lane & 15) == 0) {
+            for (int q = 0; q < NV; ++q) mx[q >> 4][(q >> 2) & 3][q & 3] = red[q];
+        }
+        if ((lane & 15) == 0) {   // table row = 32-row block (both halves of a 64-row wave tile carry the same value under G64)
 #pragma unroll
             for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    *reinterpret_cast<f32x4*>(&s_max[par][wr * 2 + hb][wc * 64 + j * 16 + g4 * 4]) = mx[hb][j];
+                    *reinterpret_cast<f32x4*>(&s_max[par][wr * 2 + hb][wc * 64 + j * 16 + g4 * 4]) = mx[G64 ? 0 : hb][j];
         }
         // coordinates of tile t+2: the load is older than this iteration's eight stores
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -1046,15 +1047,17 @@ extern "C" int cmdiad_encoder_stage1(const float* neigh, const float* w1, const 
     if (persist) {
         static bool attr = false;
         if (!attr) {
-            if (hipFuncSetAttribute((const void*)encoder_stage1_persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, Stage1Persist::LDS_BYTES) != hipSuccess) {
+            if (hipFuncSetAttribute((const void*)encoder_stage1_persist_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, Stage1Persist::LDS_BYTES) != hipSuccess ||
+                hipFuncSetAttribute((const void*)encoder_stage1_persist_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, Stage1Persist::LDS_BYTES) != hipSuccess) {
                 cmdiad_set_error("cmdiad_encoder_stage1: hipFuncSetAttribute failed");
                 return CMDIAD_ERR_LAUNCH;
             }
             attr = true;
         }
         const int n_tiles = M / 128;
-        hipLaunchKernelGGL(encoder_stage1_persist_kernel, dim3((unsigned)(n_tiles < kPersistCUs ? n_tiles : kPersistCUs)), dim3(512),
-                           Stage1Persist::LDS_BYTES, s, neigh, (const float4*)w1, (const bf16_t*)W2, p, n_tiles);
+        const dim3 grid((unsigned)(n_tiles < kPersistCUs ? n_tiles : kPersistCUs));
+        if (Mg >= 64) hipLaunchKernelGGL(encoder_stage1_persist_kernel<true>, grid, dim3(512), Stage1Persist::LDS_BYTES, s, neigh, (const float4*)w1, (const bf16_t*)W2, p, n_tiles);
+        else hipLaunchKernelGGL(encoder_stage1_persist_kernel<false>, grid, dim3(512), Stage1Persist::LDS_BYTES, s, neigh, (const float4*)w1, (const bf16_t*)W2, p, n_tiles);
         rc = CMDIAD_OK;
     } else {
         p.panel = 1;
