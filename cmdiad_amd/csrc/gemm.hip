@@ -76,7 +76,7 @@ struct Coord {
 // (row tile, column tile) bodies carried 64 inlined erff/expf expansions -- ~40 KB of code that even the skipped
 // branches had to fetch through the instruction cache (measured: the plain 4.2M x 512 x 256 product spent as long
 // in that epilogue as in its MFMA loop).  ACT = CMDIAD_ACT_*; EXTRAS = the training-only terms (dact_of, out_pre).
-template <class S, int ACT, bool EXTRAS>
+template <class S, int ACT, bool EXTRAS, bool RES_ROWS = false>
 __global__ __launch_bounds__(S::THREADS, S::WAVES_PER_SIMD) void gemm_std_kernel(GlobalTile A, GlobalTile W, StdParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -91,13 +91,14 @@ __global__ __launch_bounds__(S::THREADS, S::WAVES_PER_SIMD) void gemm_std_kernel
     // accumulator layout its 16-byte loads and stores touch 16 rows x 64 bytes per instruction; on the short-K products the
     // texture addresser, not the MFMAs, then bounds the block (proj 25120 x 768 x 768: 417 TFLOP/s against fc2's 710 on the
     // same kernel).  RowStore32: 8 rows x 128 contiguous bytes per load / store.
-    const bool res_rows = !EXTRAS && ACT == CMDIAD_ACT_NONE && p.residual && p.out_f32 && !p.out_bf16 && !p.group_bias && p.bias &&
-                          p.split_k == 1 && p.N % 64 == 0 && p.panel == 1;
+    // RES_ROWS is its own instantiation, chosen on the host (res_rows_epilogue()): with both epilogues in one kernel the
+    // compiler ran out of registers and spilled the general path's row pointers (tools/isa_lint.py).
+    static_assert(!RES_ROWS || (!EXTRAS && ACT == CMDIAD_ACT_NONE), "residual-row epilogue: no activation, no training terms");
     RowStore32 rs;
     rs.init(lds + S::LDS_BYTES + (threadIdx.x >> 6) * kRowStoreScratch, c.lane);
 
     run<S, true>(A, W, c.m0, c.nt, c.count, kt_count, lds, [&](auto& acc, int ntile, char*) {
-        if (res_rows) {
+        if constexpr (RES_ROWS) {
             const int n0 = ntile * S::BN + c.wc * 64;
             f32x4 bj[4];
 #pragma unroll
@@ -125,8 +126,7 @@ __global__ __launch_bounds__(S::THREADS, S::WAVES_PER_SIMD) void gemm_std_kernel
             };
             if (c.m0 + S::BM <= p.M) emit(std::true_type{});
             else emit(std::false_type{});
-            return;
-        }
+        } else {
         // (do NOT hoist the bias loads above the row loop: the compiler then speculates them into the K loop and
         //  guards the fragment reads with s_waitcnt vmcnt(0), which also waits for the LDS-DMA of the next stage --
         //  15 % slower on every shape; tools/isa_lint.py checks the main loops for that pattern)
@@ -171,6 +171,7 @@ v = gelu_erf4(v);
                     *reinterpret_cast<bf16x4*>(o16 + n) = o;
                 }
             }
+        }
         }
     }, kt_begin);
 }
@@ -961,7 +962,12 @@ extern "C" int cmdiad_gemm_bf16(const cmdiad_gemm_args* a, cmdiad_stream_t strea
 #define CMDIAD_STD(SH, ACT, EX) launch<SH>(gemm_std_kernel<SH, ACT, EX>, grid_for<SH>(a->M, a->N, split, p.panel), SH::LDS_BYTES + SH::WAVES * kRowStoreScratch, s, A, W, p)
     p.panel = panel_tiles<S128>(a->M, a->N, a->K, split);
     p.group_m = p.panel == 1 && split == 1 ? group_m_tiles() : 1;
-    if (extras) rc = a->act == CMDIAD_ACT_GELU ? CMDIAD_STD(S128, CMDIAD_ACT_GELU, true)
+    // fp32 residual stream in place (proj / fc2): out_f32 = acc + bias + residual through the row-contiguous epilogue
+    const bool res_rows = !extras && a->act == CMDIAD_ACT_NONE && p.residual && p.out_f32 && !p.out_bf16 && !p.group_bias && p.bias &&
+                          split == 1 && a->N % 64 == 0 && p.panel == 1;
+    if (res_rows) rc = launch<S128>(gemm_std_kernel<S128, CMDIAD_ACT_NONE, false, true>, grid_for<S128>(a->M, a->N, split, p.panel),
+                                    S128::LDS_BYTES + S128::WAVES * kRowStoreScratch, s, A, W, p);
+    else if (extras) rc = a->act == CMDIAD_ACT_GELU ? CMDIAD_STD(S128, CMDIAD_ACT_GELU, true)
                    : a->act == CMDIAD_ACT_RELU ? CMDIAD_STD(S128, CMDIAD_ACT_RELU, true) : CMDIAD_STD(S128, CMDIAD_ACT_NONE, true);
     else rc = a->act == CMDIAD_ACT_GELU ? CMDIAD_STD(S128, CMDIAD_ACT_GELU, false)
             : a->act == CMDIAD_ACT_RELU ? CMDIAD_STD(S128, CMDIAD_ACT_RELU, false) : CMDIAD_STD(S128, CMDIAD_ACT_NONE, false);

@@ -640,11 +640,12 @@ def test_reference_models_run_on_compat_shims():
     np.testing.assert_array_equal(g[0].permute(1, 2, 0).cpu().numpy(), want)
 
 
-@pytest.mark.parametrize("Mg,groups", [(128, 24), (64, 9), (32, 7), (32, 50)])
+@pytest.mark.parametrize("Mg,groups", [(128, 24), (64, 9), (32, 7), (32, 50), (128, 300), (128, 770), (64, 1031), (32, 2051)])
 def test_encoder_tail_equals_two_kernel_path(Mg, groups):
     """cmdiad_encoder_tail (h3 produced and consumed in LDS) against cmdiad_gemm_bf16(ReLU, group bias) + cmdiad_gemm_groupmax:
     the same bf16 rounding of h3 and the same K order of the fp32 accumulation -> identical tokens, for every group size
-    (blocks of 64 rows hold half a group, one group or two groups) and a ragged last block."""
+    (blocks of 128 rows hold one, two or four groups), a ragged last block, and one to four row tiles per persistent block
+    (256 blocks walk the tiles: the weight stream, the next tile's h2 and the maxima of the finished tile overlap)."""
     from oracle import nets
     from cmdiad_amd.runtime import fold_pointmae_encoder
     w = fold_pointmae_encoder(nets.synth_state_dict("pointmae", 21), "encoder.", DEV)
