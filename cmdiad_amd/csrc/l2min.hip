@@ -31,6 +31,8 @@ struct L2Params {
     unsigned row_offset;
     unsigned long long* keys;
     int nq_tiles, n_bank_tiles, splits, qgroup;
+    unsigned* diag;    // test-only build: in-kernel stamps of one workgroup (l2_min_pp3_kernel<F16, true>), else null
+    int diag_wg;
 };
 
 template <class S, bool F16>
@@ -426,7 +428,10 @@ struct SPingPong3 {
     static constexpr int LDS_BYTES = BN_OFF + 2 * 256 * 4;
 };
 
-template <bool F16>
+// DIAG (test-only build): waves 0 and 4 of workgroup p.diag_wg stamp s_memtime at five points of every phase into LDS (no global
+// traffic inside the loop: stores count in vmcnt and would shift the counted waits) and copy the stamps out at the end.
+constexpr int kDiagStamps = 1280;   // per wave: 64 K-tiles x 4 phases x 5
+template <bool F16, bool DIAG = false>
 __global__ __launch_bounds__(512, 1) void l2_min_pp3_kernel(GlobalTile A, GlobalTile W, L2Params p)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -445,6 +450,28 @@ __global__ __launch_bounds__(512, 1) void l2_min_pp3_kernel(GlobalTile A, Global
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int KT = p.D / BK, T_total = ntc * KT;
+    unsigned* diag_lds = reinterpret_cast<unsigned*>(lds + S::LDS_BYTES) + (wave >> 2) * kDiagStamps;
+    const bool diag_on = DIAG && wg == p.diag_wg && (wave & 3) == 0;
+    int diag_n = 0, diag_k = 0;
+    unsigned long long diag_t[5] = {0, 0, 0, 0, 0};
+    // s_memtime is a scalar-memory read (~100+ cycles, counted in lgkmcnt): the five stamps of a phase stay in SGPRs and are
+    // written to LDS once per phase, after the MFMAs have been issued -- a wait per stamp would serialise the fragment reads
+    auto stamp = [&]() {
+        if constexpr (DIAG) {
+            if (diag_on) {
+                diag_t[diag_k] = __builtin_amdgcn_s_memtime();
+                if (++diag_k == 5) {
+                    diag_k = 0;
+                    if (diag_n + 5 <= kDiagStamps) {
+#pragma unroll
+                        for (int e = 0; e < 5; ++e)
+                            if (lane == 0) diag_lds[diag_n + e] = (unsigned)diag_t[e];
+                    }
+                    diag_n += 5;
+                }
+            }
+        }
+    };
     // LDS byte address of the [2][256] bank-norm area (the inline-asm accesses take raw LDS addresses)
     const unsigned bn_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(lds + S::BN_OFF);
 
@@ -550,6 +577,7 @@ __global__ __launch_bounds__(512, 1) void l2_min_pp3_kernel(GlobalTile A, Global
         b_base = (T % 3) * S::BUF + b_off;
         f32x4 bnv;  // wave 0: this bank tile's squared norms on their way to LDS
         // ================= phase 0: B lo + A lo
+        stamp();
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -561,8 +589,10 @@ __global__ __launch_bounds__(512, 1) void l2_min_pp3_kernel(GlobalTile A, Global
             for (int kk = 0; kk < 2; ++kk) af[i][kk] = lda(i, kk);
         const bool bn_fetch = wave == 0 && kt_c == 0;  // wave-uniform
         if (bn_fetch) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bnv) : "v"(p.b_sqnorm + (size_t)nt_c * S::BN + lane * 4) : "memory");
-        phase_wait(issue_phase(std::integral_constant<int, 0>{}));
+        { const bool is = issue_phase(std::integral_constant<int, 0>{}); stamp(); phase_wait(is); }
+        stamp();
         pp_barrier();
+        stamp();
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
@@ -571,14 +601,18 @@ __global__ __launch_bounds__(512, 1) void l2_min_pp3_kernel(GlobalTile A, Global
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(wlo[j][kk], af[i][kk], acc[i][j]);
         __builtin_amdgcn_s_setprio(0);
+        stamp();
         pp_barrier();
         // ================= phase 1: B hi
+        stamp();
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) whi[j][kk] = ldb(2 + j, kk);
-        phase_wait(issue_phase(std::integral_constant<int, 1>{}));
+        { const bool is = issue_phase(std::integral_constant<int, 1>{}); stamp(); phase_wait(is); }
+        stamp();
         pp_barrier();
+        stamp();
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
@@ -587,14 +621,18 @@ __global__ __launch_bounds__(512, 1) void l2_min_pp3_kernel(GlobalTile A, Global
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][2 + j] = mfma16(whi[j][kk], af[i][kk], acc[i][2 + j]);
         __builtin_amdgcn_s_setprio(0);
+        stamp();
         pp_barrier();
         // ================= phase 2: A hi
+        stamp();
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) af[i][kk] = lda(4 + i, kk);
-        phase_wait(issue_phase(std::integral_constant<int, 2>{}));
+        { const bool is = issue_phase(std::integral_constant<int, 2>{}); stamp(); phase_wait(is); }
+        stamp();
         pp_barrier();
+        stamp();
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
@@ -603,12 +641,16 @@ __global__ __launch_bounds__(512, 1) void l2_min_pp3_kernel(GlobalTile A, Global
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[4 + i][2 + j] = mfma16(whi[j][kk], af[i][kk], acc[4 + i][2 + j]);
         __builtin_amdgcn_s_setprio(0);
+        stamp();
         pp_barrier();
         // ================= phase 3: no reads (B lo is still in registers)
+        stamp();
         if (bn_fetch)  // 6 DMA pieces were issued after the fetch (phases 0-2): a counted wait, then park the norms in LDS
             asm volatile("s_waitcnt vmcnt(6)\n\tds_write_b128 %0, %1" ::"v"(bn_lds + (unsigned)((nt_c & 1) * 1024 + lane * 16)), "v"(bnv) : "memory");
-        phase_wait(issue_phase(std::integral_constant<int, 3>{}));
+        { const bool is = issue_phase(std::integral_constant<int, 3>{}); stamp(); phase_wait(is); }
+        stamp();
         pp_barrier();
+        stamp();
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
@@ -617,6 +659,7 @@ __global__ __launch_bounds__(512, 1) void l2_min_pp3_kernel(GlobalTile A, Global
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[4 + i][j] = mfma16(wlo[j][kk], af[i][kk], acc[4 + i][j]);
         __builtin_amdgcn_s_setprio(0);
+        stamp();
         if (kt_c == KT - 1) {  // bank tile finished: d2 = |q|^2 + |b|^2 - 2 q.b, running (min, first index) per lane
             const int nbase = nt_c * S::BN + wc * 64 + (lane >> 4) * 4;
             f32x4 b4[4];
@@ -657,6 +700,11 @@ __global__ __launch_bounds__(512, 1) void l2_min_pp3_kernel(GlobalTile A, Global
         key = o < key ? o : key;
         const int m = m0 + wr * 128 + i * 16 + (lane & 15);
         if (lane < 16 && m < p.Q) atomicMin(p.keys + m, key);
+    }
+    if constexpr (DIAG) {
+        if (diag_on) {
+            for (int e = lane; e < kDiagStamps; e += 64) p.diag[(wave >> 2) * kDiagStamps + e] = e < min(diag_n, kDiagStamps) ? diag_lds[e] : 0u;
+        }
     }
     };
     if (wave < 4) body(std::true_type{});
@@ -839,7 +887,7 @@ int launch_l2(const uint16_t* q, const float* q_sqnorm, const uint16_t* bank, co
     int qgroup = env_qgroup > 0 ? env_qgroup : 4;
     qgroup = qgroup > nq ? nq : qgroup;
     GlobalTile A{(const bf16_t*)q, D, Q}, W{(const bf16_t*)bank, D, Nb};
-    L2Params p{Q, Nb, D, q_sqnorm, bank_sqnorm, row_offset, keys, nq, nbt, splits, qgroup};
+    L2Params p{Q, Nb, D, q_sqnorm, bank_sqnorm, row_offset, keys, nq, nbt, splits, qgroup, nullptr, -1};
     const int ngroups = (nq + qgroup - 1) / qgroup;
     hipLaunchKernelGGL((L2Kernel<S, F16>::fn), dim3(ngroups * qgroup * splits), dim3(S::THREADS), S::LDS_BYTES, stream, A, W, p);
     return CMDIAD_OK;
@@ -909,6 +957,36 @@ extern "C" int cmdiad_l2_min_keys(const uint16_t* q, const float* q_sqnorm, cons
     CMDIAD_CHECK_LAUNCH();
     return CMDIAD_OK;
 }
+
+#ifdef CMDIAD_AB_VARIANTS
+// Test-only build: the production distance GEMM with in-kernel stamps of workgroup `wg` (after the XCD remap): waves 0 and 4
+// write kDiagStamps 32-bit s_memtime values each to stamps[2][kDiagStamps] (tools/l2_stamps.py).  fp16 operands, Nb % 256 == 0.
+extern "C" int cmdiad_l2_diag(const uint16_t* q, const float* q_sqnorm, const uint16_t* bank, const float* bank_sqnorm, int Q,
+                              int Nb, int D, unsigned long long* keys, int wg, unsigned* stamps, cmdiad_stream_t stream)
+{
+    CMDIAD_REQUIRE(q && q_sqnorm && bank && bank_sqnorm && keys && stamps && Nb % 256 == 0 && D % 64 == 0 && D >= 192, CMDIAD_ERR_ARG,
+                   "cmdiad_l2_diag: bad args");
+    using S = SPingPong3;
+    const int lds_bytes = S::LDS_BYTES + 2 * kDiagStamps * (int)sizeof(unsigned);
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)l2_min_pp3_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) {
+            cmdiad_set_error("cmdiad_l2_diag: hipFuncSetAttribute failed");
+            return CMDIAD_ERR_LAUNCH;
+        }
+        attr = true;
+    }
+    const int nq = (Q + S::BM - 1) / S::BM, nbt = Nb / S::BN;
+    int splits = nbt / 4 < 1 ? 1 : (nbt / 4 > 32 ? 32 : nbt / 4);
+    int qgroup = 4 > nq ? nq : 4;
+    GlobalTile A{(const bf16_t*)q, D, Q}, W{(const bf16_t*)bank, D, Nb};
+    L2Params p{Q, Nb, D, q_sqnorm, bank_sqnorm, 0u, keys, nq, nbt, splits, qgroup, stamps, wg};
+    const int ngroups = (nq + qgroup - 1) / qgroup;
+    hipLaunchKernelGGL((l2_min_pp3_kernel<true, true>), dim3(ngroups * qgroup * splits), dim3(S::THREADS), lds_bytes, (hipStream_t)stream, A, W, p);
+    CMDIAD_CHECK_LAUNCH();
+    return CMDIAD_OK;
+}
+#endif
 
 extern "C" int cmdiad_l2_rescore(const float* q, const float* bank, const unsigned long long* keys, int Q, int Nb,
                                  int D, uint32_t row_offset, float* min_val, int64_t* min_idx, cmdiad_stream_t stream)
