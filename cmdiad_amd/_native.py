@@ -84,6 +84,7 @@ SIGNATURES = {
     "cmdiad_gather_points": [P, P, I, I, I, I, P, P],
     "cmdiad_blur8_maps": [P, I, I, I, F, P, P],
     "cmdiad_ocsvm_score_maps": [P, I, I, I, P, P, D, P, P],
+    "cmdiad_ocsvm_fit": [P, I, I, D, I, D, I, U32, P, P, P, P, P, SZ, P],
     "cmdiad_linear3": [P, P, SZ, I, I, P, P],
     "cmdiad_cast_bf16": [P, SZ, P, P],
     "cmdiad_transpose_bf16": [P, I, I, P, P],
@@ -94,6 +95,7 @@ SIZE_QUERIES = {
     "cmdiad_bank_block16_floats": [I, I],
     "cmdiad_coreset_workspace_bytes": [I, I, I],
     "cmdiad_blur8_lds_bytes": [I, I],
+    "cmdiad_ocsvm_fit_workspace_bytes": [I, I],
     "cmdiad_transformer_block_workspace_bytes": [I, I, I],
 }
 

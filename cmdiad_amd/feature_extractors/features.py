@@ -164,8 +164,15 @@ class Features(torch.nn.Module):
             print("[Fusion Block]", self.fusion.load_state_dict(ckpt))
             self.fusion.eval()
 
-        self.detect_fuser = linear_model.SGDOneClassSVM(random_state=42, nu=args.ocsvm_nu, max_iter=args.ocsvm_maxiter)
-        self.seg_fuser = linear_model.SGDOneClassSVM(random_state=42, nu=args.ocsvm_nu, max_iter=args.ocsvm_maxiter)
+        # features.py:127-128.  CMDIAD_OCSVM_DEVICE=1 fits them on the GPU (cmdiad_ocsvm_fit: scikit-learn's float32 SGD in the same
+        # update order, identical coef_ / offset_ / n_iter_, tests/test_gpu_ocsvm.py); the default stays scikit-learn on the host,
+        # which is faster at this strictly sequential recurrence
+        if os.environ.get("CMDIAD_OCSVM_DEVICE", "0") == "1":
+            from ..ocsvm import DeviceSGDOneClassSVM as _OCSVM
+        else:
+            _OCSVM = linear_model.SGDOneClassSVM
+        self.detect_fuser = _OCSVM(random_state=42, nu=args.ocsvm_nu, max_iter=args.ocsvm_maxiter)
+        self.seg_fuser = _OCSVM(random_state=42, nu=args.ocsvm_nu, max_iter=args.ocsvm_maxiter)
         self.s_lib, self.s_map_lib = [], []
         self.img_name = []
         self.save_num = 0
@@ -333,7 +340,7 @@ class Features(torch.nn.Module):
         self.au_pro_001, _ = calculate_au_pro(self.gts, self.predictions, 0.01)
 
     def run_late_fusion(self):
-        """features.py:352-358 (host scikit-learn)."""
+        """features.py:352-358 (scikit-learn on the host by default; on the device with CMDIAD_OCSVM_DEVICE=1)."""
         self.s_lib = torch.cat(self.s_lib, 0)
         self.s_map_lib = torch.cat(self.s_map_lib, 0)
         self.detect_fuser.fit(self.s_lib)

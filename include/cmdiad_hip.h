@@ -356,6 +356,17 @@ size_t cmdiad_blur8_lds_bytes(int H, int W);
 int cmdiad_ocsvm_score_maps(const float* maps, int B, int K, int HW, const float* lambdas, const double* coef, double offset,
                             double* out, cmdiad_stream_t stream);
 
+/* One-class SVM FIT on the device: scikit-learn's SGDOneClassSVM.fit for float32 inputs (feature_extractors/features.py:352-358,
+ * detect_fuser.fit / seg_fuser.fit; algorithm of the reference's dependency: sklearn _sgd_fast._plain_sgd32 with hinge loss, L2
+ * penalty alpha = nu / 2, 'optimal' schedule, shuffle = True, tol / n_iter_no_change stopping) with the same update order:
+ * coef, offset and n_iter are those of scikit-learn (tests/test_gpu_ocsvm.py).  X [n,F] f32 on the device, 1 <= F <= 4;
+ * seed = the 32-bit seed scikit-learn draws from random_state; pow2 [32][32] (host): column b of M^(2^e) of the xorshift32 step
+ * (cmdiad_amd/ocsvm.py computes it); coef_out [F], offset_out, n_iter_out on the host.  Synchronous (one host decision per epoch). */
+size_t cmdiad_ocsvm_fit_workspace_bytes(int n, int F);
+int cmdiad_ocsvm_fit(const float* X, int n, int F, double nu, int max_iter, double tol, int n_iter_no_change, uint32_t seed,
+                     const uint32_t* pow2, float* coef_out, double* offset_out, int* n_iter_out, void* workspace,
+                     size_t workspace_bytes, cmdiad_stream_t stream);
+
 /* ---- training side of the FtoF distillation network (models/hallucination_network.py:47-69,
  * hallucination_network_pretrain.py:102-159) ---- */
 

@@ -196,6 +196,37 @@ def test_coreset_vs_reference_golden(golden):
     np.testing.assert_array_equal(sel.numpy(), g["idx"])
 
 
+def test_late_fusion_fit_on_device_equals_sklearn(weights, monkeypatch):
+    """features.py:352-358 with CMDIAD_OCSVM_DEVICE=1: the drop-in's two one-class SVMs are fitted by cmdiad_ocsvm_fit and equal
+    scikit-learn fitted on the same s_lib / s_map_lib rows bit for bit (score maps of 2 train samples: 100 352 rows)."""
+    import warnings
+    from sklearn import linear_model
+    from cmdiad_amd.feature_extractors.multiple_features import DoubleRGBPointFeatures
+    from cmdiad_amd.ocsvm import DeviceSGDOneClassSVM
+    sd_vit, sd_pm = weights
+    monkeypatch.setenv("CMDIAD_OCSVM_DEVICE", "1")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = DoubleRGBPointFeatures(make_args())
+    assert isinstance(m.detect_fuser, DeviceSGDOneClassSVM) and isinstance(m.seg_fuser, DeviceSGDOneClassSVM)
+    m.deep_feature_extractor.rgb_backbone.load_state_dict(sd_vit)
+    m.deep_feature_extractor.xyz_backbone.load_state_dict(sd_pm)
+    train = [synth_sample(i) for i in range(2)]
+    for rgb, pc in train:
+        m.add_sample_to_mem_bank((rgb, pc, pc), class_name="synth")
+    m.run_coreset()
+    for rgb, pc in train:
+        m.add_sample_to_late_fusion_mem_bank((rgb, pc, pc))
+    m.run_late_fusion()
+    assert m.s_map_lib.dtype == torch.float32 and m.s_map_lib.shape == (2 * 50176, 2)
+    det = linear_model.SGDOneClassSVM(random_state=42, nu=0.5, max_iter=1000).fit(m.s_lib)
+    seg = linear_model.SGDOneClassSVM(random_state=42, nu=0.5, max_iter=1000).fit(m.s_map_lib)
+    for got, ref in ((m.detect_fuser, det), (m.seg_fuser, seg)):
+        np.testing.assert_array_equal(got.coef_, ref.coef_)
+        np.testing.assert_array_equal(got.offset_, ref.offset_)
+        assert got.n_iter_ == ref.n_iter_
+
+
 def test_full_protocol_double_rgb_point_vs_oracle(fitted):
     """cmdiad_runner.py:44-92 end to end for DINO+Point_MAE: late-fusion bank, OCSVM fit, predict, metrics --
     the drop-in against the CPU oracle driven through the same protocol (same scikit-learn on both sides)."""
