@@ -5,9 +5,10 @@ stem convolutions (3 -> 64 -> 128, 224 -> 56), twelve Bottlenecks (layer1-3; lay
 state_dict, but never called), and a 1x1 ``final_layer`` (c -> 768; the trunk is 512 wide, so c must be 512).  The
 StageModule / BasicBlock / transition code of that file is commented out or never instantiated and is not reproduced.
 
-Inference drop-in: same constructor, state_dict keys and method signatures; eval-mode arithmetic with
-BatchNorm folded, on cmdiad_conv_stem + cmdiad_conv2d_nhwc_bf16 (cmdiad_amd.runtime.PackedHRNet).  ``forward`` returns
-the loss value without an autograd graph (training this head is not implemented).
+SURVEY 8f row f4: same constructor, state_dict keys and method signatures.  Inference (``eval()`` / ``no_grad``): eval-mode
+arithmetic with BatchNorm folded, on cmdiad_conv_stem + cmdiad_conv2d_nhwc_bf16 (cmdiad_amd.runtime.PackedHRNet).  Training
+(``train()`` with gradients: --train_method *InputTo*FeatureHRNET): the module's own torch layers on the GPU (fp32,
+batch-statistics BatchNorm, autograd; MIOpen kernels, not hand-written HIP -- outside the benchmarked hot path), golden G12.
 """
 import torch
 from torch import nn
@@ -30,6 +31,13 @@ class Bottleneck(nn.Module):
         self.relu = nn.ReLU(inplace=True)
         self.downsample = downsample
         self.stride = stride
+
+    def forward(self, x):
+        """hrnet.py:23-43 (training path of HRNet.forward; inference never calls it)."""
+        out = torch.relu(self.bn1(self.conv1(x)))
+        out = torch.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        return torch.relu(out + (x if self.downsample is None else self.downsample(x)))
 
 
 class HRNet(_PackedHead):
@@ -60,7 +68,14 @@ class HRNet(_PackedHead):
         return t.view(t.shape[0], 56, 56, t.shape[2]).permute(0, 3, 1, 2)
 
     def forward(self, img, feature):
-        self._no_training()
+        """hrnet.py:290-299."""
+        if self._autograd():
+            dev = self._device()
+            x = torch.relu(self.bn1(self.conv1(img.to(dev).float())))
+            x = torch.relu(self.bn2(self.conv2(x)))
+            x = self.final_layer(self.layer3(self.layer2(self.layer1(x))))
+            assert tuple(x.shape[1:]) == (768, 56, 56) and tuple(feature.shape[1:]) == (3136, 768)
+            return self._mean_row_norm(feature_reshape_back(x), feature.to(dev), 2)
         with torch.no_grad():
             h = self.hallucination_tokens(img)
             assert tuple(h.shape[1:]) == (3136, 768) and tuple(feature.shape[1:]) == (3136, 768)

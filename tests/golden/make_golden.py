@@ -141,6 +141,54 @@ def golden_heads():
     print("g10_heads.npz", os.path.getsize(os.path.join(HERE, "g10_heads.npz")) // 1024, "KB")
 
 
+def _train_inputs(kind):
+    """Seeded batch of two samples in the shapes the pretraining loop feeds each head (hallucination_network_pretrain.py:106-140)."""
+    g = torch.Generator().manual_seed(202)
+    a, b = torch.randn(2, 3136, 768, generator=g), torch.randn(2, 3136, 768, generator=g)
+    img = torch.randn(2, 3, 224, 224, generator=g)
+    return {"conv_ftof": (a, b), "ftoi_mlp": (a, img), "ftoi_conv": (a, img), "hrnet": (img, b)}[kind]
+
+
+def golden_heads_train():
+    """G12: the reference's own conv / feature-to-input / HRNet heads in TRAINING mode (batch-statistics BatchNorm, autograd) from
+    the synthetic weights of oracle.heads.synth_head_state_dict, three torch.optim.Adam steps (hallucination_network_pretrain.py:261,
+    lr 1e-4) on one seeded batch of two: the loss before every step and checksums of every tensor of the state_dict afterwards."""
+    from oracle import heads as oh
+    from models import hallucination_network as rhn
+    from models.hrnet import HRNet as RefHRNet
+    build = {"conv_ftof": lambda: rhn.HallucinationCrossModalityConv(None, 768, 768),
+             "ftoi_mlp": lambda: rhn.HallucinationRGBFeatureToXYZInputMLP(_ns(estimate_depth=False), 768),
+             "ftoi_conv": lambda: rhn.HallucinationFeatureToInputConv(None, 768),
+             "hrnet": lambda: RefHRNet(512, 768, 0.1)}
+    out = dict(input_seed=202, weight_seed=41, lr=1e-4, steps=3)
+    torch.set_num_threads(8)
+    for kind, make in build.items():
+        m = make()
+        m.load_state_dict(oh.synth_head_state_dict(kind, 41))
+        m.train()
+        opt = torch.optim.Adam(m.parameters(), lr=float(out["lr"]))
+        x = _train_inputs(kind)
+        losses = []
+        for _ in range(3):
+            opt.zero_grad()
+            if kind == "conv_ftof":
+                lx, lr_ = m(x[0], x[1], False, "l2")
+                loss = lx + lr_
+                losses.append([float(lx), float(lr_)])
+            else:
+                loss = m(x[0], x[1])
+                losses.append([float(loss)])
+            loss.backward()
+            opt.step()
+            print(kind, losses[-1], flush=True)
+        out[f"{kind}/loss"] = np.array(losses)
+        for k, v in m.state_dict().items():
+            if v.dtype.is_floating_point:
+                out[f"{kind}/after/{k}"] = np.array([v.double().sum().item(), v.double().abs().sum().item()])
+    np.savez_compressed(os.path.join(HERE, "g12_heads_train.npz"), **out)
+    print("g12_heads_train.npz", os.path.getsize(os.path.join(HERE, "g12_heads_train.npz")) // 1024, "KB")
+
+
 class _CpuRedirect:
     """The reference hard-codes CUDA placement (features.py:96,103,106,397-399; multiple_features.py:327,334,344,350):
     inside this context `.cuda()` and `.to("cuda")` are no-ops so that its own arithmetic runs on the CPU (generator-only
@@ -269,6 +317,8 @@ def main():
         return golden_heads()
     if len(sys.argv) > 1 and sys.argv[1] == "g11":  # only the method-class fixture
         return golden_methods()
+    if len(sys.argv) > 1 and sys.argv[1] == "g12":  # only the head-training fixture
+        return golden_heads_train()
     from models import models as rmodels
     from models import pointnet2_utils as rp2
     from models.hallucination_network import HallucinationCrossModalityNetwork

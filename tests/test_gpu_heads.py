@@ -107,7 +107,7 @@ def test_heads_batched_vs_oracle_and_depth_variant():
         _check(m.to(DEV).eval().hallucination_generation(tok[:2].to(DEV)).cpu(), heads.ftoi_conv(sd, tok[:2]), "ftoi_conv B=2")
 
 
-def test_head_repacks_after_weight_update_and_refuses_training():
+def test_head_repacks_after_weight_update():
     m = _load(hn.HallucinationFeatureToInputConv(None, 768), "ftoi_conv")
     tok = torch.randn(1, 3136, 768, generator=torch.Generator().manual_seed(1)).to(DEV)
     a = m.hallucination_generation(tok)
@@ -115,9 +115,63 @@ def test_head_repacks_after_weight_update_and_refuses_training():
         m.conv4.bias.add_(1.0)
     b = m.hallucination_generation(tok)
     torch.testing.assert_close(b, a + 1.0, rtol=0, atol=1e-5)
-    m.train()
-    with pytest.raises(NotImplementedError, match="training"):
-        m(tok, torch.zeros(1, 3, 224, 224, device=DEV))
+    m.train()   # training mode with gradients builds a graph (the pretraining loop); the inference kernels serve no_grad
+    loss = m(tok, torch.zeros(1, 3, 224, 224, device=DEV))
+    assert loss.requires_grad
+    with torch.no_grad():
+        assert not m(tok, torch.zeros(1, 3, 224, 224, device=DEV)).requires_grad
+
+
+@pytest.mark.parametrize("kind", ["ftoi_mlp", "ftoi_conv", "hrnet", "conv_ftof"])
+def test_head_training_follows_the_reference_loss_curve(kind, golden):
+    """hallucination_network_pretrain.py:106-147 for the conv / feature-to-input / HRNet heads: three Adam steps (lr 1e-3) in
+    train() mode from the synthetic weights on one seeded batch of two, against the same three steps of the REFERENCE's own
+    modules on the CPU (tests/golden/g12_heads_train.npz, make_golden.py g12): the loss before every step, and sum / abs-sum of
+    every tensor of the state_dict afterwards (weights, biases, BatchNorm running statistics).  fp32 on both sides; the
+    convolution algorithms differ (MIOpen vs the CPU's), hence the tolerances."""
+    from cmdiad_amd.models.hrnet import HRNet
+    g12 = golden("g12_heads_train.npz")
+    gen = torch.Generator().manual_seed(int(g12["input_seed"]))
+    a, b = torch.randn(2, 3136, 768, generator=gen), torch.randn(2, 3136, 768, generator=gen)
+    img = torch.randn(2, 3, 224, 224, generator=gen)
+    x = {"conv_ftof": (a, b), "ftoi_mlp": (a, img), "ftoi_conv": (a, img), "hrnet": (img, b)}[kind]
+    make = {"conv_ftof": lambda: hn.HallucinationCrossModalityConv(None, 768, 768),
+            "ftoi_mlp": lambda: hn.HallucinationRGBFeatureToXYZInputMLP(types.SimpleNamespace(estimate_depth=False), 768),
+            "ftoi_conv": lambda: hn.HallucinationFeatureToInputConv(None, 768),
+            "hrnet": lambda: HRNet(512, 768, 0.1)}[kind]
+    m = make()
+    m.load_state_dict(heads.synth_head_state_dict(kind, int(g12["weight_seed"])))
+    m.to(DEV).train()
+    opt = torch.optim.Adam(m.parameters(), lr=float(g12["lr"]))
+    want = g12[f"{kind}/loss"]
+    for step in range(int(g12["steps"])):
+        opt.zero_grad()
+        if kind == "conv_ftof":
+            lx, lr_ = m(x[0], x[1], False, "l2")
+            loss, got = lx + lr_, [float(lx.detach()), float(lr_.detach())]
+        else:
+            loss = m(x[0], x[1])
+            got = [float(loss.detach())]
+        np.testing.assert_allclose(got, want[step], rtol=3e-3, err_msg=f"{kind} step {step}")
+        loss.backward()
+        opt.step()
+    for k, v in m.state_dict().items():
+        if not v.dtype.is_floating_point:
+            continue
+        ref = g12[f"{kind}/after/{k}"]
+        got = np.array([v.double().sum().item(), v.double().abs().sum().item()])
+        # abs-sum pins the magnitudes; the plain sum of a zero-mean tensor is compared against the abs-sum's scale
+        assert abs(got[1] - ref[1]) <= 2e-3 * ref[1] + 1e-6, (kind, k, got, ref)
+        assert abs(got[0] - ref[0]) <= 2e-3 * ref[1] + 1e-6, (kind, k, got, ref)
+    # the inference kernels pick the trained weights up (repack on version change) and agree with the module's own layers
+    m.eval()
+    with torch.no_grad():
+        if kind == "conv_ftof":
+            lx, lr_ = m(x[0], x[1], False, "l2")
+            ref = [float(v) for v in hn.HallucinationCrossModalityConv._losses(
+                m, hn.feature_reshape_back(m.rgb_conv(hn.feature_reshape(x[1].to(DEV)))),
+                hn.feature_reshape_back(m.xyz_conv(hn.feature_reshape(x[0].to(DEV)))), x[0].to(DEV), x[1].to(DEV), False)]
+            np.testing.assert_allclose([float(lx), float(lr_)], ref, rtol=2e-2)
 
 
 @pytest.mark.parametrize("flags,cls_name,head_kind", [
