@@ -711,6 +711,200 @@ __global__ __launch_bounds__(512, 1) void l2_min_pp3_kernel(GlobalTile A, Global
     else body(std::false_type{});
 }
 
+#ifdef CMDIAD_AB_VARIANTS  // measured formulation, test-only build: 0-3 % faster than the production kernel (profiles/r2_notes.md)
+// ------------------------------------------------------------------------------------------------
+// The two-group pipeline with 32 MFMAs per phase (K-tiles of 32 columns).  In the kernel above the MFMA segments of the two
+// groups never overlap by construction -- at any time ONE wave per SIMD issues MFMAs -- so a SIMD's matrix pipe is busy 256
+// cycles of every half-phase slot and idle for whatever else the slot contains: the barrier, the counted wait, the drain and
+// refill of the pipe (measured: 435 cycles per slot = 0.59 of the MFMA rate at the clock the chip holds).  That overhead is per
+// slot, not per MFMA: here a phase is a whole K-tile of 32 columns -- all 8 x 4 accumulator blocks of the wave, one K-slice
+// of one `v_mfma_f32_16x16x32` -- i.e. 32 MFMAs (512 cycles) per slot, half the barriers per FLOP, and fewer fragment
+// registers (8 + 4 fragments instead of 8 + 4 + 4).  A K-tile of 32 columns is 16 KiB per operand: five bank stages (three to four
+// K-tiles of lead for the stream that misses L2) + four query stages (two to three of lead) = 144 KiB.  Rows are 64 bytes in LDS;
+// the 16-byte chunk c of row r sits at c ^ f((r >> 2) & 3), f = (0, 3, 2, 1): conflict-free for the four 16-lane groups of
+// ds_read_b128 (MI355X_MICROARCH.md, LDS) and applied on the source address of the LDS-DMA pieces (16 rows x 64 B each).
+// Waves 0-3 issue the bank stream, waves 4-7 the query stream, four pieces per K-tile each, in the scalar-base form (uniform
+// 64-bit base in SGPRs, one 32-bit lane offset per stream: no per-lane pointer arithmetic in the loop).
+// Same MFMA sequence per accumulator as every other formulation (K ascending in steps of 32): identical keys.
+// ------------------------------------------------------------------------------------------------
+struct SPingPong4 {
+    static constexpr int BM = 256, BN = 256, THREADS = 512, KT = 32;
+    static constexpr int STG = 16384, NSB = 5, NSQ = 4;
+    static constexpr int A_OFF = NSB * STG, BN_OFF = A_OFF + NSQ * STG;
+    static constexpr int LDS_BYTES = BN_OFF + 2 * 256 * 4;
+};
+
+template <bool F16>
+__global__ __launch_bounds__(512, 1) void l2_min_pp4_kernel(GlobalTile A, GlobalTile W, L2Params p)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    using S = SPingPong4;
+    using frag = typename std::conditional<F16, f16x8, bf16x8>::type;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int gsz = p.qgroup * p.splits;
+    const int within = wg % gsz;
+    const int split = within / p.qgroup, qt = (wg / gsz) * p.qgroup + within % p.qgroup;
+    if (qt >= p.nq_tiles) return;
+    const int per = (p.n_bank_tiles + p.splits - 1) / p.splits;
+    const int nt0 = split * per;
+    const int ntc = min(per, p.n_bank_tiles - nt0);
+    if (ntc <= 0) return;
+    const int m0 = qt * S::BM;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int KT = p.D / S::KT, T_total = ntc * KT;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+    const unsigned bn_lds = lds0 + S::BN_OFF;
+
+    float best[8], qn[8];
+    int besti[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        best[i] = __builtin_inff();
+        besti[i] = 0;
+        const int m = m0 + wr * 128 + i * 16 + (lane & 15);
+        qn[i] = m < p.Q ? p.q_sqnorm[m] : 0.0f;
+    }
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // Everything below is instantiated twice, once per stream: a wave only ever executes its own issue path.
+    auto body = [&](auto BANK) {
+    constexpr bool bank_wave = decltype(BANK)::value;
+    constexpr int NS = bank_wave ? S::NSB : S::NSQ, LEAD = NS - 1;
+    // ---- this wave's share of every K-tile of its stream: rows 64 sw .. 64 sw + 63 as four 16-row pieces.  Lane l of a piece
+    // lands on row l >> 2, physical chunk l & 3, and therefore fetches logical chunk (l & 3) ^ f((l >> 4) & 3).
+    const int sw = wave & 3;
+    const unsigned fq = (0x1230u >> (((lane >> 4) & 3) * 4)) & 3u;   // f = (0, 3, 2, 1)
+    const unsigned src_chunk = (((unsigned)lane & 3u) ^ fq) * 16u;
+    const size_t ld2 = (size_t)(bank_wave ? W.ld : A.ld) * 2;       // row pitch in bytes
+    const bool a_full = m0 + S::BM <= A.rows;
+    // per-lane byte offset inside a tile: piece e adds 16 rows (a scalar bump of the base); query rows past Q clamp (ragged last tile)
+    const unsigned voff = (unsigned)((size_t)(sw * 64 + (lane >> 2)) * ld2) + src_chunk;
+    const char* sbase = bank_wave ? reinterpret_cast<const char*>(W.base) + (size_t)nt0 * S::BN * ld2
+                                  : reinterpret_cast<const char*>(A.base) + (size_t)m0 * ld2;   // first row of the current tile, K-tile 0
+    int hT = 0, hK = 0, slot = 0;   // stream cursor: K-tile index overall / within the row tile, stage
+    auto dma = [&](const char* ubase, unsigned vo, unsigned lds_addr) {   // (SALU copy of the base, one wait state after the M0 write:
+        unsigned long long sb;                                           //  inline asm is outside the compiler's hazard tracking)
+        asm volatile("s_mov_b64 %0, %2\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0"
+                     : "=&s"(sb) : "v"(vo), "s"(ubase), "s"(lds_addr) : "memory");
+    };
+    auto issue = [&]() {   // -> true when a K-tile was issued
+        if (hT >= T_total) return false;
+        const unsigned dst = lds0 + (bank_wave ? 0 : S::A_OFF) + slot * S::STG + sw * 64 * 64;
+        const char* ub = sbase + hK * (S::KT * 2);
+        if (bank_wave || a_full) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dma(ub + (size_t)e * 16 * ld2, voff, dst + e * 1024);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = min(m0 + sw * 64 + e * 16 + (lane >> 2), A.rows - 1) - m0;
+                dma(ub, (unsigned)((size_t)row * ld2) + src_chunk, dst + e * 1024);
+            }
+        }
+        ++hT;
+        if (++hK == KT) { hK = 0; if (bank_wave) sbase += (size_t)S::BN * ld2; }
+        slot = slot + 1 == NS ? 0 : slot + 1;
+        return true;
+    };
+    // prologue: LEAD K-tiles of this stream
+#pragma unroll
+    for (int e = 0; e < LEAD; ++e) issue();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    pp_barrier();
+    if (wr == 1) pp_barrier();  // the second group runs one barrier (half a phase) behind the first
+
+    // ---- fragment addresses: row * 64 + ((g ^ f((row >> 2) & 3)) << 4), g = lane >> 4; the row blocks i / j add 1 KiB
+    const unsigned fr = (0x1230u >> ((((lane & 15) >> 2) & 3) * 4)) & 3u;
+    const int fsw = (int)(((unsigned)(lane >> 4) ^ fr) << 4);
+    const int a_off = S::A_OFF + (wr * 128 + (lane & 15)) * 64 + fsw, b_off = (wc * 64 + (lane & 15)) * 64 + fsw;
+    frag af[8], bf[4];
+    int nt_c = nt0, kt_c = 0, sa = 0, sb = 0;   // stages of the current K-tile in the query / bank rings
+    f32x4 bnv = {0.f, 0.f, 0.f, 0.f};           // wave 0: a bank tile's squared norms on their way to LDS (fetched in its K-tile 0, parked in 2)
+    for (int T = 0; T < T_total; ++T) {
+        // ================= first half: fragments of K-tile T, this stream's K-tile T + LEAD, counted wait
+        const char* ab = lds + a_off + sa * S::STG;
+        const char* bb = lds + b_off + sb * S::STG;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const frag*>(bb + j * 1024);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) af[i] = *reinterpret_cast<const frag*>(ab + i * 1024);
+        const bool bn_fetch = wave == 0 && kt_c == 0;  // wave-uniform
+        if (bn_fetch) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bnv) : "v"(p.b_sqnorm + (size_t)nt_c * S::BN + lane * 4) : "memory");
+        const bool issued = issue();
+        // K-tile T + 1 of this stream has landed: everything issued after it may stay in flight (LEAD - 1 K-tiles of 4 pieces; the
+        // norm load of wave 0 is older than the K-tile just issued and younger than the others: at most one more piece waited for).
+        // (Issuing the K-tiles in pairs (2 m, 2 m + 1) -- the two halves of the same 128-byte lines back to back -- was measured:
+        //  TCC requests 1.43e9 -> 1.14e9 per launch against 0.72e9 for whole-line pieces, 9.9 -> 10.8 ms: the shorter lead costs more.)
+        if (!issued) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (bank_wave) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if (wave == 0 && kt_c == 2)   // the norms fetched two phases ago are older than the three K-tiles the wait above leaves in flight
+            asm volatile("ds_write_b128 %0, %1" ::"v"(bn_lds + (unsigned)((nt_c & 1) * 1024 + lane * 16)), "v"(bnv) : "memory");
+        // (the fragments are in registers before the barrier: the stage just read is refilled by the other group's next issue)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        pp_barrier();
+        // ================= second half: 32 MFMAs
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(bf[j], af[i], acc[i][j]);
+        __builtin_amdgcn_s_setprio(0);
+        if (kt_c == KT - 1) {  // bank tile finished: d2 = |q|^2 + |b|^2 - 2 q.b, running (min, first index) per lane
+            const int nbase = nt_c * S::BN + wc * 64 + (lane >> 4) * 4;
+            f32x4 b4[4];
+            {
+                const unsigned ra = bn_lds + (unsigned)((nt_c & 1) * 1024 + (wc * 64 + (lane >> 4) * 4) * 4);
+                asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:64\n\tds_read_b128 %2, %4 offset:128\n\t"
+                             "ds_read_b128 %3, %4 offset:192\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(b4[0]), "=&v"(b4[1]), "=&v"(b4[2]), "=&v"(b4[3]) : "v"(ra) : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float d2 = (qn[i] + b4[j][r]) - 2.0f * acc[i][j][r];
+                        if (d2 < best[i]) { best[i] = d2; besti[i] = nbase + j * 16 + r; }
+                    }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        pp_barrier();
+        if (++kt_c == KT) { kt_c = 0; ++nt_c; }
+        sa = sa + 1 == S::NSQ ? 0 : sa + 1;
+        sb = sb + 1 == S::NSB ? 0 : sb + 1;
+    }
+    if (wr == 0) pp_barrier();  // both groups execute the same number of barriers
+
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        unsigned long long key = pack_key(fmaxf(best[i], 0.0f), p.row_offset + (unsigned)besti[i]);
+        if (!(best[i] < __builtin_inff())) key = ~0ull;
+        unsigned long long o = shfl_xor_u64(key, 16);
+        key = o < key ? o : key;
+        o = shfl_xor_u64(key, 32);
+        key = o < key ? o : key;
+        const int m = m0 + wr * 128 + i * 16 + (lane & 15);
+        if (lane < 16 && m < p.Q) atomicMin(p.keys + m, key);
+    }
+    };
+    if (wave < 4) body(std::true_type{});
+    else body(std::false_type{});
+}
+
+#endif  // CMDIAD_AB_VARIANTS
+
 // Exact fp32 distance to the winning row: one wave per query.
 __global__ __launch_bounds__(256) void l2_rescore_kernel(const float* __restrict__ q, const float* __restrict__ bank,
                                                          const unsigned long long* __restrict__ keys, int Q, int Nb,
@@ -861,6 +1055,9 @@ template <bool F16> struct L2Kernel<SWide, F16> { static constexpr auto fn = l2_
 template <bool F16> struct L2Kernel<SPingPong, F16> { static constexpr auto fn = l2_min_pp_kernel<F16>; };
 #endif
 template <bool F16> struct L2Kernel<SPingPong3, F16> { static constexpr auto fn = l2_min_pp3_kernel<F16>; };
+#ifdef CMDIAD_AB_VARIANTS
+template <bool F16> struct L2Kernel<SPingPong4, F16> { static constexpr auto fn = l2_min_pp4_kernel<F16>; };
+#endif
 
 template <class S, bool F16>
 int launch_l2(const uint16_t* q, const float* q_sqnorm, const uint16_t* bank, const float* bank_sqnorm, int Q, int Nb,
@@ -905,7 +1102,8 @@ extern "C" int cmdiad_l2_min_keys(const uint16_t* q, const float* q_sqnorm, cons
     // production: the two-group 256 x 256 pipeline (l2_min_pp3_kernel) from Q >= 512, the 128 x 128 kernel below that, for the
     // last Nb % 256 library rows and for D < 192 (the two-group schedule assumes >= 3 K-tiles per library tile).
     // CMDIAD_L2_TILE (read per call: the parity tests force each shape on small inputs) = 0 / 5 for those two; the test-only
-    // build (make ab) also knows 2 = 256 x 256 lock-step, 3 = 4 waves of 128 x 128, 4 = two groups with two buffers.
+    // build (make ab) also knows 2 = 256 x 256 lock-step, 3 = 4 waves of 128 x 128, 4 = two groups with two buffers, 6 = two groups
+    // with K-tiles of 32 columns (32 MFMAs per phase).
     const char* env_tile = getenv("CMDIAD_L2_TILE");
     const int force = env_tile ? atoi(env_tile) : -1;
     int tile = force >= 0 ? force : (Q >= 512 ? 5 : 0);
@@ -916,15 +1114,20 @@ extern "C" int cmdiad_l2_min_keys(const uint16_t* q, const float* q_sqnorm, cons
     }
     if (tile == 5 && D < 192) tile = 0;
 #else
-    if ((tile == 4 || tile == 5) && D < 192) tile = 3;
+    if ((tile == 4 || tile == 5 || tile == 6) && D < 192) tile = 3;
 #endif
     hipStream_t s = (hipStream_t)stream;
     const bool h = dtype == CMDIAD_DT_F16;
     int rc;
 #define L2_ARGS q, q_sqnorm, bank, bank_sqnorm, Q, Nb, D, row_offset, keys, s
-    if (tile == 4 || tile == 5) {
+    if (tile == 4 || tile == 5 || tile == 6) {
         const int full = Nb / 256 * 256, rest = Nb - full;
         rc = CMDIAD_OK;
+#ifdef CMDIAD_AB_VARIANTS
+        if (full > 0 && tile == 6) rc = h ? launch_l2<SPingPong4, true>(q, q_sqnorm, bank, bank_sqnorm, Q, full, D, row_offset, keys, s)
+                                          : launch_l2<SPingPong4, false>(q, q_sqnorm, bank, bank_sqnorm, Q, full, D, row_offset, keys, s);
+        else
+#endif
         if (full > 0 && tile == 5) rc = h ? launch_l2<SPingPong3, true>(q, q_sqnorm, bank, bank_sqnorm, Q, full, D, row_offset, keys, s)
                                           : launch_l2<SPingPong3, false>(q, q_sqnorm, bank, bank_sqnorm, Q, full, D, row_offset, keys, s);
 #ifdef CMDIAD_AB_VARIANTS

@@ -354,7 +354,9 @@ def test_encoder_stage1_against_direct_reference(groups, Mg):
                                           (784, 1500, 768, "4"), (3136, 5000, 192, "4"), (100, 77, 64, "4"), (1000, 2100, 256, "4"),
                                           (700, 512, 768, "4"), (515, 9000, 320, "4"),
                                           (784, 1500, 768, "5"), (3136, 5000, 192, "5"), (1000, 2100, 256, "5"), (700, 512, 768, "5"),
-                                          (515, 9000, 320, "5"), (300, 256, 192, "5"), (260, 1024, 1024, "5")])
+                                          (515, 9000, 320, "5"), (300, 256, 192, "5"), (260, 1024, 1024, "5"),
+                                          (784, 1500, 768, "6"), (3136, 5000, 192, "6"), (1000, 2100, 256, "6"), (700, 512, 768, "6"),
+                                          (515, 9000, 320, "6"), (300, 256, 192, "6"), (260, 1024, 1024, "6"), (513, 2816, 320, "6")])
 def test_l2_min_and_rescore(Q, Nb, D, tile, monkeypatch):
     if tile:  # 3 = 4-wave 128x128-per-wave shape; 2 = 8-wave 256x256 shape; 4 / 5 = the two-group (ping-pong) 256x256 pipelines (5: three bank buffers, split issuers)
         # (whole bank tiles only: the remainder rows go through the 128x128 kernel; D < 192 falls back to the 128x128 kernel,
@@ -386,7 +388,7 @@ def test_l2_min_and_rescore(Q, Nb, D, tile, monkeypatch):
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
-@pytest.mark.parametrize("tile", ["0", "2", "3", "4", "5"])
+@pytest.mark.parametrize("tile", ["0", "2", "3", "4", "5", "6"])
 def test_l2_min_all_tiles_identical_keys(tile, dt, monkeypatch):
     """Both operand types of every distance-GEMM variant (the engine defaults to fp16): all variants must return
     IDENTICAL keys on the same operands (same products, same fp32 accumulation order per 64-deep K tile, same
