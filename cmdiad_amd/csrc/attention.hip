@@ -27,7 +27,7 @@ constexpr int kVStride = 136;      // bytes per V^T row in LDS (64 bf16 + 8 pad)
 
 // q is pre-multiplied by head_dim^-0.5 * log2(e) (cmdiad_gemm_qkv), so softmax is exp2 of the raw dot product.
 template <int OCC>
-__global__ __launch_bounds__(kThreads, OCC) void attention_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void attention_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                              const bf16_t* __restrict__ vt, int BH, int H, int T, int Tp,
                                                              bf16_t* __restrict__ out)
 {
@@ -64,14 +64,23 @@ __global__ __launch_bounds__(kThreads, OCC) void attention_kernel(const bf16_t* 
     float m_run = -__builtin_inff(), l_run = 0.0f;
 
     const int nkt = (T + kKeys - 1) / kKeys;
+    // Tile loads go through buffer instructions: the (batch, head) slice is a wave-uniform resource in SGPRs, the lane's place in
+    // a tile a 32-bit offset computed once, the tile index a scalar offset -- with flat pointers the loop carried four 64-bit
+    // per-lane addresses (25 v_lshl_add_u64 per tile) and, at four waves per SIMD, spilled the prefetch registers right after the
+    // loads were issued, i.e. waited for them (profiles/r2_notes.md).
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(kb), 0, Tp * 64 * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(vb), 0, 64 * Tp * 2, 0x00020000);
+    // thread t brings 16-byte chunk t & 7 of rows (t >> 3) and (t >> 3) + 32 of both tiles: the second row is a scalar offset
+    const int koff = ((tid >> 3) * 64 + (tid & 7) * 8) * 2, voff = ((tid >> 3) * Tp + (tid & 7) * 8) * 2;
     uint4 rk[2], rv[2];
     auto load_tile = [&](int kt) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int idx = tid + 256 * i;           // 0..511
-            const int row = idx >> 3, ch = idx & 7;  // row: key (K) or d (V^T); ch: 16-byte chunk
-            rk[i] = *reinterpret_cast<const uint4*>(kb + (size_t)(kt * kKeys + row) * 64 + ch * 8);
-            rv[i] = *reinterpret_cast<const uint4*>(vb + (size_t)row * Tp + kt * kKeys + ch * 8);
+            const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(krs, koff, kt * (kKeys * 64 * 2) + i * (32 * 64 * 2), 0);
+            const u32x4 c = __builtin_amdgcn_raw_buffer_load_b128(vrs, voff, kt * (kKeys * 2) + i * (32 * Tp * 2), 0);
+            rk[i] = make_uint4(a[0], a[1], a[2], a[3]);
+            rv[i] = make_uint4(c[0], c[1], c[2], c[3]);
         }
     };
     auto store_tile = [&](int buf) {
@@ -119,7 +128,7 @@ __global__ __launch_bounds__(kThreads, OCC) void attention_kernel(const bf16_t* 
         float mloc = fmaxf(s0[0], s1[0]);
 #pragma unroll
         for (int e = 1; e < 16; ++e) mloc = fmaxf(mloc, fmaxf(s0[e], s1[e]));
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        mloc = half_max(mloc);   // the other 32 keys of this query sit on lane ^ 32
         if (!__all(mloc <= m_run)) {
             const float m_new = fmaxf(m_run, mloc);
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // first tile: exp2(-inf) = 0
@@ -159,7 +168,7 @@ __global__ __launch_bounds__(kThreads, OCC) void attention_kernel(const bf16_t* 
         __syncthreads();
     }
 
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float l_tot = half_sum(l_run);
     const float inv = 1.0f / l_tot;
     const int qi = q0 + r;
     if (qi < T) {

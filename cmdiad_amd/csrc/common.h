@@ -150,6 +150,19 @@ __device__ __forceinline__ void row16_max_batch(float (&v)[N])
     asm volatile("s_nop 1");   // nothing the compiler places next may read a lane-crossed result too early either
 }
 
+// (a, b) = (v, v) -> v_permlane32_swap exchanges a's upper 32 lanes with b's lower 32: afterwards {a, b} = {v[lane], v[lane ^ 32]}
+// in some order on every lane, so max(a, b) / a + b are the cross-half reductions -- one VALU instruction instead of the
+// ds_bpermute round trip of __shfl_xor(v, 32).  (Inline asm: the builtin folds the two results of equal inputs into one;
+// two wait states between the VALU write of the sources and the permlane read, outside the compiler's hazard tracking.)
+__device__ __forceinline__ void half_swap(float v, float& a, float& b)
+{
+    a = v;
+    b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ float half_max(float v) { float a, b; half_swap(v, a, b); return fmaxf(a, b); }
+__device__ __forceinline__ float half_sum(float v) { float a, b; half_swap(v, a, b); return a + b; }
+
 __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int m)
 {
     unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
