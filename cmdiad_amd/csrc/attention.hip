@@ -104,8 +104,13 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(OCC, O
         const bool more = kt + 1 < nkt;
         if (more) load_tile(kt + 1);  // global loads stay in flight under the MFMAs below
 
-        // ---- S^T = K . Q^T for the two 32-key sub-tiles
-        f32x16 s0 = {}, s1 = {};
+        // ---- S^T = K . Q^T for the two 32-key sub-tiles.  The accumulators start at -m_run (column = query = lane & 31: a per-lane
+        //      constant), so the tile arrives as S - m_run and, while no query's maximum grows, goes into exp2 without a subtraction
+        //      per element (first tile: m_run = -inf, start at 0)
+        const float c0 = kt == 0 ? 0.0f : -m_run;
+        f32x16 s0, s1;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { s0[e] = c0; s1[e] = c0; }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const bf16x8 ka = *reinterpret_cast<const bf16x8*>(sk + r * kKStride + 32 * s + 16 * hh);
@@ -123,25 +128,39 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(OCC, O
                 s1[e] = key + 32 < T ? s1[e] : -__builtin_inff();
             }
         }
-        // ---- online softmax, per lane = per query; the accumulators are rescaled only when some query's
-        //      running maximum actually grew (wave-uniform branch; exact, no threshold)
-        float mloc = fmaxf(s0[0], s1[0]);
+        // ---- online softmax, per lane = per query.  mloc = tile maximum relative to the running one (absolute in the first
+        //      tile); the accumulators are rescaled only when some query's maximum actually grew (wave-uniform branch; exact)
+        float mloc;
+        {
+            float t[16];   // v_max3 tree: 32 values in 16 instructions (fmaxf() of MFMA results also emits a quieting v_max each)
 #pragma unroll
-        for (int e = 1; e < 16; ++e) mloc = fmaxf(mloc, fmaxf(s0[e], s1[e]));
+            for (int e = 0; e < 16; ++e) t[e] = s0[e];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t[e]) : "v"(t[e]), "v"(s1[2 * e]), "v"(s1[2 * e + 1]));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t[e]) : "v"(t[e]), "v"(t[8 + 2 * e]), "v"(t[9 + 2 * e]));
+            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t[0]) : "v"(t[0]), "v"(t[4]), "v"(t[5]));
+            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t[1]) : "v"(t[1]), "v"(t[6]), "v"(t[7]));
+            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mloc) : "v"(t[0]), "v"(t[1]), "v"(t[2]));
+            asm("v_max_f32 %0, %1, %2" : "=v"(mloc) : "v"(mloc), "v"(t[3]));
+        }
         mloc = half_max(mloc);   // the other 32 keys of this query sit on lane ^ 32
-        if (!__all(mloc <= m_run)) {
-            const float m_new = fmaxf(m_run, mloc);
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // first tile: exp2(-inf) = 0
+        const float thr = kt == 0 ? -__builtin_inff() : 0.0f;   // first tile: always take the full path
+        if (!__all(mloc <= thr)) {
+            // delta = growth of this query's maximum (0 where it did not grow); the tile becomes S - m_new
+            const float m_new = kt == 0 ? mloc : m_run + fmaxf(mloc, 0.0f);
+            const float delta = kt == 0 ? mloc : fmaxf(mloc, 0.0f);
+            const float alpha = kt == 0 ? 0.0f : __builtin_amdgcn_exp2f(-delta);
             m_run = m_new;
             l_run *= alpha;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) { o0[e] *= alpha; o1[e] *= alpha; }
+            for (int e = 0; e < 16; ++e) { o0[e] *= alpha; o1[e] *= alpha; s0[e] -= delta; s1[e] -= delta; }
         }
         float psum = 0.0f;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            s0[e] = __builtin_amdgcn_exp2f(s0[e] - m_run);
-            s1[e] = __builtin_amdgcn_exp2f(s1[e] - m_run);
+            s0[e] = __builtin_amdgcn_exp2f(s0[e]);
+            s1[e] = __builtin_amdgcn_exp2f(s1[e]);
             psum += s0[e] + s1[e];
         }
         l_run += psum;
