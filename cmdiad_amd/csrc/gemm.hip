@@ -559,7 +559,7 @@ __global__ __launch_bounds__(512, 1) void encoder_stage1_persist_kernel(const fl
     // conv1: a thread owns 8 channels (16-byte chunk c16 of the 128) of rows (tid >> 4) + 32 i; the folded weights sit in LDS
     const int c16 = tid & 15;
     float4* wl = reinterpret_cast<float4*>(lds + L::W1_OFF);
-    if (tid < 128) wl[tid] = wb[tid];
+    if (tid < 128) wl[(tid & 7) * 16 + (tid >> 3)] = wb[tid];   // [e][chunk]: the 16 chunks a wave touches at once are 256 contiguous bytes (bank-conflict-free)
     char* const a_dst = lds + (c16 >> 3) * L::KT_BYTES;
     auto conv1 = [&](int par) {
         const float* cb = cbuf + par * 384 + (tid >> 4) * 3;
@@ -569,7 +569,7 @@ __global__ __launch_bounds__(512, 1) void encoder_stage1_persist_kernel(const fl
         bf16x8 h[4];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {   // two rows per v_pk_fma_f32: the same FMA chain as conv1_act, element-wise
-            const float4 w = wl[c16 * 8 + e];
+            const float4 w = wl[e * 16 + c16];
 #pragma unroll
             for (int i = 0; i < 4; i += 2) {
                 f32x2 a = __builtin_elementwise_fma(f32x2{w.x, w.x}, f32x2{xs[i], xs[i + 1]}, f32x2{w.w, w.w});
