@@ -30,7 +30,7 @@ constexpr int W_STAGE = 128 * BK * 2;           // one [128][64] weight tile: 16
 #define CMDIAD_TAIL_STAGES 4
 #endif
 constexpr int NST = CMDIAD_TAIL_STAGES;         // weight stages in LDS: NST - 1 tiles stay in flight across the barriers
-constexpr int AHEAD = NST - 1;                   // (test-only kernels)
+[[maybe_unused]] constexpr int AHEAD = NST - 1;  // (test-only kernels)
 constexpr int TAIL_LDS = A2_BYTES + A3_BYTES + NST * W_STAGE;  // 160 KiB at 4 stages
 static_assert(NST >= 2 && NST <= 4 && TAIL_LDS <= 160 * 1024, "weight stages");
 constexpr int kTailCUs = 256;                   // one persistent block per CU (MI355X)
