@@ -190,6 +190,29 @@ def run_steps(pred, batches, n, first=None):
 
 
 # --------------------------------------------------------------------------------------------------------- secondary legs
+def profiled_traffic():
+    """roofline.traffic: fabric-side bytes per launch of the dominant kernel (2 x FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md).  PMC
+    counters cannot be read inside this process; the figure comes from the committed rocprofv3 --pmc pass (profiles/r2_pmc.json,
+    tools/profile_round.sh) and is emitted ONLY while the kernel's source is byte-identical to the one that was profiled
+    (profiles/r2_pmc_meta.json holds the sha256 of csrc/l2min.hip + gemm_core.h at that time): null as soon as the kernel changes."""
+    import hashlib
+    here = os.path.dirname(os.path.abspath(__file__))
+    try:
+        meta = json.load(open(os.path.join(here, "profiles", "r2_pmc_meta.json")))
+        h = hashlib.sha256()
+        for f in meta["sources"]:
+            h.update(open(os.path.join(here, f), "rb").read())
+        if h.hexdigest() != meta["sha256"]:
+            return {"traffic": None, "traffic_note": "the distance GEMM's source changed since profiles/r2_pmc.json was taken: re-profile"}
+        rows = [r for r in json.load(open(os.path.join(here, "profiles", "r2_pmc.json"))) if r["kernel"].startswith("l2_min_pp3")]
+        row = max(rows, key=lambda r: r["grid_threads"])
+        return {"traffic": round(row["fetch_bytes"] + row["write_bytes"]),
+                "traffic_note": f"bytes per launch from the committed PMC pass (profiles/r2_pmc.md, commit {meta['commit']}; kernel source unchanged "
+                                f"since: sha256 {meta['sha256'][:12]}); L2 hit {row['l2_hit']:.3f}"}
+    except (OSError, KeyError, ValueError) as e:
+        return {"traffic": None, "traffic_note": f"no usable committed PMC pass ({type(e).__name__})"}
+
+
 def cpu_baseline(n_images=10, warm=3):
     """The CPU oracle pipeline (oracle/pipeline.py, kind 'port': the reference's own torch-CPU composition + the C restatement
     of FPS / kNN) on a bounded sample of the same workload, on this box's host cores: at the thread count that is fastest
@@ -463,9 +486,7 @@ def main():
                        "weights": "seeded random init (no checkpoints offline)"},
             "roofline": {"kernel": "l2_min_pp3_kernel (xyz library distance GEMM + running min/argmin)", "bound": "mfma",
                          "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
-                         "traffic_note": "PMC counters cannot be read inside this process; the separately profiled figure for this "
-                                         "kernel is in profiles/ (see profiles/README.md), tagged with the commit it was taken at",
+                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), **profiled_traffic(),
                          "launch_ms": round(l2_ms, 3), "flops_per_launch": flops,
                          "hbm_secondary": {"algorithmic_bytes": bytes_alg,
                                            "achieved_GBs": round(bytes_alg / (l2_ms * 1e-3) / 1e9, 1),

@@ -307,3 +307,25 @@ def test_backbone_checkpoint_loading_is_strict(tmp_path, monkeypatch):
     torch.save({"base_model": {"MAE_encoder.norm.weight": torch.ones(384)}}, pm_file)
     with pytest.raises(RuntimeError, match="lacks"):
         mm.PointTransformer().load_model_from_ckpt(str(pm_file))
+
+
+def test_bench_traffic_is_tied_to_the_profiled_kernel_source(tmp_path, monkeypatch):
+    """roofline.traffic comes from the committed PMC pass only while the distance GEMM's sources hash to what was profiled
+    (profiles/r2_pmc_meta.json); any change to them makes it null instead of silently stale."""
+    import importlib.util, json, shutil
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(REPO, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    t = bench.profiled_traffic()
+    assert isinstance(t["traffic"], int) and 1e9 < t["traffic"] < 1e11 and "commit" in t["traffic_note"]
+    # a copy of the repo files with one byte appended to the kernel source
+    root = tmp_path / "repo"
+    (root / "profiles").mkdir(parents=True)
+    (root / "cmdiad_amd" / "csrc").mkdir(parents=True)
+    meta = json.load(open(os.path.join(REPO, "profiles", "r2_pmc_meta.json")))
+    for f in meta["sources"] + ["profiles/r2_pmc.json", "profiles/r2_pmc_meta.json"]:
+        shutil.copy(os.path.join(REPO, f), root / f)
+    with open(root / meta["sources"][0], "ab") as fh:
+        fh.write(b"\n")
+    monkeypatch.setattr(bench, "__file__", str(root / "bench.py"))
+    assert bench.profiled_traffic()["traffic"] is None
