@@ -318,7 +318,19 @@ __global__ __launch_bounds__(S::THREADS, S::WAVES_PER_SIMD) void gemm_qkv_kernel
             }
         });
     } else {
+        // V^T [B, H, 64, Tp]: in this orientation a lane holds FOUR CONSECUTIVE TOKENS of one channel -- 8 contiguous bytes of a V^T
+        // row -- so a 16-token x 16-channel block leaves as one 8-byte store per lane (16 rows x 32 bytes per instruction; the
+        // token offset inside an image is arbitrary, so the stores are 2-byte aligned: fine on this device, tools/
+        // unaligned_store_test.hip).  The scalar form (64 two-byte stores and 64 divisions by T per lane and tile) stays for the
+        // four-token groups that straddle two images or the end of the matrix.
         run<S, false>(A, W, c.m0, c.nt, 1, p.C / BK, lds, [&](auto& acc, int ntile, char*) {
+            int tb[S::MI], tt[S::MI];   // image and token of the lane's first token in row block i
+#pragma unroll
+            for (int i = 0; i < S::MI; ++i) {
+                const int m = c.m0 + c.wr * (S::MI * 16) + i * 16 + (c.lane >> 4) * 4;
+                tb[i] = m / p.T;
+                tt[i] = m - tb[i] * p.T;
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int n = ntile * S::BN + c.wc * 64 + j * 16 + (c.lane & 15);
@@ -326,14 +338,21 @@ __global__ __launch_bounds__(S::THREADS, S::WAVES_PER_SIMD) void gemm_qkv_kernel
                 const int h = cc >> 6, d = cc & 63;
                 const float bb = p.bias ? p.bias[n] : 0.0f;
 #pragma unroll
-                for (int i = 0; i < S::MI; ++i)
+                for (int i = 0; i < S::MI; ++i) {
+                    const int m = c.m0 + c.wr * (S::MI * 16) + i * 16 + (c.lane >> 4) * 4;
+                    if (m + 3 < p.M && tt[i] + 3 < p.T) {
+                        const f32x4 v = acc[i][j];
+                        const bf16x4 o = {f2bf(v[0] + bb), f2bf(v[1] + bb), f2bf(v[2] + bb), f2bf(v[3] + bb)};
+                        __builtin_memcpy(p.vt + (((size_t)tb[i] * p.H + h) * 64 + d) * p.Tp + tt[i], &o, 8);
+                    } else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int m = c.m0 + c.wr * (S::MI * 16) + i * 16 + (c.lane >> 4) * 4 + r;
-                        if (m >= p.M) continue;
-                        const int b = m / p.T, t = m - b * p.T;
-                        p.vt[(((size_t)b * p.H + h) * 64 + d) * p.Tp + t] = f2bf(acc[i][j][r] + bb);
+                        for (int r = 0; r < 4; ++r) {
+                            if (m + r >= p.M) continue;
+                            const int b = (m + r) / p.T, t = m + r - b * p.T;
+                            p.vt[(((size_t)b * p.H + h) * 64 + d) * p.Tp + t] = f2bf(acc[i][j][r] + bb);
+                        }
                     }
+                }
             }
         });
     }
