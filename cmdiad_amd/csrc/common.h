@@ -150,6 +150,21 @@ __device__ __forceinline__ void row16_max_batch(float (&v)[N])
     asm volatile("s_nop 1");   // nothing the compiler places next may read a lane-crossed result too early either
 }
 
+// Sum over the 64 lanes, result wave-uniform: four DPP steps inside the rows of 16 (as row16_max), then the four row sums are
+// read as scalars and added in row order -- ~11 VALU instructions against six ds_bpermute round trips for the xor butterfly
+// (whose summation order differs: results agree to fp32 rounding, not bitwise).
+__device__ __forceinline__ float wave_sum(float v)
+{
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));
+    const int i = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 48));
+    return ((r0 + r1) + r2) + r3;
+}
+
 // (a, b) = (v, v) -> v_permlane32_swap exchanges a's upper 32 lanes with b's lower 32: afterwards {a, b} = {v[lane], v[lane ^ 32]}
 // in some order on every lane, so max(a, b) / a + b are the cross-half reductions -- one VALU instruction instead of the
 // ds_bpermute round trip of __shfl_xor(v, 32).  (Inline asm: the builtin folds the two results of equal inputs into one;

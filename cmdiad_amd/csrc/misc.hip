@@ -31,8 +31,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, c
         }
         s += v[e].x + v[e].y;
     }
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+    s = wave_sum(s);
     const float mean = s / C;
     float q = 0.0f;
 #pragma unroll
@@ -40,8 +39,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, c
         const float a = v[e].x - mean, b = v[e].y - mean;
         q += a * a + b * b;
     }
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) q += __shfl_xor(q, m, 64);
+    q = wave_sum(q);
     const float rstd = rsqrtf(q / C + eps);
     if (mean_out && lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
 #pragma unroll
