@@ -925,8 +925,7 @@ __global__ __launch_bounds__(256) void l2_rescore_kernel(const float* __restrict
         const float d0 = x.x - y.x, d1 = x.y - y.y, d2 = x.z - y.z, d3 = x.w - y.w;
         s += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
     }
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+    s = wave_sum(s);
     if (lane == 0) {
         min_val[row] = sqrtf(s);
         min_idx[row] = (int64_t)gi;
@@ -965,8 +964,7 @@ __global__ __launch_bounds__(256) void normalize_cast_kernel(const float* __rest
         s += r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3;
     }
     if (sq) {
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+        s = wave_sum(s);
         if (lane == 0) sq[row] = s;
     }
 }
@@ -1025,8 +1023,7 @@ __global__ __launch_bounds__(256) void score_tail_kernel(const float* __restrict
         const float* row = bank + (size_t)gi * D;
         float s = 0.0f;
         for (int c = tid; c < D; c += 256) { const float d = m_test[(size_t)b * D + c] - row[c]; s += d * d; }
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+        s = wave_sum(s);
         if ((tid & 63) == 0) s_part[tid >> 6] = s;
         __syncthreads();
         if (tid == 0) knn_d[b * 2 + (k - 1)] = sqrtf(s_part[0] + s_part[1] + s_part[2] + s_part[3]);

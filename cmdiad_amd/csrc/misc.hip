@@ -205,7 +205,7 @@ static __global__ __launch_bounds__(256) void moments3_kernel(const float* __res
     for (int k = 0; k < 9; ++k) {
         double v = a[k];
 #pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+        for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);   // (double: once per launch)
         if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][k] = v;
     }
     __syncthreads();

@@ -90,8 +90,7 @@ __global__ __launch_bounds__(kWaves * 64) void reweight_scan_mfma_kernel(const f
                     const float4 x = *reinterpret_cast<const float4*>(probes + (size_t)p * D + c);
                     s += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
                 }
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+            s = wave_sum(s);
             if (lane == 0) s_pn[p] = s;
         }
     }
@@ -276,8 +275,7 @@ __global__ __launch_bounds__(kCand * 64) void reweight_exact_merge_kernel(const 
                 const float d0 = x.x - y.x, d1 = x.y - y.y, d2 = x.z - y.z, d3 = x.w - y.w;
                 s += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
             }
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+            s = wave_sum(s);
             exact = pack_key(s, gi);
         }
         if (lane == 0) s_exact[wave] = exact;

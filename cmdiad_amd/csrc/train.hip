@@ -38,10 +38,7 @@ __global__ __launch_bounds__(256) void loss_head_kernel(const float* __restrict_
             else { const float ad = fabsf(d); a += ad < 1.0f ? 0.5f * d * d : ad - 0.5f; }
         }
     }
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64); c += __shfl_xor(c, m, 64);
-    }
+    a = wave_sum(a); b = wave_sum(b); c = wave_sum(c);
     float loss, k0 = 0.f, k1 = 0.f;  // dL/dy = k0 * (y - t) [l2]  |  k0 * t + k1 * y [cos]
     if (mode == 0) {
         const float nrm = sqrtf(a);
@@ -96,8 +93,7 @@ __global__ __launch_bounds__(1024) void sum_vector_kernel(const float* __restric
     __shared__ float s_part[16];
     float s = 0.0f;
     for (size_t i = threadIdx.x; i < n; i += 1024) s += x[i];
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+    s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) {
