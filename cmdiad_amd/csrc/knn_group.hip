@@ -183,13 +183,50 @@ __device__ __forceinline__ unsigned long long shfl_u64(unsigned long long v, int
     return ((unsigned long long)hi << 32) | lo;
 }
 
-// compare-exchange across lanes at distance j (< 64) for one register: ascending block if `up`
+// The partner's key at lane distance j, without the LDS: the sorting networks below are chains of ~70 dependent
+// compare-exchanges per candidate batch, and a ds_bpermute round trip per 32-bit half of each was most of the kernel's time.
+//   j = 1, 2:  DPP quad permutes;  j = 4 = 7 ^ 3: half-row mirror, then quad reverse;  j = 8 = 15 ^ 7: half-row mirror, then row mirror;
+//   j = 16, 32: v_permlane16_swap / v_permlane32_swap of (v, v) leave {own, partner} in the two registers in a lane-dependent
+//   order -- which is all a compare-exchange needs (min and max are symmetric).
+__device__ __forceinline__ unsigned dpp_u32(unsigned v, int ctrl)   // ctrl: compile-time after unrolling
+{
+    switch (ctrl) {
+    case 0xB1: return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);
+    case 0x4E: return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);
+    case 0x1B: return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x1B, 0xF, 0xF, false);
+    case 0x141: return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false);
+    default: return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false);
+    }
+}
+
+// compare-exchange across lanes at distance j (< 64, compile-time after unrolling) for one register: ascending block if `up`
 __device__ __forceinline__ unsigned long long cex_lane(unsigned long long v, int j, bool up, int lane)
 {
-    const unsigned long long o = shfl_xor_u64(v, j);
+    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+    unsigned long long x, y;   // {own, partner} in some order
+    if (j >= 16) {
+        unsigned lo2 = lo, hi2 = hi;
+        if (j == 16) {
+            asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(lo), "+v"(lo2));
+            asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(hi), "+v"(hi2));
+        } else {
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(lo2));
+            asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(hi), "+v"(hi2));
+        }
+        x = ((unsigned long long)hi << 32) | lo;
+        y = ((unsigned long long)hi2 << 32) | lo2;
+    } else {
+        unsigned olo, ohi;
+        if (j == 1) { olo = dpp_u32(lo, 0xB1); ohi = dpp_u32(hi, 0xB1); }
+        else if (j == 2) { olo = dpp_u32(lo, 0x4E); ohi = dpp_u32(hi, 0x4E); }
+        else if (j == 4) { olo = dpp_u32(dpp_u32(lo, 0x141), 0x1B); ohi = dpp_u32(dpp_u32(hi, 0x141), 0x1B); }
+        else { olo = dpp_u32(dpp_u32(lo, 0x141), 0x140); ohi = dpp_u32(dpp_u32(hi, 0x141), 0x140); }
+        x = v;
+        y = ((unsigned long long)ohi << 32) | olo;
+    }
     const bool lower = (lane & j) == 0;            // this lane holds the lower-indexed element of the pair
     const bool take_min = lower == up;
-    const unsigned long long mn = o < v ? o : v, mx = o < v ? v : o;
+    const unsigned long long mn = y < x ? y : x, mx = y < x ? x : y;
     return take_min ? mn : mx;
 }
 
