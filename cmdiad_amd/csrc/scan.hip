@@ -42,6 +42,25 @@ __device__ __forceinline__ void list_insert(unsigned long long (&t)[K], unsigned
 
 __device__ __forceinline__ unsigned long long min_u64(unsigned long long a, unsigned long long b) { return a < b ? a : b; }
 
+// minimum over the 16 lanes of a DPP row, in all 16 (quad xor 1, quad xor 2, half-row mirror, row mirror on both halves of
+// the key): the 32 dependent pop rounds of the candidate merge below were 256 ds_bpermute round trips at the end of every block
+__device__ __forceinline__ unsigned long long row16_min_u64(unsigned long long v)
+{
+#define CMDIAD_DPP_MIN_STEP(CTRL)                                                                                          \
+    {                                                                                                                       \
+        const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)v, CTRL, 0xF, 0xF, false);               \
+        const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), CTRL, 0xF, 0xF, false);       \
+        const unsigned long long o = ((unsigned long long)hi << 32) | lo;                                                  \
+        v = o < v ? o : v;                                                                                                  \
+    }
+    CMDIAD_DPP_MIN_STEP(0xB1)
+    CMDIAD_DPP_MIN_STEP(0x4E)
+    CMDIAD_DPP_MIN_STEP(0x141)
+    CMDIAD_DPP_MIN_STEP(0x140)
+#undef CMDIAD_DPP_MIN_STEP
+    return v;
+}
+
 // [Nb, D] row-major -> block16 layout (rows >= Nb read as zero; they are masked by row index in the scan)
 __global__ __launch_bounds__(256) void bank_block16_kernel(const float* __restrict__ bank, int Nb, int D,
                                                            float* __restrict__ out, size_t n4)
@@ -198,9 +217,7 @@ __global__ __launch_bounds__(kWaves * 64) void reweight_scan_mfma_kernel(const f
         for (int v = 0; v < 4; ++v) {
 #pragma unroll
             for (int r = 0; r < kCand; ++r) {
-                unsigned long long best = top[pg][v][0];
-#pragma unroll
-                for (int m = 8; m >= 1; m >>= 1) best = min_u64(best, shfl_xor_u64(best, m));
+                const unsigned long long best = row16_min_u64(top[pg][v][0]);
                 if (top[pg][v][0] == best && best != ~0ull) {  // keys are unique (they carry the row): the owner pops
 #pragma unroll
                     for (int k = 0; k + 1 < kCand; ++k) top[pg][v][k] = top[pg][v][k + 1];
