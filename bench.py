@@ -407,8 +407,23 @@ def main():
         import torch.distributed as td
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1")
-        td.init_process_group("nccl", device_id=dev)
-        group = td.group.WORLD
+        # RCCL prints its version banner to STDOUT when the first communicator comes up: stdout carries exactly one JSON line
+        # (the contract), so file descriptor 1 points at stderr until the communicator exists
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            td.init_process_group("nccl", device_id=dev)
+            group = td.group.WORLD
+            warm = torch.zeros(1, device=dev)
+            td.all_reduce(warm, group=group)
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            import ctypes
+            ctypes.CDLL(None).fflush(None)   # the banner sits in the C library's stdout buffer (a pipe is fully buffered)
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
     sharded = group is not None and args.bank == "sharded"
 
     st = build_state(dev, args.workload)

@@ -1,0 +1,40 @@
+"""bench.py as the driver runs it (a child process, one JSON line on stdout): the N = 1 contract fields, and the N > 1 code path --
+RCCL process group, all-gather of the queries, per-shard distance GEMM, all_reduce(MIN) of the packed keys -- exercised on one
+GPU with CMDIAD_FORCE_DIST=1 (a world of one rank goes through the same collectives)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra_env, *args):
+    env = dict(os.environ, **extra_env)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", *args],
+                         capture_output=True, text=True, timeout=900, env=env, cwd=REPO)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines          # exactly ONE line on stdout (RCCL's banner included: it goes to stderr)
+    return json.loads(lines[0])
+
+
+def test_bench_single_gpu_line():
+    d = _run({}, "--no-extras")
+    assert d["metric"].startswith("images/sec") and d["unit"] == "images/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
+    assert d["value"] > 100 and abs(d["value"] - 32 / (d["ms_per_step"] * 1e-3)) < 0.01 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert 0.2 < r["frac"] < 1.0 and "traffic" in r
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+
+
+def test_bench_distributed_path_on_one_gpu():
+    d = _run({"CMDIAD_FORCE_DIST": "1"})
+    s = d["sharded_search"]
+    assert s["rccl_ranks"] == 1 and s["backend"] == "nccl"
+    assert d["value"] > 100
