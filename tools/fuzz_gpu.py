@@ -150,11 +150,57 @@ def case_blur(rs):
         assert torch.equal(out[i], ref), ("blur", n, H, W, radius)
 
 
+_ENC = {}
+
+
+def case_encoder(rs):
+    """Point-MAE encoder stages at random group counts / sizes: the persistent first stage and the persistent tail against the
+    one-block-per-tile kernels of the test-only build (identical outputs), one to several row tiles per persistent block."""
+    from cmdiad_amd.runtime import fold_pointmae_encoder
+    from oracle import nets
+    if "w" not in _ENC:
+        _ENC["w"] = fold_pointmae_encoder(nets.synth_state_dict("pointmae", 21), "encoder.", DEV)
+    w = _ENC["w"]
+    Mg = int(rs.choice([32, 64, 128]))
+    groups = int(rs.choice([1, 3, 7, 24, 130, 257, 300, 515, 1030])) if rs.rand() < 0.7 else int(rs.randint(1, 1200))
+    nb = torch.from_numpy((0.05 * rs.randn(groups * Mg, 3)).astype(np.float32)).to(DEV)
+    outs = {}
+    for env in ("1", "0"):
+        os.environ["CMDIAD_STAGE1_PERSIST"] = env
+        outs[env] = [t.clone() for t in ops.encoder_stage1(nb, w["w1b1"], w["W2"], w["b2"], groups, Mg)]
+    os.environ.pop("CMDIAD_STAGE1_PERSIST")
+    assert all(torch.equal(a, b) for a, b in zip(outs["1"], outs["0"])), ("stage1", groups, Mg)
+    h2 = outs["1"][0]
+    gb = torch.from_numpy(rs.randn(groups, 512).astype(np.float32)).to(DEV)
+    toks = {}
+    for env in ("", "1", "0"):
+        os.environ["CMDIAD_TAIL_PP"] = env
+        toks[env] = ops.encoder_tail(h2, gb, w["W3b"], w["W4"], w["b4"], groups, Mg).clone()
+    os.environ.pop("CMDIAD_TAIL_PP")
+    assert torch.equal(toks[""], toks["0"]) and torch.equal(toks["1"], toks["0"]), ("tail", groups, Mg)
+
+
+def case_ocsvm(rs):
+    """cmdiad_ocsvm_fit against scikit-learn on random score-like rows: identical coefficients, offset and epoch count."""
+    import warnings
+    from sklearn import linear_model
+    from cmdiad_amd.ocsvm import DeviceSGDOneClassSVM
+    n, F = int(rs.randint(2, 30000)), int(rs.randint(1, 5))
+    nu = float(rs.choice([0.5, 0.5, 0.1, 0.9]))
+    X = np.abs(rs.normal(1.0, 0.3, size=(n, F))).astype(np.float32)
+    seed = int(rs.randint(0, 1000))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref = linear_model.SGDOneClassSVM(random_state=seed, nu=nu, max_iter=50).fit(X)
+    dev = DeviceSGDOneClassSVM(random_state=seed, nu=nu, max_iter=50).fit(torch.from_numpy(X).to(DEV))
+    assert dev.n_iter_ == ref.n_iter_ and np.array_equal(dev.coef_, ref.coef_) and np.array_equal(dev.offset_, ref.offset_), ("ocsvm", n, F, nu, seed)
+
+
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     rs = np.random.RandomState(seed)
-    cases = [case_fps_knn, case_gemm, case_l2, case_attention, case_blur, case_fps_big, case_l2_big]
+    cases = [case_fps_knn, case_gemm, case_l2, case_attention, case_blur, case_fps_big, case_l2_big, case_encoder, case_ocsvm]
     counts = {c.__name__: 0 for c in cases}
     t0 = time.time()
     while time.time() - t0 < budget:
