@@ -444,12 +444,15 @@ def main():
     if group is not None:
         td.barrier()
     torch.cuda.synchronize()
+    pred.live_rows.zero_()
+    pred.xyz_searches = 0
     t0 = time.perf_counter()
     run_steps(pred, batches, args.steps, first)
     torch.cuda.synchronize()
     if group is not None:
         td.barrier()
     dt = time.perf_counter() - t0
+    q_live = float(pred.live_rows.item()) / max(pred.xyz_searches, 1)   # query rows per xyz search after the exact row de-duplication
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if group is not None:
         td.all_reduce(tmax, op=td.ReduceOp.MAX)
@@ -480,9 +483,11 @@ def main():
         l2_ms = timers["xyz"].mean_ms()
         q_total = BATCH * 3136 * (world if sharded else 1)
         rows = st["bank_xyz"].bf16.shape[0]
-        flops = 2.0 * q_total * rows * 768
+        # FLOPs of the launch as executed: the rows the kernel searched (patches without a foreground pixel repeat one row and are
+        # searched once, csrc/dedup.hip; CMDIAD_DEDUP=0 searches all q_total rows as the reference's cdist does)
+        flops = 2.0 * q_live * rows * 768
         achieved = flops / (l2_ms * 1e-3) / 1e12
-        bytes_alg = (rows + q_total) * 768 * 2 + 12 * q_total
+        bytes_alg = (rows + q_live) * 768 * 2 + 12 * q_live
         out = {
             "metric": "images/sec end-to-end (extract+distill+kNN score)", "value": round(images / dt, 2), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -497,6 +502,10 @@ def main():
                                     "24576-point clouds, batch 32/GPU"),
                        "batch_per_gpu": BATCH, "rotating_input_batches": ROTATE,
                        "bank": "row-sharded search + RCCL min-reduce" if sharded else ("replicated per rank, images sharded, no data-path collective" if world > 1 else "single"),
+                       "xyz_query_rows": {"per_step": q_total, "searched_per_step": round(q_live, 1), "dedup": bool(pred.dedup),
+                                          "note": "the 56x56 patch grid keeps a row for every patch; patches with no foreground pixel "
+                                                  "(24576 of 50176 pixels are foreground, as in the reference's clouds) are one "
+                                                  "repeated row, searched once with the key copied -- results identical to searching all"},
                        "hip_graphs": bool(pred.use_graph), "search_operands": "fp16 (fp32 accumulate, exact fp32 re-score)",
                        "weights": "seeded random init (no checkpoints offline)"},
             "roofline": {"kernel": "l2_min_pp3_kernel (xyz library distance GEMM + running min/argmin)", "bound": "mfma",

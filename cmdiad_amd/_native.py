@@ -66,6 +66,9 @@ SIGNATURES = {
     "cmdiad_encoder_stage1": [P, P, P, P, I, I, P, P, P, P],
     "cmdiad_gemm_groupmax": [P, P, P, I, I, I, I, P, P, P],
     "cmdiad_l2_min_keys": [P, P, P, P, I, I, I, U32, P, I, P],
+    "cmdiad_l2_min_keys_counted": [P, P, P, I, P, P, I, I, U32, P, I, P],
+    "cmdiad_rows_dedup_plan": [P, P, I, I, P, P, P, P, P, P, P],
+    "cmdiad_keys_expand": [P, P, I, P, P],
     "cmdiad_l2_rescore": [P, P, P, I, I, I, U32, P, P, P],
     "cmdiad_reweight_scan": [P, P, P, I, I, I, U32, P, P, SZ, P],
     "cmdiad_bank_block16": [P, I, I, P, P],
@@ -96,6 +99,7 @@ SIZE_QUERIES = {
     "cmdiad_coreset_workspace_bytes": [I, I, I],
     "cmdiad_blur8_lds_bytes": [I, I],
     "cmdiad_ocsvm_fit_workspace_bytes": [I, I],
+    "cmdiad_rows_dedup_workspace_bytes": [I],
     "cmdiad_transformer_block_workspace_bytes": [I, I, I],
 }
 

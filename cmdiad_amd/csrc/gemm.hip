@@ -193,6 +193,9 @@ v = gelu_erf4(v);
 // LDS read after LDS-DMA gets an s_waitcnt vmcnt(0), i.e. a drain of the whole prefetch queue per tile.  The bias arrives
 // by inline-asm loads issued in phase 0 of the tile's last K-tile (gemm_pp3.h `pre`), with a counted wait.
 constexpr int kPp3Scratch = kRowStoreScratch;   // per wave
+#ifndef CMDIAD_PP3_ABL
+#define CMDIAD_PP3_ABL 0   // timing-only ablations of the epilogue: tools/pp3_grid.py builds them with -DCMDIAD_PP3_ABL=n
+#endif
 
 template <int ACT>
 __global__ __launch_bounds__(512, 1) void gemm_std_pp3_kernel(GlobalTile A, GlobalTile W, StdParams p)
@@ -218,6 +221,13 @@ __global__ __launch_bounds__(512, 1) void gemm_std_pp3_kernel(GlobalTile A, Glob
         const int nw = ntile * SPP3::BN + wc * 64;                  // first column of this wave's 64
         const int mw = mt * SPP3::BM + wr * 128;                    // first row of this wave's 128
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");            // the bias fetched in phase 0
+#if CMDIAD_PP3_ABL == 3      // timing only: no epilogue (accumulators kept live)
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j][0]), "v"(acc[i][j][1]), "v"(acc[i][j][2]), "v"(acc[i][j][3]));
+        return 0;
+#endif
         __builtin_amdgcn_sched_barrier(0);
         // FULL tiles (all but the last M tile) store without a per-row test: a branch per row makes every group of stores
         // its own basic block, and the compiler then guards each with s_waitcnt vmcnt(0) -- stores count in vmcnt on gfx9,
@@ -250,14 +260,22 @@ __global__ __launch_bounds__(512, 1) void gemm_std_pp3_kernel(GlobalTile A, Glob
                 if (i < 7) compute(i + 1, h);
                 rs.fetch_wait();
                 const int m = mw + i * 16 + R;
+#if CMDIAD_PP3_ABL == 1      // timing only: no stores (the transposed rows stay live through an empty asm)
+                asm volatile("" ::"v"(t0.x), "v"(t0.y), "v"(t0.z), "v"(t0.w), "v"(t1.x), "v"(t1.y), "v"(t1.z), "v"(t1.w));
+#elif CMDIAD_PP3_ABL == 2    // timing only: every tile of a block stores to the same L2-resident window
+                bf16_t* w0 = p.out_bf16 + (size_t)((blockIdx.x & 63) * 256 + wr * 128 + R) * p.ldo16 + (blockIdx.x >> 6) * 256 + wc * 64 + u * 8;
+                *reinterpret_cast<uint4*>(w0 + (size_t)(i * 16) * p.ldo16) = t0;
+                *reinterpret_cast<uint4*>(w0 + (size_t)(i * 16 + 8) * p.ldo16) = t1;
+#else
                 if (full || m < p.M) *reinterpret_cast<uint4*>(o0 + (size_t)(i * 16) * p.ldo16) = t0;
                 if (full || m + 8 < p.M) *reinterpret_cast<uint4*>(o0 + (size_t)(i * 16 + 8) * p.ldo16) = t1;
+#endif
                 if (i < 7) rs.park(h);
             }
         };
         if (mt * SPP3::BM + SPP3::BM <= p.M) {
             emit(std::true_type{});
-            return kEpiOps;
+            return CMDIAD_PP3_ABL == 1 ? 0 : kEpiOps;
         }
         emit(std::false_type{});
         return 0;
@@ -857,7 +875,14 @@ constexpr int kPersistCUs = 256;   // one persistent block per CU (MI355X)
 unsigned persist_blocks(long M, long N)
 {
     const long jobs = ((M + 255) / 256) * (N / 256);
-    return (unsigned)(jobs < kPersistCUs ? jobs : kPersistCUs);
+#ifdef CMDIAD_AB_VARIANTS
+    if (const char* e = getenv("CMDIAD_PP3_GRID")) { const long g = atol(e); if (g > 0) return (unsigned)(jobs < g ? jobs : g); }
+#endif
+    // as many blocks as give every block the same number of tiles (+-1) at the same number of rounds: 1 188 tiles are five
+    // rounds on 256 CUs and on 238; the smaller grid is 1-2 % faster (fewer CUs share the fabric in the last round;
+    // tools/pp3_grid.py).  The vendor library picks its stream-K grids for these shapes the same way (198 blocks x 6 tiles).
+    const long rounds = (jobs + kPersistCUs - 1) / kPersistCUs;
+    return (unsigned)(jobs < kPersistCUs ? jobs : (jobs + rounds - 1) / rounds);
 }
 
 #ifdef CMDIAD_AB_VARIANTS

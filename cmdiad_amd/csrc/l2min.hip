@@ -33,14 +33,34 @@ struct L2Params {
     int nq_tiles, n_bank_tiles, splits, qgroup;
     unsigned* diag;    // test-only build: in-kernel stamps of one workgroup (l2_min_pp3_kernel<F16, true>), else null
     int diag_wg;
+    const int* q_count;   // device-resident number of live query rows (<= Q), or null: cmdiad_l2_min_keys_counted
 };
+
+// Live query rows known only on the device (the compacted query set of cmdiad_rows_dedup_plan): the grid is sized for Q, every
+// block reads the count once and the blocks of query tiles beyond it leave.
+// Returns the number of workgroups that have work: the XCD remap must run over THAT count -- it hands every XCD a contiguous range
+// of (query tile, library range) blocks, so a remap over the launched grid would leave the live query tiles to the first XCDs only.
+template <int BM>
+__device__ __forceinline__ int live_rows(GlobalTile& A, L2Params& p)
+{
+    if (!p.q_count) return gridDim.x;
+    const int q = __builtin_amdgcn_readfirstlane(*p.q_count);
+    p.Q = q;
+    A.rows = q;
+    p.nq_tiles = (q + BM - 1) / BM;
+    const int qg = min(p.qgroup, max(p.nq_tiles, 1));   // the launcher's clamp of qgroup, for the live tile count
+    p.qgroup = qg;
+    return (p.nq_tiles + qg - 1) / qg * qg * p.splits;
+}
 
 template <class S, bool F16>
 __global__ __launch_bounds__(S::THREADS, S::WAVES_PER_SIMD) void l2_min_kernel(GlobalTile A, GlobalTile W, L2Params p)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int MI = S::MI;
-    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int nwg = live_rows<S::BM>(A, p);
+    if ((int)blockIdx.x >= nwg) return;
+    const int wg = xcd_remap(blockIdx.x, nwg);
     // L2-aware 2-D arrangement: consecutive workgroup ids (= co-resident blocks of one XCD after the remap)
     // form groups of `qgroup` query tiles x `splits` bank ranges.  Per XCD the L2 then holds a handful of query
     // tiles (re-read every bank tile) while each streamed bank tile is shared by `qgroup` blocks -- with one
@@ -437,7 +457,9 @@ __global__ __launch_bounds__(512, 1) void l2_min_pp3_kernel(GlobalTile A, Global
     extern __shared__ __attribute__((aligned(16))) char lds[];
     using S = SPingPong3;
     using frag = typename std::conditional<F16, f16x8, bf16x8>::type;
-    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int nwg = live_rows<S::BM>(A, p);
+    if ((int)blockIdx.x >= nwg) return;
+    const int wg = xcd_remap(blockIdx.x, nwg);
     const int gsz = p.qgroup * p.splits;
     const int within = wg % gsz;
     const int split = within / p.qgroup, qt = (wg / gsz) * p.qgroup + within % p.qgroup;
@@ -1058,7 +1080,7 @@ template <bool F16> struct L2Kernel<SPingPong4, F16> { static constexpr auto fn 
 
 template <class S, bool F16>
 int launch_l2(const uint16_t* q, const float* q_sqnorm, const uint16_t* bank, const float* bank_sqnorm, int Q, int Nb,
-              int D, uint32_t row_offset, unsigned long long* keys, hipStream_t stream)
+              int D, uint32_t row_offset, unsigned long long* keys, hipStream_t stream, const int* q_count = nullptr)
 {
     static bool attr = false;
     if (!attr) {
@@ -1081,15 +1103,15 @@ int launch_l2(const uint16_t* q, const float* q_sqnorm, const uint16_t* bank, co
     int qgroup = env_qgroup > 0 ? env_qgroup : 4;
     qgroup = qgroup > nq ? nq : qgroup;
     GlobalTile A{(const bf16_t*)q, D, Q}, W{(const bf16_t*)bank, D, Nb};
-    L2Params p{Q, Nb, D, q_sqnorm, bank_sqnorm, row_offset, keys, nq, nbt, splits, qgroup, nullptr, -1};
+    L2Params p{Q, Nb, D, q_sqnorm, bank_sqnorm, row_offset, keys, nq, nbt, splits, qgroup, nullptr, -1, q_count};
     const int ngroups = (nq + qgroup - 1) / qgroup;
     hipLaunchKernelGGL((L2Kernel<S, F16>::fn), dim3(ngroups * qgroup * splits), dim3(S::THREADS), S::LDS_BYTES, stream, A, W, p);
     return CMDIAD_OK;
 }
 
-extern "C" int cmdiad_l2_min_keys(const uint16_t* q, const float* q_sqnorm, const uint16_t* bank,
-                                  const float* bank_sqnorm, int Q, int Nb, int D, uint32_t row_offset,
-                                  unsigned long long* keys, int dtype, cmdiad_stream_t stream)
+static int l2_min_keys_impl(const uint16_t* q, const float* q_sqnorm, const int* q_count, const uint16_t* bank,
+                           const float* bank_sqnorm, int Q, int Nb, int D, uint32_t row_offset,
+                           unsigned long long* keys, int dtype, cmdiad_stream_t stream)
 {
     CMDIAD_REQUIRE(q && q_sqnorm && bank && bank_sqnorm && keys, CMDIAD_ERR_ARG, "cmdiad_l2_min_keys: null pointer");
     CMDIAD_REQUIRE(Q >= 0 && Nb >= 0 && D > 0 && D % 64 == 0, CMDIAD_ERR_ARG, "cmdiad_l2_min_keys: need D%%64==0 (D=%d)", D);
@@ -1116,37 +1138,37 @@ extern "C" int cmdiad_l2_min_keys(const uint16_t* q, const float* q_sqnorm, cons
     hipStream_t s = (hipStream_t)stream;
     const bool h = dtype == CMDIAD_DT_F16;
     int rc;
-#define L2_ARGS q, q_sqnorm, bank, bank_sqnorm, Q, Nb, D, row_offset, keys, s
+#define L2_ARGS q, q_sqnorm, bank, bank_sqnorm, Q, Nb, D, row_offset, keys, s, q_count
     if (tile == 4 || tile == 5 || tile == 6) {
         const int full = Nb / 256 * 256, rest = Nb - full;
         rc = CMDIAD_OK;
 #ifdef CMDIAD_AB_VARIANTS
-        if (full > 0 && tile == 6) rc = h ? launch_l2<SPingPong4, true>(q, q_sqnorm, bank, bank_sqnorm, Q, full, D, row_offset, keys, s)
-                                          : launch_l2<SPingPong4, false>(q, q_sqnorm, bank, bank_sqnorm, Q, full, D, row_offset, keys, s);
+        if (full > 0 && tile == 6) rc = h ? launch_l2<SPingPong4, true>(q, q_sqnorm, bank, bank_sqnorm, Q, full, D, row_offset, keys, s, q_count)
+                                          : launch_l2<SPingPong4, false>(q, q_sqnorm, bank, bank_sqnorm, Q, full, D, row_offset, keys, s, q_count);
         else
 #endif
-        if (full > 0 && tile == 5) rc = h ? launch_l2<SPingPong3, true>(q, q_sqnorm, bank, bank_sqnorm, Q, full, D, row_offset, keys, s)
-                                          : launch_l2<SPingPong3, false>(q, q_sqnorm, bank, bank_sqnorm, Q, full, D, row_offset, keys, s);
+        if (full > 0 && tile == 5) rc = h ? launch_l2<SPingPong3, true>(q, q_sqnorm, bank, bank_sqnorm, Q, full, D, row_offset, keys, s, q_count)
+                                          : launch_l2<SPingPong3, false>(q, q_sqnorm, bank, bank_sqnorm, Q, full, D, row_offset, keys, s, q_count);
 #ifdef CMDIAD_AB_VARIANTS
-        else if (full > 0) rc = h ? launch_l2<SPingPong, true>(q, q_sqnorm, bank, bank_sqnorm, Q, full, D, row_offset, keys, s)
-                             : launch_l2<SPingPong, false>(q, q_sqnorm, bank, bank_sqnorm, Q, full, D, row_offset, keys, s);
+        else if (full > 0) rc = h ? launch_l2<SPingPong, true>(q, q_sqnorm, bank, bank_sqnorm, Q, full, D, row_offset, keys, s, q_count)
+                             : launch_l2<SPingPong, false>(q, q_sqnorm, bank, bank_sqnorm, Q, full, D, row_offset, keys, s, q_count);
 #endif
         if (rc == CMDIAD_OK && rest > 0) {
             const uint16_t* b2 = bank + (size_t)full * D;
-            rc = h ? launch_l2<S128, true>(q, q_sqnorm, b2, bank_sqnorm + full, Q, rest, D, row_offset + full, keys, s)
-                   : launch_l2<S128, false>(q, q_sqnorm, b2, bank_sqnorm + full, Q, rest, D, row_offset + full, keys, s);
+            rc = h ? launch_l2<S128, true>(q, q_sqnorm, b2, bank_sqnorm + full, Q, rest, D, row_offset + full, keys, s, q_count)
+                   : launch_l2<S128, false>(q, q_sqnorm, b2, bank_sqnorm + full, Q, rest, D, row_offset + full, keys, s, q_count);
         }
     }
 #ifdef CMDIAD_AB_VARIANTS
     else if (tile == 3) {
         const int full = Nb / 256 * 256, rest = Nb - full;
         rc = CMDIAD_OK;
-        if (full > 0) rc = h ? launch_l2<SWide, true>(q, q_sqnorm, bank, bank_sqnorm, Q, full, D, row_offset, keys, s)
-                             : launch_l2<SWide, false>(q, q_sqnorm, bank, bank_sqnorm, Q, full, D, row_offset, keys, s);
+        if (full > 0) rc = h ? launch_l2<SWide, true>(q, q_sqnorm, bank, bank_sqnorm, Q, full, D, row_offset, keys, s, q_count)
+                             : launch_l2<SWide, false>(q, q_sqnorm, bank, bank_sqnorm, Q, full, D, row_offset, keys, s, q_count);
         if (rc == CMDIAD_OK && rest > 0) {
             const uint16_t* b2 = bank + (size_t)full * D;
-            rc = h ? launch_l2<S128, true>(q, q_sqnorm, b2, bank_sqnorm + full, Q, rest, D, row_offset + full, keys, s)
-                   : launch_l2<S128, false>(q, q_sqnorm, b2, bank_sqnorm + full, Q, rest, D, row_offset + full, keys, s);
+            rc = h ? launch_l2<S128, true>(q, q_sqnorm, b2, bank_sqnorm + full, Q, rest, D, row_offset + full, keys, s, q_count)
+                   : launch_l2<S128, false>(q, q_sqnorm, b2, bank_sqnorm + full, Q, rest, D, row_offset + full, keys, s, q_count);
         }
     }
     else if (tile == 2) rc = h ? launch_l2<S2x2, true>(L2_ARGS) : launch_l2<S2x2, false>(L2_ARGS);
@@ -1156,6 +1178,21 @@ extern "C" int cmdiad_l2_min_keys(const uint16_t* q, const float* q_sqnorm, cons
     if (rc) return rc;
     CMDIAD_CHECK_LAUNCH();
     return CMDIAD_OK;
+}
+
+extern "C" int cmdiad_l2_min_keys(const uint16_t* q, const float* q_sqnorm, const uint16_t* bank,
+                                  const float* bank_sqnorm, int Q, int Nb, int D, uint32_t row_offset,
+                                  unsigned long long* keys, int dtype, cmdiad_stream_t stream)
+{
+    return l2_min_keys_impl(q, q_sqnorm, nullptr, bank, bank_sqnorm, Q, Nb, D, row_offset, keys, dtype, stream);
+}
+
+extern "C" int cmdiad_l2_min_keys_counted(const uint16_t* q, const float* q_sqnorm, const int* q_count, int Q_max,
+                                          const uint16_t* bank, const float* bank_sqnorm, int Nb, int D,
+                                          uint32_t row_offset, unsigned long long* keys, int dtype, cmdiad_stream_t stream)
+{
+    CMDIAD_REQUIRE(q_count, CMDIAD_ERR_ARG, "cmdiad_l2_min_keys_counted: null count");
+    return l2_min_keys_impl(q, q_sqnorm, q_count, bank, bank_sqnorm, Q_max, Nb, D, row_offset, keys, dtype, stream);
 }
 
 #ifdef CMDIAD_AB_VARIANTS
@@ -1180,7 +1217,7 @@ extern "C" int cmdiad_l2_diag(const uint16_t* q, const float* q_sqnorm, const ui
     int splits = nbt / 4 < 1 ? 1 : (nbt / 4 > 32 ? 32 : nbt / 4);
     int qgroup = 4 > nq ? nq : 4;
     GlobalTile A{(const bf16_t*)q, D, Q}, W{(const bf16_t*)bank, D, Nb};
-    L2Params p{Q, Nb, D, q_sqnorm, bank_sqnorm, 0u, keys, nq, nbt, splits, qgroup, stamps, wg};
+    L2Params p{Q, Nb, D, q_sqnorm, bank_sqnorm, 0u, keys, nq, nbt, splits, qgroup, stamps, wg, nullptr};
     const int ngroups = (nq + qgroup - 1) / qgroup;
     hipLaunchKernelGGL((l2_min_pp3_kernel<true, true>), dim3(ngroups * qgroup * splits), dim3(S::THREADS), lds_bytes, (hipStream_t)stream, A, W, p);
     CMDIAD_CHECK_LAUNCH();

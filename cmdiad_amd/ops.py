@@ -339,6 +339,50 @@ def l2_min_keys(q16, q_sq, bank16, bank_sq, keys, row_offset=0):
     return keys
 
 
+class DedupPlan:
+    """Device-resident plan of cmdiad_rows_dedup_plan: slot [Q] i32 (compacted row answering for q), rows [Q] i32, count [1] i32,
+    q16 [Q,D] / q_sq [Q] (first count rows live).  Buffers are reused when one is passed back in."""
+    __slots__ = ("slot", "rows", "count", "q16", "q_sq", "work")
+
+    def __init__(self, Q, D, dtype, device):
+        self.slot = torch.empty((Q,), dtype=torch.int32, device=device)
+        self.rows = torch.empty((Q,), dtype=torch.int32, device=device)
+        self.count = torch.zeros((1,), dtype=torch.int32, device=device)
+        self.q16 = torch.empty((Q, D), dtype=dtype, device=device)
+        self.q_sq = torch.empty((Q,), dtype=torch.float32, device=device)
+        self.work = torch.empty((max(int(nat.lib().cmdiad_rows_dedup_workspace_bytes(Q)), 4),), dtype=torch.uint8, device=device)
+
+
+def rows_dedup_plan(q16, q_sq, plan=None):
+    """Exact removal of the repeated constant rows (patches without a foreground pixel) of a 16-bit query set: include/cmdiad_hip.h."""
+    Q, D = q16.shape
+    if q16.dtype not in (torch.float16, torch.bfloat16) or not q16.is_contiguous():
+        raise TypeError("rows_dedup_plan: contiguous 16-bit queries")
+    _chk(q_sq, torch.float32, "rows_dedup_plan.q_sq")
+    if plan is None or plan.q16.shape != q16.shape or plan.q16.dtype != q16.dtype:
+        plan = DedupPlan(Q, D, q16.dtype, q16.device)
+    _call("cmdiad_rows_dedup_plan", _p(q16), _p(q_sq), Q, D, _p(plan.work), _p(plan.slot), _p(plan.rows), _p(plan.count),
+          _p(plan.q16), _p(plan.q_sq), _stream())
+    return plan
+
+
+def l2_min_keys_counted(q16, q_sq, count, bank16, bank_sq, keys, row_offset=0):
+    """l2_min_keys over the first count[0] (device int32) rows of q16."""
+    Q, D = q16.shape
+    if q16.dtype != bank16.dtype:
+        raise TypeError("l2_min_keys_counted: queries and bank must share the 16-bit dtype")
+    _chk(count, torch.int32, "l2_min_keys_counted.count")
+    _call("cmdiad_l2_min_keys_counted", _p(q16), _p(q_sq), _p(count), Q, _p(bank16), _p(bank_sq), bank16.shape[0], D, row_offset,
+          _p(keys), 1 if q16.dtype == torch.float16 else 0, _stream())
+    return keys
+
+
+def keys_expand(keys_compact, slot, keys):
+    _chk(slot, torch.int32, "keys_expand.slot")
+    _call("cmdiad_keys_expand", _p(keys_compact), _p(slot), slot.shape[0], _p(keys), _stream())
+    return keys
+
+
 def l2_rescore(q32, bank32, keys, min_val=None, min_idx=None, row_offset=0):
     Q, D = q32.shape
     if min_val is None:

@@ -13,6 +13,7 @@ into a ring of pinned buffers.  Two complete buffer sets alternate: the scoring 
 stream beside the extraction of step i+1, and the inputs of step i+1 are copied (H2D from pinned host memory, or
 D2D from resident batches) into the other set's static input buffers on a copy stream while step i computes.
 """
+import os
 import sys
 
 import numpy as np
@@ -96,6 +97,10 @@ class BatchPredictor:
         self.step_no = 0
         self.sets = None
         self.static = {}
+        # exact removal of the repeated background rows in front of the xyz search (csrc/dedup.hip); CMDIAD_DEDUP=0 searches every row
+        self.dedup = os.environ.get("CMDIAD_DEDUP", "1") != "0" and group is None
+        self.live_rows = torch.zeros((1,), dtype=torch.int64, device=dev)   # rows actually searched, summed over the xyz searches
+        self.xyz_searches = 0
         self.inputs = [self._new_inputs() for _ in range(2 if use_graph else 1)]
 
     def _new_inputs(self):
@@ -156,9 +161,26 @@ class BatchPredictor:
             k = self.static.get(f"keys_{name}_{buf}")
             if k is None or k.shape[0] != q_all.shape[0]:
                 k = self.static[f"keys_{name}_{buf}"] = torch.empty((q_all.shape[0],), dtype=torch.int64, device=q.device)
+            if name == "xyz" and self.dedup:
+                # patches without a foreground pixel are one and the same row: searched once, the key copied to all of them
+                plan = self.static[f"plan_{name}_{buf}"] = ops.rows_dedup_plan(q_all, s_all, self.static.get(f"plan_{name}_{buf}"))
+                kc = self.static.get(f"keysc_{name}_{buf}")
+                if kc is None or kc.shape[0] != q_all.shape[0]:
+                    kc = self.static[f"keysc_{name}_{buf}"] = torch.empty((q_all.shape[0],), dtype=torch.int64, device=q.device)
+                kc.fill_(eng.KEY_EMPTY)
+                with self.timers.get(name, _NoTimer()):
+                    ops.l2_min_keys_counted(plan.q16, plan.q_sq, plan.count, bank.bf16, bank.sqnorm, kc, bank.row_offset)
+                ops.keys_expand(kc, plan.slot, k)
+                self.live_rows += plan.count
+                self.xyz_searches += 1
+                keys[name] = k
+                continue
             k.fill_(eng.KEY_EMPTY)
             with self.timers.get(name, _NoTimer()):
                 ops.l2_min_keys(q_all, s_all, bank.bf16, bank.sqnorm, k, bank.row_offset)
+            if name == "xyz":
+                self.live_rows += q_all.shape[0]
+                self.xyz_searches += 1
             k = eng.merge_shard_keys(k, self.group)
             keys[name] = k[bank.rank * B * Q:(bank.rank + 1) * B * Q] if self.group is not None else k
         return keys

@@ -243,6 +243,26 @@ int cmdiad_l2_min_keys(const uint16_t* q, const float* q_sqnorm, const uint16_t*
                        int Q, int Nb, int D, uint32_t row_offset, unsigned long long* keys, int dtype,
                        cmdiad_stream_t stream);
 
+/* The same search over a query set whose live row count is known only on the device (*q_count <= Q_max, e.g. the compacted set of
+ * cmdiad_rows_dedup_plan): the launch is sized for Q_max, rows at and beyond *q_count are neither read nor written. */
+int cmdiad_l2_min_keys_counted(const uint16_t* q, const float* q_sqnorm, const int* q_count, int Q_max, const uint16_t* bank,
+                               const float* bank_sqnorm, int Nb, int D, uint32_t row_offset, unsigned long long* keys, int dtype,
+                               cmdiad_stream_t stream);
+
+/* Exact removal of repeated query rows in front of the search.  Every patch of the 56 x 56 grid without a foreground pixel under
+ * it is the same vector ((0 - mean) / std in every column; features.py:169-184, multiple_features.py:976-977) and the reference's
+ * torch.cdist (features.py:186-190) searches the library again for each of them.  A row REPEATS the first constant row of the
+ * batch iff its 16-bit row is the same constant and the bits of its squared norm are equal -- then everything cmdiad_l2_min_keys
+ * reads for it is identical and so is its key.  slot[Q] (row of the compacted set that answers for q), rows[Q] (compacted ->
+ * original, first *count entries), count[1], q_compact [Q,D] / q_sqnorm_compact [Q] (first *count rows written), all on the device;
+ * workspace: cmdiad_rows_dedup_workspace_bytes(Q).  Order-preserving; a batch without constant rows compacts to itself. */
+size_t cmdiad_rows_dedup_workspace_bytes(int Q);
+int cmdiad_rows_dedup_plan(const uint16_t* q, const float* q_sqnorm, int Q, int D, void* workspace, int* slot, int* rows, int* count,
+                           uint16_t* q_compact, float* q_sqnorm_compact, cmdiad_stream_t stream);
+/* keys[q] = keys_compact[slot[q]] */
+int cmdiad_keys_expand(const unsigned long long* keys_compact, const int* slot, int Q, unsigned long long* keys,
+                       cmdiad_stream_t stream);
+
 /* Exact fp32 re-score of the winners: min_val[q] = || q_f32[q] - bank_f32[idx - row_offset] ||_2,
  * min_idx[q] = idx (global row).  Queries whose winner lies outside [row_offset, row_offset+Nb) are
  * left untouched (another shard owns them). */

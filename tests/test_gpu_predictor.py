@@ -98,7 +98,7 @@ def test_feature_error_is_far_below_the_patch_distances(weights, cpu_ex, gpu_eng
     assert err_x.mean() < 0.2 * nn_x.mean() and err_r.mean() < 0.05 * nn_r.mean()
 
 
-def test_predict_batch_b32_vs_oracle(weights, cpu_ex, gpu_engine):
+def test_predict_batch_b32_vs_oracle(weights, cpu_ex, gpu_engine, monkeypatch):
     """B = 32 through BatchPredictor (HIP graphs, both buffer sets, and the eager path) against
     oracle.pipeline.CpuDoubleRGBPoint.predict sample by sample: image score, blurred pixel map, and I-/P-AUROC over the 32
     samples (10 anomalous)."""
@@ -133,6 +133,15 @@ def test_predict_batch_b32_vs_oracle(weights, cpu_ex, gpu_engine):
         assert np.array_equal(first[0], second[0]) and np.array_equal(first[1], second[1])
         outs[mode] = first
     assert np.array_equal(outs["graph"][0], outs["eager"][0]) and np.array_equal(outs["graph"][1], outs["eager"][1])
+    # the exact removal of the repeated background rows in front of the xyz search (csrc/dedup.hip) changes no output bit, and
+    # it did search fewer rows (these clouds cover 40-49 % of the image)
+    assert p.dedup and 0 < int(p.live_rows.item()) < 0.8 * B * 3136 * p.xyz_searches, (int(p.live_rows.item()), p.xyz_searches)
+    monkeypatch.setenv("CMDIAD_DEDUP", "0")
+    p_all = BatchPredictor(gpu_engine, bank_xyz, bank_rgb, stats, det, seg, lambdas=(1.0, 1.0, 0.1, 0.1), batch=B, use_graph=False)
+    monkeypatch.delenv("CMDIAD_DEDUP")
+    every = p_all.predict_batch(rgb, pcs)
+    assert not p_all.dedup and int(p_all.live_rows.item()) == B * 3136 * p_all.xyz_searches
+    assert np.array_equal(every[0], outs["graph"][0]) and np.array_equal(every[1], outs["graph"][1])
     img, pix = outs["graph"]
     assert img.shape == (B,) and pix.shape == (B, 224, 224) and img.dtype == np.float64
 
