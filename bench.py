@@ -473,6 +473,25 @@ def main():
         extras["h2d_inclusive"] = dict(value=round(BATCH * n_h2d / h2d_dt, 2), unit="images/s per GPU", steps=n_h2d,
                                        h2d_MB_per_step=round(mb, 1), note="inputs in pinned host memory, copied inside the loop; "
                                        "outputs identical to the resident run")
+        if group is None and pred.dedup:
+            # the same steps with EVERY row of the patch grid searched, as the reference's cdist does (no row de-duplication):
+            # outputs are checked bit for bit against the de-duplicated run's (run_steps compares with `first`)
+            os.environ["CMDIAD_DEDUP"] = "0"
+            pred_all = BatchPredictor(st["engine"], st["bank_xyz"], st["bank_second"], st["stats"], st["det"], st["seg"], batch=BATCH,
+                                      n_max=N_POINTS, workload=args.workload, halluc=st["halluc"], group=None,
+                                      use_graph=pred.use_graph)
+            del os.environ["CMDIAD_DEDUP"]
+            run_steps(pred_all, batches, 3, first)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            run_steps(pred_all, batches, n_h2d, first)
+            torch.cuda.synchronize()
+            all_dt = time.perf_counter() - t2
+            extras["every_row_searched"] = dict(value=round(BATCH * n_h2d / all_dt, 2), unit="images/s per GPU", steps=n_h2d,
+                                                ms_per_step=round(all_dt / n_h2d * 1e3, 3),
+                                                note="CMDIAD_DEDUP=0: all 100352 query rows per step go through the distance GEMM; "
+                                                     "outputs bit-identical to the default run")
+            del pred_all
         if group is not None:
             names = list(CLASS_TRAIN) if args.classes == "all" else [c for c in args.classes.split(",") if c]
             extras["sharded_search"] = sharded_search(dev, group, rank, world, [(c, class_rows(c)) for c in names])
