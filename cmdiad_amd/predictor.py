@@ -161,8 +161,9 @@ class BatchPredictor:
             k = self.static.get(f"keys_{name}_{buf}")
             if k is None or k.shape[0] != q_all.shape[0]:
                 k = self.static[f"keys_{name}_{buf}"] = torch.empty((q_all.shape[0],), dtype=torch.int64, device=q.device)
-            if name == "xyz" and self.dedup:
-                # patches without a foreground pixel are one and the same row: searched once, the key copied to all of them
+            if self.dedup:
+                # patches without a foreground pixel are one and the same row (and so are their hallucinated features in the MTFI
+                # workload): searched once, the key copied to all of them
                 plan = self.static[f"plan_{name}_{buf}"] = ops.rows_dedup_plan(q_all, s_all, self.static.get(f"plan_{name}_{buf}"))
                 kc = self.static.get(f"keysc_{name}_{buf}")
                 if kc is None or kc.shape[0] != q_all.shape[0]:
@@ -171,8 +172,9 @@ class BatchPredictor:
                 with self.timers.get(name, _NoTimer()):
                     ops.l2_min_keys_counted(plan.q16, plan.q_sq, plan.count, bank.bf16, bank.sqnorm, kc, bank.row_offset)
                 ops.keys_expand(kc, plan.slot, k)
-                self.live_rows += plan.count
-                self.xyz_searches += 1
+                if name == "xyz":
+                    self.live_rows += plan.count
+                    self.xyz_searches += 1
                 keys[name] = k
                 continue
             k.fill_(eng.KEY_EMPTY)

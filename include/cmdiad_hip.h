@@ -251,11 +251,13 @@ int cmdiad_l2_min_keys_counted(const uint16_t* q, const float* q_sqnorm, const i
 
 /* Exact removal of repeated query rows in front of the search.  Every patch of the 56 x 56 grid without a foreground pixel under
  * it is the same vector ((0 - mean) / std in every column; features.py:169-184, multiple_features.py:976-977) and the reference's
- * torch.cdist (features.py:186-190) searches the library again for each of them.  A row REPEATS the first constant row of the
- * batch iff its 16-bit row is the same constant and the bits of its squared norm are equal -- then everything cmdiad_l2_min_keys
- * reads for it is identical and so is its key.  slot[Q] (row of the compacted set that answers for q), rows[Q] (compacted ->
- * original, first *count entries), count[1], q_compact [Q,D] / q_sqnorm_compact [Q] (first *count rows written), all on the device;
- * workspace: cmdiad_rows_dedup_workspace_bytes(Q).  Order-preserving; a batch without constant rows compacts to itself. */
+ * torch.cdist (features.py:186-190) searches the library again for each of them (likewise the hallucinated features of those
+ * patches, multiple_features.py:596).  The MOST REPEATED row of the batch is found by a row hash; a row repeats its first
+ * occurrence iff hash and squared-norm bits are equal AND all D elements compare equal -- then everything cmdiad_l2_min_keys reads
+ * for it is identical and so is its key (a hash collision costs a comparison, never an answer).  slot[Q] (row of the compacted set
+ * that answers for q), rows[Q] (compacted -> original, first *count entries), count[1], q_compact [Q,D] / q_sqnorm_compact [Q]
+ * (first *count rows written), all on the device; workspace: cmdiad_rows_dedup_workspace_bytes(Q).  Order-preserving; a batch
+ * without a repeated row compacts to itself. */
 size_t cmdiad_rows_dedup_workspace_bytes(int Q);
 int cmdiad_rows_dedup_plan(const uint16_t* q, const float* q_sqnorm, int Q, int D, void* workspace, int* slot, int* rows, int* count,
                            uint16_t* q_compact, float* q_sqnorm_compact, cmdiad_stream_t stream);
