@@ -32,6 +32,11 @@ Prints ONE JSON line (rank 0) with the fields of the bench contract plus `roofli
 distance GEMM, MFMA-bound; duration from HIP events inside the timed region) and, at N = 1, `cpu_baseline` (the CPU
 oracle pipeline timed on a bounded sample on this box's host cores: best thread count, the reference's default 6
 threads, and all cores) and `dropin_b1` (the B = 1 drop-in protocol the reference's main.py drives).
+
+Half of the xyz query rows of a step repeat ONE row (the patches of the 56 x 56 grid without a foreground pixel); the search takes
+that row once (csrc/dedup.hip, outputs bit-identical).  `roofline.achieved` counts the FLOPs executed, `config.xyz_query_rows` says
+how many rows that was, and `every_row_searched` times the same steps with all rows searched as the reference's cdist does
+(CMDIAD_DEDUP=0), comparing every output with the default run's.
 """
 import argparse
 import json

@@ -12,7 +12,8 @@
 //   verify_rows_kernel    a row REPEATS the representative iff its tag and the bits of its squared norm are equal AND all D
 //                         elements compare equal (a wave per candidate row) -- then everything the distance kernel reads for it is
 //                         identical.  A hash collision therefore only costs the comparison, never a wrong answer.
-//   compact_kernel        order-preserving compaction of the other rows: rows[slot] = q, slot[q], count
+//   compact_*_kernel      order-preserving compaction of the other rows (1 024 rows per block: counts, then scan + write):
+//                         rows[slot] = q, slot[q], count
 //   gather_rows_kernel    the compacted 16-bit rows and norms
 //   cmdiad_l2_min_keys_counted on the compacted set (l2min.hip: device-resident row count)
 //   expand_keys_kernel    keys[q] = compact_keys[slot[q]]
@@ -53,10 +54,16 @@ __global__ __launch_bounds__(kPlanThreads) void pick_rep_kernel(const unsigned* 
         for (int i = t; i < 4096; i += kPlanThreads) s_cnt[i] = 0;
         if (t == 0) s_best = 0;
         __syncthreads();
-        for (int q = t; q < Q; q += kPlanThreads) {
-            const unsigned g = tag[q];
-            if (round == 0) atomicAdd(&s_cnt[g & 4095u], 1);
-            else if ((int)(g & 4095u) == lo) atomicAdd(&s_cnt[(g >> 12) & 4095u], 1);
+        for (int q0 = t; q0 < Q; q0 += 8 * kPlanThreads) {   // eight independent loads in flight per thread
+            unsigned g[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) g[e] = q0 + e * kPlanThreads < Q ? tag[q0 + e * kPlanThreads] : 0u;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (q0 + e * kPlanThreads >= Q) break;
+                if (round == 0) atomicAdd(&s_cnt[g[e] & 4095u], 1);
+                else if ((int)(g[e] & 4095u) == lo) atomicAdd(&s_cnt[(g[e] >> 12) & 4095u], 1);
+            }
         }
         __syncthreads();
         // bucket with the highest count, lowest index on ties: (count << 12) | (4095 - index)
@@ -72,8 +79,16 @@ __global__ __launch_bounds__(kPlanThreads) void pick_rep_kernel(const unsigned* 
             __syncthreads();
             if (n >= 2) {
                 const unsigned want = (unsigned)lo | ((unsigned)win << 12);
-                for (int q = t; q < Q; q += kPlanThreads)
-                    if ((tag[q] & 0xFFFFFFu) == want) { atomicMin(&s_rep, q); break; }
+                int found = Q;
+                for (int q0 = t; q0 < Q && found == Q; q0 += 8 * kPlanThreads) {
+                    unsigned g[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) g[e] = q0 + e * kPlanThreads < Q ? tag[q0 + e * kPlanThreads] : ~want;
+#pragma unroll
+                    for (int e = 7; e >= 0; --e)
+                        if (q0 + e * kPlanThreads < Q && (g[e] & 0xFFFFFFu) == want) found = q0 + e * kPlanThreads;
+                }
+                if (found < Q) atomicMin(&s_rep, found);
             }
             __syncthreads();
             if (t == 0) {
@@ -107,41 +122,57 @@ __global__ __launch_bounds__(256) void verify_rows_kernel(const uint16_t* __rest
     if (lane == 0) dup[row] = same ? 1 : 0;
 }
 
-// One block: Q is a few hundred thousand at most (B x 3 136).
-__global__ __launch_bounds__(kPlanThreads) void compact_kernel(const unsigned char* __restrict__ dup, const int* __restrict__ info, int Q,
-                                                               int* __restrict__ slot, int* __restrict__ rows, int* __restrict__ count)
+// Order-preserving compaction of the rows that are not repeats, 1 024 rows per block.  Every repeat comes AFTER the representative
+// (its first occurrence) and nothing before the representative is dropped, so the representative's slot is its own index.
+__device__ __forceinline__ int block_exclusive_keep(bool keep, int* s_wave, int& total)
 {
-    __shared__ int s_rep_slot;
-    __shared__ int s_cnt[kPlanThreads];
-    const int t = threadIdx.x;
-    const int per = (Q + kPlanThreads - 1) / kPlanThreads;
-    const int q0 = min(t * per, Q), q1 = min(q0 + per, Q);
-    const int rep = info[0];
-    if (t == 0) s_rep_slot = -1;
-    int n = 0;
-    for (int q = q0; q < q1; ++q) n += dup[q] ? 0 : 1;
-    s_cnt[t] = n;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long m = __ballot(keep);
+    const int before = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) s_wave[wave] = __popcll(m);
     __syncthreads();
-    // inclusive scan over the 1024 per-thread counts
-    for (int off = 1; off < kPlanThreads; off <<= 1) {
-        const int add = t >= off ? s_cnt[t - off] : 0;
-        __syncthreads();
-        s_cnt[t] += add;
-        __syncthreads();
+    int base = 0, sum = 0;
+#pragma unroll
+    for (int w = 0; w < kPlanThreads / 64; ++w) {
+        const int c = s_wave[w];
+        base += w < wave ? c : 0;
+        sum += c;
     }
-    int pos = s_cnt[t] - n;
-    for (int q = q0; q < q1; ++q) {
-        if (dup[q]) continue;
+    total = sum;
+    return base + before;
+}
+
+__global__ __launch_bounds__(kPlanThreads) void compact_count_kernel(const unsigned char* __restrict__ dup, int Q, int* __restrict__ sums)
+{
+    __shared__ int s_wave[kPlanThreads / 64];
+    const int q = blockIdx.x * kPlanThreads + threadIdx.x;
+    int total;
+    block_exclusive_keep(q < Q && !dup[q], s_wave, total);
+    if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(kPlanThreads) void compact_write_kernel(const unsigned char* __restrict__ dup, const int* __restrict__ sums,
+                                                                     const int* __restrict__ info, int Q, int* __restrict__ slot,
+                                                                     int* __restrict__ rows, int* __restrict__ count)
+{
+    __shared__ int s_wave[kPlanThreads / 64];
+    __shared__ int s_base;
+    if (threadIdx.x == 0) s_base = 0;
+    __syncthreads();
+    int part = 0;
+    for (int i = threadIdx.x; i < (int)blockIdx.x; i += kPlanThreads) part += sums[i];
+    if (part) atomicAdd(&s_base, part);
+    __syncthreads();
+    const int base = s_base;
+    const int q = blockIdx.x * kPlanThreads + threadIdx.x;
+    const bool in = q < Q, keep = in && !dup[q];
+    int total;
+    const int pos = base + block_exclusive_keep(keep, s_wave, total);
+    if (keep) {
         slot[q] = pos;
         rows[pos] = q;
-        if (q == rep) s_rep_slot = pos;
-        ++pos;
-    }
-    if (t == kPlanThreads - 1) count[0] = s_cnt[t];
-    __syncthreads();
-    const int rs = s_rep_slot;
-    for (int q = q0; q < q1; ++q)
-        if (dup[q]) slot[q] = rs;
+    } else if (in) slot[q] = info[0];
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) count[0] = base + total;
 }
 
 __global__ __launch_bounds__(256) void gather_rows_kernel(const uint16_t* __restrict__ q, const float* __restrict__ qsq,
@@ -166,8 +197,12 @@ __global__ __launch_bounds__(256) void expand_keys_kernel(const unsigned long lo
 
 }  // namespace
 
-// workspace: tag [Q] u32 | info [4] i32 | dup [Q] u8
-extern "C" size_t cmdiad_rows_dedup_workspace_bytes(int Q) { const size_t q = (size_t)(Q > 0 ? Q : 0); return q * 4 + 16 + ((q + 15) & ~(size_t)15); }
+// workspace: tag [Q] u32 | info [4] i32 | dup [Q] u8 (padded to 16) | sums [ceil(Q / 1024)] i32
+extern "C" size_t cmdiad_rows_dedup_workspace_bytes(int Q)
+{
+    const size_t q = (size_t)(Q > 0 ? Q : 0);
+    return q * 4 + 16 + ((q + 15) & ~(size_t)15) + (q + kPlanThreads - 1) / kPlanThreads * 4;
+}
 
 extern "C" int cmdiad_rows_dedup_plan(const uint16_t* q, const float* q_sqnorm, int Q, int D, void* workspace, int* slot, int* rows,
                                       int* count, uint16_t* q_compact, float* q_sqnorm_compact, cmdiad_stream_t stream)
@@ -183,7 +218,15 @@ extern "C" int cmdiad_rows_dedup_plan(const uint16_t* q, const float* q_sqnorm, 
     if (Q > 0) hipLaunchKernelGGL(hash_rows_kernel, dim3((Q + 3) / 4), dim3(256), 0, s, q, Q, D, tag);
     hipLaunchKernelGGL(pick_rep_kernel, dim3(1), dim3(kPlanThreads), 0, s, tag, Q, info);
     if (Q > 0) hipLaunchKernelGGL(verify_rows_kernel, dim3((Q + 3) / 4), dim3(256), 0, s, q, q_sqnorm, tag, info, Q, D, dup);
-    hipLaunchKernelGGL(compact_kernel, dim3(1), dim3(kPlanThreads), 0, s, dup, info, Q, slot, rows, count);
+    const int nb = (Q + kPlanThreads - 1) / kPlanThreads;
+    int* sums = (int*)(dup + (((size_t)(Q > 0 ? Q : 0) + 15) & ~(size_t)15));
+    if (Q > 0) {
+        hipLaunchKernelGGL(compact_count_kernel, dim3(nb), dim3(kPlanThreads), 0, s, dup, Q, sums);
+        hipLaunchKernelGGL(compact_write_kernel, dim3(nb), dim3(kPlanThreads), 0, s, dup, sums, info, Q, slot, rows, count);
+    } else if (hipMemsetAsync(count, 0, sizeof(int), s) != hipSuccess) {
+        cmdiad_set_error("cmdiad_rows_dedup_plan: hipMemsetAsync failed");
+        return CMDIAD_ERR_LAUNCH;
+    }
     if (Q > 0) hipLaunchKernelGGL(gather_rows_kernel, dim3((Q + 3) / 4), dim3(256), 0, s, q, q_sqnorm, rows, count, D, q_compact, q_sqnorm_compact);
     CMDIAD_CHECK_LAUNCH();
     return CMDIAD_OK;
