@@ -309,7 +309,7 @@ def dropin_b1(n=64, warm=16):
     return dict(value=round(n / dt, 2), unit="images/s", ms_per_image=round(dt / n * 1e3, 3),
                 what=f"DoubleRGBPointFeatures.predict called once per image as cmdiad_runner.py drives it, {n} images after {warm} "
                      f"warm-up, host-resident samples, bagel-sized libraries, 6 host threads; the drop-in defers the calls "
-                     f"into micro-batches of CMDIAD_PREDICT_BATCH={os.environ.get('CMDIAD_PREDICT_BATCH', '8')} (1 = strictly per call)")
+                     f"into micro-batches of CMDIAD_PREDICT_BATCH={os.environ.get('CMDIAD_PREDICT_BATCH', '16')} (1 = strictly per call)")
 
 
 def sharded_search(dev, group, rank, world, rows_list, iters=10, warm=3):

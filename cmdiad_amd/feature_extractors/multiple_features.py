@@ -56,12 +56,12 @@ class _MethodBase(Features):
 
     The five protocol calls keep the reference's signatures and order of effects, but the per-sample calls
     (add_sample_to_mem_bank / add_sample_to_late_fusion_mem_bank / predict) only QUEUE the sample: the queue is run through
-    the batched engine every CMDIAD_PREDICT_BATCH samples (default 8), at the next phase call (run_coreset /
+    the batched engine every CMDIAD_PREDICT_BATCH samples (default 16), at the next phase call (run_coreset /
     run_late_fusion / calculate_metrics) and whenever a result attribute is read.  The reference itself reads those results
     only at the phase boundaries (cmdiad_runner.py:44-92), every sample is independent of the others, and a
     sample's numbers do not depend on the batch it rode in (tests/test_gpu_engine.py::test_batch_invariance,
     test_gpu_predictor.py::test_dropin_micro_batching_is_invisible); at B = 1 the GPU is bound by a 2 ms single-CU FPS
-    chain and ~200 tiny launches per image, in a micro-batch of 8 those run side by side."""
+    chain and ~200 tiny launches per image, in a micro-batch of 16 those run side by side."""
 
     patch_xyz_lib = _lazy_result("patch_xyz_lib", "fit")
     patch_rgb_lib = _lazy_result("patch_rgb_lib", "fit")
@@ -78,7 +78,7 @@ class _MethodBase(Features):
 
     # ------------------------------------------------------------------ deferred micro-batches
     def _micro_batch(self):
-        return max(1, int(os.environ.get("CMDIAD_PREDICT_BATCH", "8")))
+        return max(1, int(os.environ.get("CMDIAD_PREDICT_BATCH", "16")))
 
     def _defer(self, kind, item):
         q = self.__dict__.setdefault("_pending", {"fit": [], "late": [], "predict": []})

@@ -276,7 +276,7 @@ def test_method_classes_vs_reference_golden(tag, golden, weights):
 
 def test_dropin_micro_batching_is_invisible(weights, monkeypatch):
     """The drop-in classes defer add_sample_to_mem_bank / add_sample_to_late_fusion_mem_bank / predict into micro-batches
-    (CMDIAD_PREDICT_BATCH, default 8).  Whatever the batch size -- 1 = the reference's strictly-per-call behaviour -- the
+    (CMDIAD_PREDICT_BATCH, default 16).  Whatever the batch size -- 1 = the reference's strictly-per-call behaviour -- the
     libraries, the late-fusion rows and every prediction are the same numbers, results appear in call order, and reading a
     result attribute mid-phase shows exactly the calls made so far."""
     from cmdiad_amd.feature_extractors import multiple_features as mf
