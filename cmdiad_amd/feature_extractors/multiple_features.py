@@ -35,6 +35,40 @@ def _side(patch):
     return (s, s)
 
 
+class _PendingScores:
+    """Scores of a micro-batch whose device work and device->host copy are queued but not yet waited for: `result()` (also
+    indexing / iteration) waits and builds the per-sample (s [1,k], s_map [gt*gt,k]) pairs.  _MethodBase._flush keeps ONE such batch in
+    flight, so the host-side work of a batch (sklearn's score_samples, the result lists) runs beside the next batch's GPU work."""
+
+    def __init__(self, host, event, keep, B, k, gt, lam_s, lam_map):
+        self._host, self._event, self._keep = host, event, keep
+        self._B, self._k, self._gt, self._lam_s, self._lam_map = B, k, gt, lam_s, lam_map
+        self._out = None
+
+    def result(self):
+        if self._out is None:
+            self._event.synchronize()
+            host, B, k, gt = self._host.numpy(), self._B, self._k, self._gt
+            out = []
+            for b in range(B):
+                s = torch.tensor([[float(self._lam_s[i] * host[B * k * gt * gt + b * k + i]) for i in range(k)]])
+                # numpy for the host-side products: torch's CPU intra-op pool (one thread per core by default) stalls for
+                # 80 ms every few calls on 50 176-element tensors on a 128-core host; same float32 arithmetic either way
+                cols = [np.float32(self._lam_map[i]) * host[(b * k + i) * gt * gt:(b * k + i + 1) * gt * gt] for i in range(k)]
+                out.append((s, torch.from_numpy(np.stack(cols, axis=1))))
+            self._out, self._keep = out, None
+        return self._out
+
+    def __getitem__(self, i):
+        return self.result()[i]
+
+    def __iter__(self):
+        return iter(self.result())
+
+    def __len__(self):
+        return self._B
+
+
 def _lazy_result(name, kind):
     """Result attribute of the reference (a plain list there) that FLUSHES the deferred micro-batch of its phase before it is
     read, so an observer sees exactly what the reference's eager loop would have appended by then."""
@@ -84,27 +118,46 @@ class _MethodBase(Features):
         q = self.__dict__.setdefault("_pending", {"fit": [], "late": [], "predict": []})
         q[kind].append(item)
         if len(q[kind]) >= self._micro_batch():
-            self._flush(kind)
+            self._flush(kind, drain=False)
 
-    def _flush(self, kind):
+    def _flush(self, kind, drain=True):
+        """Run the queued samples of a phase.  Scoring phases keep one micro-batch IN FLIGHT: its device work is queued, then the
+        previous batch is completed on the host (score_samples, result lists) while the GPU works; `drain` (every read of a result
+        attribute and every phase call) completes the batch just queued as well, so an observer never sees a partial list."""
         q = self.__dict__.get("_pending")
-        if not q or not q[kind]:
+        flight = self.__dict__.setdefault("_inflight", {})
+        if (not q or not q[kind]) and kind not in flight:
             return
-        items, q[kind] = q[kind], []
+        items = []
+        if q and q[kind]:
+            items, q[kind] = q[kind], []
         self.__dict__["_flushing"] = True
         try:
             if kind == "fit":
-                self._fit_batch(items)
-            elif kind == "late":
-                for s, s_map in self._score_batch(items, test=False):
-                    self.s_lib.append(s)
-                    self.s_map_lib.append(s_map)
-            else:
-                scores = self._score_batch([it[0] for it in items], test=True)
-                for (s, s_map), (_, mask, label, rgb_path) in zip(scores, items):
-                    self._record(s, s_map, mask, label, rgb_path)
+                if items:
+                    self._fit_batch(items)
+                return
+            new = None
+            if items:
+                new = (self._score_batch(items if kind == "late" else [it[0] for it in items], test=(kind == "predict")), items)
+            if kind in flight:
+                self._complete(kind, *flight.pop(kind))
+            if new is not None:
+                if drain:
+                    self._complete(kind, *new)
+                else:
+                    flight[kind] = new
         finally:
             self.__dict__["_flushing"] = False
+
+    def _complete(self, kind, scores, items):
+        if kind == "late":
+            for s, s_map in scores:
+                self.s_lib.append(s)
+                self.s_map_lib.append(s_map)
+        else:
+            for (s, s_map), (_, mask, label, rgb_path) in zip(scores, items):
+                self._record(s, s_map, mask, label, rgb_path)
 
     def add_sample_to_mem_bank(self, sample, class_name=None):
         self.class_name = class_name
@@ -157,7 +210,8 @@ class _MethodBase(Features):
     def _score_columns(self, columns):
         """columns: [(patch [B,Q,D] raw, mean, std, modal, lambda_s, lambda_map)] in the reference's column order ->
         per sample (s [1,k], s_map [gt*gt, k]) exactly as the reference stacks them (e.g. multiple_features.py:985-992).
-        The device work of every column is queued first, then ONE blur launch (a block per map) and ONE device->host copy."""
+        The device work of every column is queued first, then ONE blur launch (a block per map) and ONE asynchronous
+        device->host copy: the return value is a _PendingScores (list-like; waits when first read)."""
         from .. import ops
         gt = self.gt_size
         rs = []
@@ -168,15 +222,12 @@ class _MethodBase(Features):
         B, k = columns[0][0].shape[0], len(columns)
         maps = ops.blur8_maps(torch.stack([r["s_map_pre"] for r in rs], 1).reshape(B * k, gt, gt).contiguous(),
                               float(self.blur.radius))
-        host = torch.cat([maps.reshape(-1), torch.stack([r["s"] for r in rs], 1).reshape(-1).float()]).cpu().numpy()
-        out = []
-        for b in range(B):
-            s = torch.tensor([[float(columns[i][4] * host[B * k * gt * gt + b * k + i]) for i in range(k)]])
-            # numpy for the host-side products: torch's CPU intra-op pool (one thread per core by default) stalls for
-            # 80 ms every few calls on 50 176-element tensors on a 128-core host; same float32 arithmetic either way
-            cols = [np.float32(columns[i][5]) * host[(b * k + i) * gt * gt:(b * k + i + 1) * gt * gt] for i in range(k)]
-            out.append((s, torch.from_numpy(np.stack(cols, axis=1))))
-        return out
+        dev_out = torch.cat([maps.reshape(-1), torch.stack([r["s"] for r in rs], 1).reshape(-1).float()])
+        host = torch.empty(dev_out.shape, dtype=dev_out.dtype, pin_memory=True)
+        host.copy_(dev_out, non_blocking=True)
+        event = torch.cuda.Event()
+        event.record()
+        return _PendingScores(host, event, dev_out, B, k, gt, [c[4] for c in columns], [c[5] for c in columns])
 
     def _record(self, s, s_map, mask, label, rgb_path):
         # from_numpy, not torch.tensor(): no 50 176-element copy through torch's CPU thread pool (see _score_columns)

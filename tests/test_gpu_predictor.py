@@ -305,8 +305,14 @@ def test_dropin_micro_batching_is_invisible(weights, monkeypatch):
         m.seg_fuser = linear_model.SGDOneClassSVM(random_state=42, nu=0.5, max_iter=1000).fit(rs.rand(4096, 2))
         for k, (rgb, pc, mask) in enumerate(tests):
             m.predict((rgb, pc, pc), mask, np.array([int(mask.any())]), [f"t{k}.png"])
+            if k == 1 and batch == "2":
+                # a full micro-batch is queued on the GPU but not waited for (one batch stays in flight so that its host-side
+                # completion runs beside the next batch's device work): nothing recorded yet ...
+                assert "predict" in m.__dict__["_inflight"] and len(m.__dict__["_lz_image_preds"]) == 0
             if k == 2:
+                # ... and reading a result attribute completes it and the partial batch behind it
                 assert len(m.image_preds) == 3 and [n[0] for n in m.img_name] == ["t0.png", "t1.png", "t2.png"]
+                assert "predict" not in m.__dict__["_inflight"]
         m.calculate_metrics()
         assert [n[0] for n in m.img_name] == [f"t{k}.png" for k in range(5)]
         out[batch] = (m.patch_xyz_lib.cpu(), m.patch_rgb_lib.cpu(), s_lib, np.concatenate(m.image_preds).ravel(), np.stack(m.predictions),
