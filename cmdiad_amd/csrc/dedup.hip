@@ -2,7 +2,7 @@
 //
 // The 56 x 56 patch grid of a sample (multiple_features.py:216, features.py:169-184) has one row per patch whether or not any point
 // of the cloud lies under it: every patch without a foreground pixel is the SAME vector -- zeros pooled, then (0 - mean) / std, or
-// the hallucination network's image of that vector (multiple_features.py:596) -- and the reference computes its distance to every
+// the hallucination network's image of that vector (multiple_features.py:351) -- and the reference computes its distance to every
 // library row again for each of them (half of the 3 136 patches of a typical MVTec 3D-AD sample and of the bench's synthetic
 // clouds).  The nearest-row search is a pure function of one query row, so the most repeated row of a batch is searched once:
 //

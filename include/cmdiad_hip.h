@@ -252,7 +252,7 @@ int cmdiad_l2_min_keys_counted(const uint16_t* q, const float* q_sqnorm, const i
 /* Exact removal of repeated query rows in front of the search.  Every patch of the 56 x 56 grid without a foreground pixel under
  * it is the same vector ((0 - mean) / std in every column; features.py:169-184, multiple_features.py:976-977) and the reference's
  * torch.cdist (features.py:186-190) searches the library again for each of them (likewise the hallucinated features of those
- * patches, multiple_features.py:596).  The MOST REPEATED row of the batch is found by a row hash; a row repeats its first
+ * patches, multiple_features.py:351).  The MOST REPEATED row of the batch is found by a row hash; a row repeats its first
  * occurrence iff hash and squared-norm bits are equal AND all D elements compare equal -- then everything cmdiad_l2_min_keys reads
  * for it is identical and so is its key (a hash collision costs a comparison, never an answer).  slot[Q] (row of the compacted set
  * that answers for q), rows[Q] (compacted -> original, first *count entries), count[1], q_compact [Q,D] / q_sqnorm_compact [Q]

@@ -74,7 +74,7 @@ def test_plan_and_compacted_search_match_the_full_search(Q, n_const, dtype):
 
 
 def test_repeated_row_need_not_be_constant():
-    """The hallucinated features of the background patches (multiple_features.py:596) repeat a NON-constant row."""
+    """The hallucinated features of the background patches (multiple_features.py:351) repeat a NON-constant row."""
     Q, D = 3000, 768
     g = torch.Generator().manual_seed(3)
     x = torch.randn(Q, D, generator=g)
