@@ -70,6 +70,27 @@ def test_l2_search_full_size_sampled_brute_force():
     assert torch.equal(mi2.cpu(), torch.arange(4096)) and float(mv2.max()) == 0.0
 
 
+def test_deduplicated_search_full_size_equals_the_search_of_every_row():
+    """Bench-size query set with the bench's structure (46 % of the rows are one repeated background row, csrc/dedup.hip): the
+    compacted search + key expansion gives the keys of the search over all 100 352 rows, bit for bit."""
+    Q, Nb, D = B * 3136, 76518, 768
+    g = torch.Generator().manual_seed(78)
+    bank = synth_bank(Nb, D, 4321).to(DEV)
+    q = torch.randn(Q, D, generator=g)
+    back = torch.rand(Q, generator=g) < 0.46
+    q[back] = (0.0 - 0.013) / 0.21                      # (0 - mean) / std in every column
+    n_back = int(back.sum())
+    b16, _, bsq = ops.normalize_cast(bank)
+    q16, _, qsq = ops.normalize_cast(q.to(DEV))
+    full = ops.l2_min_keys(q16, qsq, b16, bsq, ops.new_keys(Q, DEV))
+    plan = ops.rows_dedup_plan(q16, qsq)
+    assert int(plan.count.item()) == Q - n_back + 1
+    first = int(torch.nonzero(back)[0])
+    assert int(plan.slot[first]) == first and bool((plan.slot[back.to(DEV)] == first).all())
+    kc = ops.l2_min_keys_counted(plan.q16, plan.q_sq, plan.count, b16, bsq, ops.new_keys(Q, DEV))
+    assert torch.equal(ops.keys_expand(kc, plan.slot, torch.empty_like(full)), full)
+
+
 def test_blur_properties_full_batch():
     maps = torch.rand(64, 224, 224, device=DEV) * 5.0
     out = ops.blur8_maps(maps, 4.0)
