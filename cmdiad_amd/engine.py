@@ -94,14 +94,15 @@ def score_patches(patch32, bank, dims, gt_size=224, group=None):
     dev = patch32.device
     flat = patch32.reshape(B * Q, D)
     q16, _, qsq = ops.normalize_cast(flat)
-    if group is None and os.environ.get("CMDIAD_DEDUP", "1") != "0":
-        # the rows of the patches without a foreground pixel repeat one vector: searched once (csrc/dedup.hip), keys identical
-        plan = ops.rows_dedup_plan(q16, qsq)
-        kc = ops.l2_min_keys_counted(plan.q16, plan.q_sq, plan.count, bank.bf16, bank.sqnorm, ops.new_keys(B * Q, dev), bank.row_offset)
-        return score_patches_from_keys(patch32, ops.keys_expand(kc, plan.slot, torch.empty_like(kc)), bank, dims, gt_size)
     q_all, s_all = gather_queries(q16, qsq, group)
     keys = ops.new_keys(q_all.shape[0], dev)
-    ops.l2_min_keys(q_all, s_all, bank.bf16, bank.sqnorm, keys, bank.row_offset)
+    if os.environ.get("CMDIAD_DEDUP", "1") != "0":
+        # the rows of the patches without a foreground pixel repeat one vector: searched once (csrc/dedup.hip), keys identical
+        plan = ops.rows_dedup_plan(q_all, s_all)
+        kc = ops.l2_min_keys_counted(plan.q16, plan.q_sq, plan.count, bank.bf16, bank.sqnorm, keys, bank.row_offset)
+        keys = ops.keys_expand(kc, plan.slot, torch.empty_like(kc))
+    else:
+        ops.l2_min_keys(q_all, s_all, bank.bf16, bank.sqnorm, keys, bank.row_offset)
     keys = merge_shard_keys(keys, group)
     if group is not None:
         keys = keys[bank.rank * B * Q:(bank.rank + 1) * B * Q].contiguous()

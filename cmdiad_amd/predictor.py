@@ -98,7 +98,7 @@ class BatchPredictor:
         self.sets = None
         self.static = {}
         # exact removal of the repeated background rows in front of the xyz search (csrc/dedup.hip); CMDIAD_DEDUP=0 searches every row
-        self.dedup = os.environ.get("CMDIAD_DEDUP", "1") != "0" and group is None
+        self.dedup = os.environ.get("CMDIAD_DEDUP", "1") != "0"
         self.live_rows = torch.zeros((1,), dtype=torch.int64, device=dev)   # rows actually searched, summed over the xyz searches
         self.xyz_searches = 0
         self.inputs = [self._new_inputs() for _ in range(2 if use_graph else 1)]
@@ -163,7 +163,7 @@ class BatchPredictor:
                 k = self.static[f"keys_{name}_{buf}"] = torch.empty((q_all.shape[0],), dtype=torch.int64, device=q.device)
             if self.dedup:
                 # patches without a foreground pixel are one and the same row (and so are their hallucinated features in the MTFI
-                # workload): searched once, the key copied to all of them
+                # workload; with a sharded library also across the ranks' gathered queries): searched once, the key copied to all
                 plan = self.static[f"plan_{name}_{buf}"] = ops.rows_dedup_plan(q_all, s_all, self.static.get(f"plan_{name}_{buf}"))
                 kc = self.static.get(f"keysc_{name}_{buf}")
                 if kc is None or kc.shape[0] != q_all.shape[0]:
@@ -172,16 +172,14 @@ class BatchPredictor:
                 with self.timers.get(name, _NoTimer()):
                     ops.l2_min_keys_counted(plan.q16, plan.q_sq, plan.count, bank.bf16, bank.sqnorm, kc, bank.row_offset)
                 ops.keys_expand(kc, plan.slot, k)
-                if name == "xyz":
-                    self.live_rows += plan.count
-                    self.xyz_searches += 1
-                keys[name] = k
-                continue
-            k.fill_(eng.KEY_EMPTY)
-            with self.timers.get(name, _NoTimer()):
-                ops.l2_min_keys(q_all, s_all, bank.bf16, bank.sqnorm, k, bank.row_offset)
+                live = plan.count
+            else:
+                k.fill_(eng.KEY_EMPTY)
+                with self.timers.get(name, _NoTimer()):
+                    ops.l2_min_keys(q_all, s_all, bank.bf16, bank.sqnorm, k, bank.row_offset)
+                live = q_all.shape[0]
             if name == "xyz":
-                self.live_rows += q_all.shape[0]
+                self.live_rows += live
                 self.xyz_searches += 1
             k = eng.merge_shard_keys(k, self.group)
             keys[name] = k[bank.rank * B * Q:(bank.rank + 1) * B * Q] if self.group is not None else k
