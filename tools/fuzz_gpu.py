@@ -196,11 +196,44 @@ def case_ocsvm(rs):
     assert dev.n_iter_ == ref.n_iter_ and np.array_equal(dev.coef_, ref.coef_) and np.array_equal(dev.offset_, ref.offset_), ("ocsvm", n, F, nu, seed)
 
 
+def case_dedup(rs):
+    """Random sizes, repeat fractions, repeated-row kinds (constant / arbitrary / none / everything) and both 16-bit types: the
+    compacted search + key expansion equals the search of every row, the plan is valid."""
+    Q, Nb, D = int(rs.randint(1, 6000)), int(rs.randint(1, 3000)), 64 * int(rs.randint(1, 13))
+    dtype = torch.float16 if rs.rand() < 0.5 else torch.bfloat16
+    x = torch.from_numpy(rs.randn(Q, D).astype(np.float32))
+    kind = int(rs.randint(4))
+    frac = float(rs.rand())
+    sel = torch.from_numpy(rs.rand(Q) < frac)
+    if kind == 0:
+        x[sel] = float(rs.randn())
+    elif kind == 1:
+        x[sel] = torch.from_numpy(rs.randn(D).astype(np.float32))
+    elif kind == 2:
+        x[:] = 0.25
+    second = kind != 3 and rs.rand() < 0.5 and Q > 8
+    if second:      # a second, smaller group of repeats: searched row by row
+        x[torch.from_numpy(rs.randint(0, Q, 3))] = -1.5
+    q16, _, qsq = ops.normalize_cast(x.to(DEV), dtype=dtype)
+    b16, _, bsq = ops.normalize_cast(torch.from_numpy(rs.randn(Nb, D).astype(np.float32)).to(DEV), dtype=dtype)
+    full = ops.l2_min_keys(q16, qsq, b16, bsq, ops.new_keys(Q, DEV))
+    plan = ops.rows_dedup_plan(q16, qsq)
+    n = int(plan.count.item())
+    rows, slot = plan.rows[:n].cpu().numpy(), plan.slot.cpu().numpy()
+    assert 1 <= n <= Q and (np.diff(rows) > 0).all() and np.array_equal(slot[rows], np.arange(n)), ("dedup plan", Q, D, kind)
+    qi = q16.view(torch.int16).cpu().numpy()
+    assert (qi == qi[rows[slot]]).all() and (qsq.cpu().numpy().view(np.uint32) == qsq.cpu().numpy().view(np.uint32)[rows[slot]]).all()
+    kc = ops.l2_min_keys_counted(plan.q16, plan.q_sq, plan.count, b16, bsq, ops.new_keys(Q, DEV))
+    assert torch.equal(ops.keys_expand(kc, plan.slot, torch.empty_like(full)), full), ("dedup keys", Q, Nb, D, kind, str(dtype))
+    if kind == 2:
+        assert n == 1 if not second else n <= 4
+
+
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     rs = np.random.RandomState(seed)
-    cases = [case_fps_knn, case_gemm, case_l2, case_attention, case_blur, case_fps_big, case_l2_big, case_encoder, case_ocsvm]
+    cases = [case_fps_knn, case_gemm, case_l2, case_attention, case_blur, case_fps_big, case_l2_big, case_encoder, case_ocsvm, case_dedup]
     counts = {c.__name__: 0 for c in cases}
     t0 = time.time()
     while time.time() - t0 < budget:
