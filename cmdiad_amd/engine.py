@@ -165,14 +165,17 @@ class Engine:
         return self._pm() if callable(self._pm) else self._pm
 
     def extract(self, rgb, organized_pc=None, xyz=None, nz=None, want_rgb=True, want_xyz=True, n_max=None,
-                side_stream=None, rgb_hook=None):
+                side_stream=None, rgb_hook=None, xyz_hook=None):
         """rgb [B,3,S,S] f32 cuda; the cloud either organised ([B,3,S,S], zeros = background) or already
         unorganised (xyz [B,N,3] + nz [B,N] int32 pixel indices, B == 1 or equal N).
         With `side_stream` the point-cloud branch (unorganise, FPS, kNN-group, Point-MAE, 3-NN) runs on that
         HIP stream concurrently with the ViT on the current stream: FPS is a latency-bound chain on B
         workgroups (B of 256 CUs), the ViT GEMMs fill the rest of the chip.  `rgb_hook(ex)` (optional) runs on the current
         stream right after the ViT and BEFORE the point-cloud branch is joined: work that needs only the rgb tokens (e.g. the
-        rgb library search) then runs beside the rest of that branch."""
+        rgb library search) then runs beside the rest of that branch.  `xyz_hook(ex)` (optional) runs at the END of the
+        point-cloud branch, on its stream: work that needs only that branch (patch pooling, the 16-bit queries, the row
+        de-duplication plan) then runs beside the ViT's last layers and the rgb library search instead of after them; it returns
+        the tensors it allocated (they are consumed on the current stream after the join)."""
         ex = Extraction()
         ex.size = self.size
         if not want_xyz:
@@ -192,12 +195,13 @@ class Engine:
                 ex.pix2pt.scatter_(1, nz.long(), torch.arange(N, dtype=torch.int32, device=xyz.device).expand(B, N))
             ex.xyz_feats, ex.center, ex.ori_idx, ex.center_idx = self.pm.forward(ex.xyz, ex.n_valid)
             ex.idx3, ex.w3 = ops.interp3nn(ex.xyz, ex.center, ex.n_valid)
+            hooked = list(xyz_hook(ex) or ()) if xyz_hook is not None else []
         ex.rgb_tokens = self.vit.forward_tokens(rgb) if want_rgb else None
         if rgb_hook is not None and want_rgb:
             rgb_hook(ex)
         if side_stream is not None:
             cur.wait_stream(side_stream)
-            for t in (ex.xyz, ex.nz, ex.pix2pt, ex.n_valid, ex.xyz_feats, ex.center, ex.ori_idx, ex.center_idx, ex.idx3, ex.w3):
+            for t in (ex.xyz, ex.nz, ex.pix2pt, ex.n_valid, ex.xyz_feats, ex.center, ex.ori_idx, ex.center_idx, ex.idx3, ex.w3, *hooked):
                 if t is not None:
                     t.record_stream(cur)  # allocated on the side stream, consumed on the current one
         return ex

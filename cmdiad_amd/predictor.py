@@ -139,13 +139,27 @@ class BatchPredictor:
                 ops.l2_min_keys(q16, qsq, bank.bf16, bank.sqnorm, k, bank.row_offset)
                 early["rgb_keys"] = k
 
-        ex = e.extract(inp["rgb"], inp["pcs"], n_max=self.n_max, side_stream=self.side, rgb_hook=rgb_branch)
-        xyz_q = e.xyz_patch(ex, 56, s["xyz_mean"], 1.0 / s["xyz_std"])        # a9 + a11 fused
-        B, Q, D = xyz_q.shape
-        q16, _, qsq = ops.normalize_cast(xyz_q.reshape(B * Q, D))
-        out = {"xyz": (xyz_q, q16, qsq), "rgb": early["rgb"]}
-        if "rgb_keys" in early:
-            out["rgb_keys"] = early["rgb_keys"]
+        def xyz_branch(ex):
+            # the tail of the point-cloud branch, on ITS stream: patch pooling, 16-bit queries and the row de-duplication plan need
+            # nothing from the ViT and run beside its last layers and the rgb library search (0.65 ms that used to follow them)
+            xyz_q = e.xyz_patch(ex, 56, s["xyz_mean"], 1.0 / s["xyz_std"])        # a9 + a11 fused
+            B, Q, D = xyz_q.shape
+            q16, _, qsq = ops.normalize_cast(xyz_q.reshape(B * Q, D))
+            early["xyz"] = (xyz_q, q16, qsq)
+            made = [xyz_q, q16, qsq]
+            if self.dedup and self.group is None:
+                plan = early["xyz_plan"] = ops.rows_dedup_plan(q16, qsq)
+                made += [plan.slot, plan.rows, plan.count, plan.q16, plan.q_sq, plan.work]
+            return made
+
+        if os.environ.get("CMDIAD_XYZ_TAIL_SIDE", "1") != "0":
+            e.extract(inp["rgb"], inp["pcs"], n_max=self.n_max, side_stream=self.side, rgb_hook=rgb_branch, xyz_hook=xyz_branch)
+        else:   # A/B: the tail of the point-cloud branch after the join, behind the rgb search
+            xyz_branch(e.extract(inp["rgb"], inp["pcs"], n_max=self.n_max, side_stream=self.side, rgb_hook=rgb_branch))
+        out = {"xyz": early["xyz"], "rgb": early["rgb"]}
+        for k in ("rgb_keys", "xyz_plan"):
+            if k in early:
+                out[k] = early[k]
         return out
 
     # ---- search: eager (HIP events around the distance GEMM; RCCL collectives when sharded)
@@ -164,7 +178,9 @@ class BatchPredictor:
             if self.dedup:
                 # patches without a foreground pixel are one and the same row (and so are their hallucinated features in the MTFI
                 # workload; with a sharded library also across the ranks' gathered queries): searched once, the key copied to all
-                plan = self.static[f"plan_{name}_{buf}"] = ops.rows_dedup_plan(q_all, s_all, self.static.get(f"plan_{name}_{buf}"))
+                plan = qs.get(f"{name}_plan")    # made in stage 1 already (unsharded library: beside the rgb search)
+                if plan is None:
+                    plan = self.static[f"plan_{name}_{buf}"] = ops.rows_dedup_plan(q_all, s_all, self.static.get(f"plan_{name}_{buf}"))
                 kc = self.static.get(f"keysc_{name}_{buf}")
                 if kc is None or kc.shape[0] != q_all.shape[0]:
                     kc = self.static[f"keysc_{name}_{buf}"] = torch.empty((q_all.shape[0],), dtype=torch.int64, device=q.device)
