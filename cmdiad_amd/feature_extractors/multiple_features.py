@@ -182,11 +182,22 @@ class _MethodBase(Features):
         """Device-resident extraction of a micro-batch (engine.Engine.extract; the zero-pixel compaction of
         organized_pc_to_unorganized_pc_no_zeros runs in cmdiad_unorganize, bit-identical order)."""
         dev = self.device
-        rgb = torch.cat([s[0] for s in samples]).to(dev, torch.float32) if want_rgb else None
+
+        def staged(tensors):
+            # gathered straight into pinned memory and copied asynchronously: a copy from pageable memory makes the host wait for
+            # everything queued before it, i.e. for the micro-batch still in flight (_flush), and the GPU then waits for the host
+            host = torch.empty((len(tensors), *tensors[0].shape[1:]), dtype=torch.float32, pin_memory=True)
+            if all(t.dtype == torch.float32 and t.device.type == "cpu" for t in tensors):
+                torch.cat(tensors, out=host)
+            else:
+                host.copy_(torch.cat([t.cpu() for t in tensors]))
+            return host, host.to(dev, non_blocking=True)
+
+        rgb = staged([s[0] for s in samples])[1] if want_rgb else None
         if not want_xyz:
             with torch.no_grad():
                 return self._engine.extract(rgb, want_xyz=False)
-        pcs = torch.cat([s[1] for s in samples])
+        pcs, pcs_dev = staged([s[1] for s in samples])
         flat = pcs.numpy().reshape(len(samples), 3, -1)   # numpy: no 150 k-element op through torch's CPU thread pool
         counts = np.count_nonzero(np.all(flat != 0, axis=1), axis=1)
         if counts.min() < self.args.group_size:
@@ -196,7 +207,7 @@ class _MethodBase(Features):
         if side is None:
             side = self.__dict__["_side_stream"] = torch.cuda.Stream()
         with torch.no_grad():
-            return self._engine.extract(rgb, pcs.to(dev, torch.float32), want_rgb=want_rgb, n_max=int(counts.max()),
+            return self._engine.extract(rgb, pcs_dev, want_rgb=want_rgb, n_max=int(counts.max()),
                                         side_stream=side if want_rgb else None)
 
     def _coreset(self, lib, name):
