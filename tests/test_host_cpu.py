@@ -329,3 +329,38 @@ def test_bench_traffic_is_tied_to_the_profiled_kernel_source(tmp_path, monkeypat
         fh.write(b"\n")
     monkeypatch.setattr(bench, "__file__", str(root / "bench.py"))
     assert bench.profiled_traffic()["traffic"] is None
+
+
+def test_fast_score_samples_is_sklearns():
+    """The drop-in's validation-free form of SGDOneClassSVM.score_samples (multiple_features._score_samples; features.py:352-358
+    fits the fusers, multiple_features.py:1005-1006 scores with them) returns scikit-learn's own bits, for float32 maps as the
+    method classes pass them, float64, non-contiguous input, and falls back to the method for anything it does not cover."""
+    import numpy as np
+    from sklearn import linear_model
+    from cmdiad_amd.feature_extractors.multiple_features import _score_samples
+    rs = np.random.RandomState(3)
+    for n_fit in (64, 4096):
+        f = linear_model.SGDOneClassSVM(random_state=42, nu=0.5, max_iter=1000).fit(rs.rand(n_fit, 2) * 3.0)
+        for x in (rs.rand(50176, 2).astype(np.float32) * 5, rs.randn(1, 2).astype(np.float32), rs.rand(777, 2),
+                  np.asfortranarray(rs.rand(1000, 2).astype(np.float32)), rs.rand(2000, 4).astype(np.float32)[:, ::2]):
+            want = f.score_samples(x)
+            got = _score_samples(f, x)
+            assert got.dtype == want.dtype and got.shape == want.shape and np.array_equal(got, want)
+
+    class Other:
+        def score_samples(self, x):
+            return "own method"
+    assert _score_samples(Other(), np.zeros((2, 2), np.float32)) == "own method"
+    f = linear_model.SGDOneClassSVM(random_state=0).fit(rs.rand(32, 2))
+    bad = np.array([[np.nan, 1.0]], np.float32)
+    try:
+        f.score_samples(bad)
+        raised = False
+    except ValueError:
+        raised = True
+    try:
+        _score_samples(f, bad)
+        raised2 = False
+    except ValueError:
+        raised2 = True
+    assert raised == raised2
