@@ -196,6 +196,30 @@ def case_ocsvm(rs):
     assert dev.n_iter_ == ref.n_iter_ and np.array_equal(dev.coef_, ref.coef_) and np.array_equal(dev.offset_, ref.offset_), ("ocsvm", n, F, nu, seed)
 
 
+def case_unorganize(rs):
+    """Random image sizes (chunk counts around the look-ahead of 7, ragged last chunks), fill fractions, zero coordinates in single
+    planes, n_max below / at / above the count: compaction order, truncation, pixel -> point map."""
+    B, H, W = int(rs.randint(1, 5)), int(rs.randint(1, 140)), int(rs.randint(1, 140))
+    HW = H * W
+    pc = rs.randn(B, 3, H, W).astype(np.float32)
+    keep = rs.rand(B, 1, H, W) < rs.rand()
+    pc = pc * keep
+    pc[:, int(rs.randint(3))][rs.rand(B, H, W) < 0.05] = 0.0          # one zero coordinate drops the pixel (multiple_features.py:16)
+    valid = np.all(pc.reshape(B, 3, HW) != 0, axis=1)
+    counts = valid.sum(1)
+    n_max = int(rs.choice([max(1, counts.max() // 2), max(1, counts.max()), HW]))
+    xyz, nz, pix2pt, nv = ops.unorganize(torch.from_numpy(pc).to(DEV), n_max)
+    for b in range(B):
+        idx = np.nonzero(valid[b])[0]
+        n = min(len(idx), n_max)
+        assert int(nv[b]) == n, ("unorganize count", B, H, W, n_max)
+        assert np.array_equal(nz[b, :n].cpu().numpy(), idx[:n]), ("unorganize order", B, H, W, n_max)
+        assert np.array_equal(xyz[b, :n].cpu().numpy(), pc[b].reshape(3, HW).T[idx[:n]]), ("unorganize xyz", B, H, W, n_max)
+        want = np.full(HW, -1, np.int32)
+        want[idx[:n]] = np.arange(n)
+        assert np.array_equal(pix2pt[b].cpu().numpy(), want), ("unorganize pix2pt", B, H, W, n_max)
+
+
 def case_dedup(rs):
     """Random sizes, repeat fractions, repeated-row kinds (constant / arbitrary / none / everything) and both 16-bit types: the
     compacted search + key expansion equals the search of every row, the plan is valid."""
@@ -233,7 +257,7 @@ def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     rs = np.random.RandomState(seed)
-    cases = [case_fps_knn, case_gemm, case_l2, case_attention, case_blur, case_fps_big, case_l2_big, case_encoder, case_ocsvm, case_dedup]
+    cases = [case_fps_knn, case_gemm, case_l2, case_attention, case_blur, case_fps_big, case_l2_big, case_encoder, case_ocsvm, case_dedup, case_unorganize]
     counts = {c.__name__: 0 for c in cases}
     t0 = time.time()
     while time.time() - t0 < budget:
