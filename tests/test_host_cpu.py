@@ -364,3 +364,44 @@ def test_fast_score_samples_is_sklearns():
     except ValueError:
         raised2 = True
     assert raised == raised2
+
+
+def test_dropin_keeps_one_micro_batch_in_flight_and_drains_on_read(monkeypatch):
+    """Host logic of the deferred micro-batches (multiple_features._MethodBase._defer / _flush / _complete), without a GPU: a full
+    batch is scored (queued) at once but recorded only when the next one has been queued; reading a result attribute or a phase
+    call records everything, in call order."""
+    from cmdiad_amd.feature_extractors import multiple_features as mf
+    monkeypatch.setenv("CMDIAD_PREDICT_BATCH", "2")
+    scored = []
+
+    class Fake(mf._MethodBase):
+        def __init__(self):
+            for name in ("s_lib", "s_map_lib", "image_preds", "img_name"):
+                self.__dict__["_lz_" + name] = []
+
+        def _score_batch(self, samples, test=False):
+            scored.append(list(samples))
+            return [(("s", x), ("map", x)) for x in samples]
+
+        def _record(self, s, s_map, mask, label, rgb_path):
+            self.image_preds.append(s)
+            self.img_name.append(rgb_path)
+
+    m = Fake()
+    m.predict("a", None, 0, "a.png")
+    assert scored == [] and m.__dict__["_lz_image_preds"] == []
+    m.predict("b", None, 0, "b.png")
+    assert scored == [["a", "b"]] and m.__dict__["_lz_image_preds"] == [] and "predict" in m.__dict__["_inflight"]
+    m.predict("c", None, 0, "c.png")
+    m.predict("d", None, 0, "d.png")
+    # the second batch has been queued, the first one recorded meanwhile
+    assert scored == [["a", "b"], ["c", "d"]] and m.__dict__["_lz_img_name"] == ["a.png", "b.png"]
+    m.predict("e", None, 0, "e.png")
+    assert m.img_name == ["a.png", "b.png", "c.png", "d.png", "e.png"]     # a read drains: batch in flight + the partial one
+    assert scored[-1] == ["e"] and "predict" not in m.__dict__["_inflight"] and not m.__dict__["_pending"]["predict"]
+    assert [s for s in m.image_preds] == [("s", x) for x in "abcde"]
+    # the late-fusion phase has its own queue and flight slot
+    for x in "xyz":
+        m.add_sample_to_late_fusion_mem_bank(x)
+    assert m.__dict__["_lz_s_lib"] == [] and "late" in m.__dict__["_inflight"]
+    assert m.s_lib == [("s", "x"), ("s", "y"), ("s", "z")] and m.s_map_lib == [("map", "x"), ("map", "y"), ("map", "z")]
