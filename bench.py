@@ -370,6 +370,58 @@ def sharded_search(dev, group, rank, world, rows_list, iters=10, warm=3):
                 rccl_ranks=td.get_world_size(group), backend=td.get_backend(group), classes=out)
 
 
+def mtfi_classes(dev, group, rank, world, classes="all", scale=0.05, n_test=20, f_coreset=0.1):
+    """configs[4] as a config: the reference's class loop (main.py:22-37 -> cmdiad_runner.CMDIAD.fit / evaluate) for the MTFI
+    feature-to-feature method (RGBorXYZWithOneHallucination, main modality xyz) over synthetic stand-ins of the ten MVTec
+    3D-AD classes, the classes dealt to the ranks by LPT (cmdiad_amd.evaluate), each class start to finish on its rank --
+    memory bank, greedy coreset of both libraries, late-fusion bank, the two one-class SVMs, predict, I-/P-AUROC + AU-PRO --
+    and ONE all_gather_object of the metric dictionaries at the end.  Train-set sizes are the MVTec counts times `scale`
+    (so the relative class costs, hence the assignment and its imbalance, are those of the real data set)."""
+    import torch
+    from cmdiad_amd import evaluate as ev
+    from cmdiad_amd.models.hallucination_network import HallucinationCrossModalityNetwork
+    from cmdiad_amd.models.models import PointTransformer, VisionTransformer
+    from cmdiad_amd.synth import sharpen_pointmae
+    os.environ.setdefault("CMDIAD_ALLOW_RANDOM_INIT", "1")    # synthetic weights: no checkpoints offline
+    torch.manual_seed(0)
+    weights = ({k: v.detach() for k, v in VisionTransformer().state_dict().items()},
+               sharpen_pointmae({k: v.detach() for k, v in PointTransformer().state_dict().items()}),
+               {k: v.detach() for k, v in HallucinationCrossModalityNetwork(None, 768, 768).state_dict().items()})
+    names = "all" if classes == "all" else [c for c in classes.split(",") if c]
+    data = ev.synthetic_mvtec3d(names, scale=scale, n_test=n_test)
+    a = ev.mtfi_args(f_coreset=f_coreset)
+    import contextlib
+    import warnings
+    if group is not None:
+        import torch.distributed as td
+        td.barrier(group)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    with warnings.catch_warnings(), contextlib.redirect_stdout(sys.stderr):   # the drop-in prints the reference's progress lines
+        warnings.simplefilter("ignore")
+        res = ev.evaluate_classes(a, data, group=group, weights=weights)
+    torch.cuda.synchronize()
+    if group is not None:
+        td.barrier(group)
+    wall = time.perf_counter() - t0
+    pc = res["per_class"]
+    n_images = sum(v["n_test"] for v in pc.values())
+    pred_s = [0.0] * world
+    for v in pc.values():
+        pred_s[v["rank"]] += v["seconds"]["predict"]
+    return dict(what=f"class-sharded MTFI FtoF evaluation (fit -> predict -> metrics per class, {len(pc)} synthetic classes with "
+                     f"MVTec 3D-AD train counts x {scale}, {n_test} test images each, f_coreset {f_coreset}), LPT over {world} rank(s), "
+                     "metrics gathered with one all_gather_object",
+                method=res["method"], world=world, assignment=res["assignment"], rank_seconds=res["rank_seconds"],
+                wall_s=round(wall, 3), test_images=n_images,
+                predict_images_per_s=round(n_images / max(max(pred_s), 1e-9), 1),
+                job_images_per_s=round(n_images / wall, 2),
+                per_class={c: {**{m: round(v[m], 4) for m in ev.METRICS}, "rank": v["rank"], "n_train": v["n_train"],
+                               "n_test": v["n_test"], "seconds": v["seconds"], "library_rows": v["library_rows"]} for c, v in pc.items()},
+                mean={m: res["table"][m]["Mean"] for m in ev.METRICS})
+
+
+
 # --------------------------------------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
@@ -387,6 +439,12 @@ def main():
                          "the libraries (no data-path collective); 'sharded' = the row-sharded search inside the pipeline.  The "
                          "row-sharded search is reported as `sharded_search` either way")
     ap.add_argument("--classes", default="all", help="'all' (ten MVTec-3D class sizes) or a comma list, for `sharded_search`")
+    ap.add_argument("--evaluate", action="store_true",
+                    help="configs[4] as a config instead of the timed predict loop: the reference's class loop (fit -> predict -> "
+                         "I-/P-AUROC, AU-PRO per class) for the MTFI FtoF method over synthetic MVTec-3D-sized classes, classes "
+                         "dealt to the ranks by LPT, metric dictionaries gathered at the end (cmdiad_amd/evaluate.py)")
+    ap.add_argument("--class-scale", type=float, default=0.05, help="train images per class = MVTec 3D-AD count x this (1.0 = full size)")
+    ap.add_argument("--class-test", type=int, default=20, help="test images per synthetic class (3 of every 10 anomalous)")
     ap.add_argument("--selftest-launch", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -430,6 +488,28 @@ def main():
             os.dup2(saved_fd, 1)
             os.close(saved_fd)
     sharded = group is not None and args.bank == "sharded"
+
+    if args.evaluate:
+        leg = mtfi_classes(dev, group, rank, world, args.classes, args.class_scale, args.class_test)
+        if group is not None:
+            td.barrier()
+            td.destroy_process_group()
+        if rank == 0:
+            line = {"metric": "images/sec end-to-end (extract+distill+kNN score)", "value": leg["predict_images_per_s"],
+                    "unit": "images/s", "n_gpus": world, "steps": 1, "warmup": 0, "ms_per_step": round(leg["wall_s"] * 1e3, 1),
+                    "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                    "config": {"workload": "configs[4]: full MTFI FtoF pipeline per class (fit: memory bank, coreset, late-fusion bank, "
+                                           "one-class SVMs; predict; I-/P-AUROC + AU-PRO), per-GPU class sharding (LPT)",
+                               "value_is": "test images / slowest rank's predict seconds; job_images_per_s divides by the whole "
+                                           "fit + predict + metrics wall time", "class_scale": args.class_scale},
+                    "mtfi_classes": leg}
+            try:
+                import ctypes
+                ctypes.CDLL(None).fflush(None)
+            except Exception:
+                pass
+            print(json.dumps(line), flush=True)
+        return
 
     st = build_state(dev, args.workload)
     if sharded:  # the pipeline itself searches row shards
@@ -500,6 +580,8 @@ def main():
         if group is not None:
             names = list(CLASS_TRAIN) if args.classes == "all" else [c for c in args.classes.split(",") if c]
             extras["sharded_search"] = sharded_search(dev, group, rank, world, [(c, class_rows(c)) for c in names])
+        # configs[4] as a config (bounded): the class loop with the classes dealt to the ranks, metrics gathered at the end
+        extras["mtfi_classes"] = mtfi_classes(dev, group, rank, world, "all", args.class_scale, args.class_test)
 
     out = None
     if rank == 0:

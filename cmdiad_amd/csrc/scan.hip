@@ -12,17 +12,20 @@
 //     LDS staging, transposition or barrier sits on the stream.  (288 GB of HBM: a second fp32 copy of a 235 MB library is
 //     free.)  The probes sit in LDS in the mirrored layout (A operand).
 //   * d2 ~ |p|^2 + |b|^2 - 2 p.b in fp32 (library row norms accumulated from the streamed values, probe norms in the
-//     prologue): absolute error ~1e-4 on d2 ~ 1e3.  The scan keeps the FOUR smallest approximate keys per probe
-//     ((d2 bits) << 32 | row: ties and exact duplicates resolve to the lowest row like torch.topk on the exact matrix), and
-//     the merge kernel re-evaluates those four EXACTLY (sum (a-b)^2 in fp32 on the row-major library) before the three
-//     smallest exact keys are written: the result is what an exact scan returns unless more than one other row lies within
-//     the approximation error of the third-smallest distance.
+//     prologue): absolute error ~1e-4 on d2 ~ 1e3.  The scan keeps the EIGHT smallest approximate keys per probe
+//     ((d2 bits) << 32 | row: ties and exact duplicates resolve to the lowest row like torch.topk on the exact matrix; a lane
+//     keeps four per (probe, row residue) slot -- 32 768 disjoint row classes -- while it streams), and the merge kernel
+//     re-evaluates those eight EXACTLY (sum (a-b)^2 in fp32 on the row-major library) before the three smallest exact keys
+//     are written: the result is what an exact scan returns unless more than FIVE other rows lie within the approximation
+//     error of the third-smallest distance (libraries built without a coreset hold clusters of near-identical patches:
+//     tests/test_gpu_kernels.py::test_reweight_scan_clustered_near_duplicates).
 #include "common.h"
 
 namespace {
 
 constexpr int kProbes = 32;      // probes per pass (two 16-row MFMA A operands)
-constexpr int kCand = 4;         // approximate candidates kept per probe
+constexpr int kLane = 4;         // approximate candidates a lane keeps per (probe, row residue) slot while it streams
+constexpr int kCand = 8;         // approximate candidates kept per probe from the wave merge on, all re-evaluated exactly
 constexpr int kWaves = 8;        // waves per block: 2 per SIMD
 constexpr int kChunk = 8;        // k-steps (of 16 floats) per software-pipeline chunk: D % 128 == 0
 
@@ -121,13 +124,13 @@ __global__ __launch_bounds__(kWaves * 64) void reweight_scan_mfma_kernel(const f
     for (int pg = 0; pg < 2; ++pg)
 #pragma unroll
         for (int v = 0; v < 4; ++v) pn[pg][v] = s_pn[pg * 16 + (lane >> 4) * 4 + v];
-    unsigned long long top[2][4][kCand];
+    unsigned long long top[2][4][kLane];
 #pragma unroll
     for (int pg = 0; pg < 2; ++pg)
 #pragma unroll
         for (int v = 0; v < 4; ++v)
 #pragma unroll
-            for (int k = 0; k < kCand; ++k) top[pg][v][k] = ~0ull;
+            for (int k = 0; k < kLane; ++k) top[pg][v][k] = ~0ull;
 
     const int groups = (Nb + 15) >> 4;
     const int slots = gridDim.x * 4;
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(kWaves * 64) void reweight_scan_mfma_kernel(const f
                     for (int v = 0; v < 4; ++v) {
                         const float d2 = fmaxf(pn[pg][v] + bn - 2.0f * acc[pg][v], 0.0f);
                         const unsigned long long key = pack_key(d2, row_offset + row);
-                        if (key < top[pg][v][kCand - 1]) list_insert<kCand>(top[pg][v], key);
+                        if (key < top[pg][v][kLane - 1]) list_insert<kLane>(top[pg][v], key);
                     }
             }
             acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -220,8 +223,8 @@ __global__ __launch_bounds__(kWaves * 64) void reweight_scan_mfma_kernel(const f
                 const unsigned long long best = row16_min_u64(top[pg][v][0]);
                 if (top[pg][v][0] == best && best != ~0ull) {  // keys are unique (they carry the row): the owner pops
 #pragma unroll
-                    for (int k = 0; k + 1 < kCand; ++k) top[pg][v][k] = top[pg][v][k + 1];
-                    top[pg][v][kCand - 1] = ~0ull;
+                    for (int k = 0; k + 1 < kLane; ++k) top[pg][v][k] = top[pg][v][k + 1];
+                    top[pg][v][kLane - 1] = ~0ull;
                 }
                 if ((lane & 15) == 0) my[(pg * 16 + (lane >> 4) * 4 + v) * kCand + r] = best;
             }

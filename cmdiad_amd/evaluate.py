@@ -1,0 +1,205 @@
+"""Class-sharded evaluation: the loop of the reference's ``main.py:22-37`` (for every class a fresh ``CMDIAD`` object,
+``fit`` then ``evaluate``, cmdiad_runner.py:33-107) with the classes dealt to the GPUs of one node.
+
+BASELINE configs[4] / SURVEY 8(e) "class sharding": classes are independent of each other (a fresh method object and
+``set_seeds(0)`` per class, main.py:23, features.py:48), so a rank evaluates its classes start to finish -- memory bank,
+coreset, late-fusion bank, the two one-class SVMs, predict, metrics -- with NO collective on the data path; the four metric
+dictionaries (image ROCAUC, pixel ROCAUC, AU-PRO, AU-PRO 0.01; cmdiad_runner.py:87-107) are gathered to every rank at the
+end and rank 0 builds the table main.py prints (per-class columns + ``Mean`` rounded to three digits, main.py:34-37).
+
+The assignment is static longest-processing-time-first over a cost model of a class (greedy coreset rounds dominate a fit:
+quadratic in the number of train images; extraction and scoring are linear): deterministic, the same on every rank, no
+communication needed to agree on it.
+
+Everything below the protocol calls is the drop-in classes of ``feature_extractors/multiple_features.py`` (HIP kernels);
+this module holds no arithmetic of its own.
+"""
+import time
+import types
+
+import numpy as np
+import torch
+
+# MVTec 3D-AD split sizes [external counts, SURVEY 8d]: 2 656 train / 1 197 test images in ten classes
+MVTEC3D_TRAIN = {"bagel": 244, "cable_gland": 223, "carrot": 286, "cookie": 210, "dowel": 288, "foam": 236, "peach": 361,
+                 "potato": 300, "rope": 298, "tire": 210}
+MVTEC3D_TEST = {"bagel": 110, "cable_gland": 108, "carrot": 159, "cookie": 131, "dowel": 130, "foam": 100, "peach": 132,
+                "potato": 114, "rope": 101, "tire": 112}
+METRICS = ("image_rocauc", "pixel_rocauc", "au_pro", "au_pro_001")
+
+
+def mtfi_args(**kw):
+    """The ``args`` namespace of main.py:85-189 with the MTFI feature-to-feature settings of configs[4]
+    (``--method_name WithHallucination --use_hn --main_modality xyz``; README.md of the reference)."""
+    a = dict(method_name="WithHallucination", rgb_backbone_name="vit_base_patch8_224_dino", xyz_backbone_name="Point_MAE",
+             group_size=128, num_group=1024, rgb_size=224, xyz_size=224, gt_size=224, f_coreset=0.1, coreset_eps=0.9,
+             coreset_dtype="FP16", random_state=None, dist_method_s="l2", dist_method_coreset="l2", main_modality="xyz",
+             use_hn=True, fusion_module_path="", ocsvm_nu=0.5, ocsvm_maxiter=1000, xyz_s_lambda=1.0, xyz_smap_lambda=1.0,
+             rgb_s_lambda=0.1, rgb_smap_lambda=0.1, fusion_s_lambda=1.0, fusion_smap_lambda=1.0, memory_bank="multiple",
+             max_sample=500, train_with_validation=False, save_feature_for_fusion=False, save_seg_results=False,
+             use_depth=False)
+    a.update(kw)
+    return types.SimpleNamespace(**a)
+
+
+def method_class(args):
+    """cmdiad_runner.py:16-31: method name -> (key of the metric dictionaries, drop-in class)."""
+    from .feature_extractors import multiple_features as mf
+    table = {"DINO": mf.RGBFeatures, "Point_MAE": mf.PointFeatures, "DINO+Point_MAE": mf.DoubleRGBPointFeatures,
+             "WithHallucination": mf.RGBorXYZWithOneHallucination,
+             "WithHallucinationFromFeature": mf.RGBorXYZWithOneHallucinationFromFeature}
+    if args.method_name not in table:
+        raise ValueError(f"unknown method_name {args.method_name!r} (cmdiad_runner.py:16-31 knows {sorted(table)})")
+    return args.method_name, table[args.method_name]
+
+
+# ------------------------------------------------------------------------------------------------ assignment
+def class_cost(n_train, n_test, f_coreset=0.1, libraries=2, rows_per_image=3136, t_image=1.0e-3, t_row_round=1.18e-10,
+               t_svm_row=1.0e-7):
+    """Estimated seconds one GPU spends on a class: two passes over the train images (memory bank, late-fusion bank) and
+    one over the test images at ``t_image`` each; per library a greedy coreset of f*rows rounds each scanning all rows
+    (csrc/coreset.hip: 90 us per round at 765 184 rows, profiles/r2_notes.md -> 1.18e-10 s per row and round); the host fit
+    of the pixel-level one-class SVM over n_train * 224^2 rows, ~9 epochs (11.4 s at 12.2 M rows)."""
+    rows = n_train * rows_per_image
+    coreset = libraries * (f_coreset * rows) * rows * t_row_round if f_coreset < 1 else 0.0
+    return (2 * n_train + n_test) * t_image + coreset + 9 * n_train * 50176 * t_svm_row
+
+
+def lpt_assign(costs, world):
+    """Longest-processing-time-first: classes by decreasing cost (ties: name), each to the rank with the least load so far
+    (ties: lowest rank).  -> list of ``world`` lists of class names; every class appears exactly once.  Deterministic, so
+    every rank computes the same assignment without talking to the others."""
+    if world < 1:
+        raise ValueError("world must be >= 1")
+    loads = [0.0] * world
+    out = [[] for _ in range(world)]
+    for name in sorted(costs, key=lambda n: (-float(costs[n]), n)):
+        r = min(range(world), key=lambda i: (loads[i], i))
+        out[r].append(name)
+        loads[r] += float(costs[name])
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ one class
+def run_class(args, data, weights=None, method=None):
+    """fit + evaluate of ONE class, in the reference's order (cmdiad_runner.py:33-107):
+    add_sample_to_mem_bank over the train loader -> run_coreset -> (memory_bank == 'multiple')
+    add_sample_to_late_fusion_mem_bank over the train loader again -> run_late_fusion -> predict over the test loader ->
+    calculate_metrics.  ``data``: an object with ``name``, ``train()`` yielding (sample, label) and ``test()`` yielding
+    (sample, mask, label, rgb_path) -- the reference's loaders, or synth.SyntheticClass.  ``weights`` (optional):
+    (ViT state_dict, Point-MAE state_dict, fusion state_dict | None) loaded into the fresh method object (offline stand-in
+    for the checkpoints).  Returns the class's metrics (unrounded), image counts and seconds per phase."""
+    from .utils.utils import set_seeds
+    if method is None:
+        _, cls = method_class(args)
+        method = cls(args)                                  # a fresh object per class, as main.py:23
+    if weights is not None:
+        method.deep_feature_extractor.rgb_backbone.load_state_dict(weights[0])
+        method.deep_feature_extractor.xyz_backbone.load_state_dict(weights[1])
+        if len(weights) > 2 and weights[2] is not None and getattr(method, "fusion", None) is not None:
+            method.fusion.load_state_dict(weights[2])
+    set_seeds(0)
+    count = getattr(args, "max_sample", 500)
+    sec = {}
+
+    def loop(it, call, what):
+        t0 = time.perf_counter()
+        n = flag = 0
+        for item in it:
+            call(item)
+            n += 1
+            flag += 1
+            if flag > count:                                 # cmdiad_runner.py:50-52: stops AFTER max_sample + 1 samples
+                break
+        return n, t0
+
+    n_train, t0 = loop(data.train(), lambda it: method.add_sample_to_mem_bank(it[0], class_name=data.name), "bank")
+    method.run_coreset()
+    torch.cuda.synchronize()
+    sec["memory_bank_and_coreset"] = time.perf_counter() - t0
+    if getattr(args, "memory_bank", "multiple") == "multiple":
+        _, t0 = loop(data.train(), lambda it: method.add_sample_to_late_fusion_mem_bank(it[0]), "late")
+        method.run_late_fusion()
+        sec["late_fusion"] = time.perf_counter() - t0
+    with torch.no_grad():
+        n_test, t0 = loop(data.test(), lambda it: method.predict(*it), "predict")
+        # the drop-in defers predict() into micro-batches; reading a result attribute completes them (multiple_features._MethodBase)
+        assert len(method.image_preds) == n_test
+        torch.cuda.synchronize()
+        sec["predict"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    method.calculate_metrics()
+    sec["metrics"] = time.perf_counter() - t0
+    out = {m: float(getattr(method, m)) for m in METRICS}
+    out.update(n_train=n_train, n_test=n_test, seconds={k: round(v, 3) for k, v in sec.items()},
+               library_rows={k: int(getattr(method, f"patch_{k}_lib").shape[0]) for k in ("xyz", "rgb", "fusion")
+                             if torch.is_tensor(getattr(method, f"patch_{k}_lib", None))})
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ all classes
+def metrics_table(per_class, method_name):
+    """main.py:27-37: one row per metric with a column per class (rounded to 3 digits, cmdiad_runner.py:98-101) and their
+    ``Mean`` (rounded to 3 digits).  Columns follow the order of ``per_class``."""
+    table = {}
+    for m in METRICS:
+        row = {cls.title(): round(per_class[cls][m], 3) for cls in per_class}
+        row["Mean"] = round(float(np.mean(list(row.values()))), 3) if row else float("nan")
+        table[m] = {"Method": method_name, **row}
+    return table
+
+
+def evaluate_classes(args, datasets, group=None, weights=None, costs=None, log=None, runner=None):
+    """``datasets``: {class name: data object (see run_class)} -- the SAME dictionary on every rank.  With ``group`` (a
+    torch.distributed process group: RCCL on the GPUs, gloo in the CPU tests) the classes are dealt to the ranks by
+    ``lpt_assign`` over ``costs`` (default: ``class_cost`` of the class sizes), every rank runs its classes, and the
+    per-class results are gathered to all ranks (``all_gather_object``: a few hundred bytes -- the only collective).
+    ``runner`` (default ``run_class``) evaluates one class -- the CPU tests of the sharding logic pass a stand-in.
+    Returns dict(per_class, table, assignment, rank_seconds, method)."""
+    rank, world = 0, 1
+    if group is not None:
+        import torch.distributed as td
+        rank, world = td.get_rank(group), td.get_world_size(group)
+    if costs is None:
+        costs = {n: class_cost(d.n_train, d.n_test, getattr(args, "f_coreset", 0.1)) for n, d in datasets.items()}
+    assignment = lpt_assign(costs, world)
+    name, _ = method_class(args)
+    mine = {}
+    t0 = time.perf_counter()
+    for cls in assignment[rank]:
+        mine[cls] = (runner or run_class)(args, datasets[cls], weights=weights)
+        mine[cls]["rank"] = rank
+        if log is not None:
+            log(f"[rank {rank}] class {cls}: " + ", ".join(f"{m} {mine[cls][m]:.3f}" for m in METRICS) + f" {mine[cls]['seconds']}")
+    mine_s = time.perf_counter() - t0
+    parts = [(rank, mine, mine_s)]
+    if group is not None:
+        parts = [None] * world
+        td.all_gather_object(parts, (rank, mine, mine_s), group=group)
+    merged, rank_seconds = {}, [0.0] * world
+    for r, part, s in parts:
+        rank_seconds[r] = round(s, 3)
+        for cls, res in part.items():
+            if cls in merged:
+                raise RuntimeError(f"class {cls} was evaluated by ranks {merged[cls]['rank']} and {r}")
+            merged[cls] = res
+    missing = [c for c in datasets if c not in merged]
+    if missing:
+        raise RuntimeError(f"classes not evaluated by any rank: {missing}")
+    per_class = {c: merged[c] for c in datasets}          # the caller's class order, as main.py's loop
+    return dict(method=name, per_class=per_class, table=metrics_table(per_class, name), assignment=assignment,
+                estimated_cost_s={c: round(float(costs[c]), 3) for c in datasets}, rank_seconds=rank_seconds, world=world)
+
+
+def synthetic_mvtec3d(classes="all", scale=1.0, n_train=None, n_test=None):
+    """{class: synth.SyntheticClass} with the MVTec 3D-AD split sizes times ``scale`` (or fixed ``n_train`` / ``n_test``)."""
+    from .synth import SyntheticClass
+    names = list(MVTEC3D_TRAIN) if classes == "all" else [c for c in classes if c]
+    out = {}
+    for c in names:
+        if c not in MVTEC3D_TRAIN:
+            raise ValueError(f"unknown MVTec 3D-AD class {c!r}")
+        tr = n_train if n_train is not None else max(2, int(round(MVTEC3D_TRAIN[c] * scale)))
+        te = n_test if n_test is not None else max(4, int(round(MVTEC3D_TEST[c] * scale)))
+        out[c] = SyntheticClass(c, tr, te, index=list(MVTEC3D_TRAIN).index(c))
+    return out

@@ -63,7 +63,9 @@ class _PendingScores:
             host, B, k, gt = self._host.numpy(), self._B, self._k, self._gt
             out = []
             for b in range(B):
-                s = torch.tensor([[float(self._lam_s[i] * host[B * k * gt * gt + b * k + i]) for i in range(k)]])
+                # np.float32 x np.float32: the reference's `lambda * tensor` is a float32 product (explicit, so the bits do not
+                # depend on NumPy's scalar promotion rules: NumPy < 2 would compute python-float x float32 in float64)
+                s = torch.tensor([[float(np.float32(self._lam_s[i]) * host[B * k * gt * gt + b * k + i]) for i in range(k)]])
                 # numpy for the host-side products: torch's CPU intra-op pool (one thread per core by default) stalls for
                 # 80 ms every few calls on 50 176-element tensors on a 128-core host; same float32 arithmetic either way
                 cols = [np.float32(self._lam_map[i]) * host[(b * k + i) * gt * gt:(b * k + i + 1) * gt * gt] for i in range(k)]
@@ -88,7 +90,12 @@ def _lazy_result(name, kind):
 
     def get(self):
         if not self.__dict__.get("_flushing", False):
-            self._flush(kind)
+            try:
+                self._flush(kind)
+            except AttributeError as e:
+                # nn.Module.__getattr__ swallows an AttributeError raised inside a property getter and reports
+                # "object has no attribute <name>" instead: keep the real cause visible
+                raise RuntimeError(f"running the deferred '{kind}' micro-batch behind .{name} failed: {e!r}") from e
         return self.__dict__[key]
 
     def set_(self, value):
@@ -135,7 +142,12 @@ class _MethodBase(Features):
     def _flush(self, kind, drain=True):
         """Run the queued samples of a phase.  Scoring phases keep one micro-batch IN FLIGHT: its device work is queued, then the
         previous batch is completed on the host (score_samples, result lists) while the GPU works; `drain` (every read of a result
-        attribute and every phase call) completes the batch just queued as well, so an observer never sees a partial list."""
+        attribute and every phase call) completes the batch just queued as well, so an observer never sees a partial list.
+
+        A sample that cannot be processed (e.g. a cloud with fewer points than the grouping needs) must not take the rest of its
+        micro-batch with it: when a batch fails its samples are run ONE BY ONE in call order -- the valid ones before the bad
+        one are recorded, the bad one raises (as its own call would have in the reference's eager loop), and the ones behind it
+        go back to the head of the queue for the next flush."""
         q = self.__dict__.get("_pending")
         flight = self.__dict__.setdefault("_inflight", {})
         if (not q or not q[kind]) and kind not in flight:
@@ -145,22 +157,35 @@ class _MethodBase(Features):
             items, q[kind] = q[kind], []
         self.__dict__["_flushing"] = True
         try:
-            if kind == "fit":
-                if items:
-                    self._fit_batch(items)
-                return
-            new = None
-            if items:
-                new = (self._score_batch(items if kind == "late" else [it[0] for it in items], test=(kind == "predict")), items)
-            if kind in flight:
-                self._complete(kind, *flight.pop(kind))
-            if new is not None:
-                if drain:
-                    self._complete(kind, *new)
-                else:
-                    flight[kind] = new
+            try:
+                self._run_items(kind, items, drain, flight)
+            except Exception:
+                if len(items) <= 1:
+                    raise
+                for k, it in enumerate(items):
+                    try:
+                        self._run_items(kind, [it], True, flight)
+                    except Exception:
+                        q[kind] = items[k + 1:] + q[kind]
+                        raise
         finally:
             self.__dict__["_flushing"] = False
+
+    def _run_items(self, kind, items, drain, flight):
+        if kind == "fit":
+            if items:
+                self._fit_batch(items)
+            return
+        new = None
+        if items:
+            new = (self._score_batch(items if kind == "late" else [it[0] for it in items], test=(kind == "predict")), items)
+        if kind in flight:
+            self._complete(kind, *flight.pop(kind))
+        if new is not None:
+            if drain:
+                self._complete(kind, *new)
+            else:
+                flight[kind] = new
 
     def _complete(self, kind, scores, items):
         if kind == "late":

@@ -73,8 +73,11 @@ class _PackedHead(nn.Module):
 class HallucinationCrossModalityNetwork(nn.Module):
     def __init__(self, args, xyz_dim, rgb_dim, hidden_ratio=2.5, mlp_depth=1):
         super().__init__()
-        if mlp_depth != 1:
-            raise NotImplementedError("cmdiad_amd implements mlp_depth=1 (the reference default)")
+        if mlp_depth < 1:
+            raise ValueError("mlp_depth must be >= 1")
+        if mlp_depth > 1 and xyz_dim != rgb_dim:
+            raise ValueError("mlp_depth > 1 chains blocks of in_features -> out_features (utils/utils.py:103-115): "
+                             "the two modalities must have the same width")
         self.args = args
         self.xyz_dim, self.rgb_dim = xyz_dim, rgb_dim
         self.xyz_norm = nn.LayerNorm(xyz_dim)

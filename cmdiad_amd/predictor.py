@@ -57,11 +57,20 @@ class Ticket:
 
     def __init__(self, host_s, host_m, event, gt):
         self._s, self._m, self._ev, self._gt = host_s, host_m, event, gt
+        self._out = None
+
+    @property
+    def taken(self):
+        """True once wait() has copied the results out of the pinned ring slot this ticket aliases."""
+        return self._out is not None
 
     def wait(self):
-        self._ev.synchronize()
-        B = self._s.shape[0]
-        return self._s.numpy().reshape(B).copy(), self._m.numpy().reshape(B, self._gt, self._gt).copy()
+        if self._out is None:
+            self._ev.synchronize()
+            B = self._s.shape[0]
+            self._out = (self._s.numpy().reshape(B).copy(), self._m.numpy().reshape(B, self._gt, self._gt).copy())
+            self._s = self._m = None
+        return self._out
 
 
 class BatchPredictor:
@@ -94,6 +103,7 @@ class BatchPredictor:
         self.ring = [(torch.empty((batch, 1), dtype=torch.float64, pin_memory=True),
                       torch.empty((batch, gt_size * gt_size), dtype=torch.float64, pin_memory=True)) for _ in range(ring)]
         self.slot = 0
+        self.tickets = [None] * ring     # the ticket that aliases each pinned slot (submit refuses to overwrite an unread one)
         self.step_no = 0
         self.sets = None
         self.static = {}
@@ -264,9 +274,14 @@ class BatchPredictor:
 
     def submit(self, rgb, pcs):
         """rgb [B,3,S,S] f32 (None for 'mtfi'), pcs [B,3,S,S] f32 organised clouds; on the GPU or in (pinned) host memory.
-        Returns a Ticket; at most len(ring) - 1 tickets may be outstanding."""
+        Returns a Ticket.  A ticket aliases one of the len(ring) pinned output slots until its wait() has copied the results
+        out: submitting into a slot whose ticket has not been waited for raises instead of overwriting that batch's results."""
         if pcs.shape[0] != self.B:
             raise ValueError(f"batch of {pcs.shape[0]} given to a predictor built for {self.B}")
+        old = self.tickets[self.slot]
+        if old is not None and not old.taken:
+            raise RuntimeError(f"BatchPredictor.submit: {len(self.ring)} tickets are outstanding; wait() for the oldest one first "
+                               "(its results live in the pinned output slot this submit would overwrite)")
         if self.use_graph and self.sets is None:
             for inp in self.inputs:  # capture (and its eager rehearsal) must see real clouds, not the zero-filled buffers
                 if inp["rgb"] is not None:
@@ -315,7 +330,7 @@ class BatchPredictor:
                 ev = torch.cuda.Event()
                 ev.record()
             st["done"] = ev
-            return Ticket(host_s, host_m, ev, self.gt)
+            return self._ticket(host_s, host_m, ev)
         inp = self.inputs[0]
         self.step_no += 1
         self._load_inputs(inp, rgb, pcs)
@@ -327,7 +342,12 @@ class BatchPredictor:
         host_m.copy_(maps_dev, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        return Ticket(host_s, host_m, ev, self.gt)
+        return self._ticket(host_s, host_m, ev)
+
+    def _ticket(self, host_s, host_m, ev):
+        t = Ticket(host_s, host_m, ev, self.gt)
+        self.tickets[(self.slot - 1) % len(self.ring)] = t
+        return t
 
     def predict_batch(self, rgb, pcs):
         """-> (image scores [B] f64, pixel maps [B,gt,gt] f64): detect_fuser / seg_fuser.score_samples of every sample."""

@@ -247,28 +247,37 @@ class PackedPointMAE:
 
 # ------------------------------------------------------------------------------------------- hallucination MLP
 class PackedHallucination:
-    """Inference-side packing of HallucinationCrossModalityNetwork (models/hallucination_network.py:18-45)."""
+    """Inference-side packing of HallucinationCrossModalityNetwork (models/hallucination_network.py:18-45); mlp_depth
+    chained MlpBlocks per direction (utils/utils.py:103-115), one in the reference's default."""
 
     def __init__(self, sd, device="cuda"):
         self.dir = {}
         for name in ("xyz", "rgb"):
-            p = f"{name}_mlp.mlp_module.0."
-            self.dir[name] = dict(
-                ln_w=_dev(sd[f"{name}_norm.weight"], device), ln_b=_dev(sd[f"{name}_norm.bias"], device),
-                w1=_bf(sd[p + "fc1.weight"], device), b1=_dev(sd[p + "fc1.bias"], device),
-                w2=_bf(sd[p + "fc2.weight"], device), b2=_dev(sd[p + "fc2.bias"], device),
-                w3=_bf(sd[p + "fc3.weight"], device), b3=_dev(sd[p + "fc3.bias"], device))
+            blocks = []
+            d = 0
+            while f"{name}_mlp.mlp_module.{d}.fc1.weight" in sd:
+                p = f"{name}_mlp.mlp_module.{d}."
+                blocks.append(dict(w1=_bf(sd[p + "fc1.weight"], device), b1=_dev(sd[p + "fc1.bias"], device),
+                                   w2=_bf(sd[p + "fc2.weight"], device), b2=_dev(sd[p + "fc2.bias"], device),
+                                   w3=_bf(sd[p + "fc3.weight"], device), b3=_dev(sd[p + "fc3.bias"], device)))
+                d += 1
+            if not blocks:
+                raise KeyError(f"{name}_mlp.mlp_module.0.fc1.weight: not a HallucinationCrossModalityNetwork state_dict")
+            self.dir[name] = dict(ln_w=_dev(sd[f"{name}_norm.weight"], device), ln_b=_dev(sd[f"{name}_norm.bias"], device),
+                                  blocks=blocks, **blocks[0])
 
     def generate(self, x, src):
         """src='xyz': xyz features -> hallucinated rgb features (out_type='rgb'); src='rgb': the reverse.
-        x [..., D] f32 cuda -> same leading shape, f32.  LN -> fc1 -> GELU -> fc2 -> GELU -> fc3 -> GELU."""
+        x [..., D] f32 cuda -> same leading shape, f32.  LN -> (fc1 -> GELU -> fc2 -> GELU -> fc3 -> GELU) x mlp_depth."""
         w = self.dir[src]
         shape = x.shape
         x2 = x.reshape(-1, shape[-1]).contiguous()
         h = ops.layernorm(x2, w["ln_w"], w["ln_b"], 1e-5)
-        _, h = ops.gemm(h, w["w1"], bias=w["b1"], act=ops.ACT_GELU)
-        _, h = ops.gemm(h, w["w2"], bias=w["b2"], act=ops.ACT_GELU)
-        out, _ = ops.gemm(h, w["w3"], bias=w["b3"], act=ops.ACT_GELU, want_f32=True, want_bf16=False)
+        for d, b in enumerate(w["blocks"]):
+            last = d == len(w["blocks"]) - 1
+            _, h = ops.gemm(h, b["w1"], bias=b["b1"], act=ops.ACT_GELU)
+            _, h = ops.gemm(h, b["w2"], bias=b["b2"], act=ops.ACT_GELU)
+            out, h = ops.gemm(h, b["w3"], bias=b["b3"], act=ops.ACT_GELU, want_f32=last, want_bf16=not last)
         return out.view(*shape[:-1], out.shape[-1])
 
 

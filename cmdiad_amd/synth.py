@@ -46,3 +46,63 @@ def synth_rgb(seed, size=224):
 def synth_bank(rows, dim=768, seed=4321):
     g = torch.Generator().manual_seed(seed)
     return torch.randn(rows, dim, generator=g)
+
+
+def synth_labeled_sample(seed, anomalous=False, frac=None, size=224, texture=0.004, dent=0.015, shift=4.0):
+    """One sample of a synthetic anomaly-detection class -> (rgb [1,3,S,S], organised cloud [1,3,S,S], mask [1,S,S]).
+    Normal samples: the textured surface above + N(0,1) image.  Anomalous ones carry a 20 x 20-pixel dent of ``dent``
+    metres in z and a colour shift of ``shift`` sigma over the same pixels (SURVEY 8d plants 5 mm / 2 sigma; on iid-noise
+    images with a 4 mm relief that leaves the image-level scores of normal and anomalous samples interleaved, so the
+    defaults give the ranking a margin -- AUROC parity then measures the scorer, not luck)."""
+    pc = synth_cloud(seed, frac if frac is not None else (0.40 + 0.03 * (seed % 4)), size=size, texture=texture)
+    rgb = synth_rgb(seed, size=size)
+    mask = torch.zeros(1, size, size)
+    if anomalous:
+        y0, x0 = 70 + 9 * (seed % 7), 80 + 7 * (seed % 5)
+        pc[0, 2, y0:y0 + 20, x0:x0 + 20] -= dent * (pc[0, 2, y0:y0 + 20, x0:x0 + 20] != 0)
+        rgb[0, :, y0:y0 + 20, x0:x0 + 20] += shift
+        mask[0, y0:y0 + 20, x0:x0 + 20] = 1
+    return rgb, pc, mask
+
+
+def sharpen_pointmae(sd, conv_gain=400.0, qk_gain=36.0):
+    """Synthetic Point-MAE weights whose features DISCRIMINATE between patches (there are no checkpoints offline).  With
+    O(1)-activation random weights the 8 mm neighbourhood coordinates vanish against the biases and random-init attention
+    is uniform (every token receives the mean of V), so all 3136 xyz patch features of a sample are near-duplicates: their
+    nearest-neighbour distances (~0.02 of |f| ~ 25) sit below the error of ANY 16-bit feature extractor.  A first-convolution
+    gain (coordinates become O(1)) and sharper attention logits (q and k rows scaled) lift the patch-to-patch distances to
+    ~4, ten times the bf16 error, so the xyz modality carries signal end to end."""
+    sd = dict(sd)
+    sd["encoder.first_conv.0.weight"] = sd["encoder.first_conv.0.weight"] * conv_gain
+    for k in list(sd):
+        if k.endswith("attn.qkv.weight"):
+            w = sd[k].clone()
+            w[: 2 * w.shape[0] // 3] *= qk_gain ** 0.5   # q and k rows: logits scale by qk_gain
+            sd[k] = w
+    return sd
+
+
+class SyntheticClass:
+    """A seeded stand-in for one MVTec-3D class directory (there is no dataset offline): ``train()`` yields what the
+    reference's train loader yields -- ``(sample, label)`` with sample = (img, organised cloud, depth stand-in), dataset.py
+    -- and ``test()`` what its test loader yields -- ``(sample, mask, label, rgb_path)``.  Three of every ten test samples
+    are anomalous.  Every class draws from its own seed range, so classes are independent of each other and a
+    class is the same whichever rank evaluates it."""
+
+    def __init__(self, name, n_train, n_test, index=0, anomalous=lambda i: i % 10 in (0, 3, 7)):
+        self.name, self.n_train, self.n_test, self.index, self._anom = name, int(n_train), int(n_test), int(index), anomalous
+
+    def _seed(self, split, i):
+        return 100_000 * (self.index + 1) + (0 if split == "train" else 50_000) + i
+
+    def train(self):
+        for i in range(self.n_train):
+            rgb, pc, _ = synth_labeled_sample(self._seed("train", i))
+            yield (rgb, pc, pc), 0
+
+    def test(self):
+        import numpy as np
+        for i in range(self.n_test):
+            an = bool(self._anom(i))
+            rgb, pc, mask = synth_labeled_sample(self._seed("test", i), anomalous=an)
+            yield (rgb, pc, pc), mask, np.array([int(an)]), [f"{self.name}/test/{i:03d}.png"]

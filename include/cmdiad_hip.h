@@ -33,7 +33,7 @@ typedef enum {
 } cmdiad_status;
 
 const char* cmdiad_last_error(void);
-int cmdiad_abi_version(void);
+int cmdiad_abi_version(void); /* 2: cmdiad_reweight_scan's limits and workspace changed (see there) */
 /* 1 when the library is the test-only build that also contains the superseded kernel formulations (A/B references). */
 int cmdiad_has_ab_variants(void);
 
@@ -288,8 +288,9 @@ int cmdiad_bank_block16(const float* bank, int Nb, int D, float* out, cmdiad_str
 /* Re-weighting scan (features.py:235-254: torch.cdist(m_star, bank) + topk(3, largest=False)): for each of R <= 32
  * probe rows (m_star) the 3 nearest library rows as packed keys (EXACT fp32 squared distance bits << 32 | global row),
  * merged into top3 [R,3] u64, which the caller initialises to UINT64_MAX or 0x7FFF...F (shards call it in turn or
- * all-gather their top3).  One pass over bank_block16 for all probes (v_mfma_f32_16x16x4_f32 cross term, 4 approximate
- * candidates per probe), then the candidates are re-evaluated exactly on the row-major library.
+ * all-gather their top3).  One pass over bank_block16 for all probes (v_mfma_f32_16x16x4_f32 cross term, 8 approximate
+ * candidates per probe), then the candidates are re-evaluated exactly on the row-major library.  ABI version 2: R <= 32 per
+ * call (version 1 took 64) and a workspace of 8 candidates per probe and block (cmdiad_reweight_workspace_bytes).
  * probes [R,D] f32, bank [Nb,D] f32 row-major, bank_block16 from cmdiad_bank_block16; D % 128 == 0. */
 size_t cmdiad_reweight_workspace_bytes(int R, int Nb);
 int cmdiad_reweight_scan(const float* probes, const float* bank, const float* bank_block16, int R, int Nb, int D,

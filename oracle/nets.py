@@ -114,10 +114,14 @@ def halluc_generate(sd, x, direction):
     models/hallucination_network.py:34-45, utils/utils.py:94-100 (GELU also on the output)."""
     name = "xyz" if direction == "xyz2rgb" else "rgb"
     h = _ln(x, sd, f"{name}_norm", 1e-5)
-    p = f"{name}_mlp.mlp_module.0"
-    h = F.gelu(_linear(h, sd, p + ".fc1"))
-    h = F.gelu(_linear(h, sd, p + ".fc2"))
-    return F.gelu(_linear(h, sd, p + ".fc3"))
+    d = 0
+    while f"{name}_mlp.mlp_module.{d}.fc1.weight" in sd:      # mlp_depth chained blocks (utils/utils.py:110-113)
+        p = f"{name}_mlp.mlp_module.{d}"
+        h = F.gelu(_linear(h, sd, p + ".fc1"))
+        h = F.gelu(_linear(h, sd, p + ".fc2"))
+        h = F.gelu(_linear(h, sd, p + ".fc3"))
+        d += 1
+    return h
 
 
 def halluc_losses(sd, xyz, rgb, dist_method="l2"):
@@ -173,15 +177,16 @@ def _shapes_pointmae(prefix="", dim=384, depth=12):
     return s
 
 
-def _shapes_halluc(xyz_dim=768, rgb_dim=768, hidden_ratio=2.5):
+def _shapes_halluc(xyz_dim=768, rgb_dim=768, hidden_ratio=2.5, mlp_depth=1):
     s = {}
     for name, din, dout in (("xyz", xyz_dim, rgb_dim), ("rgb", rgb_dim, xyz_dim)):
         hid = int(din * hidden_ratio)
-        p = f"{name}_mlp.mlp_module.0."
-        s.update({f"{name}_norm.weight": (din,), f"{name}_norm.bias": (din,),
-                  p + "fc1.weight": (hid, din), p + "fc1.bias": (hid,),
-                  p + "fc2.weight": (hid, hid), p + "fc2.bias": (hid,),
-                  p + "fc3.weight": (dout, hid), p + "fc3.bias": (dout,)})
+        s.update({f"{name}_norm.weight": (din,), f"{name}_norm.bias": (din,)})
+        for d in range(mlp_depth):
+            p = f"{name}_mlp.mlp_module.{d}."
+            s.update({p + "fc1.weight": (hid, din), p + "fc1.bias": (hid,),
+                      p + "fc2.weight": (hid, hid), p + "fc2.bias": (hid,),
+                      p + "fc3.weight": (dout, hid), p + "fc3.bias": (dout,)})
     return s
 
 
@@ -220,18 +225,7 @@ def synth_state_dict(kind, seed, prefix="", **kw):
 
 
 def sharpen_pointmae(sd, conv_gain=400.0, qk_gain=36.0):
-    """Synthetic Point-MAE weights whose features DISCRIMINATE between patches.  With the O(1)-activation weights of
-    synth_state_dict the 8 mm neighbourhood coordinates vanish against the biases and random-init attention is uniform
-    (every token receives the mean of V), so all 3136 xyz patch features of a sample are near-duplicates: their
-    nearest-neighbour distances (~0.02 of |f| ~ 25) sit below the bf16 error of ANY 16-bit feature extractor and only an
-    absolute tolerance is meaningful.  A first-convolution gain (coordinates become O(1)) and sharper attention logits
-    (q and k scaled) lift the patch-to-patch distances to ~4, ten times the bf16 error, so the xyz modality can be
-    checked relatively end to end."""
-    sd = dict(sd)
-    sd["encoder.first_conv.0.weight"] = sd["encoder.first_conv.0.weight"] * conv_gain
-    for k in list(sd):
-        if k.endswith("attn.qkv.weight"):
-            w = sd[k].clone()
-            w[: 2 * w.shape[0] // 3] *= qk_gain ** 0.5   # q and k rows: logits scale by qk_gain
-            sd[k] = w
-    return sd
+    """Synthetic Point-MAE weights whose features discriminate between patches (first-convolution gain, sharper attention
+    logits): the generator lives beside the other synthetic inputs, cmdiad_amd/synth.py, shared by tests, goldens and bench."""
+    from cmdiad_amd.synth import sharpen_pointmae as _sharpen
+    return _sharpen(sd, conv_gain, qk_gain)

@@ -310,9 +310,45 @@ def golden_methods():
     print("g11_methods.npz", os.path.getsize(os.path.join(HERE, "g11_methods.npz")) // 1024, "KB")
 
 
+def golden_halluc_depth2():
+    """G5b: the reference's HallucinationCrossModalityNetwork with mlp_depth=2 (utils/utils.py:103-115: two chained MlpBlocks
+    per direction) -- both generated outputs, the three losses and the l2 loss after each of two Adam steps, on a seeded
+    [2, 32, 1536] batch with the synthetic weights of oracle.nets.synth_state_dict("halluc", 53, mlp_depth=2)."""
+    from models.hallucination_network import HallucinationCrossModalityNetwork
+    import utils.lr_sched as rlr
+    sdh = onets.synth_state_dict("halluc", 53, mlp_depth=2)
+    net = HallucinationCrossModalityNetwork(_ns(), 768, 768, hidden_ratio=2.5, mlp_depth=2)
+    net.load_state_dict(sdh, strict=True)
+    samples = torch.randn(2, 32, 1536, generator=torch.Generator().manual_seed(54))
+    xyz, rgb = samples[:, :, :768], samples[:, :, 768:]
+    out = {}
+    with torch.no_grad():
+        out["gen_xyz2rgb"] = net.hallucination_generation(xyz_feature=xyz, out_type="rgb").numpy()
+        out["gen_rgb2xyz"] = net.hallucination_generation(rgb_feature=rgb, out_type="xyz").numpy()
+        for dm in ("l2", "cos_dist", "smooth_l1"):
+            a, b = net(xyz, rgb, False, dm)
+            out[f"loss_{dm}"] = np.array([a.item(), b.item()])
+    opt = torch.optim.Adam(net.parameters(), lr=0.0005)
+    sargs = _ns(lr=0.0005, warmup_epochs=1, epochs=10)
+    losses = []
+    net.train()
+    opt.zero_grad()
+    for it in range(3):
+        rlr.adjust_learning_rate(opt, it / 4 + 0, sargs)
+        lx, lr_ = net(xyz, rgb, False, "l2")
+        losses.append([lx.item(), lr_.item()])
+        (lx + lr_).backward()
+        opt.step()
+        opt.zero_grad()
+    out["train_losses"] = np.array(losses)
+    np.savez_compressed(os.path.join(HERE, "g5b_halluc_depth2.npz"), samples_seed=54, weights_seed=53, **out)
+
+
 def main():
     _install_stubs()
     sys.path.insert(0, REF)
+    if len(sys.argv) > 1 and sys.argv[1] == "g5b":  # only the mlp_depth = 2 hallucination fixture
+        return golden_halluc_depth2()
     if len(sys.argv) > 1 and sys.argv[1] == "g10":  # only the distillation-head fixture
         return golden_heads()
     if len(sys.argv) > 1 and sys.argv[1] == "g11":  # only the method-class fixture

@@ -1,0 +1,96 @@
+"""GPU: BASELINE configs[4] as a config -- the reference's class loop (main.py:22-37 -> cmdiad_runner.CMDIAD.fit / evaluate)
+for the MTFI feature-to-feature method through cmdiad_amd.evaluate, against the CPU oracle pipeline driven through the same
+protocol (oracle.pipeline.CpuOneHallucination, pinned to the reference's own RGBorXYZWithOneHallucination by golden G11):
+per class I-AUROC, P-AUROC and AU-PRO of both sides, every fit (libraries, statistics, both one-class SVMs) done
+independently on each side."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+from cmdiad_amd import evaluate as ev  # noqa: E402
+from cmdiad_amd.synth import SyntheticClass  # noqa: E402
+from cmdiad_amd.utils.au_pro_util import calculate_au_pro  # noqa: E402
+from oracle import nets, pipeline  # noqa: E402
+
+
+def _oracle_class(cpu_ex, sd_h, data, lambdas):
+    """cmdiad_runner.py:33-107 on the CPU oracle: fit (f_coreset = 1), late-fusion rows from the train samples, the two
+    SGDOneClassSVM fits of features.py:352-358, predict, and the metrics of features.py:302-324."""
+    from sklearn import linear_model
+    from sklearn.metrics import roc_auc_score
+    cpu = pipeline.CpuOneHallucination(cpu_ex, sd_h, "xyz", lambdas=lambdas)
+    trip = cpu.fit([(s[0], s[1]) for s, _ in data.train()])
+    rows = [cpu.score(*t)[:2] for t in trip]               # the train samples again (cmdiad_runner.py:58-66): same patches
+    det = linear_model.SGDOneClassSVM(random_state=42, nu=0.5, max_iter=1000).fit(torch.cat([r[0] for r in rows], 0).numpy())
+    seg = linear_model.SGDOneClassSVM(random_state=42, nu=0.5, max_iter=1000).fit(torch.cat([r[1] for r in rows], 0).numpy())
+    img, pix, labels, masks = [], [], [], []
+    for sample, mask, label, _ in data.test():
+        s, s_map = cpu.predict(sample[0], sample[1])[:2]
+        img.append(float(det.score_samples(s.numpy())[0]))
+        pix.append(seg.score_samples(s_map.numpy()).reshape(224, 224))
+        labels.append(int(label[0]))
+        masks.append(mask.numpy().reshape(224, 224))
+    masks, pix = np.stack(masks), np.stack(pix)
+    return dict(image_rocauc=roc_auc_score(labels, img), pixel_rocauc=roc_auc_score(masks.ravel().astype(int), pix.ravel()),
+                au_pro=calculate_au_pro(list(masks), list(pix))[0], det=det, seg=seg, img=np.array(img))
+
+
+def test_mtfi_class_loop_auroc_vs_oracle():
+    """Two synthetic classes x (4 train, 20 test of which 6 anomalous) through cmdiad_amd.evaluate.evaluate_classes
+    (drop-in RGBorXYZWithOneHallucination, main modality xyz, the whole five-call protocol on the GPU) against the oracle's
+    class loop: |dI-AUROC| <= 1e-2, |dP-AUROC| <= 1e-2, |dAU-PRO| <= 2e-2 per class, and the table's Mean column."""
+    weights = (nets.synth_state_dict("vit", 31), nets.sharpen_pointmae(nets.synth_state_dict("pointmae", 21)),
+               nets.synth_state_dict("halluc", 51))
+    cpu_ex = pipeline.CpuExtractor(weights[0], weights[1])
+    data = {"bagel": SyntheticClass("bagel", 4, 20, index=0), "rope": SyntheticClass("rope", 4, 20, index=8)}
+    assert sum(int(l[0]) for _, _, l, _ in data["bagel"].test()) == 6
+    a = ev.mtfi_args(f_coreset=1.0)
+    res = ev.evaluate_classes(a, data, weights=weights, log=print)
+    assert res["method"] == "WithHallucination" and list(res["per_class"]) == ["bagel", "rope"]
+    assert res["assignment"] == [["bagel", "rope"]] and res["world"] == 1          # equal costs: ties by name
+    lam = (a.xyz_s_lambda, a.xyz_smap_lambda, a.fusion_s_lambda, a.fusion_smap_lambda)
+    for cls, d in data.items():
+        ref = _oracle_class(cpu_ex, weights[2], d, lam)
+        got = res["per_class"][cls]
+        print(f"{cls}: I-AUROC {got['image_rocauc']:.4f} (oracle {ref['image_rocauc']:.4f}); P-AUROC {got['pixel_rocauc']:.4f} "
+              f"(oracle {ref['pixel_rocauc']:.4f}); AU-PRO {got['au_pro']:.4f} (oracle {ref['au_pro']:.4f}); "
+              f"oracle det coef {ref['det'].coef_.ravel()} seg coef {ref['seg'].coef_.ravel()}")
+        assert got["n_train"] == 4 and got["n_test"] == 20
+        assert got["library_rows"] == {"xyz": 4 * 3136, "rgb": 4 * 784, "fusion": 4 * 3136}
+        assert abs(got["image_rocauc"] - ref["image_rocauc"]) <= 1e-2, cls
+        assert abs(got["pixel_rocauc"] - ref["pixel_rocauc"]) <= 1e-2, cls
+        assert abs(got["au_pro"] - ref["au_pro"]) <= 2e-2, cls
+        assert ref["pixel_rocauc"] > 0.9, "the synthetic anomalies must be detectable, or parity says nothing"
+    t = res["table"]["image_rocauc"]
+    assert t["Method"] == "WithHallucination" and set(t) == {"Method", "Bagel", "Rope", "Mean"}
+    assert t["Mean"] == round((t["Bagel"] + t["Rope"]) / 2, 3)
+
+
+def test_bench_evaluate_mode_through_rccl_world_of_one():
+    """`bench.py --evaluate` with CMDIAD_FORCE_DIST=1: the class loop with an RCCL process group of one rank -- LPT over one
+    rank, all_gather_object of the metric dictionaries over the nccl backend -- and the coreset path (f_coreset 0.1)."""
+    env = dict(os.environ, CMDIAD_FORCE_DIST="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--evaluate", "--classes", "cookie,peach,tire",
+                          "--class-scale", "0.02", "--class-test", "10"], capture_output=True, text=True, timeout=1200, env=env, cwd=REPO)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    leg = d["mtfi_classes"]
+    assert d["n_gpus"] == 1 and leg["world"] == 1 and leg["test_images"] == 30 and d["value"] == leg["predict_images_per_s"] > 0
+    assert leg["assignment"] == [["peach", "cookie", "tire"]]          # LPT order on one rank: by decreasing cost, ties by name
+    for cls, n_train in (("cookie", 4), ("peach", 7), ("tire", 4)):
+        pc = leg["per_class"][cls]
+        assert pc["n_train"] == n_train and pc["n_test"] == 10 and pc["rank"] == 0
+        assert pc["library_rows"]["xyz"] == int(0.1 * n_train * 3136) and pc["library_rows"]["fusion"] == int(0.1 * n_train * 3136)
+        assert all(0.0 <= pc[m] <= 1.0 for m in ev.METRICS)
+    assert leg["mean"]["pixel_rocauc"] > 0.8

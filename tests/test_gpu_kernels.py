@@ -481,6 +481,29 @@ def test_reweight_scan_duplicates_near_ties_and_shards():
     assert torch.equal(t2, top3)
 
 
+
+def test_reweight_scan_clustered_near_duplicates():
+    """ADVICE (round 2): libraries built without a coreset hold clusters of near-identical patches.  Clusters of 3-8 rows
+    within d2 ~ 1e-5 ... 1e-3 of their centre -- far inside the norm-expansion's ~1e-4 error on |b|^2 = 768 -- probed with
+    the centre itself: the three smallest EXACT distances and their rows must be what an exact scan of the library returns
+    (the scan keeps 8 approximate candidates per probe and re-evaluates them exactly)."""
+    g = torch.Generator().manual_seed(23)
+    bank = torch.randn(9000, 768, generator=g)
+    probes = []
+    for c, size in enumerate((3, 4, 5, 6, 7, 8, 8, 6, 5, 4, 3, 8)):
+        centre = torch.randn(768, generator=g)
+        rows = torch.randperm(9000, generator=g)[:size]                      # scattered over row residues and groups
+        for j, r in enumerate(rows.tolist()):
+            bank[r] = centre + (1e-4 * (1 + j) * (1 + c % 3)) * torch.randn(768, generator=g)
+        probes.append(centre)
+    probes = torch.stack(probes)
+    top3 = ops.reweight_scan(probes.to(DEV), bank.to(DEV))
+    val, idx = ops.unpack_keys(top3)
+    d2 = torch.stack([(bank.double() - p.double()).pow(2).sum(1) for p in probes])
+    rv, ri = torch.topk(d2, 3, dim=1, largest=False)
+    assert torch.equal(idx.cpu(), ri), (idx.cpu(), ri)
+    np.testing.assert_allclose(val.cpu().numpy(), rv.float().numpy(), rtol=2e-5, atol=1e-12)
+
 def test_l2_dist_matrix_exact():
     g = torch.Generator().manual_seed(12)
     q, bank = torch.randn(130, 768, generator=g), torch.randn(333, 768, generator=g)

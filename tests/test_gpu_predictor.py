@@ -332,3 +332,43 @@ def test_dropin_micro_batching_is_invisible(weights, monkeypatch):
         lvl = np.ptp(out["1"][4]) / 255.0
         assert np.abs(out[batch][4] - out["1"][4]).max() <= 2.5 * lvl    # at most one 8-bit blur level per column
         assert abs(out[batch][5] - out["1"][5]) < 1e-9 and abs(out[batch][6] - out["1"][6]) < 1e-3
+
+
+def test_bad_sample_does_not_take_its_micro_batch_with_it(weights, monkeypatch):
+    """ADVICE (round 2): a sample that cannot be processed (a cloud with fewer valid points than the 128-nearest-neighbour
+    grouping needs) raises -- at the flush that would have run it, INTEGRATION.md section 4 -- but the valid samples queued
+    in front of it are recorded and the ones behind it stay queued: a caller that catches the error and continues loses
+    exactly the bad sample, as with the reference's eager per-call loop."""
+    from cmdiad_amd.feature_extractors import multiple_features as mf
+    from sklearn import linear_model
+    monkeypatch.setenv("CMDIAD_PREDICT_BATCH", "8")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = mf.PointFeatures(make_args())
+    m.deep_feature_extractor.xyz_backbone.load_state_dict(weights[1])
+    for i in range(2):
+        rgb, pc, _ = synth_sample(400 + i)
+        m.add_sample_to_mem_bank((rgb, pc, pc), class_name="synthetic")
+    m.run_coreset()
+    rs = np.random.RandomState(0)
+    m.detect_fuser = linear_model.SGDOneClassSVM(random_state=42, nu=0.5, max_iter=1000).fit(rs.rand(64, 1))
+    m.seg_fuser = linear_model.SGDOneClassSVM(random_state=42, nu=0.5, max_iter=1000).fit(rs.rand(4096, 1))
+    good = [synth_sample(410 + i) for i in range(4)]
+    bad_pc = torch.zeros(1, 3, 224, 224)
+    bad_pc[0, :, 100:105, 100:110] = good[0][1][0, :, 100:105, 100:110]          # 50 valid points < group_size 128
+    order = [good[0], good[1], (good[0][0], bad_pc, good[0][2]), good[2], good[3]]
+    for k, (rgb, pc, mask) in enumerate(order):
+        m.predict((rgb, pc, pc), mask, np.array([0]), [f"s{k}.png"])
+    with pytest.raises(ValueError, match="valid points"):
+        len(m.image_preds)
+    assert [n[0] for n in m.__dict__["_lz_img_name"]] == ["s0.png", "s1.png"]      # the two in front were recorded
+    assert [it[3][0] for it in m.__dict__["_pending"]["predict"]] == ["s3.png", "s4.png"]
+    assert [n[0] for n in m.img_name] == ["s0.png", "s1.png", "s3.png", "s4.png"]  # the next read runs the ones behind it
+    # and each of the four has the numbers it gets when predicted alone
+    alone = []
+    for rgb, pc, mask in good:
+        m2_before = len(m.image_preds)
+        m.predict((rgb, pc, pc), mask, np.array([0]), ["again.png"])
+        alone.append(np.asarray(m.image_preds[m2_before]).ravel()[0])
+    got = np.concatenate([np.asarray(v).ravel() for v in m.image_preds[:4]])
+    np.testing.assert_allclose(got, np.array(alone), rtol=1e-5, atol=1e-7)

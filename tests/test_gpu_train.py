@@ -64,6 +64,51 @@ def test_gradients_match_torch_autograd():
             assert cos > 0.995 and abs(ratio - 1) < 0.02, (dm, name, cos, ratio)
 
 
+def test_mlp_depth_2_matches_reference_golden_and_autograd(golden):
+    """mlp_depth = 2 (utils/utils.py:103-115, hallucination_network_pretrain.py:70,247): generated features and the three
+    losses against the reference's own module (golden G5b), the loss curve of three warm-up Adam steps, and every
+    parameter gradient against torch fp32 autograd through the oracle restatement."""
+    import types
+    g = golden("g5b_halluc_depth2.npz")
+    sd = nets.synth_state_dict("halluc", int(g["weights_seed"]), mlp_depth=2)
+    net = HallucinationCrossModalityNetwork(None, 768, 768, hidden_ratio=2.5, mlp_depth=2)
+    assert set(net.state_dict()) == set(sd)
+    net.load_state_dict(sd, strict=True)
+    net = net.to(DEV)
+    s = torch.randn(2, 32, 1536, generator=torch.Generator().manual_seed(int(g["samples_seed"])))
+    xyz, rgb = s[:, :, :768].contiguous(), s[:, :, 768:].contiguous()
+    with torch.no_grad():
+        for got, key in ((net.hallucination_generation(xyz_feature=xyz, out_type="rgb"), "gen_xyz2rgb"),
+                         (net.hallucination_generation(rgb_feature=rgb, out_type="xyz"), "gen_rgb2xyz")):
+            err = (got.cpu().numpy() - g[key])
+            assert np.abs(err).mean() < 4e-3 and np.abs(err).max() < 5e-2, (key, np.abs(err).mean(), np.abs(err).max())
+        for dm in ("l2", "cos_dist", "smooth_l1"):
+            a, b = net(xyz, rgb, False, dm)
+            np.testing.assert_allclose([a.item(), b.item()], g[f"loss_{dm}"], rtol=1e-2)
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    lx, lr_ = nets.halluc_losses(params, xyz, rgb, "l2")
+    ref = torch.autograd.grad(lx + lr_, list(params.values()))
+    ax, ar = net(xyz, rgb, False, "l2")
+    (ax + ar).backward()
+    got = dict(net.named_parameters())
+    for (name, _), r in zip(params.items(), ref):
+        gq = got[name].grad.cpu()
+        cos = torch.nn.functional.cosine_similarity(gq.flatten(), r.flatten(), dim=0).item()
+        ratio = (gq.norm() / r.norm()).item()
+        assert cos > 0.99 and abs(ratio - 1) < 0.03, (name, cos, ratio)      # six bf16 GEMMs each way
+    net.zero_grad()
+    opt = train.FusedAdam(net.parameters(), lr=5e-4)
+    sargs = types.SimpleNamespace(lr=5e-4, warmup_epochs=1, epochs=10)
+    net.train()
+    for it in range(3):
+        lr_sched.adjust_learning_rate(opt, it / 4 + 0, sargs)
+        lx, lr_ = net(xyz, rgb, False, "l2")
+        np.testing.assert_allclose([lx.item(), lr_.item()], g["train_losses"][it], rtol=1e-2)
+        (lx + lr_).backward()
+        opt.step()
+        opt.zero_grad()
+
+
 @pytest.mark.parametrize("opt_kind", ["torch", "fused"])
 def test_adam_steps_match_golden(golden, opt_kind):
     """Three update steps exactly as hallucination_network_pretrain.py:102-154 drives them."""
@@ -97,16 +142,31 @@ def test_adam_steps_match_golden(golden, opt_kind):
                     assert np.sign(du[np.abs(dr) > 0.5 * np.abs(dr).max()]).tolist() == np.sign(dr[np.abs(dr) > 0.5 * np.abs(dr).max()]).tolist()
 
 
-def test_config3_step_shape_runs():
-    """BASELINE configs[2] shape: batch 32 x 3136 tokens, one full step (forward, backward, Adam)."""
+def test_config3_step_full_size_loss_vs_oracle():
+    """BASELINE configs[2] shape: batch 32 x 3136 tokens, one full step (forward, backward, Adam).  The loss is a sum over
+    tokens divided by the batch size (hallucination_network.py:47-69), so the full-size value is checked through that
+    linearity -- the four quarter-batches' losses add up to it -- and anchored to the fp32 oracle on a two-sample subset
+    (2 x 3136 tokens, both directions); the step then moves every parameter by about lr."""
     net = _net()
     opt = train.FusedAdam(net.parameters(), lr=5e-4)
     s = torch.randn(32, 3136, 1536, generator=torch.Generator().manual_seed(3407)).to(DEV)
+    with torch.no_grad():
+        parts = [net(s[i:i + 8, :, :768], s[i:i + 8, :, 768:], False, "l2") for i in range(0, 32, 8)]
+        sub = net(s[[3, 20], :, :768], s[[3, 20], :, 768:], False, "l2")
+    sd = nets.synth_state_dict("halluc", 51)
+    with torch.no_grad():
+        ox, orr = nets.halluc_losses(sd, s[[3, 20], :, :768].cpu(), s[[3, 20], :, 768:].cpu(), "l2")
+    np.testing.assert_allclose([sub[0].item(), sub[1].item()], [ox.item(), orr.item()], rtol=5e-3)
+    before = {k: v.detach().clone() for k, v in net.named_parameters()}
     lx, lr_ = net(s[:, :, :768], s[:, :, 768:], False, "l2")
+    np.testing.assert_allclose(lx.item(), sum(p[0].item() for p in parts) * 8 / 32, rtol=2e-4)
+    np.testing.assert_allclose(lr_.item(), sum(p[1].item() for p in parts) * 8 / 32, rtol=2e-4)
     (lx + lr_).backward()
     opt.step()
     torch.cuda.synchronize()
-    assert torch.isfinite(lx).item() and torch.isfinite(lr_).item()
+    for k, v in net.named_parameters():
+        d = (v.detach() - before[k]).abs()
+        assert torch.isfinite(v).all() and 1e-4 < float(d.max()) <= 5e-4 * 1.001, (k, float(d.max()))   # Adam's first step: |update| <= lr
 
 
 def test_feature_ring_on_device(tmp_path):

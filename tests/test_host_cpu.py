@@ -17,7 +17,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_cabi_library_loads_and_exports_every_declared_symbol():
     from cmdiad_amd import _native as nat
     L = nat.lib()
-    assert L.cmdiad_abi_version() == 1
+    assert L.cmdiad_abi_version() == 2
     hdr = open(os.path.join(REPO, "include", "cmdiad_hip.h")).read()
     declared = set(re.findall(r"\b(cmdiad_[a-z0-9_]+)\s*\(", hdr))
     bound = set(nat.SIGNATURES) | set(nat.SIZE_QUERIES) | {"cmdiad_last_error", "cmdiad_abi_version", "cmdiad_has_ab_variants"}
@@ -405,3 +405,88 @@ def test_dropin_keeps_one_micro_batch_in_flight_and_drains_on_read(monkeypatch):
         m.add_sample_to_late_fusion_mem_bank(x)
     assert m.__dict__["_lz_s_lib"] == [] and "late" in m.__dict__["_inflight"]
     assert m.s_lib == [("s", "x"), ("s", "y"), ("s", "z")] and m.s_map_lib == [("map", "x"), ("map", "y"), ("map", "z")]
+
+
+# ------------------------------------------------------------------------------------------------ class sharding (configs[4])
+def test_lpt_assignment_covers_every_class_once_and_balances():
+    """cmdiad_amd.evaluate.lpt_assign over the cost model of the ten MVTec 3D-AD classes: every class exactly once for any
+    world size, deterministic, no rank above the LPT bound (4/3 - 1/(3m)) x optimum >= max(mean load, largest class)."""
+    from cmdiad_amd import evaluate as ev
+    costs = {c: ev.class_cost(ev.MVTEC3D_TRAIN[c], ev.MVTEC3D_TEST[c]) for c in ev.MVTEC3D_TRAIN}
+    assert max(costs, key=costs.get) == "peach" and 5 < costs["bagel"] < 60          # seconds: coreset + SVM fit dominate
+    for world in (1, 2, 3, 4, 8, 10, 16):
+        a = ev.lpt_assign(costs, world)
+        assert len(a) == world and sorted(sum(a, [])) == sorted(costs)
+        assert a == ev.lpt_assign(dict(reversed(list(costs.items()))), world)          # independent of dictionary order
+        loads = [sum(costs[c] for c in r) for r in a]
+        lower = max(sum(costs.values()) / world, max(costs.values()))
+        assert max(loads) <= (4 / 3 - 1 / (3 * world)) * lower * 1.25 + 1e-9, (world, loads)
+    a8 = ev.lpt_assign(costs, 8)
+    assert a8[0] == ["peach"] and sorted(len(r) for r in a8) == [1] * 6 + [2, 2]      # 10 classes on 8 ranks: two ranks take two
+    assert ev.lpt_assign({"b": 1.0, "a": 1.0, "c": 1.0}, 2) == [["a", "c"], ["b"]]      # ties: by name, lowest rank first
+
+
+def test_metrics_table_is_main_py_s_table():
+    """main.py:27-37: per-class values rounded to 3 digits (cmdiad_runner.py:98-101), Mean = round(mean of those, 3)."""
+    import pandas as pd
+    from cmdiad_amd import evaluate as ev
+    pc = {"bagel": dict(image_rocauc=0.91849, pixel_rocauc=0.99251, au_pro=0.9, au_pro_001=0.4),
+          "cable_gland": dict(image_rocauc=0.7777, pixel_rocauc=0.5, au_pro=0.12345, au_pro_001=0.0)}
+    t = ev.metrics_table(pc, "WithHallucination")
+    df = pd.DataFrame(["WithHallucination"], columns=["Method"])                         # the reference's own construction
+    for cls, v in pc.items():
+        df[cls.title()] = df["Method"].map({"WithHallucination": round(v["image_rocauc"], 3)})
+    df["Mean"] = round(df.iloc[:, 1:].mean(axis=1), 3)
+    assert t["image_rocauc"] == df.iloc[0].to_dict()
+    assert list(t["image_rocauc"]) == ["Method", "Bagel", "Cable_Gland", "Mean"]
+
+
+_GLOO_EVAL_WORKER = r"""
+import json, os, sys
+sys.path.insert(0, {repo!r})
+import torch.distributed as td
+from cmdiad_amd import evaluate as ev
+td.init_process_group("gloo")
+rank = td.get_rank()
+data = ev.synthetic_mvtec3d("all", scale=0.05, n_test=20)
+calls = []
+def runner(args, d, weights=None):      # stand-in for run_class: no GPU here; a class's result depends on the class alone
+    calls.append(d.name)
+    h = sum(map(ord, d.name))
+    return dict(image_rocauc=(h % 97) / 97.0, pixel_rocauc=(h % 89) / 89.0, au_pro=(h % 83) / 83.0, au_pro_001=(h % 79) / 79.0,
+                n_train=d.n_train, n_test=d.n_test, seconds=dict(predict=0.01 * d.n_test), library_rows=dict(xyz=d.n_train))
+res = ev.evaluate_classes(ev.mtfi_args(), data, group=td.group.WORLD, runner=runner)
+assert calls == res["assignment"][rank], (calls, res["assignment"])
+print("RESULT " + json.dumps(dict(rank=rank, calls=calls, per_class=res["per_class"], table=res["table"], assignment=res["assignment"])))
+td.destroy_process_group()
+"""
+
+
+def test_class_sharded_evaluate_world2_gloo(tmp_path):
+    """cmdiad_amd.evaluate.evaluate_classes with a gloo group of two ranks (the N > 1 path of configs[4]; RCCL on the GPUs):
+    the LPT assignment covers every class exactly once, each rank runs exactly its classes, and after the
+    all_gather_object BOTH ranks hold the dictionary -- and the main.py table -- a single rank produces."""
+    import json
+    from cmdiad_amd import evaluate as ev
+    script = tmp_path / "w.py"
+    script.write_text(_GLOO_EVAL_WORKER.format(repo=REPO))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    recs = [json.loads([ln for ln in o.splitlines() if ln.startswith("RESULT ")][-1][7:]) for o in outs]
+    recs.sort(key=lambda r: r["rank"])
+    assert sorted(recs[0]["calls"] + recs[1]["calls"]) == sorted(ev.MVTEC3D_TRAIN) and not set(recs[0]["calls"]) & set(recs[1]["calls"])
+    assert 4 <= len(recs[0]["calls"]) <= 6
+
+    def runner(args, d, weights=None):
+        h = sum(map(ord, d.name))
+        return dict(image_rocauc=(h % 97) / 97.0, pixel_rocauc=(h % 89) / 89.0, au_pro=(h % 83) / 83.0, au_pro_001=(h % 79) / 79.0,
+                    n_train=d.n_train, n_test=d.n_test, seconds=dict(predict=0.01 * d.n_test), library_rows=dict(xyz=d.n_train))
+    single = ev.evaluate_classes(ev.mtfi_args(), ev.synthetic_mvtec3d("all", scale=0.05, n_test=20), runner=runner)
+    for r in recs:
+        assert r["table"] == single["table"] and list(r["per_class"]) == list(single["per_class"]) == list(ev.MVTEC3D_TRAIN)
+        for cls, v in r["per_class"].items():
+            want = dict(single["per_class"][cls], rank=v["rank"])
+            assert v == want and cls in r["assignment"][v["rank"]]

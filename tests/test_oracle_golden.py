@@ -115,6 +115,31 @@ def test_g4_blur(golden):
     np.testing.assert_array_equal(scoring.knn_gaussian_blur(smooth).numpy()[:, ::2, ::2], g["blur_out"])
 
 
+def test_g5b_hallucination_mlp_depth_2(golden):
+    """The oracle's hallucination net with mlp_depth = 2 (utils/utils.py:103-115) against the reference's own module."""
+    g = golden("g5b_halluc_depth2.npz")
+    sd = {k: v.clone() for k, v in nets.synth_state_dict("halluc", int(g["weights_seed"]), mlp_depth=2).items()}
+    assert "xyz_mlp.mlp_module.1.fc3.weight" in sd and len(sd) == 2 * (2 + 12)
+    s = torch.randn(2, 32, 1536, generator=torch.Generator().manual_seed(int(g["samples_seed"])))
+    xyz, rgb = s[:, :, :768], s[:, :, 768:]
+    with torch.no_grad():
+        np.testing.assert_allclose(nets.halluc_generate(sd, xyz, "xyz2rgb").numpy(), g["gen_xyz2rgb"], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(nets.halluc_generate(sd, rgb, "rgb2xyz").numpy(), g["gen_rgb2xyz"], rtol=1e-4, atol=1e-5)
+        for dm in ("l2", "cos_dist", "smooth_l1"):
+            a, b = nets.halluc_losses(sd, xyz, rgb, dm)
+            np.testing.assert_allclose([a.item(), b.item()], g[f"loss_{dm}"], rtol=1e-5)
+    params = {k: v.requires_grad_(True) for k, v in sd.items()}
+    opt = torch.optim.Adam(list(params.values()), lr=5e-4)
+    for it in range(3):
+        for pg in opt.param_groups:
+            pg["lr"] = 5e-4 * (it / 4)
+        lx, lr_ = nets.halluc_losses(params, xyz, rgb, "l2")
+        np.testing.assert_allclose([lx.item(), lr_.item()], g["train_losses"][it], rtol=1e-4)
+        (lx + lr_).backward()
+        opt.step()
+        opt.zero_grad()
+
+
 def test_g5_hallucination(golden):
     g = golden("g5_halluc.npz")
     sd = {k: v.clone() for k, v in nets.synth_state_dict("halluc", 51).items()}
