@@ -56,6 +56,14 @@ def shard_range(n, rank, world):
 KEY_EMPTY = ops.KEY_EMPTY
 
 
+class _Null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
 def merge_shard_keys(keys, group=None):
     """Combine per-shard packed keys: key = (fp32 bits of d2 >= 0) << 32 | global row.  The keys -- and the "no
     candidate" sentinel ops.KEY_EMPTY a rank with an EMPTY shard leaves behind -- are non-negative as int64, so
@@ -79,6 +87,93 @@ def gather_queries(q16, qsq, group=None):
     return q_all, s_all
 
 
+class _HipSearch:
+    """The device-side pieces of the row-sharded search (HIP kernels); tests/test_host_cpu.py swaps in a torch stand-in to check
+    the host-side composition -- who gathers what, which rows are searched, how the keys come back -- without a GPU."""
+
+    @staticmethod
+    def plan(q16, q_sq, reuse=None):
+        return ops.rows_dedup_plan(q16, q_sq, reuse)
+
+    @staticmethod
+    def search(q16, q_sq, bank, keys):
+        return ops.l2_min_keys(q16, q_sq, bank.bf16, bank.sqnorm, keys, bank.row_offset)
+
+    @staticmethod
+    def expand(keys_compact, slot, out):
+        return ops.keys_expand(keys_compact, slot, out)
+
+
+class ShardedSearch:
+    """Nearest-neighbour keys of this rank's queries against the WHOLE library when every rank holds a row shard of it
+    (features.py:186-190,227 for one device).  Compact first, then gather -- in three stages, so that a caller
+    can put step i + 1's exchange under step i's distance GEMM (bench.py `sharded_search`):
+
+      gather(q16, q_sq): the repeated background row of the rank's own queries is removed locally (csrc/dedup.hip): `count`
+              live rows; the ranks exchange their counts (W int32 -- the one host read of the step, it sizes the exchange);
+              all-gather of the first cap = max(count) rows (rounded up to 256) of every rank's compacted queries + norms:
+              about half of the 154 MB per rank that gathering every row takes (45 % of a batch's patches have no
+              foreground pixel);
+      gemm(): per rank segment, the distance GEMM over that rank's live rows against this rank's shard (global rows via
+              row_offset) -- no collective;
+      reduce(): ONE integer-MIN all-reduce of the packed (distance, global row) keys, then the rank's own segment is expanded
+              back to one key per original row -> keys [Q] int64.
+
+    `stats` (a dict) receives the bytes this rank received in the gather, the live counts and cap."""
+
+    def __init__(self, bank, group, impl=_HipSearch, stats=None):
+        import torch.distributed as td
+        self.bank, self.group, self.impl, self.stats = bank, group, impl, stats
+        self.world, self.rank = td.get_world_size(group), td.get_rank(group)
+        self.plan = None
+
+    def gather(self, q16, q_sq):
+        import torch.distributed as td
+        Q, D = q16.shape
+        self.Q = Q
+        self.plan = self.impl.plan(q16, q_sq, self.plan)
+        counts_t = torch.empty((self.world,), dtype=torch.int32, device=q16.device)
+        td.all_gather_into_tensor(counts_t, self.plan.count.view(1), group=self.group)
+        self.counts = [int(c) for c in counts_t.cpu().tolist()]
+        cap = self.cap = min(Q, (max(self.counts) + 255) // 256 * 256)
+        self.q_all = torch.empty((self.world * cap, D), dtype=q16.dtype, device=q16.device)
+        self.s_all = torch.empty((self.world * cap,), dtype=torch.float32, device=q16.device)
+        td.all_gather_into_tensor(self.q_all.view(torch.uint8), self.plan.q16[:cap].view(torch.uint8), group=self.group)   # raw bytes: gloo has no bf16
+        td.all_gather_into_tensor(self.s_all, self.plan.q_sq[:cap], group=self.group)
+        if self.stats is not None:
+            row = D * q16.element_size() + 4
+            self.stats.update(world=self.world, rows_per_rank=Q, live_rows=self.counts, gathered_rows_per_rank=cap,
+                              gather_bytes_received=(self.world - 1) * cap * row,
+                              gather_bytes_received_without_compaction=(self.world - 1) * Q * row,
+                              reduce_bytes=self.world * cap * 8)
+        return self
+
+    def gemm(self, timer=None):
+        cap = self.cap
+        self.keys_all = torch.full((self.world * cap,), KEY_EMPTY, dtype=torch.int64, device=self.q_all.device)
+        with (timer if timer is not None else _Null()):
+            for w in range(self.world):
+                n = self.counts[w]
+                if n > 0:
+                    self.impl.search(self.q_all[w * cap:w * cap + n], self.s_all[w * cap:w * cap + n], self.bank,
+                                     self.keys_all[w * cap:w * cap + n])
+        return self
+
+    def reduce(self):
+        cap = self.cap
+        keys_all = merge_shard_keys(self.keys_all, self.group)
+        return self.impl.expand(keys_all[self.rank * cap:(self.rank + 1) * cap].contiguous(), self.plan.slot,
+                                torch.empty((self.Q,), dtype=torch.int64, device=keys_all.device))
+
+
+def sharded_min_keys(q16, q_sq, bank, group, plan=None, timer=None, stats=None, impl=_HipSearch):
+    """ShardedSearch's three stages in line -> (keys [Q] int64, plan)."""
+    s = ShardedSearch(bank, group, impl, stats)
+    s.plan = plan
+    keys = s.gather(q16, q_sq).gemm(timer).reduce()
+    return keys, s.plan
+
+
 def _call(name, *args):
     nat.check(getattr(nat.lib(), name)(*args), name)
 
@@ -94,6 +189,9 @@ def score_patches(patch32, bank, dims, gt_size=224, group=None):
     dev = patch32.device
     flat = patch32.reshape(B * Q, D)
     q16, _, qsq = ops.normalize_cast(flat)
+    if group is not None and os.environ.get("CMDIAD_DEDUP", "1") != "0":
+        keys, _ = sharded_min_keys(q16, qsq, bank, group)      # compact locally, gather the live rows only
+        return score_patches_from_keys(patch32, keys, bank, dims, gt_size)
     q_all, s_all = gather_queries(q16, qsq, group)
     keys = ops.new_keys(q_all.shape[0], dev)
     if os.environ.get("CMDIAD_DEDUP", "1") != "0":
@@ -134,14 +232,6 @@ def score_patches_from_keys(patch32, keys, bank, dims, gt_size=224):
     s_map = ops.bilinear_up(min_val.view(B, dims[0], dims[1]), gt_size)
     return dict(min_val=min_val.view(B, Q), min_idx=min_idx.view(B, Q), s_idx=s_idx, s_star=s_star, s=s,
                 s_map_pre=s_map, top3=top3, knn_d=knn_d)
-
-
-class _Null:
-    def __enter__(self):
-        return self
-
-    def __exit__(self, *a):
-        return False
 
 
 class Extraction:

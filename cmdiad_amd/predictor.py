@@ -111,6 +111,7 @@ class BatchPredictor:
         self.dedup = os.environ.get("CMDIAD_DEDUP", "1") != "0"
         self.live_rows = torch.zeros((1,), dtype=torch.int64, device=dev)   # rows actually searched, summed over the xyz searches
         self.xyz_searches = 0
+        self.shard_stats = {}        # per library: what the last row-sharded search exchanged (engine.sharded_min_keys)
         self.inputs = [self._new_inputs() for _ in range(2 if use_graph else 1)]
 
     def _new_inputs(self):
@@ -181,6 +182,17 @@ class BatchPredictor:
                 continue
             q, q16, qsq = qs[name]
             B, Q, D = q.shape
+            if self.group is not None and self.dedup:
+                # row-sharded library: compact locally, all-gather the live rows only (engine.sharded_min_keys)
+                st = self.shard_stats.setdefault(name, {})
+                k, plan = eng.sharded_min_keys(q16, qsq, bank, self.group, plan=self.static.get(f"plan_{name}_{buf}"),
+                                               timer=self.timers.get(name), stats=st)
+                self.static[f"plan_{name}_{buf}"] = plan
+                if name == "xyz":
+                    self.live_rows += sum(st["live_rows"])
+                    self.xyz_searches += 1
+                keys[name] = k
+                continue
             q_all, s_all = eng.gather_queries(q16, qsq, self.group)
             k = self.static.get(f"keys_{name}_{buf}")
             if k is None or k.shape[0] != q_all.shape[0]:

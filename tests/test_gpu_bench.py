@@ -38,3 +38,13 @@ def test_bench_distributed_path_on_one_gpu():
     s = d["sharded_search"]
     assert s["rccl_ranks"] == 1 and s["backend"] == "nccl"
     assert d["value"] > 100
+    # compact-then-gather: the exchange carries the live rows only, and the line says what moved and where the time went
+    c = s["classes"][0]
+    assert c["cls"] == "bagel" and c["rows"] == 76518 and c["rows_this_rank"] == 76518
+    assert len(c["live_rows_per_rank"]) == 1 and 0.5 * 100352 < c["live_rows_per_rank"][0] < 0.7 * 100352
+    assert c["gathered_rows_per_rank"] % 256 == 0 and c["live_rows_per_rank"][0] <= c["gathered_rows_per_rank"] < 100352
+    assert c["gather_MB_received_per_rank"] == 0.0 and c["gather_MB_received_without_compaction"] == 0.0      # a world of one
+    assert set(c["serial_ms_rank0"]) == {"dedup_and_gather", "gemm", "reduce_and_expand"} and c["serial_ms_rank0"]["gemm"] > 1.0
+    assert c["gemm_tflops_rank0"] > 500 and c["ms_per_search"] > 0
+    m = d["mtfi_classes"]
+    assert m["world"] == 1 and len(m["per_class"]) == 10 and m["assignment"][0][0] == "peach" and 0.0 <= m["mean"]["image_rocauc"] <= 1.0

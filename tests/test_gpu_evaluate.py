@@ -21,12 +21,13 @@ from cmdiad_amd.utils.au_pro_util import calculate_au_pro  # noqa: E402
 from oracle import nets, pipeline  # noqa: E402
 
 
-def _oracle_class(cpu_ex, sd_h, data, lambdas):
-    """cmdiad_runner.py:33-107 on the CPU oracle: fit (f_coreset = 1), late-fusion rows from the train samples, the two
-    SGDOneClassSVM fits of features.py:352-358, predict, and the metrics of features.py:302-324."""
+def _oracle_class(cpu_ex, sd_h, data, lambdas, f_coreset, random_state):
+    """cmdiad_runner.py:33-107 on the CPU oracle: fit (memory bank, statistics, greedy coreset of both libraries), late-fusion
+    rows from the train samples, the two SGDOneClassSVM fits of features.py:352-358, predict, and the metrics of
+    features.py:302-324."""
     from sklearn import linear_model
     from sklearn.metrics import roc_auc_score
-    cpu = pipeline.CpuOneHallucination(cpu_ex, sd_h, "xyz", lambdas=lambdas)
+    cpu = pipeline.CpuOneHallucination(cpu_ex, sd_h, "xyz", lambdas=lambdas, f_coreset=f_coreset, random_state=random_state)
     trip = cpu.fit([(s[0], s[1]) for s, _ in data.train()])
     rows = [cpu.score(*t)[:2] for t in trip]               # the train samples again (cmdiad_runner.py:58-66): same patches
     det = linear_model.SGDOneClassSVM(random_state=42, nu=0.5, max_iter=1000).fit(torch.cat([r[0] for r in rows], 0).numpy())
@@ -40,31 +41,49 @@ def _oracle_class(cpu_ex, sd_h, data, lambdas):
         masks.append(mask.numpy().reshape(224, 224))
     masks, pix = np.stack(masks), np.stack(pix)
     return dict(image_rocauc=roc_auc_score(labels, img), pixel_rocauc=roc_auc_score(masks.ravel().astype(int), pix.ravel()),
-                au_pro=calculate_au_pro(list(masks), list(pix))[0], det=det, seg=seg, img=np.array(img))
+                au_pro=calculate_au_pro(list(masks), list(pix))[0], det=det, seg=seg, img=np.array(img),
+                picks=[cpu.main_coreset, cpu.fus_coreset])
 
 
-def test_mtfi_class_loop_auroc_vs_oracle():
+def test_mtfi_class_loop_auroc_vs_oracle(monkeypatch):
     """Two synthetic classes x (4 train, 20 test of which 6 anomalous) through cmdiad_amd.evaluate.evaluate_classes
-    (drop-in RGBorXYZWithOneHallucination, main modality xyz, the whole five-call protocol on the GPU) against the oracle's
-    class loop: |dI-AUROC| <= 1e-2, |dP-AUROC| <= 1e-2, |dAU-PRO| <= 2e-2 per class, and the table's Mean column."""
+    (drop-in RGBorXYZWithOneHallucination, main modality xyz, the whole five-call protocol on the GPU: memory bank, statistics,
+    coreset, late-fusion bank, both one-class-SVM fits, predict, metrics) against the oracle's class loop, every fit done
+    independently on each side: |dI-AUROC| <= 1e-2, |dP-AUROC| <= 1e-2, |dAU-PRO| <= 2e-2 per class, and the table's Mean
+    column.  f_coreset = 0.1 as in the reference's runs (with 1.0 every late-fusion sample is its own nearest neighbour and
+    the SVMs are fitted on zeros).  The greedy coreset is chaotic in the last bit of its input (its own parity gate is G9), so
+    the oracle's picks are handed to the GPU side; the drop-in's OWN selection on its bf16 features must overlap them."""
+    from cmdiad_amd.feature_extractors import multiple_features as mf
     weights = (nets.synth_state_dict("vit", 31), nets.sharpen_pointmae(nets.synth_state_dict("pointmae", 21)),
                nets.synth_state_dict("halluc", 51))
     cpu_ex = pipeline.CpuExtractor(weights[0], weights[1])
     data = {"bagel": SyntheticClass("bagel", 4, 20, index=0), "rope": SyntheticClass("rope", 4, 20, index=8)}
     assert sum(int(l[0]) for _, _, l, _ in data["bagel"].test()) == 6
-    a = ev.mtfi_args(f_coreset=1.0)
+    a = ev.mtfi_args(f_coreset=0.1, random_state=3)
+    lam = (a.xyz_s_lambda, a.xyz_smap_lambda, a.fusion_s_lambda, a.fusion_smap_lambda)
+    refs = {cls: _oracle_class(cpu_ex, weights[2], d, lam, a.f_coreset, a.random_state) for cls, d in data.items()}
+    queue = [pk for cls in ("bagel", "rope") for pk in refs[cls]["picks"]]      # run_coreset: main library, then fusion
+    own = []
+    inner = mf.RGBorXYZWithOneHallucination.get_coreset_idx_randomp
+
+    def picker(self, *args, **kw):
+        own.append(inner(self, *args, **kw))
+        return torch.as_tensor(queue[len(own) - 1]).long()
+
+    monkeypatch.setattr(mf.RGBorXYZWithOneHallucination, "get_coreset_idx_randomp", picker)
     res = ev.evaluate_classes(a, data, weights=weights, log=print)
+    assert len(own) == 4
+    for o, pk in zip(own, queue):
+        assert len(o) == len(pk) == int(0.1 * 4 * 3136) and len(set(o.tolist()) & set(torch.as_tensor(pk).tolist())) > 0.5 * len(pk)
     assert res["method"] == "WithHallucination" and list(res["per_class"]) == ["bagel", "rope"]
     assert res["assignment"] == [["bagel", "rope"]] and res["world"] == 1          # equal costs: ties by name
-    lam = (a.xyz_s_lambda, a.xyz_smap_lambda, a.fusion_s_lambda, a.fusion_smap_lambda)
-    for cls, d in data.items():
-        ref = _oracle_class(cpu_ex, weights[2], d, lam)
+    for cls, ref in refs.items():
         got = res["per_class"][cls]
         print(f"{cls}: I-AUROC {got['image_rocauc']:.4f} (oracle {ref['image_rocauc']:.4f}); P-AUROC {got['pixel_rocauc']:.4f} "
               f"(oracle {ref['pixel_rocauc']:.4f}); AU-PRO {got['au_pro']:.4f} (oracle {ref['au_pro']:.4f}); "
               f"oracle det coef {ref['det'].coef_.ravel()} seg coef {ref['seg'].coef_.ravel()}")
         assert got["n_train"] == 4 and got["n_test"] == 20
-        assert got["library_rows"] == {"xyz": 4 * 3136, "rgb": 4 * 784, "fusion": 4 * 3136}
+        assert got["library_rows"] == {"xyz": 1254, "rgb": 4 * 784, "fusion": 1254}
         assert abs(got["image_rocauc"] - ref["image_rocauc"]) <= 1e-2, cls
         assert abs(got["pixel_rocauc"] - ref["pixel_rocauc"]) <= 1e-2, cls
         assert abs(got["au_pro"] - ref["au_pro"]) <= 2e-2, cls

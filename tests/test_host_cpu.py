@@ -490,3 +490,97 @@ def test_class_sharded_evaluate_world2_gloo(tmp_path):
         for cls, v in r["per_class"].items():
             want = dict(single["per_class"][cls], rank=v["rank"])
             assert v == want and cls in r["assignment"][v["rank"]]
+
+
+# ------------------------------------------------------------------------------------------------ compact, then gather (configs[3])
+_GLOO_COMPACT_WORKER = r"""
+import os, sys, types
+sys.path.insert(0, {repo!r})
+import torch
+import torch.distributed as td
+from cmdiad_amd import engine as eng
+td.init_process_group("gloo")
+rank, world = td.get_rank(), td.get_world_size()
+
+
+def pack(d2, idx):
+    return (d2.contiguous().view(torch.int32).to(torch.int64) << 32) | idx
+
+
+def d2_of(q, q_sq, b, b_sq):
+    return ((q_sq[:, None] + b_sq[None, :]) - 2.0 * (q.float() @ b.float().T)).clamp_min(0.0)
+
+
+class TorchSearch:      # stand-in for the HIP kernels behind engine.sharded_min_keys (same contracts, host tensors)
+    searched = 0
+
+    @staticmethod
+    def plan(q16, q_sq, reuse=None):
+        Q = q16.shape[0]
+        _, inv, cnt = torch.unique(q16.float(), dim=0, return_inverse=True, return_counts=True)
+        dup = inv == cnt.argmax()
+        first = int(dup.nonzero()[0])
+        keep = ~dup
+        keep[first] = True
+        rows = keep.nonzero().flatten()
+        slot = (torch.cumsum(keep.int(), 0) - 1).int()
+        slot[dup] = slot[first]
+        p = types.SimpleNamespace(q16=torch.zeros_like(q16), q_sq=torch.zeros_like(q_sq), slot=slot,
+                                  count=torch.tensor([len(rows)], dtype=torch.int32))
+        p.q16[:len(rows)] = q16[rows]
+        p.q_sq[:len(rows)] = q_sq[rows]
+        return p
+
+    @staticmethod
+    def search(q16, q_sq, bank, keys):
+        TorchSearch.searched += q16.shape[0]
+        if bank.bf16.shape[0]:
+            v, i = d2_of(q16, q_sq, bank.bf16, bank.sqnorm).min(1)
+            keys.copy_(torch.minimum(keys, pack(v, i + bank.row_offset)))
+        return keys
+
+    @staticmethod
+    def expand(kc, slot, out):
+        out.copy_(kc[slot.long()])
+        return out
+
+
+g = torch.Generator().manual_seed(21)
+Nb, D, Q = 1500, 16, 700
+lib = torch.randn(Nb, D, generator=g).half()                   # the same library on every rank; each keeps its row shard
+lib_sq = lib.float().pow(2).sum(1)
+lo, hi = eng.shard_range(Nb, rank, world)
+bank = types.SimpleNamespace(bf16=lib[lo:hi], sqnorm=lib_sq[lo:hi], row_offset=lo)
+gq = torch.Generator().manual_seed(100 + rank)                 # every rank's own queries, with its own share of background rows
+q = torch.randn(Q, D, generator=gq).half()
+bg = torch.rand(Q, generator=gq) < (0.35 + 0.2 * rank)
+q[bg] = torch.full((D,), -0.25).half()
+q_sq = q.float().pow(2).sum(1)
+stats = {{}}
+keys, plan = eng.sharded_min_keys(q, q_sq, bank, td.group.WORLD, stats=stats, impl=TorchSearch)
+# gather-then-search of EVERY row against the whole library: the single-device answer
+v, i = d2_of(q, q_sq, lib, lib_sq).min(1)
+want = pack(v, i)
+assert torch.equal(keys, want), (keys != want).nonzero().flatten()[:8]
+live = int(plan.count)
+assert live == int((~bg).sum()) + 1 and stats["live_rows"][rank] == live
+assert stats["gathered_rows_per_rank"] == min(Q, (max(stats["live_rows"]) + 255) // 256 * 256) < Q
+assert stats["gather_bytes_received"] < 0.8 * stats["gather_bytes_received_without_compaction"]
+assert TorchSearch.searched == sum(stats["live_rows"])       # every rank searched the live rows of all ranks, nothing else
+td.barrier()
+td.destroy_process_group()
+print("rank", rank, "ok", stats["live_rows"], stats["gathered_rows_per_rank"])
+"""
+
+
+def test_compact_then_gather_equals_gather_then_search_world2_gloo(tmp_path):
+    """engine.sharded_min_keys on a gloo group of two ranks with a torch stand-in for the kernels: removing each rank's repeated
+    background row BEFORE the all-gather (only the live rows + a per-rank count travel) returns, for every original row, the
+    key that searching every row of every rank against the whole library returns -- ties to the lowest global row included."""
+    script = tmp_path / "w.py"
+    script.write_text(_GLOO_COMPACT_WORKER.format(repo=REPO))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29561", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
