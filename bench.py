@@ -406,6 +406,93 @@ def sharded_search(dev, group, rank, world, rows_list, iters=10, warm=3):
                 rccl_ranks=td.get_world_size(group), backend=td.get_backend(group), classes=out)
 
 
+def train_step_leg(dev, steps=50, warm=10):
+    """BASELINE configs[2]: one FtoF distillation training step = both directions forward + loss + backward + Adam on a
+    [32, 3136, 1536] feature batch (xyz first, rgb second), N(0,1), seed 3407 (hallucination_network_pretrain.py:53,102-159), lr
+    schedule per iteration (utils/lr_sched.py:4-17), l2 loss; 7.99 TFLOP per step (3 x forward, both directions, 100 352
+    tokens).  The batch is resident in HBM (tools/train_bench.py also times the FeatureRing-fed loop)."""
+    import types
+    import torch
+    from cmdiad_amd import train
+    from cmdiad_amd.models.hallucination_network import HallucinationCrossModalityNetwork
+    from cmdiad_amd.utils import lr_sched
+    torch.manual_seed(3407)
+    net = HallucinationCrossModalityNetwork(None, 768, 768).to(dev)
+    opt = train.FusedAdam(net.parameters(), lr=5e-4)
+    sched = types.SimpleNamespace(lr=5e-4, warmup_epochs=10, epochs=100)
+    x = torch.randn(32, 3136, 1536, generator=torch.Generator(device=dev).manual_seed(3407), device=dev)
+    losses = []
+
+    def step(it):
+        lr_sched.adjust_learning_rate(opt, it / 100.0, sched)
+        lx, lr_ = net(x[:, :, :768], x[:, :, 768:], False, "l2")
+        opt.zero_grad(set_to_none=True)
+        (lx + lr_).backward()
+        opt.step()
+        return lx, lr_
+
+    for i in range(warm):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        lx, lr_ = step(warm + i)
+        if i in (0, steps - 1):
+            losses.append((lx, lr_))
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    l0, l1 = [float(a.item() + b.item()) for a, b in losses]
+    assert l1 == l1 and l1 < l0, (l0, l1)            # finite, and the optimiser is descending
+    return dict(what="configs[2]: HallucinationCrossModality feature-to-feature distillation training step (forward + l2 loss + "
+                     "backward, both directions, + Adam) on [32, 3136, 1536] synthetic features resident in HBM",
+                ms_per_step=round(dt * 1e3, 3), steps_per_s=round(1.0 / dt, 2), tflop_per_step=7.99,
+                achieved_TFLOPs=round(7.99 / dt, 1), frac_of_mfma_peak=round(7.99 / dt / PEAK_BF16_TFLOPS, 4),
+                steps=steps, warmup=warm, loss_first_timed=round(l0, 2), loss_last_timed=round(l1, 2),
+                tokens_per_s=round(32 * 3136 / dt, 0))
+
+
+def var_n_leg(st, dev, steps=8, warm=3):
+    """SURVEY 8(d) var-N regime: every cloud keeps a different share of the image -- foreground 35 ... 65 % of the 224 x 224 pixels
+    (N ~ 17.5 k ... 32.6 k points) -- instead of the fixed 24 576 points of the headline batches: the same predictor, ragged
+    point counts inside a batch of 32 (padded to the largest, per-sample lengths on the device), and a DIFFERENT share of
+    repeated background rows in front of the xyz search."""
+    import numpy as np
+    import torch
+    from cmdiad_amd.predictor import BatchPredictor, EventTimer
+    from cmdiad_amd.synth import synth_cloud, synth_rgb
+    rs = np.random.RandomState(8)
+    batches, n_pts = [], []
+    for j in range(2):
+        fr = (0.35 + 0.30 * rs.rand(BATCH)) / 0.85     # synth_cloud's ellipse covers 0.85 x frac of the image
+        pcs = torch.cat([synth_cloud(7000 + j * BATCH + i, float(fr[i])) for i in range(BATCH)])
+        n_pts += [int((pcs[i] != 0).all(0).sum()) for i in range(BATCH)]
+        rgb = torch.cat([synth_rgb(7000 + j * BATCH + i) for i in range(BATCH)]) if st["workload"] == "dino_pointmae" else None
+        batches.append((rgb.to(dev) if rgb is not None else None, pcs.to(dev)))
+    n_max = (max(n_pts) + 255) // 256 * 256
+    timers = {"xyz": EventTimer(), "rgb": EventTimer()}
+    pred = BatchPredictor(st["engine"], st["bank_xyz"], st["bank_second"], st["stats"], st["det"], st["seg"], batch=BATCH,
+                          n_max=n_max, workload=st["workload"], halluc=st["halluc"], group=None,
+                          use_graph=os.environ.get("CMDIAD_GRAPH", "1") != "0", timers=timers)
+    first = run_steps(pred, batches, warm)
+    for t in timers.values():
+        t.pairs.clear()
+    torch.cuda.synchronize()
+    pred.live_rows.zero_()
+    pred.xyz_searches = 0
+    t0 = time.perf_counter()
+    run_steps(pred, batches, steps, first)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    live = float(pred.live_rows.item()) / max(pred.xyz_searches, 1)
+    l2_ms = timers["xyz"].mean_ms()
+    rows = st["bank_xyz"].bf16.shape[0]
+    return dict(what="var-N regime (SURVEY 8d): foreground 35-65 % of the image per cloud, ragged point counts inside the batch of 32",
+                value=round(BATCH * steps / dt, 2), unit="images/s per GPU", ms_per_step=round(dt / steps * 1e3, 3), steps=steps,
+                points_per_cloud=dict(min=min(n_pts), mean=round(sum(n_pts) / len(n_pts), 1), max=max(n_pts), padded_to=n_max),
+                xyz_query_rows=dict(per_step=BATCH * 3136, searched_per_step=round(live, 1)),
+                xyz_search_ms=round(l2_ms, 3), xyz_search_TFLOPs=round(2.0 * live * rows * 768 / (l2_ms * 1e-3) / 1e12, 1))
+
+
 def mtfi_classes(dev, group, rank, world, classes="all", scale=0.05, n_test=20, f_coreset=0.1):
     """configs[4] as a config: the reference's class loop (main.py:22-37 -> cmdiad_runner.CMDIAD.fit / evaluate) for the MTFI
     feature-to-feature method (RGBorXYZWithOneHallucination, main modality xyz) over synthetic stand-ins of the ten MVTec
@@ -616,6 +703,9 @@ def main():
         if group is not None:
             names = list(CLASS_TRAIN) if args.classes == "all" else [c for c in args.classes.split(",") if c]
             extras["sharded_search"] = sharded_search(dev, group, rank, world, [(c, class_rows(c)) for c in names])
+        if group is None:
+            extras["var_n"] = var_n_leg(st, dev)
+            extras["train_step"] = train_step_leg(dev)
         # configs[4] as a config (bounded): the class loop with the classes dealt to the ranks, metrics gathered at the end
         extras["mtfi_classes"] = mtfi_classes(dev, group, rank, world, "all", args.class_scale, args.class_test)
 

@@ -444,84 +444,12 @@ __global__ __launch_bounds__(512, 1) void l2_min_pp_kernel(GlobalTile A, GlobalT
 struct SPingPong3 {
     static constexpr int BM = 256, BN = 256, THREADS = 512;
     static constexpr int BUF = 32768, HALF = 16384;
-    static constexpr int A_OFF = 3 * BUF, BN_OFF = A_OFF + 3 * HALF, QN_OFF = BN_OFF + 2 * 256 * 4;
-    static constexpr int LDS_BYTES = QN_OFF + 2 * 256 * 4;
+    static constexpr int A_OFF = 3 * BUF, BN_OFF = A_OFF + 3 * HALF;
+    static constexpr int LDS_BYTES = BN_OFF + 2 * 256 * 4;
 };
 
-// ---- the work list of a PERSISTENT block ---------------------------------------------------------------------------------
-// A job = one query tile against `per` consecutive library tiles (the last range of a query tile may be shorter); jobs are
-// numbered [group of `qgroup` query tiles][library range][query tile of the group], so that 32 consecutive jobs = 8 ranges x
-// 4 query tiles: what the 32 CUs of an XCD work on at the same time (a streamed library tile is then shared through that XCD's
-// L2 by four blocks, and only four query tiles are hot in it).  The launch is ONE block per CU; block `pos` (its place after
-// the XCD remap: every XCD holds a contiguous run of positions) takes job r * nblk + pos in round r = 0 .. R - 1, so the
-// co-resident blocks of an XCD stay on consecutive jobs round after round.  The J - R * nblk jobs of the last, partial round
-// are cut into equal runs of library tiles, one per block (a run may cover the end of one job and the start of the next):
-// partial minima meet in the 64-bit atomicMin on the keys anyway, so any cut of the library gives the same keys.
-// Both operand streams run on across segment boundaries (no pipeline fill or drain between jobs), the block count does not
-// depend on the number of live query rows (the de-duplicated search reads it on the device: no dead blocks to dispatch).
-struct L2Seg { int qt, bt0, cnt; };
-struct L2Walk {
-    int nq, qgroup, per, splits, nbt;   // live query tiles, query tiles per group, library tiles per job, jobs per query tile
-    int R, nblk, pos;                   // full rounds, persistent blocks, this block's place in a round
-    int u0, u1;                         // this block's run of the last round, in units of (tail job) * per + tile
-    int r, tj;                          // cursor
-    __device__ __forceinline__ void setup(int nq_, int qgroup_, int splits_target, int nbt_, int nblk_, int pos_)
-    {
-        nq = nq_; nbt = nbt_; nblk = nblk_; pos = pos_;
-        qgroup = min(qgroup_, max(nq, 1));
-        per = (nbt + splits_target - 1) / splits_target;
-        splits = (nbt + per - 1) / per;
-        const int J = nq * splits;
-        R = J / nblk;
-        const long U = (long)(J - R * nblk) * per;
-        u0 = (int)(U * pos / nblk);
-        u1 = (int)(U * (pos + 1) / nblk);
-        r = -1; tj = -1;
-    }
-    __device__ __forceinline__ void job(int j, L2Seg& s) const
-    {
-        const int gsz = qgroup * splits;
-        const int g = j / gsz;
-        const int rows = min(qgroup, nq - g * qgroup);   // only the last group can be short
-        const int rem = j - g * gsz;
-        const int split = rem / rows;
-        s.qt = g * qgroup + rem - split * rows;
-        s.bt0 = split * per;
-        s.cnt = min(per, nbt - s.bt0);
-    }
-    __device__ __forceinline__ bool next(L2Seg& s)
-    {
-        if (r + 1 < R) { ++r; job(r * nblk + pos, s); return true; }
-        r = R;
-        tj = tj < 0 ? u0 / per : tj + 1;
-        for (; tj * per < u1; ++tj) {
-            L2Seg f;
-            job(R * nblk + tj, f);
-            const int lo = max(u0 - tj * per, 0), hi = min(u1 - tj * per, f.cnt);
-            if (hi > lo) { s.qt = f.qt; s.bt0 = f.bt0 + lo; s.cnt = hi - lo; return true; }
-        }
-        return false;
-    }
-};
-
-// min of a packed key over the four 16-lane groups of a wave (lanes l, l ^ 16, l ^ 32, l ^ 48), VALU only: v_permlane16_swap /
-// v_permlane32_swap of (v, v) leave {own, partner} in the two registers in a lane-dependent order, which is all a minimum needs
-__device__ __forceinline__ unsigned long long groups_min_u64(unsigned long long v)
-{
-    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32), lo2 = lo, hi2 = hi;
-    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(lo), "+v"(lo2));
-    asm volatile("v_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(hi), "+v"(hi2));
-    unsigned long long x = ((unsigned long long)hi << 32) | lo, y = ((unsigned long long)hi2 << 32) | lo2;
-    v = y < x ? y : x;
-    lo = (unsigned)v; hi = (unsigned)(v >> 32); lo2 = lo; hi2 = hi;
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(lo2));
-    asm volatile("v_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(hi), "+v"(hi2));
-    x = ((unsigned long long)hi << 32) | lo; y = ((unsigned long long)hi2 << 32) | lo2;
-    return y < x ? y : x;
-}
-
-// DIAG (test-only build): waves 0 and 4 of the block at position p.diag_wg stamp s_memtime at five points of every phase into LDS (no
-// global traffic inside the loop: stores count in vmcnt and would shift the counted waits) and copy the stamps out at the end.
+// DIAG (test-only build): waves 0 and 4 of workgroup p.diag_wg stamp s_memtime at five points of every phase into LDS (no global
+// traffic inside the loop: stores count in vmcnt and would shift the counted waits) and copy the stamps out at the end.
 constexpr int kDiagStamps = 1280;   // per wave: 64 K-tiles x 4 phases x 5
 template <bool F16, bool DIAG = false>
 __global__ __launch_bounds__(512, 1) void l2_min_pp3_kernel(GlobalTile A, GlobalTile W, L2Params p)
@@ -529,28 +457,23 @@ __global__ __launch_bounds__(512, 1) void l2_min_pp3_kernel(GlobalTile A, Global
     extern __shared__ __attribute__((aligned(16))) char lds[];
     using S = SPingPong3;
     using frag = typename std::conditional<F16, f16x8, bf16x8>::type;
-    if (p.q_count) {   // live query rows known only on the device (the compacted query set of cmdiad_rows_dedup_plan)
-        const int q = __builtin_amdgcn_readfirstlane(*p.q_count);
-        p.Q = q;
-        A.rows = q;
-        p.nq_tiles = (q + S::BM - 1) / S::BM;
-    }
-    if (p.nq_tiles <= 0) return;
-    const int pos = xcd_remap(blockIdx.x, gridDim.x);
-    L2Walk walk0;
-    walk0.setup(p.nq_tiles, p.qgroup, p.splits, p.n_bank_tiles, gridDim.x, pos);
-    const int KT = p.D / BK;
-    int T_total = 0;
-    {
-        L2Walk w = walk0;
-        L2Seg s;
-        while (w.next(s)) T_total += s.cnt * KT;
-    }
-    if (T_total == 0) return;   // block-uniform
+    const int nwg = live_rows<S::BM>(A, p);
+    if ((int)blockIdx.x >= nwg) return;
+    const int wg = xcd_remap(blockIdx.x, nwg);
+    const int gsz = p.qgroup * p.splits;
+    const int within = wg % gsz;
+    const int split = within / p.qgroup, qt = (wg / gsz) * p.qgroup + within % p.qgroup;
+    if (qt >= p.nq_tiles) return;
+    const int per = (p.n_bank_tiles + p.splits - 1) / p.splits;
+    const int nt0 = split * per;
+    const int ntc = min(per, p.n_bank_tiles - nt0);
+    if (ntc <= 0) return;
+    const int m0 = qt * S::BM;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = wave >> 2, wc = wave & 3;
+    const int KT = p.D / BK, T_total = ntc * KT;
     unsigned* diag_lds = reinterpret_cast<unsigned*>(lds + S::LDS_BYTES) + (wave >> 2) * kDiagStamps;
-    const bool diag_on = DIAG && pos == p.diag_wg && (wave & 3) == 0;
+    const bool diag_on = DIAG && wg == p.diag_wg && (wave & 3) == 0;
     int diag_n = 0, diag_k = 0;
     unsigned long long diag_t[5] = {0, 0, 0, 0, 0};
     // s_memtime is a scalar-memory read (~100+ cycles, counted in lgkmcnt): the five stamps of a phase stay in SGPRs and are
@@ -571,22 +494,16 @@ __global__ __launch_bounds__(512, 1) void l2_min_pp3_kernel(GlobalTile A, Global
             }
         }
     };
-    // LDS byte addresses of the [2][256] library-norm and query-norm areas (the inline-asm accesses take raw LDS addresses)
+    // LDS byte address of the [2][256] bank-norm area (the inline-asm accesses take raw LDS addresses)
     const unsigned bn_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(lds + S::BN_OFF);
-    const unsigned qn_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(lds + S::QN_OFF);
 
-    // compute-side cursor: the segment in hand and the one after it (its query norms are fetched a library tile ahead)
-    L2Walk walk_c = walk0;
-    L2Seg cs, ns;
-    walk_c.next(cs);
-    bool has_next = walk_c.next(ns);
     float best[8], qn[8];
     int besti[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         best[i] = __builtin_inff();
         besti[i] = 0;
-        const int m = cs.qt * S::BM + wr * 128 + i * 16 + (lane & 15);
+        const int m = m0 + wr * 128 + i * 16 + (lane & 15);
         qn[i] = m < p.Q ? p.q_sqnorm[m] : 0.0f;
     }
     f32x4 acc[8][4];
@@ -606,19 +523,11 @@ __global__ __launch_bounds__(512, 1) void l2_min_pp3_kernel(GlobalTile A, Global
     const int src_chunk = ((lane & 7) ^ (lane >> 3)) * 8;  // element offset of the 16-byte chunk this lane fetches (rule 21)
     const int row_w = bank_wave ? (sw >> 1) * 64 + (sw & 1) * 16 : sw * 16;  // this wave's share of every half-unit
     const size_t ld2 = (size_t)(bank_wave ? W.ld : A.ld) * 2;                  // row pitch in bytes
-    // the stream's own cursor over the block's segments; per-lane pointer to (first row of the current tile + row_w + lane / 8,
-    // k-tile column + chunk); query rows past Q clamp
-    L2Walk walk_s = walk0;
-    L2Seg ss;
-    walk_s.next(ss);
-    int s_tile = 0;
-    auto seg_ptr = [&]() {
-        return bank_wave ? reinterpret_cast<const char*>(W.base + (size_t)(ss.bt0 * S::BN + row_w + (lane >> 3)) * W.ld + src_chunk)
-                         : reinterpret_cast<const char*>(A.base + (size_t)(ss.qt * S::BM + row_w + (lane >> 3)) * A.ld + src_chunk);
-    };
-    const char* ptr = seg_ptr();
-    bool a_full = ss.qt * S::BM + S::BM <= A.rows;
-    int hT = 0, hK = 0;           // stream cursor: K-tile index over the whole work list, k tile inside the library tile
+    // per-lane pointer to (first row of the current tile + row_w + lane / 8, k-tile column + chunk); query rows past Q clamp
+    const bool a_full = m0 + S::BM <= A.rows;
+    const char* ptr = bank_wave ? reinterpret_cast<const char*>(W.base + (size_t)(nt0 * S::BN + row_w + (lane >> 3)) * W.ld + src_chunk)
+                                : reinterpret_cast<const char*>(A.base + (size_t)(m0 + row_w + (lane >> 3)) * A.ld + src_chunk);
+    int hT = 0, hK = 0;           // stream cursor: tile index, k tile
     int slot_lo = 0, slot_hi = 1;  // bank: both = buffer of tile hT;  query: half slots of (lo, hi) of tile hT
     if (bank_wave) slot_hi = 0;
     auto issue_part = [&](auto PART) {  // -> true when the half-unit was issued
@@ -635,7 +544,7 @@ __global__ __launch_bounds__(512, 1) void l2_min_pp3_kernel(GlobalTile A, Global
             } else {
                 constexpr int rows = hsel * 128 + hi * 64;
                 if (a_full) src = ptr + (size_t)(rows + e * 8) * ld2;
-                else src = reinterpret_cast<const char*>(A.base + (size_t)min(ss.qt * S::BM + row_w + rows + e * 8 + (lane >> 3), A.rows - 1) * A.ld + hK * BK + src_chunk);
+                else src = reinterpret_cast<const char*>(A.base + (size_t)min(m0 + row_w + rows + e * 8 + (lane >> 3), A.rows - 1) * A.ld + hK * BK + src_chunk);
                 dst = lds + S::A_OFF + (hi ? slot_hi : slot_lo) * S::HALF + (row_w + hsel * 64 + e * 8) * 128;
             }
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -643,15 +552,9 @@ __global__ __launch_bounds__(512, 1) void l2_min_pp3_kernel(GlobalTile A, Global
         }
         if constexpr (part == 3) {  // next K-tile of this stream
             ++hT;
-            if (++hK == KT) {       // next library tile
+            if (++hK == KT) {
                 hK = 0;
-                if (++s_tile == ss.cnt) {   // next segment: another library range and / or another query tile
-                    s_tile = 0;
-                    if (walk_s.next(ss)) {
-                        ptr = seg_ptr();
-                        a_full = ss.qt * S::BM + S::BM <= A.rows;
-                    }
-                } else ptr += bank_wave ? (size_t)S::BN * ld2 - (size_t)(KT - 1) * BK * 2 : (size_t)0 - (size_t)(KT - 1) * BK * 2;
+                ptr += bank_wave ? (size_t)S::BN * ld2 - (size_t)(KT - 1) * BK * 2 : (size_t)0 - (size_t)(KT - 1) * BK * 2;
             } else ptr += BK * 2;
             if (bank_wave) { slot_lo = slot_lo == 2 ? 0 : slot_lo + 1; slot_hi = slot_lo; }
             else { slot_lo = slot_lo == 0 ? 2 : slot_lo - 1; slot_hi = slot_hi == 0 ? 2 : slot_hi - 1; }  // (x + 2) mod 3
@@ -663,18 +566,11 @@ __global__ __launch_bounds__(512, 1) void l2_min_pp3_kernel(GlobalTile A, Global
         constexpr int j = decltype(J)::value;
         return bank_wave ? issue_part(std::integral_constant<int, (j + 2) % 4>{}) : issue_part(std::integral_constant<int, (j + 1) % 4>{});
     };
-    // counted wait of a phase: the bank stream keeps 7 half-units in flight, the query stream 3 (see the header comment).  The
-    // eight atomics of a segment's key flush count in vmcnt like the DMA pieces and retire in order: while they are younger
-    // than the piece a wait protects (7 phases for the bank stream, 3 for the query stream) the immediate is raised by eight --
-    // vmcnt(14) right after them would wait for the atomics to reach L2 with all eight waves of the CU at the next barrier.
-    int ep_age = 1 << 20;   // phases since a flush that is GUARANTEED to have issued eight atomics (full query tile); wave-uniform
+    // counted wait of a phase: the bank stream keeps 7 half-units in flight, the query stream 3 (see the header comment)
     auto phase_wait = [&](bool issued) {
-        constexpr int lead = bank_wave ? 7 : 3;
         if (!issued) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (ep_age < lead) { if (bank_wave) asm volatile("s_waitcnt vmcnt(22)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); }
         else if (bank_wave) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        ++ep_age;
     };
     // prologue: bank half-units 0..9 (tiles 0, 1 and the lo unit of tile 2), query half-units 0..4 (tile 0 and lo h0 of tile 1)
     {
@@ -696,15 +592,12 @@ __global__ __launch_bounds__(512, 1) void l2_min_pp3_kernel(GlobalTile A, Global
     auto ldb = [&](int j, int kk) { return *reinterpret_cast<const frag*>(lds + ((b_base + j * 2048) ^ (kk << 6))); };
 
     frag af[4][2], wlo[2][2], whi[2][2];
-    int c_tile = 0, kt_c = 0;     // library tile inside the segment, k tile inside the library tile
-    int tiles_done = 0, segs_done = 0;   // parities of the two norm areas
+    int nt_c = nt0, kt_c = 0;
     for (int T = 0; T < T_total; ++T) {
         a_lo = S::A_OFF + ((2 * T) % 3) * S::HALF + a_off;
         a_hi = S::A_OFF + ((2 * T + 1) % 3) * S::HALF + a_off;
         b_base = (T % 3) * S::BUF + b_off;
-        const int nt_c = cs.bt0 + c_tile;
-        f32x4 bnv;  // wave 0: this library tile's squared norms on their way to LDS
-        f32x4 qnv;  // wave 4: the NEXT segment's query norms on their way to LDS
+        f32x4 bnv;  // wave 0: this bank tile's squared norms on their way to LDS
         // ================= phase 0: B lo + A lo
         stamp();
 #pragma unroll
@@ -718,16 +611,6 @@ __global__ __launch_bounds__(512, 1) void l2_min_pp3_kernel(GlobalTile A, Global
             for (int kk = 0; kk < 2; ++kk) af[i][kk] = lda(i, kk);
         const bool bn_fetch = wave == 0 && kt_c == 0;  // wave-uniform
         if (bn_fetch) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bnv) : "v"(p.b_sqnorm + (size_t)nt_c * S::BN + lane * 4) : "memory");
-        // more work follows a segment that is not the last, so the query stream is still issuing during this K-tile: the six pieces
-        // of phases 0-2 are younger than the fetch and vmcnt(6) in phase 3 covers it
-        const bool qn_fetch = !bank_wave && wave == 4 && kt_c == 0 && c_tile == cs.cnt - 1 && has_next;  // wave-uniform
-        if (qn_fetch) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float* src = p.q_sqnorm + min(ns.qt * S::BM + lane * 4 + e, p.Q - 1);
-                asm volatile("global_load_dword %0, %1, off" : "=v"(qnv[e]) : "v"(src) : "memory");
-            }
-        }
         { const bool is = issue_phase(std::integral_constant<int, 0>{}); stamp(); phase_wait(is); }
         stamp();
         pp_barrier();
@@ -785,9 +668,7 @@ __global__ __launch_bounds__(512, 1) void l2_min_pp3_kernel(GlobalTile A, Global
         // ================= phase 3: no reads (B lo is still in registers)
         stamp();
         if (bn_fetch)  // 6 DMA pieces were issued after the fetch (phases 0-2): a counted wait, then park the norms in LDS
-            asm volatile("s_waitcnt vmcnt(6)\n\tds_write_b128 %0, %1" ::"v"(bn_lds + (unsigned)((tiles_done & 1) * 1024 + lane * 16)), "v"(bnv) : "memory");
-        if (qn_fetch)
-            asm volatile("s_waitcnt vmcnt(6)\n\tds_write_b128 %0, %1" ::"v"(qn_lds + (unsigned)(((segs_done + 1) & 1) * 1024 + lane * 16)), "v"(qnv) : "memory");
+            asm volatile("s_waitcnt vmcnt(6)\n\tds_write_b128 %0, %1" ::"v"(bn_lds + (unsigned)((nt_c & 1) * 1024 + lane * 16)), "v"(bnv) : "memory");
         { const bool is = issue_phase(std::integral_constant<int, 3>{}); stamp(); phase_wait(is); }
         stamp();
         pp_barrier();
@@ -805,7 +686,7 @@ __global__ __launch_bounds__(512, 1) void l2_min_pp3_kernel(GlobalTile A, Global
             const int nbase = nt_c * S::BN + wc * 64 + (lane >> 4) * 4;
             f32x4 b4[4];
             {
-                const unsigned ra = bn_lds + (unsigned)((tiles_done & 1) * 1024 + (wc * 64 + (lane >> 4) * 4) * 4);
+                const unsigned ra = bn_lds + (unsigned)((nt_c & 1) * 1024 + (wc * 64 + (lane >> 4) * 4) * 4);
                 asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:64\n\tds_read_b128 %2, %4 offset:128\n\t"
                              "ds_read_b128 %3, %4 offset:192\n\ts_waitcnt lgkmcnt(0)"
                              : "=&v"(b4[0]), "=&v"(b4[1]), "=&v"(b4[2]), "=&v"(b4[3]) : "v"(ra) : "memory");
@@ -825,39 +706,23 @@ __global__ __launch_bounds__(512, 1) void l2_min_pp3_kernel(GlobalTile A, Global
             for (int i = 0; i < 8; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            ++tiles_done;
-            if (c_tile == cs.cnt - 1) {   // segment finished: one 64-bit atomicMin per query and wave row, then the next segment
-                const int mq = cs.qt * S::BM + wr * 128 + (lane & 15);
-                const bool full = cs.qt * S::BM + S::BM <= p.Q;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    unsigned long long key = pack_key(fmaxf(best[i], 0.0f), p.row_offset + (unsigned)besti[i]);
-                    if (!(best[i] < __builtin_inff())) key = ~0ull;
-                    key = groups_min_u64(key);
-                    if (lane < 16 && (full || mq + i * 16 < p.Q)) atomicMin(p.keys + mq + i * 16, key);
-                    best[i] = __builtin_inff();
-                    besti[i] = 0;
-                }
-                ep_age = full ? 0 : 1 << 20;
-                if (has_next) {
-                    ++segs_done;
-                    cs = ns;
-                    has_next = walk_c.next(ns);
-                    const unsigned qa = qn_lds + (unsigned)((segs_done & 1) * 1024 + (wr * 128 + (lane & 15)) * 4);
-                    asm volatile("ds_read_b32 %0, %8\n\tds_read_b32 %1, %8 offset:64\n\tds_read_b32 %2, %8 offset:128\n\t"
-                                 "ds_read_b32 %3, %8 offset:192\n\tds_read_b32 %4, %8 offset:256\n\tds_read_b32 %5, %8 offset:320\n\t"
-                                 "ds_read_b32 %6, %8 offset:384\n\tds_read_b32 %7, %8 offset:448\n\ts_waitcnt lgkmcnt(0)"
-                                 : "=&v"(qn[0]), "=&v"(qn[1]), "=&v"(qn[2]), "=&v"(qn[3]), "=&v"(qn[4]), "=&v"(qn[5]), "=&v"(qn[6]), "=&v"(qn[7])
-                                 : "v"(qa) : "memory");
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                c_tile = -1;
-            }
         }
         pp_barrier();
-        if (++kt_c == KT) { kt_c = 0; ++c_tile; }
+        if (++kt_c == KT) { kt_c = 0; ++nt_c; }
     }
     if (wr == 0) pp_barrier();  // both groups execute the same number of barriers
+
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        unsigned long long key = pack_key(fmaxf(best[i], 0.0f), p.row_offset + (unsigned)besti[i]);
+        if (!(best[i] < __builtin_inff())) key = ~0ull;
+        unsigned long long o = shfl_xor_u64(key, 16);
+        key = o < key ? o : key;
+        o = shfl_xor_u64(key, 32);
+        key = o < key ? o : key;
+        const int m = m0 + wr * 128 + i * 16 + (lane & 15);
+        if (lane < 16 && m < p.Q) atomicMin(p.keys + m, key);
+    }
     if constexpr (DIAG) {
         if (diag_on) {
             for (int e = lane; e < kDiagStamps; e += 64) p.diag[(wave >> 2) * kDiagStamps + e] = e < min(diag_n, kDiagStamps) ? diag_lds[e] : 0u;
@@ -1213,23 +1078,6 @@ template <bool F16> struct L2Kernel<SPingPong3, F16> { static constexpr auto fn 
 template <bool F16> struct L2Kernel<SPingPong4, F16> { static constexpr auto fn = l2_min_pp4_kernel<F16>; };
 #endif
 
-// blocks of the persistent distance GEMM: the CU count of the device (one 144 KiB-LDS block per CU); CMDIAD_L2_BLOCKS overrides
-static int persistent_blocks()
-{
-    static int n = 0;
-    if (n == 0) {
-        const char* e = getenv("CMDIAD_L2_BLOCKS");
-        int v = e ? atoi(e) : 0;
-        if (v <= 0) {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) v = prop.multiProcessorCount;
-        }
-        n = v > 0 ? v : 256;
-    }
-    return n;
-}
-
 template <class S, bool F16>
 int launch_l2(const uint16_t* q, const float* q_sqnorm, const uint16_t* bank, const float* bank_sqnorm, int Q, int Nb,
               int D, uint32_t row_offset, unsigned long long* keys, hipStream_t stream, const int* q_count = nullptr)
@@ -1256,13 +1104,6 @@ int launch_l2(const uint16_t* q, const float* q_sqnorm, const uint16_t* bank, co
     qgroup = qgroup > nq ? nq : qgroup;
     GlobalTile A{(const bf16_t*)q, D, Q}, W{(const bf16_t*)bank, D, Nb};
     L2Params p{Q, Nb, D, q_sqnorm, bank_sqnorm, row_offset, keys, nq, nbt, splits, qgroup, nullptr, -1, q_count};
-    if constexpr (std::is_same<S, SPingPong3>::value) {
-        // persistent: one block per CU (fewer when the whole job list is shorter), whatever the live query count turns out to be
-        const int per = (nbt + splits - 1) / splits, jobs = nq * ((nbt + per - 1) / per);
-        const int nblk = jobs < persistent_blocks() ? jobs : persistent_blocks();
-        hipLaunchKernelGGL((L2Kernel<S, F16>::fn), dim3(nblk), dim3(S::THREADS), S::LDS_BYTES, stream, A, W, p);
-        return CMDIAD_OK;
-    }
     const int ngroups = (nq + qgroup - 1) / qgroup;
     hipLaunchKernelGGL((L2Kernel<S, F16>::fn), dim3(ngroups * qgroup * splits), dim3(S::THREADS), S::LDS_BYTES, stream, A, W, p);
     return CMDIAD_OK;
@@ -1377,9 +1218,8 @@ extern "C" int cmdiad_l2_diag(const uint16_t* q, const float* q_sqnorm, const ui
     int qgroup = 4 > nq ? nq : 4;
     GlobalTile A{(const bf16_t*)q, D, Q}, W{(const bf16_t*)bank, D, Nb};
     L2Params p{Q, Nb, D, q_sqnorm, bank_sqnorm, 0u, keys, nq, nbt, splits, qgroup, stamps, wg, nullptr};
-    const int per = (nbt + splits - 1) / splits, jobs = nq * ((nbt + per - 1) / per);
-    hipLaunchKernelGGL((l2_min_pp3_kernel<true, true>), dim3(jobs < persistent_blocks() ? jobs : persistent_blocks()), dim3(S::THREADS), lds_bytes,
-                       (hipStream_t)stream, A, W, p);
+    const int ngroups = (nq + qgroup - 1) / qgroup;
+    hipLaunchKernelGGL((l2_min_pp3_kernel<true, true>), dim3(ngroups * qgroup * splits), dim3(S::THREADS), lds_bytes, (hipStream_t)stream, A, W, p);
     CMDIAD_CHECK_LAUNCH();
     return CMDIAD_OK;
 }

@@ -48,20 +48,26 @@ def synth_bank(rows, dim=768, seed=4321):
     return torch.randn(rows, dim, generator=g)
 
 
-def synth_labeled_sample(seed, anomalous=False, frac=None, size=224, texture=0.004, dent=0.015, shift=4.0):
+def synth_labeled_sample(seed, anomalous=False, frac=None, size=224, texture=0.004, dent=0.015, shift=4.0, rough=0.0, side=20):
     """One sample of a synthetic anomaly-detection class -> (rgb [1,3,S,S], organised cloud [1,3,S,S], mask [1,S,S]).
     Normal samples: the textured surface above + N(0,1) image.  Anomalous ones carry a 20 x 20-pixel dent of ``dent``
     metres in z and a colour shift of ``shift`` sigma over the same pixels (SURVEY 8d plants 5 mm / 2 sigma; on iid-noise
     images with a 4 mm relief that leaves the image-level scores of normal and anomalous samples interleaved, so the
-    defaults give the ranking a margin -- AUROC parity then measures the scorer, not luck)."""
+    defaults give the ranking a margin -- AUROC parity then measures the scorer, not luck).  ``rough`` (metres) adds seeded
+    per-pixel noise inside the ``side`` x ``side`` defect: a flat dent changes the local geometry only along its rim, a rough one
+    everywhere inside it."""
     pc = synth_cloud(seed, frac if frac is not None else (0.40 + 0.03 * (seed % 4)), size=size, texture=texture)
     rgb = synth_rgb(seed, size=size)
     mask = torch.zeros(1, size, size)
     if anomalous:
         y0, x0 = 70 + 9 * (seed % 7), 80 + 7 * (seed % 5)
-        pc[0, 2, y0:y0 + 20, x0:x0 + 20] -= dent * (pc[0, 2, y0:y0 + 20, x0:x0 + 20] != 0)
-        rgb[0, :, y0:y0 + 20, x0:x0 + 20] += shift
-        mask[0, y0:y0 + 20, x0:x0 + 20] = 1
+        fg = (pc[0, 2, y0:y0 + side, x0:x0 + side] != 0)
+        pc[0, 2, y0:y0 + side, x0:x0 + side] -= dent * fg
+        if rough:
+            g = torch.Generator().manual_seed(77_000 + seed)
+            pc[0, 2, y0:y0 + side, x0:x0 + side] += rough * torch.randn(side, side, generator=g) * fg
+        rgb[0, :, y0:y0 + side, x0:x0 + side] += shift
+        mask[0, y0:y0 + side, x0:x0 + side] = 1
     return rgb, pc, mask
 
 
@@ -89,8 +95,9 @@ class SyntheticClass:
     are anomalous.  Every class draws from its own seed range, so classes are independent of each other and a
     class is the same whichever rank evaluates it."""
 
-    def __init__(self, name, n_train, n_test, index=0, anomalous=lambda i: i % 10 in (0, 3, 7)):
+    def __init__(self, name, n_train, n_test, index=0, anomalous=lambda i: i % 10 in (0, 3, 7), defect=None):
         self.name, self.n_train, self.n_test, self.index, self._anom = name, int(n_train), int(n_test), int(index), anomalous
+        self.defect = dict(dent=0.02, rough=0.008, side=28) if defect is None else dict(defect)
 
     def _seed(self, split, i):
         return 100_000 * (self.index + 1) + (0 if split == "train" else 50_000) + i
@@ -104,5 +111,5 @@ class SyntheticClass:
         import numpy as np
         for i in range(self.n_test):
             an = bool(self._anom(i))
-            rgb, pc, mask = synth_labeled_sample(self._seed("test", i), anomalous=an)
+            rgb, pc, mask = synth_labeled_sample(self._seed("test", i), anomalous=an, **self.defect)
             yield (rgb, pc, pc), mask, np.array([int(an)]), [f"{self.name}/test/{i:03d}.png"]

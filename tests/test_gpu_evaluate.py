@@ -87,7 +87,9 @@ def test_mtfi_class_loop_auroc_vs_oracle(monkeypatch):
         assert abs(got["image_rocauc"] - ref["image_rocauc"]) <= 1e-2, cls
         assert abs(got["pixel_rocauc"] - ref["pixel_rocauc"]) <= 1e-2, cls
         assert abs(got["au_pro"] - ref["au_pro"]) <= 2e-2, cls
-        assert ref["pixel_rocauc"] > 0.9, "the synthetic anomalies must be detectable, or parity says nothing"
+        # the synthetic defects (a rough 28 x 28-pixel dent, synth.SyntheticClass) leave a ~50 % margin between the image scores of
+        # normal and anomalous samples on the oracle, so the image-level ranking does not hinge on a 2 % score difference
+        assert ref["pixel_rocauc"] > 0.9 and ref["image_rocauc"] > 0.95, "the synthetic anomalies must be detectable, or parity says nothing"
     t = res["table"]["image_rocauc"]
     assert t["Method"] == "WithHallucination" and set(t) == {"Method", "Bagel", "Rope", "Mean"}
     assert t["Mean"] == round((t["Bagel"] + t["Rope"]) / 2, 3)

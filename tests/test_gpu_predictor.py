@@ -182,13 +182,16 @@ def test_predict_batch_b32_vs_oracle(weights, cpu_ex, gpu_engine, monkeypatch):
 
 def test_mtfi_batch_vs_oracle(weights, cpu_ex, gpu_engine):
     """`--workload mtfi` (configs[4] per-GPU work): BatchPredictor with the hallucination network against
-    oracle.pipeline.CpuOneHallucination(main xyz).predict -- [xyz, hallucinated-rgb] columns, cross-wired statistics."""
+    oracle.pipeline.CpuOneHallucination(main xyz).predict -- [xyz, hallucinated-rgb] columns, cross-wired statistics -- at
+    B = 24 (8 anomalous): image scores, pixel maps, and I-/P-AUROC over the batch."""
     cpu = pipeline.CpuOneHallucination(cpu_ex, weights[2], "xyz", lambdas=(1.0, 1.0, 1.0, 1.0))
     cpu.fit([synth_sample(100 + i)[:2] for i in range(4)])
     rows = [cpu.predict(*synth_sample(200 + i)[:2])[:2] for i in range(2)]
     det, seg = _fit_svms([r[0] for r in rows], [r[1] for r in rows])
-    B = 8
-    samples = [synth_sample(i, anomalous=(i % 2 == 0)) for i in range(B)]
+    B = 24
+    samples = [synth_sample(i, anomalous=(i % 3 == 0)) for i in range(B)]
+    labels = np.array([int(s[2].any()) for s in samples])
+    assert labels.sum() == 8
     ref_img, ref_pix = [], []
     for rgb, pc, _ in samples:
         s, s_map = cpu.predict(rgb, pc)[:2]
@@ -210,6 +213,11 @@ def test_mtfi_batch_vs_oracle(weights, cpu_ex, gpu_engine):
     # both columns inherit the bf16 xyz features (the hallucinated column through the distilled MLP as well)
     assert (np.abs(img - ref_img) / np.abs(ref_img)).max() <= 0.03 and np.abs(img - ref_img).mean() <= 0.08 * spread
     assert d_pix.mean() <= 0.015 * np.ptp(ref_pix) and d_pix.max() <= 0.10 * np.ptp(ref_pix)
+    i_got, i_ref = _auroc_pair(labels, img, ref_img)
+    masks = np.stack([s[2].numpy().reshape(224, 224) for s in samples]).astype(int)
+    p_got, p_ref = _auroc_pair(masks.ravel(), pix.ravel(), ref_pix.ravel())
+    print(f"mtfi I-AUROC {i_got:.4f} (oracle {i_ref:.4f}); P-AUROC {p_got:.4f} (oracle {p_ref:.4f})")
+    assert abs(i_got - i_ref) <= 1e-2 and abs(p_got - p_ref) <= 1e-2
 
 
 @pytest.mark.parametrize("tag", ["rgb", "xyz", "mtfi_xyz", "mtfi_rgb"])
