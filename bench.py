@@ -485,7 +485,7 @@ def var_n_leg(st, dev, steps=8, warm=3):
     dt = time.perf_counter() - t0
     live = float(pred.live_rows.item()) / max(pred.xyz_searches, 1)
     l2_ms = timers["xyz"].mean_ms()
-    rows = st["bank_xyz"].bf16.shape[0]
+    rows = st["bank_xyz"].shard_rows
     return dict(what="var-N regime (SURVEY 8d): foreground 35-65 % of the image per cloud, ragged point counts inside the batch of 32",
                 value=round(BATCH * steps / dt, 2), unit="images/s per GPU", ms_per_step=round(dt / steps * 1e3, 3), steps=steps,
                 points_per_cloud=dict(min=min(n_pts), mean=round(sum(n_pts) / len(n_pts), 1), max=max(n_pts), padded_to=n_max),
@@ -714,7 +714,7 @@ def main():
         images = BATCH * world * args.steps
         l2_ms = timers["xyz"].mean_ms()
         q_total = BATCH * 3136 * (world if sharded else 1)
-        rows = st["bank_xyz"].bf16.shape[0]
+        rows = st["bank_xyz"].shard_rows
         # FLOPs of the launch as executed: the rows the kernel searched (patches without a foreground pixel repeat one row and are
         # searched once, csrc/dedup.hip; CMDIAD_DEDUP=0 searches all q_total rows as the reference's cdist does)
         flops = 2.0 * q_live * rows * 768

@@ -23,7 +23,7 @@ class GemmArgs(Structure):
                 ("bias", c_void_p), ("group_bias", c_void_p), ("group_rows", c_int), ("act", c_int),
                 ("residual", c_void_p), ("ldr", c_int),
                 ("out_f32", c_void_p), ("ldo32", c_int), ("out_bf16", c_void_p), ("ldo16", c_int),
-                ("out_pre_bf16", c_void_p), ("dact_of", c_void_p), ("split_k", c_int)]
+                ("out_pre_bf16", c_void_p), ("dact_of", c_void_p), ("split_k", c_int), ("m_count", c_void_p)]
 
 
 class ConvArgs(Structure):
@@ -69,6 +69,7 @@ SIGNATURES = {
     "cmdiad_l2_min_keys_counted": [P, P, P, I, P, P, I, I, U32, P, I, P],
     "cmdiad_rows_dedup_plan": [P, P, I, I, P, P, P, P, P, P, P],
     "cmdiad_keys_expand": [P, P, I, P, P],
+    "cmdiad_rows_expand_f32": [P, P, I, I, P, P],
     "cmdiad_l2_rescore": [P, P, P, I, I, I, U32, P, P, P],
     "cmdiad_reweight_scan": [P, P, P, I, I, I, U32, P, P, SZ, P],
     "cmdiad_bank_block16": [P, I, I, P, P],

@@ -214,6 +214,16 @@ __global__ __launch_bounds__(256) void expand_keys_kernel(const unsigned long lo
 }  // namespace
 
 // workspace: tag [Q] u32 | info [4] i32 | dup [Q] u8 (padded to 16) | sums [ceil(Q / 1024)] i32
+__global__ __launch_bounds__(256) void expand_rows_f32_kernel(const float4* __restrict__ src, const int* __restrict__ slot, int Q, int D4,
+                                                              float4* __restrict__ out)
+{
+    const int lane = threadIdx.x & 63, q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= Q) return;
+    const float4* a = src + (size_t)slot[q] * D4;
+    float4* b = out + (size_t)q * D4;
+    for (int c = lane; c < D4; c += 64) b[c] = a[c];
+}
+
 extern "C" size_t cmdiad_rows_dedup_workspace_bytes(int Q)
 {
     const size_t q = (size_t)(Q > 0 ? Q : 0);
@@ -255,6 +265,17 @@ extern "C" int cmdiad_keys_expand(const unsigned long long* keys_compact, const 
     CMDIAD_REQUIRE(keys_compact && slot && keys, CMDIAD_ERR_ARG, "cmdiad_keys_expand: null pointer");
     if (Q <= 0) return CMDIAD_OK;
     hipLaunchKernelGGL(expand_keys_kernel, dim3((Q + 255) / 256), dim3(256), 0, (hipStream_t)stream, keys_compact, slot, Q, keys);
+    CMDIAD_CHECK_LAUNCH();
+    return CMDIAD_OK;
+}
+
+extern "C" int cmdiad_rows_expand_f32(const float* rows_compact, const int* slot, int Q, int D, float* out, cmdiad_stream_t stream)
+{
+    CMDIAD_REQUIRE(rows_compact && slot && out, CMDIAD_ERR_ARG, "cmdiad_rows_expand_f32: null pointer");
+    CMDIAD_REQUIRE(D > 0 && D % 4 == 0 && aligned16(rows_compact) && aligned16(out), CMDIAD_ERR_ARG, "cmdiad_rows_expand_f32: D%%4, alignment");
+    if (Q <= 0) return CMDIAD_OK;
+    hipLaunchKernelGGL(expand_rows_f32_kernel, dim3((Q + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const float4*)rows_compact, slot, Q, D / 4,
+                       (float4*)out);
     CMDIAD_CHECK_LAUNCH();
     return CMDIAD_OK;
 }

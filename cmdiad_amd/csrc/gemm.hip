@@ -33,7 +33,17 @@ struct StdParams {
     int split_k;                  // > 1: block y handles K/split_k, writes slab y of out_f32 (no epilogue terms)
     int panel;                    // N tiles walked by one block (see panel_tiles)
     int group_m;                  // M tiles per L2 group (Coord)
+    const int* m_count;           // device-resident live row count (rows >= it are neither computed nor stored), or null
 };
+
+// rows the launch really has: the caller's M, or the device-side count of a compacted row set (block-uniform)
+__device__ __forceinline__ void live_m(StdParams& p, GlobalTile& A)
+{
+    if (p.m_count) {
+        p.M = min(p.M, __builtin_amdgcn_readfirstlane(*p.m_count));
+        A.rows = max(p.M, 1);
+    }
+}
 
 __device__ __forceinline__ float gelu_grad_f(float x) { return gelu_erf_grad(x); }
 
@@ -80,7 +90,10 @@ template <class S, int ACT, bool EXTRAS, bool RES_ROWS = false>
 __global__ __launch_bounds__(S::THREADS, S::WAVES_PER_SIMD) void gemm_std_kernel(GlobalTile A, GlobalTile W, StdParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    const Coord<S> c((p.N + S::BN - 1) / S::BN, p.panel, p.group_m, (p.M + S::BM - 1) / S::BM);
+    const int m_tiles_launched = (p.M + S::BM - 1) / S::BM;     // the grid was sized for the caller's M
+    live_m(p, A);
+    const Coord<S> c((p.N + S::BN - 1) / S::BN, p.panel, p.group_m, m_tiles_launched);
+    if (c.m0 >= p.M) return;                                      // block-uniform: a row tile beyond the live rows
     const int kt_per = (p.K / BK + p.split_k - 1) / p.split_k;
     const int kt_begin = blockIdx.y * kt_per;
     const int kt_count = min(kt_per, p.K / BK - kt_begin);
@@ -201,6 +214,7 @@ template <int ACT>
 __global__ __launch_bounds__(512, 1) void gemm_std_pp3_kernel(GlobalTile A, GlobalTile W, StdParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
+    live_m(p, A);
     const int NT = p.N / SPP3::BN, MT = (p.M + SPP3::BM - 1) / SPP3::BM;
     const int jobs = MT * NT;
     const int vb = xcd_remap(blockIdx.x, gridDim.x);
@@ -954,12 +968,13 @@ extern "C" int cmdiad_gemm_bf16(const cmdiad_gemm_args* a, cmdiad_stream_t strea
                    CMDIAD_ERR_ARG, "cmdiad_gemm_bf16: out_pre_bf16 / dact_of alignment");
     GlobalTile A{(const bf16_t*)a->A, a->lda, a->M}, W{(const bf16_t*)a->W, a->ldw, a->N};
     StdParams p{a->M, a->N, a->K, a->bias, a->group_bias, a->group_rows, a->act, a->residual, a->ldr,
-                a->out_f32, a->ldo32, (bf16_t*)a->out_bf16, a->ldo16, (bf16_t*)a->out_pre_bf16, (const bf16_t*)a->dact_of, split, 1, 1};
+                a->out_f32, a->ldo32, (bf16_t*)a->out_bf16, a->ldo16, (bf16_t*)a->out_pre_bf16, (const bf16_t*)a->dact_of, split, 1, 1, a->m_count};
+    CMDIAD_REQUIRE(!a->m_count || split == 1, CMDIAD_ERR_ARG, "cmdiad_gemm_bf16: m_count with split_k > 1");
     hipStream_t s = (hipStream_t)stream;
     const bool extras = a->out_pre_bf16 || a->dact_of;
     int rc;
 #ifdef CMDIAD_AB_VARIANTS
-    const int wide = wide_choice(a->M, a->N, a->K, !extras && !a->residual && a->ldo16 % 4 == 0, split);
+    const int wide = a->m_count ? 0 : wide_choice(a->M, a->N, a->K, !extras && !a->residual && a->ldo16 % 4 == 0, split);
     if (wide) {
 #define CMDIAD_WIDE(NJ, ACT) launch_wide<WideShape<NJ>>(gemm_std_wide_kernel<NJ, ACT>, a->M, a->N, a->K, p, A, W, s)
         if (wide == 8) rc = a->act == CMDIAD_ACT_GELU ? CMDIAD_WIDE(8, CMDIAD_ACT_GELU) : a->act == CMDIAD_ACT_RELU ? CMDIAD_WIDE(8, CMDIAD_ACT_RELU) : CMDIAD_WIDE(8, CMDIAD_ACT_NONE);

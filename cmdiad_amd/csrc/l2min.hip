@@ -1096,9 +1096,12 @@ int launch_l2(const uint16_t* q, const float* q_sqnorm, const uint16_t* bank, co
     static const int env_splits = getenv("CMDIAD_L2_SPLITS") ? atoi(getenv("CMDIAD_L2_SPLITS")) : 0;
     static const int env_qgroup = getenv("CMDIAD_L2_QGROUP") ? atoi(getenv("CMDIAD_L2_QGROUP")) : 0;
     // measured on the bagel xyz library (profiles/r1_notes.md): 8 bank ranges for the 8-wave shapes; the 4-wave wide
-    // shape gains another 5 % from 16-32 (shorter ranges, better tail balance), as long as a range keeps >= 4 tiles
+    // shape gains another 5 % from 16-32 (shorter ranges, better tail balance), as long as a range keeps >= 4 tiles.
+    // Round 3 (profiles/r3_notes.md, the two-group kernel on the de-duplicated 54 401 rows): 20 ranges of 15 tiles 5.40 ms against
+    // 5.55 ms for 30 ranges of 10 -- a block's pipeline fill and drain are paid per range, and 213 live query tiles leave no
+    // tail to balance; all 100 352 rows: within 1 % from 15 to 50 ranges.
     int splits = env_splits > 0 ? env_splits : 8;
-    if (env_splits <= 0 && S::BM == 256 && !std::is_same<S, S2x2>::value) splits = nbt / 4 < 1 ? 1 : (nbt / 4 > 32 ? 32 : nbt / 4);
+    if (env_splits <= 0 && S::BM == 256 && !std::is_same<S, S2x2>::value) splits = nbt / 4 < 1 ? 1 : (nbt / 4 > 20 ? 20 : nbt / 4);
     splits = splits > nbt ? nbt : splits;
     int qgroup = env_qgroup > 0 ? env_qgroup : 4;
     qgroup = qgroup > nq ? nq : qgroup;

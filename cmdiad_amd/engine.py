@@ -32,7 +32,17 @@ class Bank:
         n = self.f32.shape[0]
         lo, hi = shard_range(n, rank, world)
         self.row_offset, self.rank, self.world = lo, rank, world
-        self.bf16, _, self.sqnorm = ops.normalize_cast(self.f32[lo:hi])
+        self.shard_rows = hi - lo
+        b16, _, sq = ops.normalize_cast(self.f32[lo:hi])
+        # The distance GEMM's production kernel takes whole 256-row library tiles and hands the last n % 256 rows to a second,
+        # much less efficient launch (76 518 = 298 x 256 + 230).  Pad the SEARCH operand to a tile boundary with rows that cannot
+        # win -- all-zero rows whose squared norm is +inf, so d2 = (|q|^2 + inf) - 2 * 0 = inf never passes `d2 < best` -- and the
+        # whole library is one launch.  Keys never name a pad row; the fp32 library (re-score, re-weighting) is untouched.
+        pad = (-self.shard_rows) % 256
+        if pad and self.shard_rows >= 256:
+            b16 = torch.cat([b16, torch.zeros((pad, b16.shape[1]), dtype=b16.dtype, device=b16.device)])
+            sq = torch.cat([sq, torch.full((pad,), float("inf"), dtype=sq.dtype, device=sq.device)])
+        self.bf16, self.sqnorm = b16.contiguous(), sq.contiguous()
         self._blk16 = None
 
     @property

@@ -81,23 +81,25 @@ def lpt_assign(costs, world):
 
 
 # ------------------------------------------------------------------------------------------------ one class
-def run_class(args, data, weights=None, method=None):
+def run_class(args, data, weights=None, method=None, extractor=None):
     """fit + evaluate of ONE class, in the reference's order (cmdiad_runner.py:33-107):
     add_sample_to_mem_bank over the train loader -> run_coreset -> (memory_bank == 'multiple')
     add_sample_to_late_fusion_mem_bank over the train loader again -> run_late_fusion -> predict over the test loader ->
     calculate_metrics.  ``data``: an object with ``name``, ``train()`` yielding (sample, label) and ``test()`` yielding
     (sample, mask, label, rgb_path) -- the reference's loaders, or synth.SyntheticClass.  ``weights`` (optional):
     (ViT state_dict, Point-MAE state_dict, fusion state_dict | None) loaded into the fresh method object (offline stand-in
-    for the checkpoints).  Returns the class's metrics (unrounded), image counts and seconds per phase."""
+    for the checkpoints).  ``extractor`` (optional): the frozen backbones (``Features.deep_feature_extractor``) of an earlier
+    class on this rank -- every other piece of state (banks, statistics, SVMs, result lists) is the fresh object's.
+    Returns the class's metrics (unrounded), image counts, seconds per phase, and the extractor under "_extractor"."""
     from .utils.utils import set_seeds
     if method is None:
         _, cls = method_class(args)
-        method = cls(args)                                  # a fresh object per class, as main.py:23
-    if weights is not None:
+        method = cls(args, shared_extractor=extractor)      # a fresh object per class, as main.py:23
+    if weights is not None and extractor is None:
         method.deep_feature_extractor.rgb_backbone.load_state_dict(weights[0])
         method.deep_feature_extractor.xyz_backbone.load_state_dict(weights[1])
-        if len(weights) > 2 and weights[2] is not None and getattr(method, "fusion", None) is not None:
-            method.fusion.load_state_dict(weights[2])
+    if weights is not None and len(weights) > 2 and weights[2] is not None and getattr(method, "fusion", None) is not None:
+        method.fusion.load_state_dict(weights[2])
     set_seeds(0)
     count = getattr(args, "max_sample", 500)
     sec = {}
@@ -134,6 +136,7 @@ def run_class(args, data, weights=None, method=None):
     out.update(n_train=n_train, n_test=n_test, seconds={k: round(v, 3) for k, v in sec.items()},
                library_rows={k: int(getattr(method, f"patch_{k}_lib").shape[0]) for k in ("xyz", "rgb", "fusion")
                              if torch.is_tensor(getattr(method, f"patch_{k}_lib", None))})
+    out["_extractor"] = method.deep_feature_extractor
     return out
 
 
@@ -165,9 +168,14 @@ def evaluate_classes(args, datasets, group=None, weights=None, costs=None, log=N
     assignment = lpt_assign(costs, world)
     name, _ = method_class(args)
     mine = {}
+    extractor = None
     t0 = time.perf_counter()
     for cls in assignment[rank]:
-        mine[cls] = (runner or run_class)(args, datasets[cls], weights=weights)
+        if runner is None:
+            mine[cls] = run_class(args, datasets[cls], weights=weights, extractor=extractor)
+            extractor = mine[cls].pop("_extractor")          # the frozen backbones stay on the rank; everything else is per class
+        else:
+            mine[cls] = runner(args, datasets[cls], weights=weights)
         mine[cls]["rank"] = rank
         if log is not None:
             log(f"[rank {rank}] class {cls}: " + ", ".join(f"{m} {mine[cls][m]:.3f}" for m in METRICS) + f" {mine[cls]['seconds']}")

@@ -110,17 +110,23 @@ class _NeedsFit(Exception):
 
 
 class Features(torch.nn.Module):
-    def __init__(self, args, image_size=224, f_coreset=0.1, coreset_eps=0.9):
+    def __init__(self, args, image_size=224, f_coreset=0.1, coreset_eps=0.9, shared_extractor=None):
+        """shared_extractor (not in the reference's signature): an already constructed ``Model`` to use instead of building and
+        loading the frozen backbones again -- the reference's class loop builds a fresh object, i.e. re-loads both checkpoints,
+        for every class (main.py:23); cmdiad_amd.evaluate hands the rank's extractor from class to class."""
         super().__init__()
         from .. import _native
         _native.lib()  # fail loudly at construction when libcmdiad_hip.so is missing
         self.device = "cuda" if torch.cuda.is_available() else "cpu"
-        self.deep_feature_extractor = Model(
-            device=self.device, rgb_backbone_name=args.rgb_backbone_name, xyz_backbone_name=args.xyz_backbone_name,
-            group_size=args.group_size, num_group=args.num_group,
-            checkpoint_path=getattr(args, "rgb_checkpoint_path", "") or "")   # offline stand-in for timm's hub download
-        self.deep_feature_extractor.to(self.device)
-        self.deep_feature_extractor.eval()
+        if shared_extractor is not None:
+            self.deep_feature_extractor = shared_extractor
+        else:
+            self.deep_feature_extractor = Model(
+                device=self.device, rgb_backbone_name=args.rgb_backbone_name, xyz_backbone_name=args.xyz_backbone_name,
+                group_size=args.group_size, num_group=args.num_group,
+                checkpoint_path=getattr(args, "rgb_checkpoint_path", "") or "")   # offline stand-in for timm's hub download
+            self.deep_feature_extractor.to(self.device)
+            self.deep_feature_extractor.eval()
 
         self.args = args
         self.class_name = None

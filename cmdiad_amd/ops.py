@@ -140,8 +140,9 @@ def xyz_patch_fused(feat, idx3, w3, pix2pt, size=224, P=56, mean=0.0, inv_std=1.
 
 # ------------------------------------------------------------------------------------ dense blocks
 def gemm(A, W, bias=None, act=ACT_NONE, residual=None, group_bias=None, group_rows=1, out_f32=None, out_bf16=None,
-         want_f32=False, want_bf16=True, out_pre_bf16=None, dact_of=None, split_k=1):
-    """epilogue(A[M,K] . W[N,K]^T); A, W bf16.  Returns (out_f32 | None, out_bf16 | None)."""
+         want_f32=False, want_bf16=True, out_pre_bf16=None, dact_of=None, split_k=1, m_count=None):
+    """epilogue(A[M,K] . W[N,K]^T); A, W bf16.  Returns (out_f32 | None, out_bf16 | None).  m_count (device int32 [1]): only the
+    first min(M, m_count) rows are computed and stored (a compacted row set whose size is known on the device only)."""
     _chk(A, torch.bfloat16, "gemm.A"); _chk(W, torch.bfloat16, "gemm.W")
     M, K = A.shape
     N = W.shape[0]
@@ -150,7 +151,7 @@ def gemm(A, W, bias=None, act=ACT_NONE, residual=None, group_bias=None, group_ro
     if out_bf16 is None and want_bf16:
         out_bf16 = torch.empty((M, N), dtype=torch.bfloat16, device=A.device)
     a = nat.GemmArgs(_p(A), K, _p(W), K, M, N, K, _p(bias), _p(group_bias), group_rows, act,
-                     _p(residual), N, _p(out_f32), N, _p(out_bf16), N, _p(out_pre_bf16), _p(dact_of), split_k)
+                     _p(residual), N, _p(out_f32), N, _p(out_bf16), N, _p(out_pre_bf16), _p(dact_of), split_k, _p(m_count))
     _call("cmdiad_gemm_bf16", ctypes.byref(a), _stream())
     return out_f32, out_bf16
 
@@ -375,6 +376,16 @@ def l2_min_keys_counted(q16, q_sq, count, bank16, bank_sq, keys, row_offset=0):
     _call("cmdiad_l2_min_keys_counted", _p(q16), _p(q_sq), _p(count), Q, _p(bank16), _p(bank_sq), bank16.shape[0], D, row_offset,
           _p(keys), 1 if q16.dtype == torch.float16 else 0, _stream())
     return keys
+
+
+def rows_expand_f32(rows_compact, slot, out=None):
+    """out[q] = rows_compact[slot[q]] (f32 rows): per-row results computed on the compacted rows, back on every original row."""
+    _chk(rows_compact, torch.float32, "rows_expand.rows"); _chk(slot, torch.int32, "rows_expand.slot")
+    Q, D = slot.shape[0], rows_compact.shape[1]
+    if out is None:
+        out = torch.empty((Q, D), dtype=torch.float32, device=rows_compact.device)
+    _call("cmdiad_rows_expand_f32", _p(rows_compact), _p(slot), Q, D, _p(out), _stream())
+    return out
 
 
 def keys_expand(keys_compact, slot, keys):

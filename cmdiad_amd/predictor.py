@@ -44,6 +44,14 @@ class EventTimer:
         return sum(v) / max(len(v), 1)
 
 
+class _SharedPlan:
+    """The compacted 16-bit queries of one library search whose row plan (live count, slot map) is shared with another search."""
+    __slots__ = ("q16", "q_sq", "count", "slot")
+
+    def __init__(self, q16, q_sq, count, slot):
+        self.q16, self.q_sq, self.count, self.slot = q16, q_sq, count, slot
+
+
 class _NoTimer:
     def __enter__(self):
         return self
@@ -111,6 +119,7 @@ class BatchPredictor:
         self.dedup = os.environ.get("CMDIAD_DEDUP", "1") != "0"
         self.live_rows = torch.zeros((1,), dtype=torch.int64, device=dev)   # rows actually searched, summed over the xyz searches
         self.xyz_searches = 0
+        self._raw_norm = None
         self.shard_stats = {}        # per library: what the last row-sharded search exchanged (engine.sharded_min_keys)
         self.inputs = [self._new_inputs() for _ in range(2 if use_graph else 1)]
 
@@ -125,13 +134,32 @@ class BatchPredictor:
         e, s = self.e, self.stats
         if self.workload == "mtfi":
             ex = e.extract(None, inp["pcs"], want_rgb=False, n_max=self.n_max)
-            xyz_raw = e.xyz_patch(ex, 56)                                       # a9
+            xyz_raw = e.xyz_patch(ex, 56)                                       # a9  [B,3136,768] f32
+            B, Q, D = xyz_raw.shape
+            xyz_q = eng.normalize(xyz_raw, s["xyz_mean"], s["xyz_std"])         # a11 (every row: the exact re-score reads them)
+            if self.dedup and self.group is None:
+                # Patches without a foreground pixel are ONE row of the raw xyz features (bit for bit), so their hallucinated
+                # features are one row too: the rows are de-duplicated ONCE, on the fp32 bit patterns (the plan kernels compare
+                # rows as opaque 16-bit words: an fp32 row is 2 D of them), the distillation MLP (a15) and both 16-bit query sets
+                # are computed on the compacted rows only -- the GEMMs read the live row count on the device -- and the one plan
+                # serves both library searches.  Outputs are bit-identical to running every row (CMDIAD_DEDUP=0).
+                flat = xyz_raw.reshape(B * Q, D)
+                if self._raw_norm is None or self._raw_norm.shape[0] != B * Q:
+                    self._raw_norm = torch.zeros((B * Q,), dtype=torch.float32, device=flat.device)
+                plan = ops.rows_dedup_plan(flat.view(torch.float16), self._raw_norm)
+                raw_c = plan.q16.view(torch.float32)                            # [B*Q, D] f32, first plan.count rows live
+                hall_c = self.halluc.generate(raw_c, "xyz", m_count=plan.count)  # a15 on the live rows
+                out = {}
+                for name, rows_c, mean, std in (("xyz", raw_c, s["xyz_mean"], s["xyz_std"]), ("rgb", hall_c, s["rgb_mean"], s["rgb_std"])):
+                    q16_c, q32_c, qsq_c = ops.normalize_cast(rows_c, float(mean), 1.0 / float(std), want_f32=(name == "rgb"))
+                    out[f"{name}_plan"] = _SharedPlan(q16_c, qsq_c, plan.count, plan.slot)
+                    full = xyz_q if name == "xyz" else ops.rows_expand_f32(q32_c, plan.slot).view(B, Q, D)
+                    out[name] = (full, None, None)
+                return out
             hall = self.halluc.generate(xyz_raw, "xyz")                         # a15: hallucinated rgb features [B,3136,768]
-            xyz_q = eng.normalize(xyz_raw, s["xyz_mean"], s["xyz_std"])         # a11
             sec_q = eng.normalize(hall, s["rgb_mean"], s["rgb_std"])
             out = {}
             for name, q in (("xyz", xyz_q), ("rgb", sec_q)):
-                B, Q, D = q.shape
                 q16, _, qsq = ops.normalize_cast(q.reshape(B * Q, D))
                 out[name] = (q, q16, qsq)
             return out
@@ -193,19 +221,20 @@ class BatchPredictor:
                     self.xyz_searches += 1
                 keys[name] = k
                 continue
-            q_all, s_all = eng.gather_queries(q16, qsq, self.group)
+            plan = qs.get(f"{name}_plan") if self.dedup else None    # made in stage 1 already (unsharded library)
+            q_all, s_all = (None, None) if plan is not None else eng.gather_queries(q16, qsq, self.group)
+            n_rows = B * Q if q_all is None else q_all.shape[0]
             k = self.static.get(f"keys_{name}_{buf}")
-            if k is None or k.shape[0] != q_all.shape[0]:
-                k = self.static[f"keys_{name}_{buf}"] = torch.empty((q_all.shape[0],), dtype=torch.int64, device=q.device)
+            if k is None or k.shape[0] != n_rows:
+                k = self.static[f"keys_{name}_{buf}"] = torch.empty((n_rows,), dtype=torch.int64, device=q.device)
             if self.dedup:
                 # patches without a foreground pixel are one and the same row (and so are their hallucinated features in the MTFI
-                # workload; with a sharded library also across the ranks' gathered queries): searched once, the key copied to all
-                plan = qs.get(f"{name}_plan")    # made in stage 1 already (unsharded library: beside the rgb search)
+                # workload): searched once, the key copied to all
                 if plan is None:
                     plan = self.static[f"plan_{name}_{buf}"] = ops.rows_dedup_plan(q_all, s_all, self.static.get(f"plan_{name}_{buf}"))
                 kc = self.static.get(f"keysc_{name}_{buf}")
-                if kc is None or kc.shape[0] != q_all.shape[0]:
-                    kc = self.static[f"keysc_{name}_{buf}"] = torch.empty((q_all.shape[0],), dtype=torch.int64, device=q.device)
+                if kc is None or kc.shape[0] != n_rows:
+                    kc = self.static[f"keysc_{name}_{buf}"] = torch.empty((n_rows,), dtype=torch.int64, device=q.device)
                 kc.fill_(eng.KEY_EMPTY)
                 with self.timers.get(name, _NoTimer()):
                     ops.l2_min_keys_counted(plan.q16, plan.q_sq, plan.count, bank.bf16, bank.sqnorm, kc, bank.row_offset)

@@ -266,18 +266,21 @@ class PackedHallucination:
             self.dir[name] = dict(ln_w=_dev(sd[f"{name}_norm.weight"], device), ln_b=_dev(sd[f"{name}_norm.bias"], device),
                                   blocks=blocks, **blocks[0])
 
-    def generate(self, x, src):
+    def generate(self, x, src, m_count=None):
         """src='xyz': xyz features -> hallucinated rgb features (out_type='rgb'); src='rgb': the reverse.
-        x [..., D] f32 cuda -> same leading shape, f32.  LN -> (fc1 -> GELU -> fc2 -> GELU -> fc3 -> GELU) x mlp_depth."""
+        x [..., D] f32 cuda -> same leading shape, f32.  LN -> (fc1 -> GELU -> fc2 -> GELU -> fc3 -> GELU) x mlp_depth.
+        m_count (device int32 [1]): x is a compacted row set (cmdiad_rows_dedup_plan) of which only the first m_count rows are
+        live -- the products run on those rows only (every output row depends on its own input row alone), the rest of the
+        output is left unwritten."""
         w = self.dir[src]
         shape = x.shape
         x2 = x.reshape(-1, shape[-1]).contiguous()
         h = ops.layernorm(x2, w["ln_w"], w["ln_b"], 1e-5)
         for d, b in enumerate(w["blocks"]):
             last = d == len(w["blocks"]) - 1
-            _, h = ops.gemm(h, b["w1"], bias=b["b1"], act=ops.ACT_GELU)
-            _, h = ops.gemm(h, b["w2"], bias=b["b2"], act=ops.ACT_GELU)
-            out, h = ops.gemm(h, b["w3"], bias=b["b3"], act=ops.ACT_GELU, want_f32=last, want_bf16=not last)
+            _, h = ops.gemm(h, b["w1"], bias=b["b1"], act=ops.ACT_GELU, m_count=m_count)
+            _, h = ops.gemm(h, b["w2"], bias=b["b2"], act=ops.ACT_GELU, m_count=m_count)
+            out, h = ops.gemm(h, b["w3"], bias=b["b3"], act=ops.ACT_GELU, want_f32=last, want_bf16=not last, m_count=m_count)
         return out.view(*shape[:-1], out.shape[-1])
 
 

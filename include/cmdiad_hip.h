@@ -33,7 +33,7 @@ typedef enum {
 } cmdiad_status;
 
 const char* cmdiad_last_error(void);
-int cmdiad_abi_version(void); /* 2: cmdiad_reweight_scan's limits and workspace changed (see there) */
+int cmdiad_abi_version(void); /* 2: cmdiad_reweight_scan's limits and workspace changed (see there); cmdiad_gemm_args gained m_count */
 /* 1 when the library is the test-only build that also contains the superseded kernel formulations (A/B references). */
 int cmdiad_has_ab_variants(void);
 
@@ -117,6 +117,8 @@ typedef struct {
     uint16_t* out_pre_bf16;          /* [M,N] bf16 copy BEFORE the activation (training keeps z), or NULL */
     const uint16_t* dact_of;         /* [M,N] bf16 z: acc *= GELU'(z) before everything else, or NULL */
     int split_k;                     /* > 1: K is split; slab s of out_f32 ([split_k][M][ldo32]) gets partial s */
+    const int* m_count;              /* ABI 2: device-resident live row count or NULL: only rows < min(M, *m_count) are computed
+                                        and stored (the compacted row set of cmdiad_rows_dedup_plan: the launch is sized for M) */
 } cmdiad_gemm_args;
 int cmdiad_gemm_bf16(const cmdiad_gemm_args* args, cmdiad_stream_t stream);
 
@@ -264,6 +266,9 @@ int cmdiad_rows_dedup_plan(const uint16_t* q, const float* q_sqnorm, int Q, int 
 /* keys[q] = keys_compact[slot[q]] */
 int cmdiad_keys_expand(const unsigned long long* keys_compact, const int* slot, int Q, unsigned long long* keys,
                        cmdiad_stream_t stream);
+/* out[q, :] = rows_compact[slot[q], :] (f32, D % 4 == 0): the per-row results of a computation that ran on the compacted rows
+ * only (the hallucination MLP of the MTFI path, hallucination_network.py:34-45), back on every original row. */
+int cmdiad_rows_expand_f32(const float* rows_compact, const int* slot, int Q, int D, float* out, cmdiad_stream_t stream);
 
 /* Exact fp32 re-score of the winners: min_val[q] = || q_f32[q] - bank_f32[idx - row_offset] ||_2,
  * min_idx[q] = idx (global row).  Queries whose winner lies outside [row_offset, row_offset+Nb) are

@@ -1,6 +1,8 @@
 """GPU parity tests, kernel by kernel, through the C ABI (cmdiad_amd.ops -> libcmdiad_hip.so) against the
 CPU oracle (oracle/) on the same seeded inputs.  Integer/index outputs must be bit-exact; floating
 point outputs are compared with the tolerance written next to each assertion."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -681,3 +683,37 @@ def test_encoder_tail_equals_two_kernel_path(Mg, groups):
     want, _ = ops.gemm_groupmax(h3, w["W4"], w["b4"], groups, Mg)
     got = ops.encoder_tail(h2, gb, w["W3b"], w["W4"], w["b4"], groups, Mg)
     assert torch.equal(got, want)
+
+
+def test_gemm_device_row_count_and_rows_expand():
+    """cmdiad_gemm_bf16 with m_count (ABI 2): a launch sized for M rows computes and stores only the first *m_count of them (both
+    the 128 x 128 kernel and the persistent 256 x 256 kernel), bit-identical to a launch of exactly that many rows, and leaves
+    the other output rows untouched; cmdiad_rows_expand_f32 puts compacted per-row results back on every original row."""
+    g = torch.Generator().manual_seed(41)
+    M, K = 3000, 256
+    A = torch.randn(M, K, generator=g).to(DEV).bfloat16()
+    for N in (1920, 768, 2048):
+        W = (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV).bfloat16()
+        bias = torch.randn(N, generator=g).to(DEV)
+        for live in (0, 1, 129, 1537, 2999, 3000, 5000):
+            cnt = torch.tensor([live], dtype=torch.int32, device=DEV)
+            n = min(live, M)
+            for env in ("0", "1"):
+                os.environ["CMDIAD_GEMM_PP3"] = env
+                try:
+                    o16 = torch.full((M, N), 7.0, dtype=torch.bfloat16, device=DEV)
+                    o32 = torch.full((M, N), 7.0, dtype=torch.float32, device=DEV)
+                    if env == "1" and N % 256 == 0:
+                        ops.gemm(A, W, bias=bias, act=ops.ACT_GELU, out_bf16=o16, m_count=cnt)                 # persistent kernel: bf16 only
+                        _, want = ops.gemm(A[:max(n, 1)], W, bias=bias, act=ops.ACT_GELU)
+                        assert torch.equal(o16[:n], want[:n]) and bool((o16[n:] == 7.0).all()), (N, live, env)
+                    else:
+                        ops.gemm(A, W, bias=bias, act=ops.ACT_GELU, out_f32=o32, out_bf16=o16, m_count=cnt)
+                        want32, want16 = ops.gemm(A[:max(n, 1)], W, bias=bias, act=ops.ACT_GELU, want_f32=True)
+                        assert torch.equal(o32[:n], want32[:n]) and torch.equal(o16[:n], want16[:n]), (N, live, env)
+                        assert bool((o32[n:] == 7.0).all()) and bool((o16[n:] == 7.0).all()), (N, live, env)
+                finally:
+                    del os.environ["CMDIAD_GEMM_PP3"]
+    rows = torch.randn(37, 768, generator=g).to(DEV)
+    slot = torch.randint(0, 37, (500,), generator=g).int().to(DEV)
+    assert torch.equal(ops.rows_expand_f32(rows, slot), rows[slot.long()])

@@ -180,7 +180,7 @@ def test_predict_batch_b32_vs_oracle(weights, cpu_ex, gpu_engine, monkeypatch):
         assert np.abs(m1[0] - pix[b]).max() <= 2.5 * np.ptp(pix[b]) / 255.0 + 1e-9   # at most one 8-bit blur level per column
 
 
-def test_mtfi_batch_vs_oracle(weights, cpu_ex, gpu_engine):
+def test_mtfi_batch_vs_oracle(weights, cpu_ex, gpu_engine, monkeypatch):
     """`--workload mtfi` (configs[4] per-GPU work): BatchPredictor with the hallucination network against
     oracle.pipeline.CpuOneHallucination(main xyz).predict -- [xyz, hallucinated-rgb] columns, cross-wired statistics -- at
     B = 24 (8 anomalous): image scores, pixel maps, and I-/P-AUROC over the batch."""
@@ -206,6 +206,16 @@ def test_mtfi_batch_vs_oracle(weights, cpu_ex, gpu_engine):
     img, pix = p.predict_batch(None, pcs)
     img2, pix2 = p.predict_batch(None, pcs)
     assert p.use_graph and np.array_equal(img, img2) and np.array_equal(pix, pix2)
+    # the distillation MLP and both searches ran on the de-duplicated rows only (one plan on the fp32 bit patterns of the raw xyz
+    # patches, GEMMs sized by the device-side row count): fewer rows, the same bits as running every row
+    assert p.dedup and 0 < int(p.live_rows.item()) < 0.8 * B * 3136 * p.xyz_searches
+    monkeypatch.setenv("CMDIAD_DEDUP", "0")
+    p_all = BatchPredictor(gpu_engine, p.bank_xyz, p.bank_second, stats, det, seg, lambdas=(1.0, 1.0, 1.0, 1.0), batch=B, workload="mtfi",
+                           halluc=p.halluc, use_graph=False)
+    monkeypatch.delenv("CMDIAD_DEDUP")
+    img_all, pix_all = p_all.predict_batch(None, pcs)
+    assert not p_all.dedup and int(p_all.live_rows.item()) == B * 3136 * p_all.xyz_searches
+    assert np.array_equal(img_all, img) and np.array_equal(pix_all, pix)
     spread = float(ref_img.max() - ref_img.min())
     d_pix = np.abs(pix - ref_pix)
     print(f"mtfi image score max |d| {np.abs(img - ref_img).max():.4f} of spread {spread:.4f}; pixel max |d| {d_pix.max():.5f} "

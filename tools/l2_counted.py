@@ -5,7 +5,7 @@ import os, sys, torch
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tools"))
 from cmdiad_amd import ops
 from microbench import timeit
-Qmax, Nb, live = 100352, 76518, int(os.environ.get("L2_LIVE", 54401))
+Qmax, Nb, live = 100352, int(os.environ.get("L2_NB", 76544)), int(os.environ.get("L2_LIVE", 54401))
 g = torch.Generator().manual_seed(0)
 b16, _, bsq = ops.normalize_cast(torch.randn(Nb, 768, generator=g).cuda(), want_f32=False)
 q16, _, qsq = ops.normalize_cast(torch.randn(Qmax, 768, generator=g).cuda(), want_f32=False)
