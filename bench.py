@@ -197,25 +197,35 @@ def run_steps(pred, batches, n, first=None):
 # --------------------------------------------------------------------------------------------------------- secondary legs
 def profiled_traffic():
     """roofline.traffic: fabric-side bytes per launch of the dominant kernel (2 x FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md).  PMC
-    counters cannot be read inside this process; the figure comes from the committed rocprofv3 --pmc pass (profiles/r2_pmc.json,
-    tools/profile_round.sh) and is emitted ONLY while the kernel's source is byte-identical to the one that was profiled
-    (profiles/r2_pmc_meta.json holds the sha256 of csrc/l2min.hip + gemm_core.h at that time): null as soon as the kernel changes."""
+    counters cannot be read inside this process; the figure comes from the newest committed rocprofv3 --pmc pass
+    (profiles/rN_pmc.json, tools/profile_round.sh) and is emitted ONLY while the kernel's source is byte-identical to the one that
+    was profiled (profiles/rN_pmc_meta.json holds the sha256 of csrc/l2min.hip + gemm_core.h at that time): null as soon as the
+    kernel changes."""
+    import glob
     import hashlib
+    import re
     here = os.path.dirname(os.path.abspath(__file__))
-    try:
-        meta = json.load(open(os.path.join(here, "profiles", "r2_pmc_meta.json")))
-        h = hashlib.sha256()
-        for f in meta["sources"]:
-            h.update(open(os.path.join(here, f), "rb").read())
-        if h.hexdigest() != meta["sha256"]:
-            return {"traffic": None, "traffic_note": "the distance GEMM's source changed since profiles/r2_pmc.json was taken: re-profile"}
-        rows = [r for r in json.load(open(os.path.join(here, "profiles", "r2_pmc.json"))) if r["kernel"].startswith("l2_min_pp3")]
-        row = max(rows, key=lambda r: r["grid_threads"])
-        return {"traffic": round(row["fetch_bytes"] + row["write_bytes"]),
-                "traffic_note": f"bytes per launch from the committed PMC pass (profiles/r2_pmc.md, commit {meta['commit']}; kernel source unchanged "
-                                f"since: sha256 {meta['sha256'][:12]}); L2 hit {row['l2_hit']:.3f}"}
-    except (OSError, KeyError, ValueError) as e:
-        return {"traffic": None, "traffic_note": f"no usable committed PMC pass ({type(e).__name__})"}
+    metas = sorted(glob.glob(os.path.join(here, "profiles", "r*_pmc_meta.json")),
+                   key=lambda f: int(re.search(r"r(\d+)_pmc_meta", f).group(1)), reverse=True)
+    note = "no committed PMC pass"
+    for meta_path in metas:
+        tag = re.search(r"(r\d+)_pmc_meta", meta_path).group(1)
+        try:
+            meta = json.load(open(meta_path))
+            h = hashlib.sha256()
+            for f in meta["sources"]:
+                h.update(open(os.path.join(here, f), "rb").read())
+            if h.hexdigest() != meta["sha256"]:
+                note = f"the distance GEMM's source changed since profiles/{tag}_pmc.json was taken: re-profile"
+                continue
+            rows = [r for r in json.load(open(os.path.join(here, "profiles", f"{tag}_pmc.json"))) if r["kernel"].startswith("l2_min_pp3")]
+            row = max(rows, key=lambda r: r["grid_threads"])
+            return {"traffic": round(row["fetch_bytes"] + row["write_bytes"]),
+                    "traffic_note": f"bytes per launch from the committed PMC pass (profiles/{tag}_pmc.md, commit {meta['commit']}; kernel source "
+                                    f"unchanged since: sha256 {meta['sha256'][:12]}); L2 hit {row['l2_hit']:.3f}"}
+        except (OSError, KeyError, ValueError) as e:
+            note = f"no usable committed PMC pass ({type(e).__name__})"
+    return {"traffic": None, "traffic_note": note}
 
 
 def cpu_baseline(n_images=10, warm=3):

@@ -46,347 +46,7 @@ struct TailParams {
 };
 
 #ifdef CMDIAD_AB_VARIANTS  // the lock-step form (both waves of a SIMD in the same part of a phase): A/B reference of the test-only build
-// acc[2][4] += A(32 rows of this wave, k-block `ta`) . W(64 columns of this wave, tile `tw`)^T, swapped orientation
-__device__ __forceinline__ void phase(f32x4 (&acc)[2][4], const char* ta, const char* tw, int wr, int wc, int lane)
-{
-    bf16x8 af[2][2], wf[2][4];  // both 32-deep halves requested up front: the second half's LDS latency hides under the first's MFMAs
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-        const int chunk = kk * 4 + (lane >> 4);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) af[kk][i] = *reinterpret_cast<const bf16x8*>(ta + lds_off(wr * 32 + i * 16 + (lane & 15), chunk));
-#pragma unroll
-        for (int j = 0; j < 4; ++j) wf[kk][j] = *reinterpret_cast<const bf16x8*>(tw + lds_off(wc * 64 + j * 16 + (lane & 15), chunk));
-    }
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(wf[kk][j], af[kk][i], acc[i][j]);
-}
-
-__global__ __launch_bounds__(TW * 64, 2) void encoder_tail_kernel(GlobalTile H2, GlobalTile W3, GlobalTile W4, TailParams p)
-{
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    char* A2 = lds;
-    char* A3 = lds + A2_BYTES;
-    char* WS = A3 + A3_BYTES;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
-    const int m0 = blockIdx.x * TM;
-
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb) H2.stage<TM, TW>(A2 + kb * KB_BYTES, m0, kb * BK, tid);
-    // weight tile t of the block's sequence: chunk c = t / 10; u = t % 10: u < 4 -> W3b rows [128c, +128), K-step u;
-    // else output chunk o = (u - 4) / 2, K-step k2 = (u - 4) % 2 of W4 rows [128 o, +128), columns 128 c + 64 k2
-    auto stage_w = [&](int t, int slot) {
-        const int c = t / 10, u = t - c * 10;
-        char* buf = WS + slot * W_STAGE;
-        if (u < 4) W3.stage<128, TW>(buf, c * 128, u * BK, tid);
-        else W4.stage<128, TW>(buf, ((u - 4) >> 1) * 128, c * 128 + ((u - 4) & 1) * BK, tid);
-    };
-    // Group-bias values of a chunk (16 per lane) are fetched long before they are used, by inline asm: a load the compiler
-    // can see gets a compiler-placed s_waitcnt vmcnt(0) at its use -- a drain of the weight stream per chunk.  In-order
-    // retirement makes the counted waits of the phases in between (>= 4) cover them.
-    const int row0 = m0 + wr * 32;                 // this wave's 32 rows share a group (32 | Mg)
-    const float* gb = p.gb + (size_t)(min(row0, p.M - 1) / p.Mg) * 512 + wc * 64 + (lane >> 4) * 4;
-    f32x4 gbv[4];
-    auto fetch_gb = [&](int c) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(gbv[j]) : "v"(gb + c * 128 + j * 16) : "memory");
-    };
-    fetch_gb(0);
-#pragma unroll
-    for (int t0 = 0; t0 < AHEAD; ++t0) stage_w(t0, t0);
-    // tile 0 (and the h2 tile, issued before it: the counter retires in order) landed; AHEAD - 1 tiles stay in flight
-    if constexpr (AHEAD == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if constexpr (AHEAD == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    block_barrier();
-
-    f32x4 acc3[2][4], acco[3][2][4];
-#pragma unroll
-    for (int o = 0; o < 3; ++o)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acco[o][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // one phase = (issue the weight tile AHEAD steps on, into the stage the previous phase just left) + 16 MFMAs per wave
-    // + counted wait + barrier; t counts the 40 tiles of the block
-    int t = 0;
-    auto step = [&](f32x4 (&acc)[2][4], const char* ta) {
-        if (t + AHEAD < 40) stage_w(t + AHEAD, (t + AHEAD) % NST);
-        phase(acc, ta, WS + (t % NST) * W_STAGE, wr, wc, lane);
-        ++t;
-    };
-    int gb_young = 0;  // syncs for which the 4 group-bias loads are still YOUNGER than the tile being waited for
-    auto sync = [&]() {  // tile t must have landed; the loads issued after it (2 pieces per wave per tile) may stay in flight
-        const int n = min(t - 1 + AHEAD, 39) - t;
-        if (gb_young > 0) {  // only in the body of the stream, where n == AHEAD - 1
-            --gb_young;
-            if constexpr (AHEAD == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else if constexpr (AHEAD == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        } else if (n >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else if (n == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        block_barrier();
-    };
-#pragma unroll 1
-    for (int c = 0; c < 4; ++c) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc3[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            step(acc3, A2 + u * KB_BYTES);
-            if (u < 3) sync();
-        }
-        // h3 chunk c: + group bias, ReLU, bf16, into LDS in the A-operand layout of the next product
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = wc * 64 + j * 16 + (lane >> 4) * 4;  // column inside the chunk
-            const f32x4 b = gbv[j];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int m = wr * 32 + i * 16 + (lane & 15);
-                const f32x4 v = acc3[i][j];
-                bf16x4 o = {f2bf(fmaxf(v[0] + b[0], 0.f)), f2bf(fmaxf(v[1] + b[1], 0.f)), f2bf(fmaxf(v[2] + b[2], 0.f)),
-                            f2bf(fmaxf(v[3] + b[3], 0.f))};
-                *reinterpret_cast<bf16x4*>(A3 + (n >> 6) * KB_BYTES + lds_off(m, (n & 63) >> 3) + (n & 7) * 2) = o;
-            }
-        }
-        if (c < 3) { fetch_gb(c + 1); gb_young = AHEAD; }  // used six phases on; younger than the awaited tile for AHEAD syncs
-        sync();
-        step(acco[0], A3); sync(); step(acco[0], A3 + KB_BYTES); sync();
-        step(acco[1], A3); sync(); step(acco[1], A3 + KB_BYTES); sync();
-        step(acco[2], A3); sync(); step(acco[2], A3 + KB_BYTES); sync();
-    }
-
-    // Group maximum.  A block's 128 rows are whole groups (Mg divides 128 and blocks start at multiples of 128), so nothing
-    // is shared between blocks: the four 32-row partial maxima meet in LDS (the h2 tile is dead by now) and each output is
-    // stored once -- no atomics (they were 1 536 per block, 50 M per batch, 1.2 GB of L2 atomic traffic) and no pre-fill.
-    float* s_part = reinterpret_cast<float*>(A2);  // [4 row blocks][384]
-#pragma unroll
-    for (int o = 0; o < 3; ++o)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = o * 128 + wc * 64 + j * 16 + (lane >> 4) * 4;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = fmaxf(acco[o][0][j][r], acco[o][1][j][r]);
-                v = row16_max(v);
-                if ((lane & 15) == 0) s_part[wr * 384 + n + r] = v;
-            }
-        }
-    __syncthreads();
-    const int per = p.Mg / 32;                     // 32-row blocks per group: 1, 2 or 4
-    for (int e = tid; e < (4 / per) * 384; e += TW * 64) {
-        const int g = e / 384, n = e - g * 384;
-        const int row = m0 + g * p.Mg;
-        if (row >= p.M) continue;
-        float v = s_part[(g * per) * 384 + n];
-        for (int q = 1; q < per; ++q) v = fmaxf(v, s_part[(g * per + q) * 384 + n]);
-        p.tok[(size_t)(row / p.Mg) * 384 + n] = v + p.b4[n];
-    }
-}
-
-
-
-// ------------------------------------------------------------------------------------------------
-// The same block in TWO GROUPS half a phase apart (production).  In the kernel above both waves of a SIMD are in the same
-// part of a phase at the same time: 96 KiB of fragment reads (750 LDS cycles), THEN 2 x 16 MFMAs (512 cycles), then the barrier
-// -- 46 % of the wave-cycles are parked (profiles/r2_pmc.md).  Here waves 0-3 (rows 0-63) and waves 4-7 (rows 64-127) -- one
-// wave of each on every SIMD -- run one barrier apart: a phase is [fragment reads | barrier | MFMAs | barrier], and one group's
-// reads sit under the other group's MFMAs.  Only the first group issues (and waits for) the weight stream, four pieces per wave
-// and tile, into the stage the second group left one barrier earlier; the stream keeps its three tiles of lead.  The second
-// product walks K outside and the three output chunks inside, so a wave's h3 fragments are read once per K-step, not three
-// times.  Arithmetic per output element is unchanged (same K order per accumulator): bit-identical tokens.
-// ------------------------------------------------------------------------------------------------
-template <bool ABL>   // ABL: timing ablations (results are garbage), instantiated in the test-only build
-__global__ __launch_bounds__(TW * 64, 1) void encoder_tail_pp_kernel(GlobalTile H2, GlobalTile W3, GlobalTile W4, TailParams p)
-{
-    static_assert(NST == 4, "the two-group schedule is written for four weight stages");
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    char* A2 = lds;
-    char* A3 = lds + A2_BYTES;
-    char* WS = A3 + A3_BYTES;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
-    const bool lead = wave < 4;
-    const int m0 = blockIdx.x * TM;
-
-    if (!(ABL && (p.ablate & 32)))
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb) H2.stage<TM, TW>(A2 + kb * KB_BYTES, m0, kb * BK, tid);
-    // Weight tile t of the block's sequence: chunk c = t / 10, u = t % 10: u < 4 -> W3b rows [128 c, +128), K-step u; else
-    // v = u - 4: K-step k2 = v / 3 of W4 rows [128 (v % 3), +128), columns 128 c + 64 k2.  Issued by the first group only: wave w
-    // (0..3) brings rows 32 w .. 32 w + 31 as four 8-row pieces; lane l of a piece fetches the 16-byte chunk (l & 7) ^ (row & 7) of
-    // row l >> 3 (the swizzle goes on the source address, gemm_core.h).  Per-lane byte offsets inside a tile are computed once.
-    const int prow = (wave & 3) * 32 + (lane >> 3);
-    const unsigned pch = (unsigned)(((lane & 7) ^ ((lane >> 3) & 7)) * 16);
-    const unsigned off3 = (unsigned)prow * 512u + pch, off4 = (unsigned)prow * 1024u + pch;   // row pitches: 256 / 512 bf16
-    auto stage_w = [&](int c, int u, int slot) {   // all three wave-uniform
-        char* dst = WS + slot * W_STAGE + (wave & 3) * 32 * 128;
-        const char* src;
-        unsigned step;
-        if (u < 4) { src = reinterpret_cast<const char*>(W3.base) + ((size_t)c * 128 * 256 + u * BK) * 2 + off3; step = 8 * 512; }
-        else {
-            const int v = u - 4, k2 = v >= 3 ? 1 : 0, o = v - 3 * k2;
-            src = reinterpret_cast<const char*>(W4.base) + ((size_t)o * 128 * 512 + c * 128 + k2 * BK) * 2 + off4;
-            step = 8 * 1024;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + j * step),
-                                             (__attribute__((address_space(3))) void*)(dst + j * 8 * 128), 16, 0, 0);
-    };
-    const int row0 = m0 + wr * 32;                 // this wave's 32 rows share a group (32 | Mg)
-    const float* gb = p.gb + (size_t)(min(row0, p.M - 1) / p.Mg) * 512 + wc * 64 + (lane >> 4) * 4;
-    f32x4 gbv[4];
-    auto fetch_gb = [&](int c) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(gbv[j]) : "v"(gb + c * 128 + j * 16) : "memory");
-    };
-    fetch_gb(0);
-    if (lead) {
-        stage_w(0, 0, 0); stage_w(0, 1, 1); stage_w(0, 2, 2);
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // h2, the group bias and tile 0 landed; tiles 1, 2 in flight
-    } else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // h2 landed (this wave's pieces)
-    block_barrier();
-    if (!lead) pp_barrier();   // the second group runs one barrier behind
-
-    f32x4 acc3[2][4], acco[3][2][4];
-#pragma unroll
-    for (int o = 0; o < 3; ++o)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acco[o][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // fragment addresses: row * 128 + ((chunk ^ (row & 7)) << 4) with chunk = 4 kk + (lane >> 4): kk flips bit 6, the 16-row
-    // blocks i / j add 2 KiB.  h3 is written as 8-byte units: column 16 j + 4 (lane >> 4) of the wave's half = chunk 2 j + (g >> 1).
-    const int swz = ((lane >> 4) ^ (lane & 7)) << 4;
-    const int a_frag = (wr * 32 + (lane & 15)) * 128 + swz, w_frag = (wc * 64 + (lane & 15)) * 128 + swz;
-    const int h_dst = wc * KB_BYTES + (wr * 32 + (lane & 15)) * 128 + ((((lane >> 5)) ^ (lane & 7)) << 4) + ((lane >> 4) & 1) * 8;
-    bf16x8 af[2][2], wf[2][4];
-    int gb_young = 0;
-    // first half of a phase: (first group) issue the tile three ahead, then this wave's fragments of the current tile; barrier
-    auto reads = [&](const char* ta, bool load_a, int slot, int ic, int iu, bool issue) {
-        if (lead && issue && !(ABL && (p.ablate & 1))) stage_w(ic, iu, (slot + AHEAD) & 3);
-        const char* tw = WS + slot * W_STAGE;
-        if (!(ABL && (p.ablate & 4)))
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            if (load_a) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i) af[kk][i] = *reinterpret_cast<const bf16x8*>(ta + ((a_frag + i * 2048) ^ (kk << 6)));
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) wf[kk][j] = *reinterpret_cast<const bf16x8*>(tw + ((w_frag + j * 2048) ^ (kk << 6)));
-        }
-        if (!(ABL && (p.ablate & 16))) block_barrier();
-    };
-    auto mfmas = [&](f32x4 (&acc)[2][4]) {
-        if (ABL && (p.ablate & 2)) return;
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(wf[kk][j], af[kk][i], acc[i][j]);
-        __builtin_amdgcn_s_setprio(0);
-    };
-    // end of phase t: the first group waits for tile t + 1 (four pieces per wave and tile; what was issued after it stays in
-    // flight: two tiles in the body of the stream, plus the four group-bias loads while they are younger than the awaited tile)
-    auto finish = [&](int t) {
-        if (lead && !(ABL && (p.ablate & 1))) {
-            const int n = min(t + AHEAD, 39) - (t + 1);
-            if (gb_young > 0) { --gb_young; asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); }   // n == 2 there
-            else if (n >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else if (n == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        if (!(ABL && (p.ablate & 16))) block_barrier();
-    };
-    // one chunk = ten phases; S0 = stage of its first tile ((10 c) & 3: 0 for even c, 2 for odd c), so every stage is a
-    // compile-time offset
-    auto chunk = [&](auto S0C, int c) {
-        constexpr int S0 = decltype(S0C)::value;
-        const int t0 = c * 10;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc3[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int u = 0; u < 10; ++u) {
-            // the tile three ahead: (c, u + 3) or (c + 1, u - 7)
-            const int ic = u + AHEAD < 10 ? c : c + 1, iu = u + AHEAD < 10 ? u + AHEAD : u + AHEAD - 10;
-            if (u < 4) reads(A2 + u * KB_BYTES, true, (S0 + u) & 3, ic, iu, ic < 4);
-            else reads(A3 + ((u - 4) / 3) * KB_BYTES, (u - 4) % 3 == 0, (S0 + u) & 3, ic, iu, ic < 4);
-            if (u < 4) mfmas(acc3);
-            else mfmas(acco[(u - 4) % 3]);
-            if (u == 3) {
-                // h3 chunk c: + group bias, ReLU, bf16, into LDS in the A-operand layout of the next product (own rows only)
-                if (!lead || (ABL && (p.ablate & 1))) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // second group: nothing but the group bias is in flight
-                if (!(ABL && (p.ablate & 8)))
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const f32x4 b = gbv[j];
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        const f32x4 v = acc3[i][j];
-                        bf16x4 o = {f2bf(fmaxf(v[0] + b[0], 0.f)), f2bf(fmaxf(v[1] + b[1], 0.f)), f2bf(fmaxf(v[2] + b[2], 0.f)),
-                                    f2bf(fmaxf(v[3] + b[3], 0.f))};
-                        *reinterpret_cast<bf16x4*>(A3 + ((h_dst + i * 2048) ^ (j << 5))) = o;
-                    }
-                }
-                if (c < 3) { fetch_gb(c + 1); gb_young = AHEAD; }
-            }
-            finish(t0 + u);
-        }
-    };
-#pragma unroll 1
-    for (int cc = 0; cc < 2; ++cc) {
-        chunk(std::integral_constant<int, 0>{}, 2 * cc);
-        chunk(std::integral_constant<int, 2>{}, 2 * cc + 1);
-    }
-    if (lead) pp_barrier();   // both groups execute the same number of barriers
-
-    // Group maximum: in-lane over the wave's two 16-row blocks, across the 16 row lanes by DPP (96 values per lane in batches of
-    // 32: one instruction per value and step), then the four 32-row partial maxima meet in LDS (the h2 tile is dead by now).
-    float* s_part = reinterpret_cast<float*>(A2);  // [4 row blocks][384]
-    if (!(ABL && (p.ablate & 64)))
-#pragma unroll
-    for (int o = 0; o < 3; ++o) {
-        float red[32];
-#pragma unroll
-        for (int q = 0; q < 32; ++q) red[q] = fmaxf(acco[o][0][q >> 2][q & 3], acco[o][1][q >> 2][q & 3]);
-        row16_max_batch(red);
-        if ((lane & 15) == 0) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                *reinterpret_cast<f32x4*>(s_part + wr * 384 + o * 128 + wc * 64 + j * 16 + (lane >> 4) * 4) =
-                    f32x4{red[4 * j], red[4 * j + 1], red[4 * j + 2], red[4 * j + 3]};
-        }
-    }
-    __syncthreads();
-    const int per = p.Mg / 32;                     // 32-row blocks per group: 1, 2 or 4
-    for (int e = tid; e < (4 / per) * 384; e += TW * 64) {
-        const int g = e / 384, n = e - g * 384;
-        const int row = m0 + g * p.Mg;
-        if (row >= p.M) continue;
-        float v = s_part[(g * per) * 384 + n];
-        for (int q = 1; q < per; ++q) v = fmaxf(v, s_part[(g * per + q) * 384 + n]);
-        p.tok[(size_t)(row / p.Mg) * 384 + n] = v + p.b4[n];
-    }
-}
-
-
+#include "ab/encoder_tail_lockstep.inc"
 #endif  // CMDIAD_AB_VARIANTS
 
 // ------------------------------------------------------------------------------------------------

@@ -40,71 +40,7 @@ __device__ __forceinline__ unsigned long long fps_key(float v, int idx)
 }
 
 #ifdef CMDIAD_AB_VARIANTS  // first formulation of the round: test-only build (make ab), A/B reference for fps_pk_kernel
-template <int kThreads, int PPT>
-__global__ __launch_bounds__(kThreads) void fps_reg_kernel(const float* __restrict__ xyz,
-                                                           const int32_t* __restrict__ n_valid, int N, int G,
-                                                           int32_t* __restrict__ idx_out,
-                                                           float* __restrict__ center_out)
-{
-    constexpr int kWaves = kThreads / 64;
-    __shared__ unsigned long long s_key[2][kWaves];
-    const int b = blockIdx.x;
-    const int tid = threadIdx.x;
-    const int n = n_valid ? n_valid[b] : N;
-    const float* p = xyz + (size_t)b * N * 3;
-    int32_t* out = idx_out + (size_t)b * G;
-    float* cen = center_out ? center_out + (size_t)b * G * 3 : nullptr;
-
-    float px[PPT], py[PPT], pz[PPT], t[PPT];
-#pragma unroll
-    for (int s = 0; s < PPT; ++s) {
-        const int k = s * kThreads + tid;
-        float x = 0.f, y = 0.f, z = 0.f;
-        if (k < n) { x = p[k * 3 + 0]; y = p[k * 3 + 1]; z = p[k * 3 + 2]; }
-        px[s] = x; py[s] = y; pz[s] = z;
-        const float mag = (x * x + y * y) + z * z;
-        // skipped / out-of-range points carry -inf: min() keeps it and "> best" never selects it
-        t[s] = (k < n && !(mag <= 1e-3f)) ? 1e10f : -__builtin_inff();
-    }
-
-    int old = 0;
-    if (tid == 0 && G > 0) {
-        out[0] = 0;
-        if (cen) { cen[0] = p[0]; cen[1] = p[1]; cen[2] = p[2]; }
-    }
-    for (int j = 1; j < G; ++j) {
-        const int so = __builtin_amdgcn_readfirstlane(old);
-        const float x1 = p[so * 3 + 0], y1 = p[so * 3 + 1], z1 = p[so * 3 + 2];
-        float best = -1.0f;
-        int bests = 0;  // winning SLOT (an inline constant per unrolled step: no index registers)
-#pragma unroll
-        for (int s = 0; s < PPT; ++s) {
-            const float dx = px[s] - x1, dy = py[s] - y1, dz = pz[s] - z1;
-            const float d = (dx * dx + dy * dy) + dz * dz;
-            const float d2 = fminf(d, t[s]);
-            t[s] = d2;
-            const bool gt = d2 > best;
-            best = gt ? d2 : best;
-            bests = gt ? s : bests;
-        }
-        const int besti = bests * kThreads + tid;
-        unsigned long long key = wave_max_u64(fps_key(best, besti));
-        const int buf = j & 1;
-        if ((tid & 63) == 0) s_key[buf][tid >> 6] = key;
-        __syncthreads();
-        unsigned long long m = s_key[buf][0];
-#pragma unroll
-        for (int w = 1; w < kWaves; ++w) {
-            const unsigned long long o = s_key[buf][w];
-            m = o > m ? o : m;
-        }
-        old = m == 0ull ? 0 : (int)(0xFFFFFFFFu - (unsigned)(m & 0xFFFFFFFFull));
-        if (tid == 0) {
-            out[j] = old;
-            if (cen) { cen[j * 3 + 0] = p[old * 3 + 0]; cen[j * 3 + 1] = p[old * 3 + 1]; cen[j * 3 + 2] = p[old * 3 + 2]; }
-        }
-    }
-}
+#include "ab/fps_reg.inc"
 #endif  // CMDIAD_AB_VARIANTS
 
 // Second formulation of the same round, built for VALU throughput: one CU retires 64 lanes x 4 SIMDs / 4 cycles, and the

@@ -57,9 +57,12 @@ struct Coord {
     // co-resident on an XCD (64 of them) touch ~3 A tiles and EVERY W tile: for fc1 (24 W tiles = 4.7 MB) that alone exceeds
     // the 4 MB L2 and the PMC pass shows each launch fetching 10x its operands from beyond L2.  In groups of `group_m` M tiles
     // walked M-fastest, 64 consecutive blocks cover group_m A tiles x 64/group_m W tiles (8 + 8 tiles = 3 MB at group_m = 8).
-    __device__ __forceinline__ Coord(int n_tiles_n, int panel = 1, int group_m = 1, int m_tiles = 0)
+    // nwg: workgroups that have a tile (default: the launched grid).  A launch sized for more rows than are live (m_count)
+    // remaps over the LIVE count: the remap hands every XCD a contiguous range of the tile order, so over the launched grid the
+    // live row tiles would all land on the first XCDs and the others would idle.
+    __device__ __forceinline__ Coord(int n_tiles_n, int panel = 1, int group_m = 1, int m_tiles = 0, int nwg = -1)
     {
-        const int wg = xcd_remap(blockIdx.x, gridDim.x);
+        const int wg = xcd_remap(blockIdx.x, nwg < 0 ? (int)gridDim.x : nwg);
         const int groups = (n_tiles_n + panel - 1) / panel;
         if (group_m > 1) {
             const int per_group = group_m * groups;
@@ -90,10 +93,11 @@ template <class S, int ACT, bool EXTRAS, bool RES_ROWS = false>
 __global__ __launch_bounds__(S::THREADS, S::WAVES_PER_SIMD) void gemm_std_kernel(GlobalTile A, GlobalTile W, StdParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int m_tiles_launched = (p.M + S::BM - 1) / S::BM;     // the grid was sized for the caller's M
-    live_m(p, A);
-    const Coord<S> c((p.N + S::BN - 1) / S::BN, p.panel, p.group_m, m_tiles_launched);
-    if (c.m0 >= p.M) return;                                      // block-uniform: a row tile beyond the live rows
+    live_m(p, A);                                                 // the grid was sized for the caller's M; p.M is the live row count now
+    const int n_tiles_n = (p.N + S::BN - 1) / S::BN, m_tiles = (p.M + S::BM - 1) / S::BM;
+    const int nwg = m_tiles * ((n_tiles_n + p.panel - 1) / p.panel);
+    if ((int)blockIdx.x >= nwg) return;                           // block-uniform: no tile left for this workgroup
+    const Coord<S> c(n_tiles_n, p.panel, p.group_m, m_tiles, nwg);
     const int kt_per = (p.K / BK + p.split_k - 1) / p.split_k;
     const int kt_begin = blockIdx.y * kt_per;
     const int kt_count = min(kt_per, p.K / BK - kt_begin);
@@ -734,109 +738,7 @@ __global__ __launch_bounds__(512, 1) void encoder_stage1_persist_kernel(const fl
 template <class S> constexpr int group_max_lds() { return S::LDS_BYTES + (S::BM / 32) * S::BN * (int)sizeof(float); }
 
 #ifdef CMDIAD_AB_VARIANTS
-// ------------------------------------------------------------------------------------------------
-// The same two products on the 4-wave 256-row shapes of gemm_wide.h (256 x 256 or 256 x 128 blocks): half / three
-// quarters of the operand bytes per FLOP through the L1 / LDS-DMA path, which is what bounds the 128 x 128 shape on
-// the tall short-K products (a 128 x 128 x 64 step moves 32 KiB per 512 MFMA cycles = the path's 64 B/clk/CU).
-// Epilogue terms supported: bias, group bias, activation, bf16 and/or f32 output (no residual / training extras).
-// ------------------------------------------------------------------------------------------------
-template <int NJ, int ACT>
-__global__ __launch_bounds__(256, 1) void gemm_std_wide_kernel(GlobalTile A, GlobalTile W, StdParams p)
-{
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    using S = WideShape<NJ>;
-    const int n_tiles_n = (p.N + S::BN - 1) / S::BN;
-    const int wg = xcd_remap(blockIdx.x, gridDim.x);
-    const int groups = (n_tiles_n + p.panel - 1) / p.panel;
-    const int m0 = (wg / groups) * S::BM, nt0 = (wg % groups) * p.panel;
-    const int count = min(p.panel, n_tiles_n - nt0);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
-
-    run_wide<true, false, NJ>(A, W, m0, nt0, count, p.K / BK, lds, [&](auto I, f32x4 (&row)[NJ], int ntile) {
-        const int m = m0 + wr * 128 + decltype(I)::value * 16 + (lane & 15);
-        if (m >= p.M) return;
-        const float* gb = p.group_bias ? p.group_bias + (size_t)(m / p.group_rows) * p.N : nullptr;
-        float* o32 = p.out_f32 ? p.out_f32 + (size_t)m * p.ldo32 : nullptr;
-        bf16_t* o16 = p.out_bf16 ? p.out_bf16 + (size_t)m * p.ldo16 : nullptr;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int n = ntile * S::BN + wc * S::WCOLS + j * 16 + (lane >> 4) * 4;
-            if (n >= p.N) continue;
-            f32x4 v = row[j];
-            if (p.bias) { const float4 b = *reinterpret_cast<const float4*>(p.bias + n); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
-            if (gb) { const float4 b = *reinterpret_cast<const float4*>(gb + n); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
-            if constexpr (ACT == CMDIAD_ACT_GELU) {
-v = gelu_erf4(v);
-            } else if constexpr (ACT == CMDIAD_ACT_RELU) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
-            }
-            if (o32) *reinterpret_cast<f32x4*>(o32 + n) = v;
-            if (o16) {
-                bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-                *reinterpret_cast<bf16x4*>(o16 + n) = o;
-            }
-        }
-    });
-}
-
-// Per-group max pooling on the wide shapes.  A wave owns 128 consecutive rows = whole groups (Mg in {32, 64, 128}), so
-// the row maximum never leaves the wave: running max over the 16-row blocks of a group per lane, then over the 16 row
-// lanes by shuffles; no LDS table, no extra barrier.
-template <int NJ>
-__global__ __launch_bounds__(256, 1) void gemm_groupmax_wide_kernel(GlobalTile A, GlobalTile W, GroupMaxParams p)
-{
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    using S = WideShape<NJ>;
-    const int n_tiles_n = (p.N + S::BN - 1) / S::BN;
-    const int wg = xcd_remap(blockIdx.x, gridDim.x);
-    const int groups = (n_tiles_n + p.panel - 1) / p.panel;
-    const int m0 = (wg / groups) * S::BM, nt0 = (wg % groups) * p.panel;
-    const int count = min(p.panel, n_tiles_n - nt0);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
-    const int blocks_per_group = p.Mg / 16;  // 2, 4 or 8 row blocks
-
-    f32x4 mx[NJ];
-    run_wide<true, false, NJ>(A, W, m0, nt0, count, p.K / BK, lds, [&](auto I, f32x4 (&row)[NJ], int ntile) {
-        constexpr int i = decltype(I)::value;
-        const bool first = (i % blocks_per_group) == 0, last = ((i + 1) % blocks_per_group) == 0;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            if (first) mx[j] = row[j];
-            else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) mx[j][r] = fmaxf(mx[j][r], row[j][r]);
-            }
-        }
-        if (!last) return;
-        const int grow = m0 + wr * 128 + (i / blocks_per_group) * p.Mg;  // first row of the finished group
-        const int grp = grow / p.Mg;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int n = ntile * S::BN + wc * S::WCOLS + j * 16 + (lane >> 4) * 4;
-            f32x4 v = mx[j];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float t = v[r];
-                t = fmaxf(t, __shfl_xor(t, 1, 64));
-                t = fmaxf(t, __shfl_xor(t, 2, 64));
-                t = fmaxf(t, __shfl_xor(t, 4, 64));
-                t = fmaxf(t, __shfl_xor(t, 8, 64));
-                v[r] = t;
-            }
-            if ((lane & 15) == 0 && n < p.N && grow < p.M) {
-                if (p.bias) { const float4 b = *reinterpret_cast<const float4*>(p.bias + n); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
-                if (p.max_f32) *reinterpret_cast<f32x4*>(p.max_f32 + (size_t)grp * p.N + n) = v;
-                if (p.max_bf16) {
-                    bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-                    *reinterpret_cast<bf16x4*>(p.max_bf16 + (size_t)grp * p.N + n) = o;
-                }
-            }
-        }
-    });
-}
+#include "ab/gemm_wide_kernels.inc"
 #endif  // CMDIAD_AB_VARIANTS
 
 bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }

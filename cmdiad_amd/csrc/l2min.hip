@@ -121,309 +121,7 @@ __global__ __launch_bounds__(S::THREADS, S::WAVES_PER_SIMD) void l2_min_kernel(G
 __device__ __forceinline__ void pp_barrier() { asm volatile("s_barrier" ::: "memory"); }
 
 #ifdef CMDIAD_AB_VARIANTS  // superseded formulations of the 256 x 256 distance GEMM: test-only build (make ab), A/B references
-// The same contraction on the 4-wave 128 x 128-per-wave shape (gemm_wide.h).
-template <bool F16>
-__global__ __launch_bounds__(256, 1) void l2_min_wide_kernel(GlobalTile A, GlobalTile W, L2Params p)
-{
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    using S = SWide;
-    const int wg = xcd_remap(blockIdx.x, gridDim.x);
-    const int gsz = p.qgroup * p.splits;
-    const int within = wg % gsz;
-    const int split = within / p.qgroup, qt = (wg / gsz) * p.qgroup + within % p.qgroup;
-    if (qt >= p.nq_tiles) return;
-    const int per = (p.n_bank_tiles + p.splits - 1) / p.splits;
-    const int nt0 = split * per;
-    const int ntc = min(per, p.n_bank_tiles - nt0);
-    if (ntc <= 0) return;
-    const int m0 = qt * S::BM;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
-
-    float best[8], qn[8];
-    int besti[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        best[i] = __builtin_inff();
-        besti[i] = 0;
-        const int m = m0 + wr * 128 + i * 16 + (lane & 15);
-        qn[i] = m < p.Q ? p.q_sqnorm[m] : 0.0f;
-    }
-    // The tile's bank norms are fetched at its FIRST K-step by inline asm and retire with that step's wait.  Loaded where they
-    // are used (the epilogue, which runs after the next tile's first DMA has been issued) the compiler guards them with
-    // s_waitcnt vmcnt(0): the ~2 us of epilogue arithmetic then starts only after that DMA has landed instead of covering
-    // its flight.  Whole bank tiles only (the launcher gives the last Nb % 256 rows to l2_min_kernel<S128>).
-    f32x4 bn[8];
-    const float* bnp = p.b_sqnorm + wc * 128 + (lane >> 4) * 4;
-    run_wide<true, F16>(A, W, m0, nt0, ntc, p.D / BK, lds, [&](auto I, f32x4 (&row)[8], int ntile) {
-        constexpr int i = decltype(I)::value;
-        const int nbase = ntile * S::BN + wc * 128 + (lane >> 4) * 4;
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float d2 = (qn[i] + bn[j][r]) - 2.0f * row[j][r];
-                if (d2 < best[i]) { best[i] = d2; besti[i] = nbase + j * 16 + r; }  // n increases with j, r: first occurrence wins
-            }
-    }, [&](int ntile) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bn[j]) : "v"(bnp + (size_t)ntile * S::BN + j * 16) : "memory");
-    });
-
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        unsigned long long key = pack_key(fmaxf(best[i], 0.0f), p.row_offset + (unsigned)besti[i]);
-        if (!(best[i] < __builtin_inff())) key = ~0ull;
-        unsigned long long o = shfl_xor_u64(key, 16);
-        key = o < key ? o : key;
-        o = shfl_xor_u64(key, 32);
-        key = o < key ? o : key;
-        const int m = m0 + wr * 128 + i * 16 + (lane & 15);
-        if (lane < 16 && m < p.Q) atomicMin(p.keys + m, key);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// The same contraction as a two-group ("ping-pong") pipeline: 256 x 256 block tile, 8 waves of 128 x 64 in two groups of
-// four (one wave of each group per SIMD) that run HALF A PHASE apart, so one group's LDS reads and LDS-DMA issue sit
-// under the other group's MFMAs -- in the 4-wave kernel above one wave per SIMD has to issue its 16 DMA pieces per K-step
-// (60-185 issue cycles each) in the same instruction stream as its 128 MFMAs.
-//
-// A K-tile (64 deep) is 4 phases of 16 MFMAs (one 64 x 32 quadrant of the wave's tile):
-//   phase 0: read B lo (4 x ds_read_b128) + A lo (8), multiply A lo x B lo      phase 2: read A hi (8), A hi x B hi
-//   phase 1: read B hi (4),                     multiply A lo x B hi            phase 3: no reads,      A hi x B lo (kept)
-// and each phase = { fragment reads, 2 DMA pieces, counted s_waitcnt vmcnt(8) } barrier { MFMAs } barrier.
-// Staging is in four 16-KiB UNITS per K-tile, cut by WHEN they are last read, not by position:
-//   U0 = A rows {0..63, 128..191} (the "lo" halves of both groups' query rows; read in phase 0)     U3 = the A "hi" halves (phase 2)
-//   U1 = B rows = 0..31 mod 64 (every wave's "lo" bank columns; phase 0)                            U2 = B rows = 32..63 mod 64 (phase 1)
-// One unit is issued per phase, 16 pieces over the 8 waves:  phase 0: U2 of tile T+1,  1: U3 of T+1,  2: U0 of T+2,  3: U1 of T+2
-// (two LDS buffers, tile T in buffer T & 1).  With that order
-//   * every unit is overwritten >= 2 phases after the phase that last read its predecessor in the same buffer (the later
-//     group finishes those reads one barrier after the earlier one: two phases is the safe distance),
-//   * vmcnt(8) after a phase's issue leaves the four newest units in flight and retires the unit issued four phases
-//     earlier -- which is read one phase LATER at the earliest (U0: +2, U1/U2/U3: +1), after one more barrier that both
-//     groups' waits precede.  The counter is never drained inside the stream; phases with nothing left to issue wait vmcnt(0).
-// Bank norms for the epilogue travel through LDS: wave 0 fetches the tile's 256 norms in the first K-tile of a bank tile and
-// parks them three phases later -- both in inline asm with a COUNTED wait, because a compiler-visible load (or LDS read)
-// next to the DMA stream gets an s_waitcnt vmcnt(0), i.e. a drain of the whole prefetch queue, per bank tile.  The kernel
-// therefore takes WHOLE bank tiles only (Nb % 256 == 0): the launcher hands the last Nb % 256 rows to l2_min_kernel<S128>,
-// whose keys merge through the same atomicMin.  Same keys as the other kernels.  Needs D >= 192 (three K-tiles).
-// ------------------------------------------------------------------------------------------------
-struct SPingPong {
-    static constexpr int BM = 256, BN = 256, THREADS = 512;
-    static constexpr int BUF = 32768;                       // one buffer of one operand: 256 rows x 128 B
-    static constexpr int LDS_BYTES = 4 * BUF + 2 * 256 * 4;  // [A buf0][A buf1][B buf0][B buf1][bank norms x 2]
-};
-
-
-template <bool F16>
-__global__ __launch_bounds__(512, 1) void l2_min_pp_kernel(GlobalTile A, GlobalTile W, L2Params p)
-{
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    using S = SPingPong;
-    using frag = typename std::conditional<F16, f16x8, bf16x8>::type;
-    const int wg = xcd_remap(blockIdx.x, gridDim.x);
-    const int gsz = p.qgroup * p.splits;
-    const int within = wg % gsz;
-    const int split = within / p.qgroup, qt = (wg / gsz) * p.qgroup + within % p.qgroup;
-    if (qt >= p.nq_tiles) return;
-    const int per = (p.n_bank_tiles + p.splits - 1) / p.splits;
-    const int nt0 = split * per;
-    const int ntc = min(per, p.n_bank_tiles - nt0);
-    if (ntc <= 0) return;
-    const int m0 = qt * S::BM;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
-    const int KT = p.D / BK, T_total = ntc * KT;
-    // LDS byte address of the [2][256] bank-norm area (the inline-asm accesses take raw LDS addresses)
-    const unsigned bn_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(lds + 4 * S::BUF);
-
-    float best[8], qn[8];
-    int besti[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        best[i] = __builtin_inff();
-        besti[i] = 0;
-        const int m = m0 + wr * 128 + i * 16 + (lane & 15);
-        qn[i] = m < p.Q ? p.q_sqnorm[m] : 0.0f;
-    }
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // ---- staging: piece e (0, 1) of unit u for this wave; rows of a piece are 8 consecutive tile rows
-    const int pc0 = wave * 2;
-    const int src_chunk = ((lane & 7) ^ (lane >> 3)) * 8;  // element offset of the 16-byte chunk this lane fetches (rule 21)
-    auto piece_row = [&](int u, int e) {                   // first tile row of the piece
-        const int pc = pc0 + e;
-        if (u == 0) return (pc >> 3) * 128 + (pc & 7) * 8;
-        if (u == 3) return (pc >> 3) * 128 + 64 + (pc & 7) * 8;
-        if (u == 1) return (pc >> 2) * 64 + (pc & 3) * 8;
-        return (pc >> 2) * 64 + 32 + (pc & 3) * 8;
-    };
-    auto stage_unit = [&](int u, int nt, int kt, int buf) {
-        const bool isA = u == 0 || u == 3;
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int r0 = piece_row(u, e);
-            const int r = r0 + (lane >> 3);
-            const bf16_t* src = isA ? A.base + (size_t)min(m0 + r, A.rows - 1) * A.ld + kt * BK + src_chunk
-                                    : W.base + (size_t)min(nt * S::BN + r, W.rows - 1) * W.ld + kt * BK + src_chunk;
-            char* dst = lds + (isA ? 0 : 2 * S::BUF) + buf * S::BUF + r0 * 128;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-        }
-    };
-    // cursors of the four unit streams (tile index, bank tile, k tile): advanced after every issue
-    int uT[4], uN[4], uK[4];
-    auto advance = [&](int u) {
-        ++uT[u];
-        if (++uK[u] == KT) { uK[u] = 0; ++uN[u]; }
-    };
-#pragma unroll
-    for (int u = 0; u < 4; ++u) { uT[u] = 0; uN[u] = nt0; uK[u] = 0; }
-    // prologue: tile 0 complete, U0 and U1 of tile 1
-#pragma unroll
-    for (int u = 0; u < 4; ++u) { stage_unit(u, uN[u], uK[u], 0); advance(u); }
-    if (T_total > 1) {
-        stage_unit(0, uN[0], uK[0], 1); advance(0);
-        stage_unit(1, uN[1], uK[1], 1); advance(1);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    pp_barrier();
-    if (wr == 1) pp_barrier();  // the second group runs one barrier (half a phase) behind the first
-
-    // ---- fragment addresses: row*128 + ((chunk ^ (row & 7)) << 4), chunk = kk*4 + (lane >> 4); kk = 1 flips bit 6
-    const int arow = wr * 128 + (lane & 15), brow = wc * 64 + (lane & 15);
-    int a_base = arow * 128 + ((((lane >> 4)) ^ (arow & 7)) << 4);
-    int b_base = 2 * S::BUF + brow * 128 + ((((lane >> 4)) ^ (brow & 7)) << 4);
-    auto lda = [&](int i, int kk) { return *reinterpret_cast<const frag*>(lds + ((a_base + i * 2048) ^ (kk << 6))); };
-    auto ldb = [&](int j, int kk) { return *reinterpret_cast<const frag*>(lds + ((b_base + j * 2048) ^ (kk << 6))); };
-
-    frag af[4][2], wlo[2][2], whi[2][2];
-    int nt_c = nt0, kt_c = 0;
-    for (int T = 0; T < T_total; ++T) {
-        const int buf = T & 1;
-        f32x4 bnv;  // wave 0: this bank tile's squared norms on their way to LDS
-        // ================= phase 0: B lo + A lo
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) wlo[j][kk] = ldb(j, kk);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) af[i][kk] = lda(i, kk);
-        const bool bn_fetch = wave == 0 && kt_c == 0;  // wave-uniform
-        if (bn_fetch) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bnv) : "v"(p.b_sqnorm + (size_t)nt_c * S::BN + lane * 4) : "memory");
-        if (uT[2] < T_total) { stage_unit(2, uN[2], uK[2], buf ^ 1); advance(2); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        pp_barrier();
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(wlo[j][kk], af[i][kk], acc[i][j]);
-        __builtin_amdgcn_s_setprio(0);
-        pp_barrier();
-        // ================= phase 1: B hi
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) whi[j][kk] = ldb(2 + j, kk);
-        if (uT[3] < T_total) { stage_unit(3, uN[3], uK[3], buf ^ 1); advance(3); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        pp_barrier();
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][2 + j] = mfma16(whi[j][kk], af[i][kk], acc[i][2 + j]);
-        __builtin_amdgcn_s_setprio(0);
-        pp_barrier();
-        // ================= phase 2: A hi
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) af[i][kk] = lda(4 + i, kk);
-        if (uT[0] < T_total) { stage_unit(0, uN[0], uK[0], buf); advance(0); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        pp_barrier();
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[4 + i][2 + j] = mfma16(whi[j][kk], af[i][kk], acc[4 + i][2 + j]);
-        __builtin_amdgcn_s_setprio(0);
-        pp_barrier();
-        // ================= phase 3: no reads (B lo is still in registers)
-        if (bn_fetch)  // 6 DMA pieces were issued after the fetch (phases 0-2): a counted wait, then park the norms in LDS
-            asm volatile("s_waitcnt vmcnt(6)\n\tds_write_b128 %0, %1" ::"v"(bn_lds + (unsigned)((nt_c & 1) * 1024 + lane * 16)), "v"(bnv) : "memory");
-        if (uT[1] < T_total) { stage_unit(1, uN[1], uK[1], buf); advance(1); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        pp_barrier();
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[4 + i][j] = mfma16(wlo[j][kk], af[i][kk], acc[4 + i][j]);
-        __builtin_amdgcn_s_setprio(0);
-        if (kt_c == KT - 1) {  // bank tile finished: d2 = |q|^2 + |b|^2 - 2 q.b, running (min, first index) per lane
-            const int nbase = nt_c * S::BN + wc * 64 + (lane >> 4) * 4;
-            f32x4 b4[4];
-            {
-                const unsigned ra = bn_lds + (unsigned)((nt_c & 1) * 1024 + (wc * 64 + (lane >> 4) * 4) * 4);
-                asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:64\n\tds_read_b128 %2, %4 offset:128\n\t"
-                             "ds_read_b128 %3, %4 offset:192\n\ts_waitcnt lgkmcnt(0)"
-                             : "=&v"(b4[0]), "=&v"(b4[1]), "=&v"(b4[2]), "=&v"(b4[3]) : "v"(ra) : "memory");
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float d2 = (qn[i] + b4[j][r]) - 2.0f * acc[i][j][r];
-                        if (d2 < best[i]) { best[i] = d2; besti[i] = nbase + j * 16 + r; }
-                    }
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        pp_barrier();
-        if (++kt_c == KT) { kt_c = 0; ++nt_c; }
-        a_base ^= S::BUF;
-        b_base ^= S::BUF;
-    }
-    if (wr == 0) pp_barrier();  // both groups execute the same number of barriers
-
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        unsigned long long key = pack_key(fmaxf(best[i], 0.0f), p.row_offset + (unsigned)besti[i]);
-        if (!(best[i] < __builtin_inff())) key = ~0ull;
-        unsigned long long o = shfl_xor_u64(key, 16);
-        key = o < key ? o : key;
-        o = shfl_xor_u64(key, 32);
-        key = o < key ? o : key;
-        const int m = m0 + wr * 128 + i * 16 + (lane & 15);
-        if (lane < 16 && m < p.Q) atomicMin(p.keys + m, key);
-    }
-}
+#include "ab/l2min_wide_pp.inc"
 #endif  // CMDIAD_AB_VARIANTS
 
 // ------------------------------------------------------------------------------------------------
@@ -734,197 +432,7 @@ __global__ __launch_bounds__(512, 1) void l2_min_pp3_kernel(GlobalTile A, Global
 }
 
 #ifdef CMDIAD_AB_VARIANTS  // measured formulation, test-only build: 0-3 % faster than the production kernel (profiles/r2_notes.md)
-// ------------------------------------------------------------------------------------------------
-// The two-group pipeline with 32 MFMAs per phase (K-tiles of 32 columns).  In the kernel above the MFMA segments of the two
-// groups never overlap by construction -- at any time ONE wave per SIMD issues MFMAs -- so a SIMD's matrix pipe is busy 256
-// cycles of every half-phase slot and idle for whatever else the slot contains: the barrier, the counted wait, the drain and
-// refill of the pipe (measured: 435 cycles per slot = 0.59 of the MFMA rate at the clock the chip holds).  That overhead is per
-// slot, not per MFMA: here a phase is a whole K-tile of 32 columns -- all 8 x 4 accumulator blocks of the wave, one K-slice
-// of one `v_mfma_f32_16x16x32` -- i.e. 32 MFMAs (512 cycles) per slot, half the barriers per FLOP, and fewer fragment
-// registers (8 + 4 fragments instead of 8 + 4 + 4).  A K-tile of 32 columns is 16 KiB per operand: five bank stages (three to four
-// K-tiles of lead for the stream that misses L2) + four query stages (two to three of lead) = 144 KiB.  Rows are 64 bytes in LDS;
-// the 16-byte chunk c of row r sits at c ^ f((r >> 2) & 3), f = (0, 3, 2, 1): conflict-free for the four 16-lane groups of
-// ds_read_b128 (MI355X_MICROARCH.md, LDS) and applied on the source address of the LDS-DMA pieces (16 rows x 64 B each).
-// Waves 0-3 issue the bank stream, waves 4-7 the query stream, four pieces per K-tile each, in the scalar-base form (uniform
-// 64-bit base in SGPRs, one 32-bit lane offset per stream: no per-lane pointer arithmetic in the loop).
-// Same MFMA sequence per accumulator as every other formulation (K ascending in steps of 32): identical keys.
-// ------------------------------------------------------------------------------------------------
-struct SPingPong4 {
-    static constexpr int BM = 256, BN = 256, THREADS = 512, KT = 32;
-    static constexpr int STG = 16384, NSB = 5, NSQ = 4;
-    static constexpr int A_OFF = NSB * STG, BN_OFF = A_OFF + NSQ * STG;
-    static constexpr int LDS_BYTES = BN_OFF + 2 * 256 * 4;
-};
-
-template <bool F16>
-__global__ __launch_bounds__(512, 1) void l2_min_pp4_kernel(GlobalTile A, GlobalTile W, L2Params p)
-{
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    using S = SPingPong4;
-    using frag = typename std::conditional<F16, f16x8, bf16x8>::type;
-    const int wg = xcd_remap(blockIdx.x, gridDim.x);
-    const int gsz = p.qgroup * p.splits;
-    const int within = wg % gsz;
-    const int split = within / p.qgroup, qt = (wg / gsz) * p.qgroup + within % p.qgroup;
-    if (qt >= p.nq_tiles) return;
-    const int per = (p.n_bank_tiles + p.splits - 1) / p.splits;
-    const int nt0 = split * per;
-    const int ntc = min(per, p.n_bank_tiles - nt0);
-    if (ntc <= 0) return;
-    const int m0 = qt * S::BM;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
-    const int KT = p.D / S::KT, T_total = ntc * KT;
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
-    const unsigned bn_lds = lds0 + S::BN_OFF;
-
-    float best[8], qn[8];
-    int besti[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        best[i] = __builtin_inff();
-        besti[i] = 0;
-        const int m = m0 + wr * 128 + i * 16 + (lane & 15);
-        qn[i] = m < p.Q ? p.q_sqnorm[m] : 0.0f;
-    }
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // Everything below is instantiated twice, once per stream: a wave only ever executes its own issue path.
-    auto body = [&](auto BANK) {
-    constexpr bool bank_wave = decltype(BANK)::value;
-    constexpr int NS = bank_wave ? S::NSB : S::NSQ, LEAD = NS - 1;
-    // ---- this wave's share of every K-tile of its stream: rows 64 sw .. 64 sw + 63 as four 16-row pieces.  Lane l of a piece
-    // lands on row l >> 2, physical chunk l & 3, and therefore fetches logical chunk (l & 3) ^ f((l >> 4) & 3).
-    const int sw = wave & 3;
-    const unsigned fq = (0x1230u >> (((lane >> 4) & 3) * 4)) & 3u;   // f = (0, 3, 2, 1)
-    const unsigned src_chunk = (((unsigned)lane & 3u) ^ fq) * 16u;
-    const size_t ld2 = (size_t)(bank_wave ? W.ld : A.ld) * 2;       // row pitch in bytes
-    const bool a_full = m0 + S::BM <= A.rows;
-    // per-lane byte offset inside a tile: piece e adds 16 rows (a scalar bump of the base); query rows past Q clamp (ragged last tile)
-    const unsigned voff = (unsigned)((size_t)(sw * 64 + (lane >> 2)) * ld2) + src_chunk;
-    const char* sbase = bank_wave ? reinterpret_cast<const char*>(W.base) + (size_t)nt0 * S::BN * ld2
-                                  : reinterpret_cast<const char*>(A.base) + (size_t)m0 * ld2;   // first row of the current tile, K-tile 0
-    int hT = 0, hK = 0, slot = 0;   // stream cursor: K-tile index overall / within the row tile, stage
-    auto dma = [&](const char* ubase, unsigned vo, unsigned lds_addr) {   // (SALU copy of the base, one wait state after the M0 write:
-        unsigned long long sb;                                           //  inline asm is outside the compiler's hazard tracking)
-        asm volatile("s_mov_b64 %0, %2\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0"
-                     : "=&s"(sb) : "v"(vo), "s"(ubase), "s"(lds_addr) : "memory");
-    };
-    auto issue = [&]() {   // -> true when a K-tile was issued
-        if (hT >= T_total) return false;
-        const unsigned dst = lds0 + (bank_wave ? 0 : S::A_OFF) + slot * S::STG + sw * 64 * 64;
-        const char* ub = sbase + hK * (S::KT * 2);
-        if (bank_wave || a_full) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) dma(ub + (size_t)e * 16 * ld2, voff, dst + e * 1024);
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int row = min(m0 + sw * 64 + e * 16 + (lane >> 2), A.rows - 1) - m0;
-                dma(ub, (unsigned)((size_t)row * ld2) + src_chunk, dst + e * 1024);
-            }
-        }
-        ++hT;
-        if (++hK == KT) { hK = 0; if (bank_wave) sbase += (size_t)S::BN * ld2; }
-        slot = slot + 1 == NS ? 0 : slot + 1;
-        return true;
-    };
-    // prologue: LEAD K-tiles of this stream
-#pragma unroll
-    for (int e = 0; e < LEAD; ++e) issue();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    pp_barrier();
-    if (wr == 1) pp_barrier();  // the second group runs one barrier (half a phase) behind the first
-
-    // ---- fragment addresses: row * 64 + ((g ^ f((row >> 2) & 3)) << 4), g = lane >> 4; the row blocks i / j add 1 KiB
-    const unsigned fr = (0x1230u >> ((((lane & 15) >> 2) & 3) * 4)) & 3u;
-    const int fsw = (int)(((unsigned)(lane >> 4) ^ fr) << 4);
-    const int a_off = S::A_OFF + (wr * 128 + (lane & 15)) * 64 + fsw, b_off = (wc * 64 + (lane & 15)) * 64 + fsw;
-    frag af[8], bf[4];
-    int nt_c = nt0, kt_c = 0, sa = 0, sb = 0;   // stages of the current K-tile in the query / bank rings
-    f32x4 bnv = {0.f, 0.f, 0.f, 0.f};           // wave 0: a bank tile's squared norms on their way to LDS (fetched in its K-tile 0, parked in 2)
-    for (int T = 0; T < T_total; ++T) {
-        // ================= first half: fragments of K-tile T, this stream's K-tile T + LEAD, counted wait
-        const char* ab = lds + a_off + sa * S::STG;
-        const char* bb = lds + b_off + sb * S::STG;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const frag*>(bb + j * 1024);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) af[i] = *reinterpret_cast<const frag*>(ab + i * 1024);
-        const bool bn_fetch = wave == 0 && kt_c == 0;  // wave-uniform
-        if (bn_fetch) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bnv) : "v"(p.b_sqnorm + (size_t)nt_c * S::BN + lane * 4) : "memory");
-        const bool issued = issue();
-        // K-tile T + 1 of this stream has landed: everything issued after it may stay in flight (LEAD - 1 K-tiles of 4 pieces; the
-        // norm load of wave 0 is older than the K-tile just issued and younger than the others: at most one more piece waited for).
-        // (Issuing the K-tiles in pairs (2 m, 2 m + 1) -- the two halves of the same 128-byte lines back to back -- was measured:
-        //  TCC requests 1.43e9 -> 1.14e9 per launch against 0.72e9 for whole-line pieces, 9.9 -> 10.8 ms: the shorter lead costs more.)
-        if (!issued) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (bank_wave) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        if (wave == 0 && kt_c == 2)   // the norms fetched two phases ago are older than the three K-tiles the wait above leaves in flight
-            asm volatile("ds_write_b128 %0, %1" ::"v"(bn_lds + (unsigned)((nt_c & 1) * 1024 + lane * 16)), "v"(bnv) : "memory");
-        // (the fragments are in registers before the barrier: the stage just read is refilled by the other group's next issue)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        pp_barrier();
-        // ================= second half: 32 MFMAs
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(bf[j], af[i], acc[i][j]);
-        __builtin_amdgcn_s_setprio(0);
-        if (kt_c == KT - 1) {  // bank tile finished: d2 = |q|^2 + |b|^2 - 2 q.b, running (min, first index) per lane
-            const int nbase = nt_c * S::BN + wc * 64 + (lane >> 4) * 4;
-            f32x4 b4[4];
-            {
-                const unsigned ra = bn_lds + (unsigned)((nt_c & 1) * 1024 + (wc * 64 + (lane >> 4) * 4) * 4);
-                asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:64\n\tds_read_b128 %2, %4 offset:128\n\t"
-                             "ds_read_b128 %3, %4 offset:192\n\ts_waitcnt lgkmcnt(0)"
-                             : "=&v"(b4[0]), "=&v"(b4[1]), "=&v"(b4[2]), "=&v"(b4[3]) : "v"(ra) : "memory");
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float d2 = (qn[i] + b4[j][r]) - 2.0f * acc[i][j][r];
-                        if (d2 < best[i]) { best[i] = d2; besti[i] = nbase + j * 16 + r; }
-                    }
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        pp_barrier();
-        if (++kt_c == KT) { kt_c = 0; ++nt_c; }
-        sa = sa + 1 == S::NSQ ? 0 : sa + 1;
-        sb = sb + 1 == S::NSB ? 0 : sb + 1;
-    }
-    if (wr == 0) pp_barrier();  // both groups execute the same number of barriers
-
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        unsigned long long key = pack_key(fmaxf(best[i], 0.0f), p.row_offset + (unsigned)besti[i]);
-        if (!(best[i] < __builtin_inff())) key = ~0ull;
-        unsigned long long o = shfl_xor_u64(key, 16);
-        key = o < key ? o : key;
-        o = shfl_xor_u64(key, 32);
-        key = o < key ? o : key;
-        const int m = m0 + wr * 128 + i * 16 + (lane & 15);
-        if (lane < 16 && m < p.Q) atomicMin(p.keys + m, key);
-    }
-    };
-    if (wave < 4) body(std::true_type{});
-    else body(std::false_type{});
-}
-
+#include "ab/l2min_pp4.inc"
 #endif  // CMDIAD_AB_VARIANTS
 
 // Exact fp32 distance to the winning row: one wave per query.

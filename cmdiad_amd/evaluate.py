@@ -54,14 +54,17 @@ def method_class(args):
 
 
 # ------------------------------------------------------------------------------------------------ assignment
-def class_cost(n_train, n_test, f_coreset=0.1, libraries=2, rows_per_image=3136, t_image=1.0e-3, t_row_round=1.18e-10,
-               t_svm_row=1.0e-7):
-    """Estimated seconds one GPU spends on a class: two passes over the train images (memory bank, late-fusion bank) and
-    one over the test images at ``t_image`` each; per library a greedy coreset of f*rows rounds each scanning all rows
-    (csrc/coreset.hip: 90 us per round at 765 184 rows, profiles/r2_notes.md -> 1.18e-10 s per row and round); the host fit
-    of the pixel-level one-class SVM over n_train * 224^2 rows, ~9 epochs (11.4 s at 12.2 M rows)."""
+def class_cost(n_train, n_test, f_coreset=0.1, libraries=2, rows_per_image=3136, t_image=2.0e-3, t_row_round=1.18e-10,
+               t_proj_row=7.0e-6, t_svm_row=1.0e-7):
+    """Estimated seconds one GPU (and its host thread) spends on a class: two passes over the train images (memory bank,
+    late-fusion bank) and one over the test images at ``t_image`` each; per library the sparse random projection on the host
+    (``t_proj_row`` per library row) and a greedy coreset of f*rows rounds each scanning all rows (csrc/coreset.hip: 90 us per
+    round at 765 184 rows, profiles/r2_notes.md -> 1.18e-10 s per row and round); the host fit of the pixel-level one-class SVM over
+    n_train * 224^2 rows, ~9 epochs (11.4 s at 12.2 M rows).  Calibrated on `bench.py --evaluate` (profiles/r3_notes.md:
+    61 / 90 train images -> 4.7 / 8.4 s bank + coreset, 3.4 / 5.8 s late fusion); only the ORDER of the costs matters to the
+    assignment."""
     rows = n_train * rows_per_image
-    coreset = libraries * (f_coreset * rows) * rows * t_row_round if f_coreset < 1 else 0.0
+    coreset = libraries * ((f_coreset * rows) * rows * t_row_round + rows * t_proj_row) if f_coreset < 1 else 0.0
     return (2 * n_train + n_test) * t_image + coreset + 9 * n_train * 50176 * t_svm_row
 
 
@@ -115,16 +118,22 @@ def run_class(args, data, weights=None, method=None, extractor=None):
                 break
         return n, t0
 
-    n_train, t0 = loop(data.train(), lambda it: method.add_sample_to_mem_bank(it[0], class_name=data.name), "bank")
+    # the loaders are drained first (the reference's DataLoader workers prefetch beside the model; a synthetic class generates its
+    # samples on this thread): "load" is reported on its own and the phase timings below are the method's
+    t0 = time.perf_counter()
+    train_items = list(data.train())
+    test_items = list(data.test())
+    sec["load"] = time.perf_counter() - t0
+    n_train, t0 = loop(train_items, lambda it: method.add_sample_to_mem_bank(it[0], class_name=data.name), "bank")
     method.run_coreset()
     torch.cuda.synchronize()
     sec["memory_bank_and_coreset"] = time.perf_counter() - t0
     if getattr(args, "memory_bank", "multiple") == "multiple":
-        _, t0 = loop(data.train(), lambda it: method.add_sample_to_late_fusion_mem_bank(it[0]), "late")
+        _, t0 = loop(train_items, lambda it: method.add_sample_to_late_fusion_mem_bank(it[0]), "late")
         method.run_late_fusion()
         sec["late_fusion"] = time.perf_counter() - t0
     with torch.no_grad():
-        n_test, t0 = loop(data.test(), lambda it: method.predict(*it), "predict")
+        n_test, t0 = loop(test_items, lambda it: method.predict(*it), "predict")
         # the drop-in defers predict() into micro-batches; reading a result attribute completes them (multiple_features._MethodBase)
         assert len(method.image_preds) == n_test
         torch.cuda.synchronize()

@@ -137,7 +137,8 @@ class BatchPredictor:
             xyz_raw = e.xyz_patch(ex, 56)                                       # a9  [B,3136,768] f32
             B, Q, D = xyz_raw.shape
             xyz_q = eng.normalize(xyz_raw, s["xyz_mean"], s["xyz_std"])         # a11 (every row: the exact re-score reads them)
-            if self.dedup and self.group is None:
+            if self.dedup and self.group is None and os.environ.get("CMDIAD_MTFI_ROWPLAN", "1") != "0":
+                # (CMDIAD_MTFI_ROWPLAN=0: the MLP on every row and one plan per search, round 2's form, for A/B runs.)
                 # Patches without a foreground pixel are ONE row of the raw xyz features (bit for bit), so their hallucinated
                 # features are one row too: the rows are de-duplicated ONCE, on the fp32 bit patterns (the plan kernels compare
                 # rows as opaque 16-bit words: an fp32 row is 2 D of them), the distillation MLP (a15) and both 16-bit query sets

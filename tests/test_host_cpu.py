@@ -310,20 +310,24 @@ def test_backbone_checkpoint_loading_is_strict(tmp_path, monkeypatch):
 
 
 def test_bench_traffic_is_tied_to_the_profiled_kernel_source(tmp_path, monkeypatch):
-    """roofline.traffic comes from the committed PMC pass only while the distance GEMM's sources hash to what was profiled
-    (profiles/r2_pmc_meta.json); any change to them makes it null instead of silently stale."""
-    import importlib.util, json, shutil
+    """roofline.traffic comes from the newest committed PMC pass only while the distance GEMM's sources hash to what was profiled
+    (profiles/rN_pmc_meta.json); any change to them makes it null instead of silently stale -- and the committed pass of this
+    round IS of the committed sources."""
+    import glob, importlib.util, json, re, shutil
     spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(REPO, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     t = bench.profiled_traffic()
-    assert isinstance(t["traffic"], int) and 1e9 < t["traffic"] < 1e11 and "commit" in t["traffic_note"]
+    assert isinstance(t["traffic"], int) and 1e9 < t["traffic"] < 1e11 and "commit" in t["traffic_note"], t
+    newest = max(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_meta.json")), key=lambda f: int(re.search(r"r(\d+)_pmc_meta", f).group(1)))
+    tag = re.search(r"(r\d+)_pmc_meta", newest).group(1)
+    assert f"profiles/{tag}_pmc.md" in t["traffic_note"]
     # a copy of the repo files with one byte appended to the kernel source
     root = tmp_path / "repo"
     (root / "profiles").mkdir(parents=True)
     (root / "cmdiad_amd" / "csrc").mkdir(parents=True)
-    meta = json.load(open(os.path.join(REPO, "profiles", "r2_pmc_meta.json")))
-    for f in meta["sources"] + ["profiles/r2_pmc.json", "profiles/r2_pmc_meta.json"]:
+    meta = json.load(open(newest))
+    for f in meta["sources"] + [f"profiles/{tag}_pmc.json", f"profiles/{tag}_pmc_meta.json"]:
         shutil.copy(os.path.join(REPO, f), root / f)
     with open(root / meta["sources"][0], "ab") as fh:
         fh.write(b"\n")
