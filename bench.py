@@ -441,56 +441,24 @@ def train_step_leg(dev, steps=50, warm=10):
         opt.step()
         return lx, lr_
 
-    def timed(n, it0):
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        first = last = None
-        for i in range(n):
-            pair = step(it0 + i)
-            first = first or pair
-            last = pair
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / n, float(first[0].item() + first[1].item()), float(last[0].item() + last[1].item())
-
-    # eager launches first (what hallucination_network_pretrain.py gets by default), then the same steps with a direction's forward +
-    # backward replayed as a HIP graph (cmdiad_amd.train._GraphedDirection, CMDIAD_TRAIN_GRAPH=1): the kernel trace shows ~8 ms of GPU
-    # work in a 12.8 ms eager step -- ~150 launches through Python bound it
     for i in range(warm):
         step(i)
-    dt_eager, _, _ = timed(max(10, steps // 3), warm)
-    os.environ["CMDIAD_TRAIN_GRAPH"] = "1"
-    try:
-        for i in range(3):            # the first call registers the shape, the second captures
-            step(warm + steps + i)
-        dt, l0, l1 = timed(steps, warm + steps + 3)
-    finally:
-        del os.environ["CMDIAD_TRAIN_GRAPH"]
-        train._GraphedDirection._cache.clear()
-        train._GraphedDirection._seen.clear()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        lx, lr_ = step(warm + i)
+        if i in (0, steps - 1):
+            losses.append((lx, lr_))
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    l0, l1 = [float(a.item() + b.item()) for a, b in losses]
     assert l1 == l1 and l1 < l0, (l0, l1)            # finite, and the optimiser is descending
     return dict(what="configs[2]: HallucinationCrossModality feature-to-feature distillation training step (forward + l2 loss + "
-                     "backward, both directions, + Adam) on [32, 3136, 1536] synthetic features resident in HBM; each direction's "
-                     "forward + backward replayed as a HIP graph (CMDIAD_TRAIN_GRAPH=1)",
+                     "backward, both directions, + Adam) on [32, 3136, 1536] synthetic features resident in HBM",
                 ms_per_step=round(dt * 1e3, 3), steps_per_s=round(1.0 / dt, 2), tflop_per_step=7.99,
                 achieved_TFLOPs=round(7.99 / dt, 1), frac_of_mfma_peak=round(7.99 / dt / PEAK_BF16_TFLOPS, 4),
-                eager_launches=dict(ms_per_step=round(dt_eager * 1e3, 3), achieved_TFLOPs=round(7.99 / dt_eager, 1)),
                 steps=steps, warmup=warm, loss_first_timed=round(l0, 2), loss_last_timed=round(l1, 2),
                 tokens_per_s=round(32 * 3136 / dt, 0))
-
-
-def train_step_subprocess(timeout_s=300):
-    """The train_step leg in a child process: it replays HIP graphs, and a process that has done so must not start new host threads
-    afterwards (cmdiad_amd/train.py) -- the legs that follow in this process (scikit-learn fits, torch's CPU pool) do.  The child
-    gets its own GPU context; a time-out turns into an error entry instead of a hung bench."""
-    try:
-        res = subprocess.run([sys.executable, os.path.abspath(__file__), "--train-step-only"], stdout=subprocess.PIPE, text=True,
-                             timeout=timeout_s, env=dict(os.environ, CMDIAD_ALLOW_RANDOM_INIT="1"))
-        lines = [ln for ln in res.stdout.splitlines() if ln.lstrip().startswith("{")]
-        if res.returncode == 0 and lines:
-            return json.loads(lines[-1])
-        return {"error": f"train_step child exited with {res.returncode}"}
-    except subprocess.TimeoutExpired:
-        return {"error": f"train_step child did not finish within {timeout_s} s"}
 
 
 def var_n_leg(st, dev, steps=8, warm=3):
@@ -611,18 +579,12 @@ def main():
     ap.add_argument("--class-scale", type=float, default=0.05, help="train images per class = MVTec 3D-AD count x this (1.0 = full size)")
     ap.add_argument("--class-test", type=int, default=20, help="test images per synthetic class (3 of every 10 anomalous)")
     ap.add_argument("--selftest-launch", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--train-step-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch(args.gpus, sys.argv[1:]))        # before ANY GPU call in this process
     if args.selftest_launch:
         sys.exit(selftest_launch())
-    if args.train_step_only:
-        import torch
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-        print(json.dumps(train_step_leg(torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))))), flush=True)
-        return
 
     import numpy as np
     import torch
@@ -753,7 +715,7 @@ def main():
             extras["sharded_search"] = sharded_search(dev, group, rank, world, [(c, class_rows(c)) for c in names])
         if group is None:
             extras["var_n"] = var_n_leg(st, dev)
-            extras["train_step"] = train_step_subprocess()
+            extras["train_step"] = train_step_leg(dev)
         # configs[4] as a config (bounded): the class loop with the classes dealt to the ranks, metrics gathered at the end
         extras["mtfi_classes"] = mtfi_classes(dev, group, rank, world, "all", args.class_scale, args.class_test)
 

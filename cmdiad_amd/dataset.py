@@ -95,11 +95,6 @@ class FeatureRing:
         return out
 
     def __iter__(self):
-        from . import train
-        if train._GraphedDirection._cache:
-            raise RuntimeError("FeatureRing: this process has replayed HIP graphs of the training step (CMDIAD_TRAIN_GRAPH=1); starting "
-                               "the ring's producer thread then blocks on this stack -- feed a graphed trainer from resident batches, "
-                               "or leave CMDIAD_TRAIN_GRAPH unset when training from the ring")
         plan = self.batches()
         ready = queue.Queue(maxsize=self.depth - 1)     # filled slots waiting for the consumer
         free = queue.Queue()

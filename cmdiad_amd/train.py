@@ -149,16 +149,13 @@ class _GraphedDirection:
     bound it.  The second call with the same shapes captures the ~45 launches of a direction (weights are re-cast to bf16 inside
     the graph, so every replay sees the optimiser's latest values; activations, losses and gradients live in the graph's pool);
     a call copies the batch into the graph's static inputs (0.3 GB at the configs[2] shape: 0.15 ms) and replays.  Same kernels,
-    same order: losses and gradients are the eager ones bit for bit (tests/test_gpu_train.py).
-    OPT-IN (CMDIAD_TRAIN_GRAPH=1; bench.py's train_step leg turns it on): once graphs have been replayed in a process, starting
-    the producer thread of dataset.FeatureRing blocks in Thread.start() on this stack (ROCm 7.2 / torch 2.10; seen with
-    tools/train_bench.py, cause not found) -- FeatureRing refuses to start in that state instead of hanging."""
+    same order: losses and gradients are the eager ones bit for bit (tests/test_gpu_train.py)."""
     _cache = {}
     _seen = set()
 
     @staticmethod
     def enabled():
-        return os.environ.get("CMDIAD_TRAIN_GRAPH", "0") == "1"
+        return os.environ.get("CMDIAD_TRAIN_GRAPH", "1") != "0"
 
     @classmethod
     def run(cls, x, target, params, dist_method, batch):
