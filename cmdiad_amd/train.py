@@ -143,64 +143,10 @@ def forward_backward(x, target, params, dist_method, batch, need_grad=True):
     return loss, (g_lnw, g_lnb) + tuple(g for blk in grads for g in blk)
 
 
-class _GraphedDirection:
-    """forward_backward of one direction for one (shape, parameter set, loss) as a replayed HIP graph.  The kernel trace of the
-    training step shows 7.5 ms of GPU work inside a 12.8 ms step (profiles/r3_notes.md): ~150 launches per step through Python
-    bound it.  The second call with the same shapes captures the ~45 launches of a direction (weights are re-cast to bf16 inside
-    the graph, so every replay sees the optimiser's latest values; activations, losses and gradients live in the graph's pool);
-    a call copies the batch into the graph's static inputs (0.3 GB at the configs[2] shape: 0.15 ms) and replays.  Same kernels,
-    same order: losses and gradients are the eager ones bit for bit (tests/test_gpu_train.py)."""
-    _cache = {}
-    _seen = set()
-
-    @staticmethod
-    def enabled():
-        return os.environ.get("CMDIAD_TRAIN_GRAPH", "1") != "0"
-
-    @classmethod
-    def run(cls, x, target, params, dist_method, batch):
-        key = (tuple(x.shape), tuple(target.shape), dist_method, int(batch), tuple(p.data_ptr() for p in params), x.device.index)
-        g = cls._cache.get(key)
-        if g is None:
-            if key not in cls._seen:          # first time this shape shows up: run eagerly (a one-off shape is never captured)
-                cls._seen.add(key)
-                return forward_backward(x, target, params, dist_method, batch, True) + (None,)
-            g = cls._cache[key] = cls(x, target, params, dist_method, batch)
-            if len(cls._cache) > 8:           # a trainer has two directions and at most a ragged last batch: bound the pools
-                cls._cache.pop(next(iter(cls._cache)))
-        if g.pending:                         # a second forward before the first one's backward (its gradients still sit in the
-            return forward_backward(x, target, params, dist_method, batch, True) + (None,)   # graph's buffers): run this one eagerly
-        g.x.copy_(x)
-        g.t.copy_(target)
-        g.graph.replay()
-        g.pending = True
-        return g.loss.clone(), g.grads, g
-
-    def __init__(self, x, target, params, dist_method, batch):
-        self.x, self.t = x.clone(), target.clone()
-        self.pending = False
-        self.params = params                     # keeps the parameter storages alive (their addresses are baked into the graph)
-        torch.cuda.synchronize()
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):            # warm-up outside capture, on the capture stream (allocator pools, lazy module loads)
-            forward_backward(self.x, self.t, params, dist_method, batch, True)
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.loss, self.grads = forward_backward(self.x, self.t, params, dist_method, batch, True)
-
-
 class _DirectionLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, target, dist_method, batch, need_grad, *params):
-        det = tuple(p.detach() for p in params)
-        ctx.graphed = None
-        if need_grad and _GraphedDirection.enabled():
-            loss, grads, ctx.graphed = _GraphedDirection.run(x, target, det, dist_method, batch)
-        else:
-            loss, grads = forward_backward(x, target, det, dist_method, batch, need_grad)
+        loss, grads = forward_backward(x, target, tuple(p.detach() for p in params), dist_method, batch, need_grad)
         ctx.grads, ctx.n_params = grads, len(params)
         return loss
 
@@ -209,11 +155,7 @@ class _DirectionLoss(torch.autograd.Function):
         grads = ctx.grads
         if grads is None:
             return (None,) * (5 + ctx.n_params)
-        # `gr * g` are fresh tensors: autograd may keep them as .grad while the graph's own buffers are overwritten by the next replay
-        out = (None, None, None, None, None) + tuple(gr * g for gr in grads)
-        if ctx.graphed is not None:
-            ctx.graphed.pending = False
-        return out
+        return (None, None, None, None, None) + tuple(gr * g for gr in grads)
 
 
 def direction_params(module, src):
