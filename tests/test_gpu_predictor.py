@@ -163,7 +163,8 @@ def test_predict_batch_b32_vs_oracle(weights, cpu_ex, gpu_engine, monkeypatch):
     # (narrow) spread between samples on this class
     assert d_img.max() <= 0.10 * spread and d_img.mean() <= 0.03 * spread, (d_img.max(), d_img.mean(), spread)
     assert (d_img / np.abs(ref_img)).max() <= 0.03, (d_img / np.abs(ref_img)).max()
-    assert d_pix.mean() <= 0.01 * np.ptp(ref_pix) and d_pix.max() <= 0.08 * np.ptp(ref_pix), (d_pix.mean(), d_pix.max(), np.ptp(ref_pix))
+    # measured on MI355X (round 3): mean 0.08 %, max 1.4 % of the map range
+    assert d_pix.mean() <= 0.003 * np.ptp(ref_pix) and d_pix.max() <= 0.03 * np.ptp(ref_pix), (d_pix.mean(), d_pix.max(), np.ptp(ref_pix))
     for b in range(B):
         assert np.corrcoef(pix[b].ravel(), ref_pix[b].ravel())[0, 1] > 0.995, b
     i_got, i_ref = _auroc_pair(labels, img, ref_img)
@@ -222,7 +223,8 @@ def test_mtfi_batch_vs_oracle(weights, cpu_ex, gpu_engine, monkeypatch):
           f"mean {d_pix.mean():.6f} of range {np.ptp(ref_pix):.4f}")
     # both columns inherit the bf16 xyz features (the hallucinated column through the distilled MLP as well)
     assert (np.abs(img - ref_img) / np.abs(ref_img)).max() <= 0.03 and np.abs(img - ref_img).mean() <= 0.08 * spread
-    assert d_pix.mean() <= 0.015 * np.ptp(ref_pix) and d_pix.max() <= 0.10 * np.ptp(ref_pix)
+    # measured (round 3): mean 0.26 %, max 3.6 % of the (narrow: 0.018) map range
+    assert d_pix.mean() <= 0.006 * np.ptp(ref_pix) and d_pix.max() <= 0.06 * np.ptp(ref_pix)
     i_got, i_ref = _auroc_pair(labels, img, ref_img)
     masks = np.stack([s[2].numpy().reshape(224, 224) for s in samples]).astype(int)
     p_got, p_ref = _auroc_pair(masks.ravel(), pix.ravel(), ref_pix.ravel())
@@ -282,7 +284,7 @@ def test_method_classes_vs_reference_golden(tag, golden, weights):
     s_lib = torch.cat(m.s_lib, 0).numpy()
     ref_s = G("s_lib")
     print(tag, "s_lib", s_lib.tolist(), "ref", ref_s.tolist())
-    np.testing.assert_allclose(s_lib, ref_s, rtol=0.06, atol=0.02 * np.abs(ref_s).max())
+    np.testing.assert_allclose(s_lib, ref_s, rtol=0.04, atol=0.02 * np.abs(ref_s).max())      # measured: <= 1.9 %
     m.run_late_fusion()
     assert m.detect_fuser.coef_.shape == G("detect_coef").shape
     # predictions under the REFERENCE's fitted models (an SGD fit on three rows flips with 1e-3 input changes)
@@ -295,8 +297,8 @@ def test_method_classes_vs_reference_golden(tag, golden, weights):
     maps = np.stack(m.predictions)[:, ::4, ::4]
     ref_maps = G("pred_maps_sub")
     print(tag, "image_preds", got, "ref", ref, "map max |d|", np.abs(maps - ref_maps).max(), "range", np.ptp(ref_maps))
-    np.testing.assert_allclose(got, ref, rtol=0.05, atol=0.02 * np.abs(ref).max())
-    assert np.abs(maps - ref_maps).mean() <= 0.015 * np.ptp(ref_maps) and np.abs(maps - ref_maps).max() <= 0.10 * np.ptp(ref_maps)
+    np.testing.assert_allclose(got, ref, rtol=0.035, atol=0.01 * np.abs(ref).max())            # measured: <= 2.4 % (xyz), 0.02 % (rgb)
+    assert np.abs(maps - ref_maps).mean() <= 0.015 * np.ptp(ref_maps) and np.abs(maps - ref_maps).max() <= 0.06 * np.ptp(ref_maps)   # max measured 3.7 %
     assert (got[1] > got[0]) == (ref[1] > ref[0])
 
 
