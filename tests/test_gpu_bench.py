@@ -48,3 +48,14 @@ def test_bench_distributed_path_on_one_gpu():
     assert c["gemm_tflops_rank0"] > 500 and c["ms_per_search"] > 0
     m = d["mtfi_classes"]
     assert m["world"] == 1 and len(m["per_class"]) == 10 and m["assignment"][0][0] == "peach" and 0.0 <= m["mean"]["image_rocauc"] <= 1.0
+
+
+def test_bench_row_sharded_pipeline_on_one_gpu():
+    """`--bank sharded` with CMDIAD_FORCE_DIST=1: the row-sharded search INSIDE the timed pipeline (engine.sharded_min_keys in
+    BatchPredictor.search: local de-duplication, counts exchange, all-gather of the live rows, per-shard GEMM, all_reduce(MIN),
+    expansion) through RCCL with a world of one rank; the searched-row count says the compaction happened before the exchange."""
+    d = _run({"CMDIAD_FORCE_DIST": "1"}, "--no-extras", "--bank", "sharded")
+    assert d["config"]["bank"].startswith("row-sharded") and d["value"] > 100
+    rows = d["config"]["xyz_query_rows"]
+    assert rows["dedup"] and 0.5 * rows["per_step"] < rows["searched_per_step"] < 0.7 * rows["per_step"]
+    assert 0.2 < d["roofline"]["frac"] < 1.0
