@@ -107,7 +107,7 @@ def run_class(args, data, weights=None, method=None, extractor=None):
     count = getattr(args, "max_sample", 500)
     sec = {}
 
-    def loop(it, call, what):
+    def loop(it, call):
         t0 = time.perf_counter()
         n = flag = 0
         for item in it:
@@ -124,16 +124,16 @@ def run_class(args, data, weights=None, method=None, extractor=None):
     train_items = list(data.train())
     test_items = list(data.test())
     sec["load"] = time.perf_counter() - t0
-    n_train, t0 = loop(train_items, lambda it: method.add_sample_to_mem_bank(it[0], class_name=data.name), "bank")
+    n_train, t0 = loop(train_items, lambda it: method.add_sample_to_mem_bank(it[0], class_name=data.name))
     method.run_coreset()
     torch.cuda.synchronize()
     sec["memory_bank_and_coreset"] = time.perf_counter() - t0
     if getattr(args, "memory_bank", "multiple") == "multiple":
-        _, t0 = loop(train_items, lambda it: method.add_sample_to_late_fusion_mem_bank(it[0]), "late")
+        _, t0 = loop(train_items, lambda it: method.add_sample_to_late_fusion_mem_bank(it[0]))
         method.run_late_fusion()
         sec["late_fusion"] = time.perf_counter() - t0
     with torch.no_grad():
-        n_test, t0 = loop(test_items, lambda it: method.predict(*it), "predict")
+        n_test, t0 = loop(test_items, lambda it: method.predict(*it))
         # the drop-in defers predict() into micro-batches; reading a result attribute completes them (multiple_features._MethodBase)
         assert len(method.image_preds) == n_test
         torch.cuda.synchronize()
