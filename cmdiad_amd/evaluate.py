@@ -178,23 +178,32 @@ def evaluate_classes(args, datasets, group=None, weights=None, costs=None, log=N
     name, _ = method_class(args)
     mine = {}
     extractor = None
+    error = None
     t0 = time.perf_counter()
-    for cls in assignment[rank]:
-        if runner is None:
-            mine[cls] = run_class(args, datasets[cls], weights=weights, extractor=extractor)
-            extractor = mine[cls].pop("_extractor")          # the frozen backbones stay on the rank; everything else is per class
-        else:
-            mine[cls] = runner(args, datasets[cls], weights=weights)
-        mine[cls]["rank"] = rank
-        if log is not None:
-            log(f"[rank {rank}] class {cls}: " + ", ".join(f"{m} {mine[cls][m]:.3f}" for m in METRICS) + f" {mine[cls]['seconds']}")
+    try:
+        for cls in assignment[rank]:
+            if runner is None:
+                mine[cls] = run_class(args, datasets[cls], weights=weights, extractor=extractor)
+                extractor = mine[cls].pop("_extractor")          # the frozen backbones stay on the rank; everything else is per class
+            else:
+                mine[cls] = runner(args, datasets[cls], weights=weights)
+            mine[cls]["rank"] = rank
+            if log is not None:
+                log(f"[rank {rank}] class {cls}: " + ", ".join(f"{m} {mine[cls][m]:.3f}" for m in METRICS) + f" {mine[cls]['seconds']}")
+    except Exception as exc:      # a rank that fails must still reach the gather: the others would wait for it until the collective times out
+        if group is None:
+            raise
+        error = f"{type(exc).__name__}: {exc}"
     mine_s = time.perf_counter() - t0
-    parts = [(rank, mine, mine_s)]
+    parts = [(rank, mine, mine_s, error)]
     if group is not None:
         parts = [None] * world
-        td.all_gather_object(parts, (rank, mine, mine_s), group=group)
+        td.all_gather_object(parts, (rank, mine, mine_s, error), group=group)
+    failed = [(r, e) for r, _, _, e in parts if e is not None]
+    if failed:
+        raise RuntimeError("class-sharded evaluation failed on " + "; ".join(f"rank {r}: {e}" for r, e in failed))
     merged, rank_seconds = {}, [0.0] * world
-    for r, part, s in parts:
+    for r, part, s, _ in parts:
         rank_seconds[r] = round(s, 3)
         for cls, res in part.items():
             if cls in merged:

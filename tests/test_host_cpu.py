@@ -588,3 +588,38 @@ def test_compact_then_gather_equals_gather_then_search_world2_gloo(tmp_path):
                               stderr=subprocess.STDOUT) for r in range(2)]
     outs = [p.communicate(timeout=240)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
+
+
+_GLOO_EVAL_FAIL_WORKER = r"""
+import sys
+sys.path.insert(0, {repo!r})
+import torch.distributed as td
+from cmdiad_amd import evaluate as ev
+td.init_process_group("gloo")
+rank = td.get_rank()
+data = ev.synthetic_mvtec3d(["bagel", "peach", "tire"], scale=0.05, n_test=20)
+def runner(args, d, weights=None):
+    if rank == 1:
+        raise ValueError("cloud has 7 valid points")
+    return dict(image_rocauc=1.0, pixel_rocauc=1.0, au_pro=1.0, au_pro_001=1.0, n_train=d.n_train, n_test=d.n_test, seconds={{}}, library_rows={{}})
+try:
+    ev.evaluate_classes(ev.mtfi_args(), data, group=td.group.WORLD, runner=runner)
+    print("NO ERROR")
+except RuntimeError as e:
+    print("RAISED", e)
+td.destroy_process_group()
+"""
+
+
+def test_class_sharded_evaluate_propagates_a_rank_failure_world2_gloo(tmp_path):
+    """A rank whose class loop raises still reaches the gather, and EVERY rank then raises naming the rank and the cause -- no
+    rank is left waiting in the collective until it times out."""
+    script = tmp_path / "w.py"
+    script.write_text(_GLOO_EVAL_FAIL_WORKER.format(repo=REPO))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29573", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=120)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    for o in outs:
+        assert "RAISED class-sharded evaluation failed on rank 1: ValueError: cloud has 7 valid points" in o, o
