@@ -23,7 +23,9 @@ class GemmArgs(Structure):
                 ("bias", c_void_p), ("group_bias", c_void_p), ("group_rows", c_int), ("act", c_int),
                 ("residual", c_void_p), ("ldr", c_int),
                 ("out_f32", c_void_p), ("ldo32", c_int), ("out_bf16", c_void_p), ("ldo16", c_int),
-                ("out_pre_bf16", c_void_p), ("dact_of", c_void_p), ("split_k", c_int), ("m_count", c_void_p)]
+                ("out_pre_bf16", c_void_p), ("dact_of", c_void_p), ("split_k", c_int), ("m_count", c_void_p),
+                ("row_scale", c_void_p), ("ln_xb", c_void_p), ("ld_xb", c_int), ("ln_part", c_void_p),
+                ("add2", c_void_p), ("ld_add2", c_int)]
 
 
 class ConvArgs(Structure):
@@ -35,7 +37,7 @@ class ConvArgs(Structure):
 
 class BlockWeights(Structure):
     _fields_ = [(n, c_void_p) for n in ("ln1_w", "ln1_b", "ln2_w", "ln2_b", "qkv_w", "qkv_b", "proj_w", "proj_b",
-                                        "fc1_w", "fc1_b", "fc2_w", "fc2_b")]
+                                        "fc1_w", "fc1_b", "fc2_w", "fc2_b", "qkv_wf", "qkv_bf", "fc1_wf", "fc1_bf")]
 
 
 P, I, F, SZ, U32, D = c_void_p, c_int, c_float, c_size_t, c_uint32, c_double
@@ -48,14 +50,15 @@ SIGNATURES = {
     "cmdiad_interp_gather": [P, P, P, P, I, I, I, I, P, P],
     "cmdiad_xyz_patch_fused": [P, P, P, P, I, I, I, I, I, I, F, F, P, P, P],
     "cmdiad_gemm_bf16": [POINTER(GemmArgs), P],
-    "cmdiad_gemm_qkv": [P, P, P, I, I, I, P, P, P, P],
+    "cmdiad_gemm_qkv": [P, P, P, P, I, I, I, P, P, P, P],
+    "cmdiad_ln_stats_finalize": [P, I, I, F, P, P, P],
     "cmdiad_gemm_tn_bf16": [P, I, P, I, I, I, I, I, P, I, P, P],
     "cmdiad_attention": [P, P, P, I, I, I, P, P],
     "cmdiad_encoder_tail": [P, P, P, P, P, I, I, P, P],
     "cmdiad_conv2d_nhwc_bf16": [POINTER(ConvArgs), P],
     "cmdiad_conv_stem": [P, P, P, I, I, I, I, I, I, P, P],
     "cmdiad_upsample_bicubic": [P, I, I, I, I, I, I, I, P, I, P, P],
-    "cmdiad_transformer_block_fwd": [P, P, POINTER(BlockWeights), I, I, I, I, I, F, P, P, P, P, SZ, P],
+    "cmdiad_transformer_block_fwd": [P, P, POINTER(BlockWeights), I, I, I, I, I, F, I, P, P, P, P, SZ, P],
     "cmdiad_layernorm": [P, P, P, P, F, I, I, P, P, I, P, P, P],
     "cmdiad_loss_head": [P, P, I, I, I, F, P, P, P, P],
     "cmdiad_reduce_slabs": [P, I, SZ, SZ, F, P, P],

@@ -34,7 +34,37 @@ struct StdParams {
     int panel;                    // N tiles walked by one block (see panel_tiles)
     int group_m;                  // M tiles per L2 group (Coord)
     const int* m_count;           // device-resident live row count (rows >= it are neither computed nor stored), or null
+    // LayerNorm folded into the products on either side of it (see "LayerNorm fold" below)
+    const float* row_scale;       // consumer: out = act(row_scale[m] * acc + bias) (1 / sigma of row m), or null
+    bf16_t* ln_xb; int ld_xb;     // producer (residual-row epilogue): bf16 copy of the new residual rows ...
+    float* ln_part;               // ... and [N/64][M] (sum, M2 about the chunk mean) of every 64-column chunk of them
+    const float* add2; int ld_add2;  // producer: a second fp32 addend (Point-MAE's positional embedding of the NEXT block), or null
 };
+
+// (sum, M2 about the chunk mean) of `chunks` 64-column chunks of row m -> 1 / sqrt(var + eps); merged in chunk order (Chan et al.)
+__device__ __forceinline__ float ln_merge_chunks(const float2* __restrict__ part, int M, int chunks, int m, float eps, float* mean_out)
+{
+    float sum = 0.0f;
+    for (int c = 0; c < chunks; ++c) sum += part[(size_t)c * M + m].x;
+    const float mean = sum / (float)(chunks * 64);
+    float m2 = 0.0f;
+    for (int c = 0; c < chunks; ++c) {
+        const float2 v = part[(size_t)c * M + m];
+        const float d = v.x * (1.0f / 64) - mean;
+        m2 += v.y + 64.0f * d * d;
+    }
+    if (mean_out) *mean_out = mean;
+    return rsqrtf(m2 / (float)(chunks * 64) + eps);
+}
+
+// sum over the 8 lanes of a half DPP row (lanes 8 h .. 8 h + 7), result in all 8
+__device__ __forceinline__ float half_row_sum(float v)
+{
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));
+    return v;
+}
 
 // rows the launch really has: the caller's M, or the device-side count of a compacted row set (block-uniform)
 __device__ __forceinline__ void live_m(StdParams& p, GlobalTile& A)
@@ -89,7 +119,17 @@ struct Coord {
 // (row tile, column tile) bodies carried 64 inlined erff/expf expansions -- ~40 KB of code that even the skipped
 // branches had to fetch through the instruction cache (measured: the plain 4.2M x 512 x 256 product spent as long
 // in that epilogue as in its MFMA loop).  ACT = CMDIAD_ACT_*; EXTRAS = the training-only terms (dact_of, out_pre).
-template <class S, int ACT, bool EXTRAS, bool RES_ROWS = false>
+// LayerNorm fold (models/models.py:177-180: x = x + attn(norm1(x)); x = x + mlp(norm2(x))).  A stand-alone LayerNorm reads the
+// fp32 residual rows the previous product has just written and writes their normalised bf16 copy: 6 bytes per element of pure
+// traffic, 25 launches per network, 24 us each.  With  LN(x) . W^T = rstd (x - mean) . (gamma o W)^T + beta . W^T  and weights
+// centred over k (W''[n,k] = gamma[k] W[n,k] - mean_k(gamma[k] W[n,k]), so that sum_k x[k] W''[n,k] = sum_k (x[k] - mean) gamma[k] W[n,k]
+// for ANY row mean), the consumer multiplies the RAW rows: out = rstd[m] * (xb . W''^T) + (b + W beta).  The producer's
+// residual-row epilogue (LN_OUT) therefore also stores the rows as bf16 (xb) and, per 64-column chunk, their sum and their
+// squared deviation from the chunk mean; cmdiad_ln_stats_finalize merges the chunks (Chan's formula: no E[x^2] - mean^2
+// cancellation, no atomics: bit-reproducible) into rstd[m], which the consumer's epilogue applies (row_scale).
+// Rounding: x is rounded to bf16 instead of LN(x): the operand's rounding noise is sqrt(1 + (mean / sigma)^2) times that of
+// the unfused form -- the same for the zero-mean-ish rows of a pre-LN residual stream.
+template <class S, int ACT, bool EXTRAS, bool RES_ROWS = false, bool LN_OUT = false>
 __global__ __launch_bounds__(S::THREADS, S::WAVES_PER_SIMD) void gemm_std_kernel(GlobalTile A, GlobalTile W, StdParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -111,33 +151,92 @@ __global__ __launch_bounds__(S::THREADS, S::WAVES_PER_SIMD) void gemm_std_kernel
     // RES_ROWS is its own instantiation, chosen on the host (res_rows_epilogue()): with both epilogues in one kernel the
     // compiler ran out of registers and spilled the general path's row pointers (tools/isa_lint.py).
     static_assert(!RES_ROWS || (!EXTRAS && ACT == CMDIAD_ACT_NONE), "residual-row epilogue: no activation, no training terms");
+    static_assert(!LN_OUT || RES_ROWS, "the LayerNorm statistics come from the residual-row epilogue");
     RowStore32 rs;
     rs.init(lds + S::LDS_BYTES + (threadIdx.x >> 6) * kRowStoreScratch, c.lane);
 
     run<S, true>(A, W, c.m0, c.nt, c.count, kt_count, lds, [&](auto& acc, int ntile, char*) {
         if constexpr (RES_ROWS) {
             const int n0 = ntile * S::BN + c.wc * 64;
+            if (n0 >= p.N) return;   // N = 64 (2 t + 1): the last tile's second wave column has nothing to store (wave-uniform)
             f32x4 bj[4];
+            if constexpr (!LN_OUT) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bj[j] = *reinterpret_cast<const f32x4*>(p.bias + n0 + j * 16 + (c.lane >> 4) * 4);
+                for (int j = 0; j < 4; ++j) bj[j] = *reinterpret_cast<const f32x4*>(p.bias + n0 + j * 16 + (c.lane >> 4) * 4);
+            }
             // full tiles run without a per-row test (a branch per row = a basic block per store group = s_waitcnt vmcnt(0)
             // in front of each: stores count in vmcnt on gfx9)
             auto emit = [&](auto FULL) {
                 constexpr bool full = decltype(FULL)::value;
+                if constexpr (LN_OUT) {
+                    // loaded INSIDE each of the two paths: fetched ahead of the full / ragged branch, the compiler's counter
+                    // model sees them pending on the way back to the loop header and puts s_waitcnt vmcnt(0) between the
+                    // LDS-DMA issue and the fragment reads of EVERY K-step (tools/isa_lint.py)
+                    // (the two empty asm statements differ, so the identical loads of the two paths are not merged and hoisted back)
+                    const float* bp = p.bias + n0 + (c.lane >> 4) * 4;
+                    if constexpr (full) asm volatile("; bias of a full tile" : "+v"(bp));
+                    else asm volatile("; bias of the ragged tile" : "+v"(bp));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) bj[j] = *reinterpret_cast<const f32x4*>(bp + j * 16);
+                }
 #pragma unroll
                 for (int i = 0; i < S::MI; ++i) {
-                    const int m0r = c.m0 + c.wr * (S::MI * 16) + i * 16 + rs.R;
+                    int m0r = c.m0 + c.wr * (S::MI * 16) + i * 16 + rs.R;
+                    // (LN_OUT has twice the row pointers: computed ahead of the K loop, as the compiler would, they spill)
+                    if constexpr (LN_OUT) asm volatile("" : "+v"(m0r));
                     const int ma = full ? m0r : min(m0r, p.M - 1), mb = full ? m0r + 8 : min(m0r + 8, p.M - 1);
+                    f32x4 o0[2], o1[2];   // the new residual values of rows R / R + 8: columns ch * 32 + 4 u .. + 3 of the wave's 64
 #pragma unroll
                     for (int ch = 0; ch < 2; ++ch) {
                         const int col = n0 + ch * 32 + rs.u * 4;
                         const f32x4 r0 = *reinterpret_cast<const f32x4*>(p.residual + (size_t)ma * p.ldr + col);
                         const f32x4 r1 = *reinterpret_cast<const f32x4*>(p.residual + (size_t)mb * p.ldr + col);
+                        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+                        if (LN_OUT && p.add2) {
+                            a0 = *reinterpret_cast<const f32x4*>(p.add2 + (size_t)ma * p.ld_add2 + col);
+                            a1 = *reinterpret_cast<const f32x4*>(p.add2 + (size_t)mb * p.ld_add2 + col);
+                        }
                         rs.park(acc[i][2 * ch] + bj[2 * ch], acc[i][2 * ch + 1] + bj[2 * ch + 1]);
                         f32x4 t0, t1;
                         rs.fetch(t0, t1);
-                        if (full || m0r < p.M) *reinterpret_cast<f32x4*>(out32 + (size_t)m0r * p.ldo32 + col) = t0 + r0;
-                        if (full || m0r + 8 < p.M) *reinterpret_cast<f32x4*>(out32 + (size_t)(m0r + 8) * p.ldo32 + col) = t1 + r1;
+                        o0[ch] = t0 + r0;
+                        o1[ch] = t1 + r1;
+                        if (LN_OUT && p.add2) { o0[ch] += a0; o1[ch] += a1; }   // (x + f(x)) + pos: the order of the unfused LayerNorm
+                        if (full || m0r < p.M) *reinterpret_cast<f32x4*>(out32 + (size_t)m0r * p.ldo32 + col) = o0[ch];
+                        if (full || m0r + 8 < p.M) *reinterpret_cast<f32x4*>(out32 + (size_t)(m0r + 8) * p.ldo32 + col) = o1[ch];
+                        if constexpr (LN_OUT) {
+                            const bf16x4 h0 = {f2bf(o0[ch][0]), f2bf(o0[ch][1]), f2bf(o0[ch][2]), f2bf(o0[ch][3])};
+                            const bf16x4 h1 = {f2bf(o1[ch][0]), f2bf(o1[ch][1]), f2bf(o1[ch][2]), f2bf(o1[ch][3])};
+                            if (full || m0r < p.M) *reinterpret_cast<bf16x4*>(p.ln_xb + (size_t)m0r * p.ld_xb + col) = h0;
+                            if (full || m0r + 8 < p.M) *reinterpret_cast<bf16x4*>(p.ln_xb + (size_t)(m0r + 8) * p.ld_xb + col) = h1;
+                        }
+                    }
+                    if constexpr (LN_OUT) {   // the eight lanes of a half DPP row hold one row's 64 columns
+                        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+                        for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) { s0 += o0[ch][q]; s1 += o1[ch][q]; }
+                        s0 = half_row_sum(s0);
+                        s1 = half_row_sum(s1);
+                        const float c0 = s0 * (1.0f / 64), c1 = s1 * (1.0f / 64);
+                        float q0 = 0.f, q1 = 0.f;
+#pragma unroll
+                        for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const float d0 = o0[ch][q] - c0, d1 = o1[ch][q] - c1;
+                                q0 = fmaf(d0, d0, q0);
+                                q1 = fmaf(d1, d1, q1);
+                            }
+                        q0 = half_row_sum(q0);
+                        q1 = half_row_sum(q1);
+                        if (rs.u == 0) {   // (one lane of the eight)
+                            float2* part = reinterpret_cast<float2*>(p.ln_part) + (size_t)(n0 >> 6) * p.M;
+                            if (full || m0r < p.M) part[m0r] = make_float2(s0, q0);
+                            if (full || m0r + 8 < p.M) part[m0r + 8] = make_float2(s1, q1);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);   // keep the next row block's loads behind this one's: 64 more live VGPRs spill
                     }
                 }
             };
@@ -155,6 +254,7 @@ __global__ __launch_bounds__(S::THREADS, S::WAVES_PER_SIMD) void gemm_std_kernel
             const float* res = p.residual ? p.residual + (size_t)m * p.ldr : nullptr;
             float* o32 = out32 ? out32 + (size_t)m * p.ldo32 : nullptr;
             bf16_t* o16 = p.out_bf16 ? p.out_bf16 + (size_t)m * p.ldo16 : nullptr;
+            const float rsc = p.row_scale ? p.row_scale[m] : 1.0f;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int n = c.n(ntile, j);
@@ -167,7 +267,10 @@ __global__ __launch_bounds__(S::THREADS, S::WAVES_PER_SIMD) void gemm_std_kernel
                         for (int r = 0; r < 4; ++r) v[r] *= gelu_grad_f(bf2f(z[r]));
                     }
                 }
-                if (p.bias) { const float4 b = *reinterpret_cast<const float4*>(p.bias + n); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+                if (p.row_scale) {   // one fused multiply-add per element, as the persistent kernel's epilogue: identical bits
+                    const f32x4 b = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    v = __builtin_elementwise_fma(v, f32x4{rsc, rsc, rsc, rsc}, b);
+                } else if (p.bias) { const float4 b = *reinterpret_cast<const float4*>(p.bias + n); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
                 if (gb) { const float4 b = *reinterpret_cast<const float4*>(gb + n); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
                 if constexpr (EXTRAS) {
                     if (p.out_pre_bf16) {
@@ -214,7 +317,9 @@ constexpr int kPp3Scratch = kRowStoreScratch;   // per wave
 #define CMDIAD_PP3_ABL 0   // timing-only ablations of the epilogue: tools/pp3_grid.py builds them with -DCMDIAD_PP3_ABL=n
 #endif
 
-template <int ACT>
+// RSCALE: out = act(row_scale[m] * acc + bias), the consumer side of the LayerNorm fold; row_scale must be readable up to the
+// row count rounded up to 256 (the ragged last tile reads, and never uses, the rows past M).
+template <int ACT, bool RSCALE = false>
 __global__ __launch_bounds__(512, 1) void gemm_std_pp3_kernel(GlobalTile A, GlobalTile W, StdParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -231,10 +336,17 @@ __global__ __launch_bounds__(512, 1) void gemm_std_pp3_kernel(GlobalTile A, Glob
     // vector-memory operations of a FULL-tile epilogue per wave (the four bias loads come earlier and are not counted)
     constexpr int kEpiOps = 16;
     f32x4 bias[4];
+    float rsc[8];   // RSCALE: 1 / sigma of the lane's row in each of its eight 16-row blocks
     run_pp3_jobs<false, kEpiOps>(A, W, j0, j1, NT, p.K / BK, lds, [&](int mt, int ntile) {
         const float* bp = p.bias + ntile * SPP3::BN + wc * 64 + g * 4;
 #pragma unroll
         for (int j = 0; j < 4; ++j) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bias[j]) : "v"(bp + j * 16) : "memory");
+        if constexpr (RSCALE) {   // one VGPR offset + immediates: rows mt * 256 + wr * 128 + 16 i + (lane & 15)
+            const unsigned off = (unsigned)(mt * SPP3::BM + wr * 128 + (lane & 15)) * 4u;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                asm volatile("global_load_dword %0, %1, %2 offset:%3" : "=v"(rsc[i]) : "v"(off), "s"(p.row_scale), "n"(i * 64) : "memory");
+        }
     }, [&](auto& acc, int mt, int ntile) -> int {
         const int nw = ntile * SPP3::BN + wc * 64;                  // first column of this wave's 64
         const int mw = mt * SPP3::BM + wr * 128;                    // first row of this wave's 128
@@ -257,7 +369,9 @@ __global__ __launch_bounds__(512, 1) void gemm_std_pp3_kernel(GlobalTile A, Glob
             auto compute = [&](int i, bf16x4 (&h)[4]) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    f32x4 v = acc[i][j] + bias[j];
+                    f32x4 v;
+                    if constexpr (RSCALE) v = __builtin_elementwise_fma(acc[i][j], f32x4{rsc[i], rsc[i], rsc[i], rsc[i]}, bias[j]);
+                    else v = acc[i][j] + bias[j];
                     if constexpr (ACT == CMDIAD_ACT_GELU) v = gelu_erf4(v);
                     else if constexpr (ACT == CMDIAD_ACT_RELU) {
 #pragma unroll
@@ -309,9 +423,10 @@ struct QkvParams {
     int M, T, Tp, C, H, group_m;
     const float* bias;
     bf16_t *q, *k, *vt;
+    const float* row_scale;   // LayerNorm fold (see gemm_std_kernel): qkv = row_scale[m] * (A . W^T) + bias, or null
 };
 
-template <class S>
+template <class S, bool RSCALE = false>
 __global__ __launch_bounds__(S::THREADS, S::WAVES_PER_SIMD) void gemm_qkv_kernel(GlobalTile A, GlobalTile W, QkvParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -335,9 +450,15 @@ __global__ __launch_bounds__(S::THREADS, S::WAVES_PER_SIMD) void gemm_qkv_kernel
 #pragma unroll
             for (int i = 0; i < S::MI; ++i) {
                 bf16x4 h[4];
+                float rsc = 1.0f;
+                if constexpr (RSCALE) {
+                    int mi = min(c.m(i), p.M - 1);
+                    asm volatile("" : "+v"(mi));   // address arithmetic stays in the epilogue (hoisted above the K loop it spills)
+                    rsc = p.row_scale[mi];
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const f32x4 v = (acc[i][j] + bj[j]) * scale;
+                    const f32x4 v = (RSCALE ? __builtin_elementwise_fma(acc[i][j], f32x4{rsc, rsc, rsc, rsc}, bj[j]) : acc[i][j] + bj[j]) * scale;
                     h[j] = bf16x4{f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
                 }
                 rs.park(h);
@@ -361,11 +482,19 @@ __global__ __launch_bounds__(S::THREADS, S::WAVES_PER_SIMD) void gemm_qkv_kernel
         // four-token groups that straddle two images or the end of the matrix.
         run<S, false>(A, W, c.m0, c.nt, 1, p.C / BK, lds, [&](auto& acc, int ntile, char*) {
             int tb[S::MI], tt[S::MI];   // image and token of the lane's first token in row block i
+            f32x4 rsc[S::MI];           // 1 / sigma of the lane's four tokens
 #pragma unroll
             for (int i = 0; i < S::MI; ++i) {
                 const int m = c.m0 + c.wr * (S::MI * 16) + i * 16 + (c.lane >> 4) * 4;
                 tb[i] = m / p.T;
                 tt[i] = m - tb[i] * p.T;
+                rsc[i] = f32x4{1.f, 1.f, 1.f, 1.f};
+                if constexpr (RSCALE) {
+                    int mm = m;
+                    asm volatile("" : "+v"(mm));
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) rsc[i][r] = p.row_scale[min(mm + r, p.M - 1)];
+                }
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -377,15 +506,15 @@ __global__ __launch_bounds__(S::THREADS, S::WAVES_PER_SIMD) void gemm_qkv_kernel
                 for (int i = 0; i < S::MI; ++i) {
                     const int m = c.m0 + c.wr * (S::MI * 16) + i * 16 + (c.lane >> 4) * 4;
                     if (m + 3 < p.M && tt[i] + 3 < p.T) {
-                        const f32x4 v = acc[i][j];
-                        const bf16x4 o = {f2bf(v[0] + bb), f2bf(v[1] + bb), f2bf(v[2] + bb), f2bf(v[3] + bb)};
+                        const f32x4 v = RSCALE ? __builtin_elementwise_fma(acc[i][j], rsc[i], f32x4{bb, bb, bb, bb}) : acc[i][j] + bb;
+                        const bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
                         __builtin_memcpy(p.vt + (((size_t)tb[i] * p.H + h) * 64 + d) * p.Tp + tt[i], &o, 8);
                     } else {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             if (m + r >= p.M) continue;
                             const int b = (m + r) / p.T, t = m + r - b * p.T;
-                            p.vt[(((size_t)b * p.H + h) * 64 + d) * p.Tp + t] = f2bf(acc[i][j][r] + bb);
+                            p.vt[(((size_t)b * p.H + h) * 64 + d) * p.Tp + t] = f2bf(RSCALE ? __builtin_fmaf(acc[i][j][r], rsc[i][r], bb) : acc[i][j][r] + bb);
                         }
                     }
                 }
@@ -741,6 +870,16 @@ template <class S> constexpr int group_max_lds() { return S::LDS_BYTES + (S::BM 
 #include "ab/gemm_wide_kernels.inc"
 #endif  // CMDIAD_AB_VARIANTS
 
+// part [chunks][M] (sum, M2 about the chunk mean) of 64-column chunks -> rstd[m] = 1 / sqrt(var + eps) (and the row mean).
+// The chunks are merged in chunk order by one thread per row (Chan et al.): the result does not depend on launch geometry.
+__global__ __launch_bounds__(256) void ln_stats_finalize_kernel(const float2* __restrict__ part, int M, int chunks, float eps,
+                                                                float* __restrict__ rstd, float* __restrict__ mean_out)
+{
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    rstd[m] = ln_merge_chunks(part, M, chunks, m, eps, mean_out ? mean_out + m : nullptr);
+}
+
 bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 // Every network GEMM runs the 128 x 128 shape: the tile sweep on MI355X (profiles/r1_notes.md) had it ahead of
@@ -870,7 +1009,14 @@ extern "C" int cmdiad_gemm_bf16(const cmdiad_gemm_args* a, cmdiad_stream_t strea
                    CMDIAD_ERR_ARG, "cmdiad_gemm_bf16: out_pre_bf16 / dact_of alignment");
     GlobalTile A{(const bf16_t*)a->A, a->lda, a->M}, W{(const bf16_t*)a->W, a->ldw, a->N};
     StdParams p{a->M, a->N, a->K, a->bias, a->group_bias, a->group_rows, a->act, a->residual, a->ldr,
-                a->out_f32, a->ldo32, (bf16_t*)a->out_bf16, a->ldo16, (bf16_t*)a->out_pre_bf16, (const bf16_t*)a->dact_of, split, 1, 1, a->m_count};
+                a->out_f32, a->ldo32, (bf16_t*)a->out_bf16, a->ldo16, (bf16_t*)a->out_pre_bf16, (const bf16_t*)a->dact_of, split, 1, 1, a->m_count,
+                a->row_scale, (bf16_t*)a->ln_xb, a->ld_xb, a->ln_part, a->add2, a->ld_add2};
+    const bool ln_out = a->ln_xb || a->ln_part || a->add2;
+    CMDIAD_REQUIRE(!ln_out || (a->ln_xb && a->ln_part && a->ld_xb % 4 == 0 && ((uintptr_t)a->ln_xb & 7) == 0 && ((uintptr_t)a->ln_part & 7) == 0 &&
+                               (!a->add2 || (aligned16(a->add2) && a->ld_add2 % 4 == 0))),
+                   CMDIAD_ERR_ARG, "cmdiad_gemm_bf16: ln_xb and ln_part come together (8-byte aligned, ld_xb%%4==0); add2 only with them");
+    CMDIAD_REQUIRE(!a->row_scale || (split == 1 && !a->out_pre_bf16 && !a->dact_of && !a->m_count), CMDIAD_ERR_ARG,
+                   "cmdiad_gemm_bf16: row_scale with split_k / training terms / m_count");
     CMDIAD_REQUIRE(!a->m_count || split == 1, CMDIAD_ERR_ARG, "cmdiad_gemm_bf16: m_count with split_k > 1");
     hipStream_t s = (hipStream_t)stream;
     const bool extras = a->out_pre_bf16 || a->dact_of;
@@ -891,7 +1037,7 @@ extern "C" int cmdiad_gemm_bf16(const cmdiad_gemm_args* a, cmdiad_stream_t strea
         // two-group persistent kernel: whole 256-column tiles, bias, bf16-only output; chosen when every CU gets >= 2 tiles of
         // a wide product.  CMDIAD_GEMM_PP3=1 / 0 forces it on / off wherever it is legal (A/B runs, parity tests; read per call)
         const char* e3 = getenv("CMDIAD_GEMM_PP3");
-        const bool plain3 = !extras && !a->group_bias && split == 1 && a->N % 256 == 0 && a->K % 64 == 0 && a->K >= 192 && a->bias &&
+        const bool plain3 = !extras && !ln_out && !a->group_bias && split == 1 && a->N % 256 == 0 && a->K % 64 == 0 && a->K >= 192 && a->bias &&
                             !a->residual && !a->out_f32 && a->out_bf16 && a->ldo16 % 8 == 0 && aligned16(a->out_bf16);
         const bool want3 = e3 ? e3[0] != '0' : (a->N >= 1536 && ((long)(a->M + 255) / 256) * (a->N / 256) >= 2 * kPersistCUs);
         if (plain3 && want3) {
@@ -913,6 +1059,10 @@ extern "C" int cmdiad_gemm_bf16(const cmdiad_gemm_args* a, cmdiad_stream_t strea
                 return CMDIAD_OK;
             };
             p.group_m = 1;
+            if (a->row_scale)
+                rc = a->act == CMDIAD_ACT_GELU ? go(gemm_std_pp3_kernel<CMDIAD_ACT_GELU, true>)
+                   : a->act == CMDIAD_ACT_RELU ? go(gemm_std_pp3_kernel<CMDIAD_ACT_RELU, true>) : go(gemm_std_pp3_kernel<CMDIAD_ACT_NONE, true>);
+            else
             rc = a->act == CMDIAD_ACT_GELU ? go(gemm_std_pp3_kernel<CMDIAD_ACT_GELU>)
                : a->act == CMDIAD_ACT_RELU ? go(gemm_std_pp3_kernel<CMDIAD_ACT_RELU>) : go(gemm_std_pp3_kernel<CMDIAD_ACT_NONE>);
             if (rc) return rc;
@@ -926,7 +1076,12 @@ extern "C" int cmdiad_gemm_bf16(const cmdiad_gemm_args* a, cmdiad_stream_t strea
     // fp32 residual stream in place (proj / fc2): out_f32 = acc + bias + residual through the row-contiguous epilogue
     const bool res_rows = !extras && a->act == CMDIAD_ACT_NONE && p.residual && p.out_f32 && !p.out_bf16 && !p.group_bias && p.bias &&
                           split == 1 && a->N % 64 == 0 && p.panel == 1;
-    if (res_rows) rc = launch<S128>(gemm_std_kernel<S128, CMDIAD_ACT_NONE, false, true>, grid_for<S128>(a->M, a->N, split, p.panel),
+    CMDIAD_REQUIRE(!ln_out || (res_rows && !a->row_scale && !a->m_count), CMDIAD_ERR_ARG,
+                   "cmdiad_gemm_bf16: ln_xb / ln_part need the in-place residual form (bias, residual, out_f32 only, N%%64==0)");
+    CMDIAD_REQUIRE(!a->row_scale || !res_rows, CMDIAD_ERR_ARG, "cmdiad_gemm_bf16: row_scale with the residual-row form");
+    if (res_rows && ln_out) rc = launch<S128>(gemm_std_kernel<S128, CMDIAD_ACT_NONE, false, true, true>, grid_for<S128>(a->M, a->N, split, p.panel),
+                                              S128::LDS_BYTES + S128::WAVES * kRowStoreScratch, s, A, W, p);
+    else if (res_rows) rc = launch<S128>(gemm_std_kernel<S128, CMDIAD_ACT_NONE, false, true>, grid_for<S128>(a->M, a->N, split, p.panel),
                                     S128::LDS_BYTES + S128::WAVES * kRowStoreScratch, s, A, W, p);
     else if (extras) rc = a->act == CMDIAD_ACT_GELU ? CMDIAD_STD(S128, CMDIAD_ACT_GELU, true)
                    : a->act == CMDIAD_ACT_RELU ? CMDIAD_STD(S128, CMDIAD_ACT_RELU, true) : CMDIAD_STD(S128, CMDIAD_ACT_NONE, true);
@@ -938,7 +1093,17 @@ extern "C" int cmdiad_gemm_bf16(const cmdiad_gemm_args* a, cmdiad_stream_t strea
     return CMDIAD_OK;
 }
 
-extern "C" int cmdiad_gemm_qkv(const uint16_t* A, const uint16_t* W, const float* bias, int B, int T, int C,
+extern "C" int cmdiad_ln_stats_finalize(const float* part, int M, int chunks, float eps, float* rstd, float* mean_out,
+                                        cmdiad_stream_t stream)
+{
+    CMDIAD_REQUIRE(part && rstd && M > 0 && chunks > 0 && ((uintptr_t)part & 7) == 0, CMDIAD_ERR_ARG, "cmdiad_ln_stats_finalize: bad args");
+    hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float2*)part, M, chunks, eps, rstd, mean_out);
+    CMDIAD_CHECK_LAUNCH();
+    return CMDIAD_OK;
+}
+
+extern "C" int cmdiad_gemm_qkv(const uint16_t* A, const uint16_t* W, const float* bias, const float* row_scale, int B, int T, int C,
                                uint16_t* q_out, uint16_t* k_out, uint16_t* vt_out, cmdiad_stream_t stream)
 {
     CMDIAD_REQUIRE(A && W && q_out && k_out && vt_out, CMDIAD_ERR_ARG, "cmdiad_gemm_qkv: null pointer");
@@ -947,9 +1112,10 @@ extern "C" int cmdiad_gemm_qkv(const uint16_t* A, const uint16_t* W, const float
                    CMDIAD_ERR_ARG, "cmdiad_gemm_qkv: 16-byte alignment");
     const int M = B * T;
     GlobalTile At{(const bf16_t*)A, C, M}, Wt{(const bf16_t*)W, C, 3 * C};
-    QkvParams p{M, T, (T + 63) / 64 * 64, C, C / 64, group_m_tiles(), bias, (bf16_t*)q_out, (bf16_t*)k_out, (bf16_t*)vt_out};
+    QkvParams p{M, T, (T + 63) / 64 * 64, C, C / 64, group_m_tiles(), bias, (bf16_t*)q_out, (bf16_t*)k_out, (bf16_t*)vt_out, row_scale};
     hipStream_t s = (hipStream_t)stream;
-    const int rc = launch<S128>(gemm_qkv_kernel<S128>, grid_for<S128>(M, 3 * C), S128::LDS_BYTES + S128::WAVES * kRowStoreScratch, s, At, Wt, p);
+    const int rc = row_scale ? launch<S128>(gemm_qkv_kernel<S128, true>, grid_for<S128>(M, 3 * C), S128::LDS_BYTES + S128::WAVES * kRowStoreScratch, s, At, Wt, p)
+                             : launch<S128>(gemm_qkv_kernel<S128, false>, grid_for<S128>(M, 3 * C), S128::LDS_BYTES + S128::WAVES * kRowStoreScratch, s, At, Wt, p);
     if (rc) return rc;
     CMDIAD_CHECK_LAUNCH();
     return CMDIAD_OK;

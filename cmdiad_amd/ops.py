@@ -140,20 +140,40 @@ def xyz_patch_fused(feat, idx3, w3, pix2pt, size=224, P=56, mean=0.0, inv_std=1.
 
 # ------------------------------------------------------------------------------------ dense blocks
 def gemm(A, W, bias=None, act=ACT_NONE, residual=None, group_bias=None, group_rows=1, out_f32=None, out_bf16=None,
-         want_f32=False, want_bf16=True, out_pre_bf16=None, dact_of=None, split_k=1, m_count=None):
+         want_f32=False, want_bf16=True, out_pre_bf16=None, dact_of=None, split_k=1, m_count=None,
+         row_scale=None, ln_xb=None, ln_part=None, add2=None):
     """epilogue(A[M,K] . W[N,K]^T); A, W bf16.  Returns (out_f32 | None, out_bf16 | None).  m_count (device int32 [1]): only the
-    first min(M, m_count) rows are computed and stored (a compacted row set whose size is known on the device only)."""
+    first min(M, m_count) rows are computed and stored (a compacted row set whose size is known on the device only).
+    LayerNorm fold (cmdiad_gemm_args, ABI 3): row_scale [>= M rounded up to 256] f32 multiplies the accumulator per row (consumer);
+    ln_xb [M,N] bf16 + ln_part [N/64, M, 2] f32 (+ add2 [M,N] f32) are the producer's extra outputs of the in-place residual form."""
     _chk(A, torch.bfloat16, "gemm.A"); _chk(W, torch.bfloat16, "gemm.W")
+    _chk(row_scale, torch.float32, "gemm.row_scale"); _chk(ln_xb, torch.bfloat16, "gemm.ln_xb")
+    _chk(ln_part, torch.float32, "gemm.ln_part"); _chk(add2, torch.float32, "gemm.add2")
     M, K = A.shape
     N = W.shape[0]
+    if row_scale is not None and row_scale.numel() < (M + 255) // 256 * 256:
+        raise ValueError(f"gemm.row_scale: {row_scale.numel()} values, need M rounded up to 256 = {(M + 255) // 256 * 256}")
+    if ln_part is not None and ln_part.numel() < (N // 64) * M * 2:
+        raise ValueError(f"gemm.ln_part: {ln_part.numel()} values, need (N/64) * M * 2 = {(N // 64) * M * 2}")
     if out_f32 is None and want_f32:
         out_f32 = torch.empty((split_k, M, N) if split_k > 1 else (M, N), dtype=torch.float32, device=A.device)
     if out_bf16 is None and want_bf16:
         out_bf16 = torch.empty((M, N), dtype=torch.bfloat16, device=A.device)
     a = nat.GemmArgs(_p(A), K, _p(W), K, M, N, K, _p(bias), _p(group_bias), group_rows, act,
-                     _p(residual), N, _p(out_f32), N, _p(out_bf16), N, _p(out_pre_bf16), _p(dact_of), split_k, _p(m_count))
+                     _p(residual), N, _p(out_f32), N, _p(out_bf16), N, _p(out_pre_bf16), _p(dact_of), split_k, _p(m_count),
+                     _p(row_scale), _p(ln_xb), N, _p(ln_part), _p(add2), N)
     _call("cmdiad_gemm_bf16", ctypes.byref(a), _stream())
     return out_f32, out_bf16
+
+
+def ln_stats_finalize(part, M, chunks, eps, rstd=None, want_mean=False):
+    """part [chunks, M, 2] f32 (gemm(..., ln_part=)) -> rstd [M rounded up to 256] f32 (first M valid) (, mean [M])."""
+    _chk(part, torch.float32, "ln_stats.part")
+    if rstd is None:
+        rstd = torch.empty(((M + 255) // 256 * 256,), dtype=torch.float32, device=part.device)
+    mean = torch.empty((M,), dtype=torch.float32, device=part.device) if want_mean else None
+    _call("cmdiad_ln_stats_finalize", _p(part), M, chunks, float(eps), _p(rstd), _p(mean), _stream())
+    return (rstd, mean) if want_mean else rstd
 
 
 def gemm_tn(P, Q, split_k=1, want_colsum=False):
@@ -168,11 +188,12 @@ def gemm_tn(P, Q, split_k=1, want_colsum=False):
     return (out, cs) if want_colsum else out
 
 
-def gemm_qkv(A, W, bias, B, T, q, k, vt):
-    """A [B*T,C] bf16 -> q,k [B,H,Tp,64], vt [B,H,64,Tp] (pre-allocated, zero-initialised padding)."""
-    _chk(A, torch.bfloat16, "qkv.A"); _chk(W, torch.bfloat16, "qkv.W")
+def gemm_qkv(A, W, bias, B, T, q, k, vt, row_scale=None):
+    """A [B*T,C] bf16 -> q,k [B,H,Tp,64], vt [B,H,64,Tp] (pre-allocated, zero-initialised padding).  row_scale [B*T] f32:
+    the LayerNorm-folded form (qkv = row_scale[m] * (A . W^T) + bias)."""
+    _chk(A, torch.bfloat16, "qkv.A"); _chk(W, torch.bfloat16, "qkv.W"); _chk(row_scale, torch.float32, "qkv.row_scale")
     C = A.shape[1]
-    _call("cmdiad_gemm_qkv", _p(A), _p(W), _p(bias), B, T, C, _p(q), _p(k), _p(vt), _stream())
+    _call("cmdiad_gemm_qkv", _p(A), _p(W), _p(bias), _p(row_scale), B, T, C, _p(q), _p(k), _p(vt), _stream())
 
 
 def attention(q, k, vt, B, H, T, out=None):
@@ -241,18 +262,22 @@ def transformer_block_workspace_bytes(M, C, hidden):
     return int(nat.lib().cmdiad_transformer_block_workspace_bytes(M, C, hidden))
 
 
-def transformer_block(x, pos, blk, B, T, H, eps, q, k, vt, workspace):
+BLOCK_LN1_READY, BLOCK_PREP_NEXT = 1, 2   # include/cmdiad_hip.h CMDIAD_BLOCK_*
+_BLOCK_FIELDS = ("ln1_w", "ln1_b", "ln2_w", "ln2_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b",
+                 "qkv_wf", "qkv_bf", "fc1_wf", "fc1_bf")
+
+
+def transformer_block(x, pos, blk, B, T, H, eps, q, k, vt, workspace, flags=0):
     """x [B*T, C] f32 updated in place by one whole pre-LN block (cmdiad_transformer_block_fwd).  blk: dict of packed
-    weights (runtime._pack_block); its ctypes struct is built once and cached in the dict."""
+    weights (runtime._pack_block); its ctypes struct is built once and cached in the dict.  flags: BLOCK_LN1_READY /
+    BLOCK_PREP_NEXT chain the LayerNorm fold across consecutive calls on one workspace (needs blk's folded weights)."""
     _chk(x, torch.float32, "block.x"); _chk(pos, torch.float32, "block.pos")
     w = blk.get("_struct")
     if w is None:
-        w = nat.BlockWeights(*[blk[n].data_ptr() if blk[n] is not None else None
-                               for n in ("ln1_w", "ln1_b", "ln2_w", "ln2_b", "qkv_w", "qkv_b", "proj_w", "proj_b",
-                                         "fc1_w", "fc1_b", "fc2_w", "fc2_b")])
+        w = nat.BlockWeights(*[blk[n].data_ptr() if blk.get(n) is not None else None for n in _BLOCK_FIELDS])
         blk["_struct"] = w
     C = x.shape[1]
-    _call("cmdiad_transformer_block_fwd", _p(x), _p(pos), ctypes.byref(w), B, T, C, H, blk["fc1_w"].shape[0], float(eps),
+    _call("cmdiad_transformer_block_fwd", _p(x), _p(pos), ctypes.byref(w), B, T, C, H, blk["fc1_w"].shape[0], float(eps), int(flags),
           _p(q), _p(k), _p(vt), _p(workspace), workspace.numel(), _stream())
     return x
 

@@ -22,9 +22,28 @@ def _bf(t, device):
     return ops.cast_bf16(_dev(t, device)) if t.numel() % 4 == 0 else _dev(t, device).to(torch.bfloat16)
 
 
-def _pack_block(sd, p, device, qkv_bias):
+def ln_fold(weight, bias, gamma, beta):
+    """LayerNorm folded into the Linear that follows it (csrc/gemm.hip "LayerNorm fold"):  LN(x) . W^T + b  =
+    rstd * (x . W''^T) + b'  with  W''[n,k] = gamma[k] W[n,k] - mean_k(gamma[k] W[n,k])  (centred over k, so the row mean of x
+    drops out of the product) and  b' = b + W beta.  -> (W'' fp32 [N,K], b' fp32 [N]); computed in float64."""
+    W = weight.detach().double().cpu()
+    Wg = W * gamma.detach().double().cpu()[None, :]
+    Wc = Wg - Wg.mean(dim=1, keepdim=True)
+    b0 = bias.detach().double().cpu() if bias is not None else torch.zeros(W.shape[0], dtype=torch.float64)
+    return Wc.float(), (b0 + W @ beta.detach().double().cpu()).float()
+
+
+def ln_fold_enabled(net=""):
+    """Which networks run with their LayerNorms folded into the neighbouring products.  CMDIAD_LN_FOLD = pmae (default) | vit | 1
+    (both) | 0 (none: every LayerNorm its own launch).  Measured inside the batch-32 pipeline on one box (profiles/r3_notes.md):
+    Point-MAE only 23.55 ms per step against 23.67 unfolded; both 23.6-24.3; ViT only 24.3-24.9 -- hence the default."""
+    v = os.environ.get("CMDIAD_LN_FOLD", "pmae")
+    return v == "1" or (v not in ("0", "1") and v == net)
+
+
+def _pack_block(sd, p, device, qkv_bias, net=""):
     g = lambda k: sd[p + k]  # noqa: E731
-    return dict(
+    blk = dict(
         ln1_w=_dev(g("norm1.weight"), device), ln1_b=_dev(g("norm1.bias"), device),
         ln2_w=_dev(g("norm2.weight"), device), ln2_b=_dev(g("norm2.bias"), device),
         qkv_w=_bf(g("attn.qkv.weight"), device),
@@ -32,6 +51,20 @@ def _pack_block(sd, p, device, qkv_bias):
         proj_w=_bf(g("attn.proj.weight"), device), proj_b=_dev(g("attn.proj.bias"), device),
         fc1_w=_bf(g("mlp.fc1.weight"), device), fc1_b=_dev(g("mlp.fc1.bias"), device),
         fc2_w=_bf(g("mlp.fc2.weight"), device), fc2_b=_dev(g("mlp.fc2.bias"), device))
+    if ln_fold_enabled(net):
+        wq, bq = ln_fold(g("attn.qkv.weight"), g("attn.qkv.bias") if qkv_bias else None, g("norm1.weight"), g("norm1.bias"))
+        w1, b1 = ln_fold(g("mlp.fc1.weight"), g("mlp.fc1.bias"), g("norm2.weight"), g("norm2.bias"))
+        blk.update(qkv_wf=_bf(wq, device), qkv_bf=_dev(bq, device), fc1_wf=_bf(w1, device), fc1_bf=_dev(b1, device))
+    return blk
+
+
+def block_flags(i, n, folded, read_after=()):
+    """LayerNorm-fold chaining flags of block i of n run back to back on one workspace: block i prepares block i + 1's first
+    LayerNorm unless its output is read in between (read_after: Point-MAE's fetch layers) or it is the last."""
+    if not folded:
+        return 0
+    prep = lambda j: 0 <= j < n - 1 and j not in read_after  # noqa: E731
+    return (ops.BLOCK_LN1_READY if prep(i - 1) else 0) | (ops.BLOCK_PREP_NEXT if prep(i) else 0)
 
 
 class _QkvBuffers:
@@ -58,25 +91,47 @@ class _QkvBuffers:
         return self.q, self.k, self.vt
 
 
-def transformer_block(x, blk, B, T, H, eps, bufs, pos=None):
+def transformer_block(x, blk, B, T, H, eps, bufs, pos=None, flags=0):
     """In-place pre-LN block on the fp32 residual stream x [B*T, C] (models/models.py:177-180).
     pos (Point-MAE) is added to x first, fused into the first LayerNorm (models/models.py:240).
-    One FFI call (cmdiad_transformer_block_fwd sequences the seven launches inside the library)."""
+    One FFI call (cmdiad_transformer_block_fwd sequences the launches inside the library).  flags (block_flags): with the
+    folded weights the LayerNorms run inside the products around them; PREP_NEXT / LN1_READY chain that across blocks."""
     q, k, vt = bufs.get(B, H, T, x.device)
-    ops.transformer_block(x, pos, blk, B, T, H, eps, q, k, vt, bufs.workspace(B * T, x.shape[1], blk["fc1_w"].shape[0], x.device))
+    ops.transformer_block(x, pos, blk, B, T, H, eps, q, k, vt, bufs.workspace(B * T, x.shape[1], blk["fc1_w"].shape[0], x.device),
+                          flags=flags)
     return x
 
 
-def transformer_block_unfused(x, blk, B, T, H, eps, bufs, pos=None):
-    """The same block as seven separate entry-point calls (kept for tests: both forms must agree bit for bit)."""
-    h = ops.layernorm(x, blk["ln1_w"], blk["ln1_b"], eps, add=pos)
+def transformer_block_unfused(x, blk, B, T, H, eps, bufs, pos=None, flags=0, state=None):
+    """The same block as separate entry-point calls (kept for tests: both forms must agree bit for bit).  state: a dict that
+    carries the raw bf16 rows / 1 / sigma from a PREP_NEXT call to the LN1_READY call that follows it."""
+    M, C = x.shape
+    folded = "qkv_wf" in blk
+    state = {} if state is None else state
     q, k, vt = bufs.get(B, H, T, x.device)
-    ops.gemm_qkv(h, blk["qkv_w"], blk["qkv_b"], B, T, q, k, vt)
+    if flags & ops.BLOCK_LN1_READY:
+        ops.gemm_qkv(state["xb"], blk["qkv_wf"], blk["qkv_bf"], B, T, q, k, vt, row_scale=state["rstd"])
+    else:
+        h = ops.layernorm(x, blk["ln1_w"], blk["ln1_b"], eps, add=pos)
+        ops.gemm_qkv(h, blk["qkv_w"], blk["qkv_b"], B, T, q, k, vt)
     a = ops.attention(q, k, vt, B, H, T)
-    ops.gemm(a, blk["proj_w"], bias=blk["proj_b"], residual=x, out_f32=x, want_bf16=False)
-    h = ops.layernorm(x, blk["ln2_w"], blk["ln2_b"], eps)
-    _, m = ops.gemm(h, blk["fc1_w"], bias=blk["fc1_b"], act=ops.ACT_GELU)
-    ops.gemm(m, blk["fc2_w"], bias=blk["fc2_b"], residual=x, out_f32=x, want_bf16=False)
+    if folded:
+        xb = torch.empty((M, C), dtype=torch.bfloat16, device=x.device)
+        part = torch.empty((C // 64, M, 2), dtype=torch.float32, device=x.device)
+        ops.gemm(a, blk["proj_w"], bias=blk["proj_b"], residual=x, out_f32=x, want_bf16=False, ln_xb=xb, ln_part=part)
+        rstd = ops.ln_stats_finalize(part, M, C // 64, eps)
+        _, m = ops.gemm(xb, blk["fc1_wf"], bias=blk["fc1_bf"], act=ops.ACT_GELU, row_scale=rstd)
+    else:
+        ops.gemm(a, blk["proj_w"], bias=blk["proj_b"], residual=x, out_f32=x, want_bf16=False)
+        h = ops.layernorm(x, blk["ln2_w"], blk["ln2_b"], eps)
+        _, m = ops.gemm(h, blk["fc1_w"], bias=blk["fc1_b"], act=ops.ACT_GELU)
+    if flags & ops.BLOCK_PREP_NEXT:
+        xb = torch.empty((M, C), dtype=torch.bfloat16, device=x.device)
+        part = torch.empty((C // 64, M, 2), dtype=torch.float32, device=x.device)
+        ops.gemm(m, blk["fc2_w"], bias=blk["fc2_b"], residual=x, out_f32=x, want_bf16=False, ln_xb=xb, ln_part=part, add2=pos)
+        state["xb"], state["rstd"] = xb, ops.ln_stats_finalize(part, M, C // 64, eps)
+    else:
+        ops.gemm(m, blk["fc2_w"], bias=blk["fc2_b"], residual=x, out_f32=x, want_bf16=False)
     return x
 
 
@@ -90,7 +145,7 @@ class PackedViT:
         self.patch_b = _dev(sd[prefix + "patch_embed.proj.bias"], device)
         self.cls = _dev(sd[prefix + "cls_token"].reshape(-1), device)
         self.pos = _dev(sd[prefix + "pos_embed"].reshape(-1, self.dim), device)
-        self.blocks = [_pack_block(sd, f"{prefix}blocks.{i}.", device, True) for i in range(depth)]
+        self.blocks = [_pack_block(sd, f"{prefix}blocks.{i}.", device, True, "vit") for i in range(depth)]
         self.norm_w, self.norm_b = _dev(sd[prefix + "norm.weight"], device), _dev(sd[prefix + "norm.bias"], device)
         self.bufs = _QkvBuffers()
 
@@ -102,8 +157,9 @@ class PackedViT:
         patches = ops.im2col_patch8(rgb.contiguous())
         po, _ = ops.gemm(patches, self.patch_w, bias=self.patch_b, want_f32=True, want_bf16=False)
         x = ops.vit_assemble(po, self.cls, self.pos, B, P, self.dim)
-        for blk in self.blocks:
-            transformer_block(x, blk, B, T, self.heads, 1e-6, self.bufs)
+        n = len(self.blocks)
+        for i, blk in enumerate(self.blocks):
+            transformer_block(x, blk, B, T, self.heads, 1e-6, self.bufs, flags=block_flags(i, n, "qkv_wf" in blk))
         out = torch.empty_like(x)
         ops.layernorm(x, self.norm_w, self.norm_b, 1e-6, out_f32=out, want_bf16=False)
         return out.view(B, T, self.dim)
@@ -166,7 +222,7 @@ class PackedPointMAE:
         self.pos0 = _dev(torch.cat([sd[prefix + "pos_embed.0.weight"], sd[prefix + "pos_embed.0.bias"][:, None]], 1), device)
         self.pos2_w = _bf(sd[prefix + "pos_embed.2.weight"], device)
         self.pos2_b = _dev(sd[prefix + "pos_embed.2.bias"], device)
-        self.blocks = [_pack_block(sd, f"{prefix}blocks.blocks.{i}.", device, False) for i in range(depth)]
+        self.blocks = [_pack_block(sd, f"{prefix}blocks.blocks.{i}.", device, False, "pmae") for i in range(depth)]
         self.norm_w, self.norm_b = _dev(sd[prefix + "norm.weight"], device), _dev(sd[prefix + "norm.bias"], device)
         self.bufs = _QkvBuffers()
 
@@ -228,8 +284,10 @@ class PackedPointMAE:
         feats = torch.empty((B * G, C * len(self.taps)), dtype=torch.float32, device=tokens.device)
         x = tokens
         t = 0
+        n = len(self.blocks)
         for i, blk in enumerate(self.blocks):
-            transformer_block(x, blk, B, G, self.heads, 1e-5, self.bufs, pos=pos)
+            # (a fetch layer's output is read before the next block adds pos to it: that block runs its own first LayerNorm)
+            transformer_block(x, blk, B, G, self.heads, 1e-5, self.bufs, pos=pos, flags=block_flags(i, n, "qkv_wf" in blk, self.taps))
             if i in self.taps:
                 ops.layernorm(x, self.norm_w, self.norm_b, 1e-5, out_f32=feats[:, t * C:(t + 1) * C], want_bf16=False)
                 t += 1

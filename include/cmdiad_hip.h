@@ -33,7 +33,10 @@ typedef enum {
 } cmdiad_status;
 
 const char* cmdiad_last_error(void);
-int cmdiad_abi_version(void); /* 2: cmdiad_reweight_scan's limits and workspace changed (see there); cmdiad_gemm_args gained m_count */
+int cmdiad_abi_version(void); /* 2: cmdiad_reweight_scan's limits and workspace changed (see there); cmdiad_gemm_args gained m_count
+                                 3: LayerNorm fold -- cmdiad_gemm_args gained row_scale / ln_xb / ln_part / add2, cmdiad_gemm_qkv gained
+                                    row_scale, cmdiad_block_weights the folded weights, cmdiad_transformer_block_fwd its flags;
+                                    cmdiad_ln_stats_finalize is new */
 /* 1 when the library is the test-only build that also contains the superseded kernel formulations (A/B references). */
 int cmdiad_has_ab_variants(void);
 
@@ -119,8 +122,25 @@ typedef struct {
     int split_k;                     /* > 1: K is split; slab s of out_f32 ([split_k][M][ldo32]) gets partial s */
     const int* m_count;              /* ABI 2: device-resident live row count or NULL: only rows < min(M, *m_count) are computed
                                         and stored (the compacted row set of cmdiad_rows_dedup_plan: the launch is sized for M) */
+    /* ABI 3, LayerNorm folded into the products on either side of it (models/models.py:177-180; all NULL = off):
+     * consumer: out = act(row_scale[m] * acc + bias): W holds gamma o W centred over k, bias = b + W beta, A the RAW rows as
+     * bf16 (ln_xb of the producer), row_scale = 1 / sigma per row from cmdiad_ln_stats_finalize; it must be readable up to
+     * M rounded up to 256 rows (the values past M are never used). */
+    const float* row_scale;
+    /* producer, only with the in-place residual form (bias + residual -> out_f32, no activation, N % 64 == 0):
+     * out_f32 = acc + bias + residual (+ add2); ln_xb [M, ld_xb] = the same rows as bf16; ln_part [N/64][M][2] f32 = (sum,
+     * squared deviation from the chunk mean) of every 64-column chunk of every row. */
+    uint16_t* ln_xb; int ld_xb;
+    float* ln_part;
+    const float* add2; int ld_add2;  /* second f32 addend [M,N] (the next block's positional embedding, models.py:240), or NULL */
 } cmdiad_gemm_args;
 int cmdiad_gemm_bf16(const cmdiad_gemm_args* args, cmdiad_stream_t stream);
+
+/* LayerNorm statistics from the producer's chunk partials (nn.LayerNorm inside Block, models/models.py:170,175): part
+ * [chunks][M][2] as written through cmdiad_gemm_args.ln_part -> rstd[m] = 1 / sqrt(var_m + eps) over the chunks * 64 columns
+ * (biased variance, as torch) and, optionally, mean_out[m].  Chunks are merged in order (Chan's formula): bit-reproducible. */
+int cmdiad_ln_stats_finalize(const float* part, int M, int chunks, float eps, float* rstd, float* mean_out,
+                             cmdiad_stream_t stream);
 
 /* Weight-gradient product of the trainer (hallucination_network_pretrain.py:114-131, loss.backward() through
  * utils/utils.py:94-100): C[N1,N2] = sum_m P[m,n1] * Q[m,n2] with BOTH operands row-major bf16 (P = dZ [M,N1], Q = the
@@ -134,8 +154,10 @@ int cmdiad_gemm_tn_bf16(const uint16_t* P, int ldp, const uint16_t* Q, int ldq, 
 /* QKV projection with head-split stores for the attention kernel (models/models.py:150-151):
  * A [B*T, C] bf16, W [3C, C], bias [3C] or NULL.  head_dim = 64, C = H*64.
  * q_out, k_out [B,H,Tp,64] bf16 (q pre-multiplied by head_dim^-0.5 (models.py:153) times log2(e)),
- * vt_out [B,H,64,Tp] bf16 (V transposed); Tp = T rounded up to 64; padding is never written. */
-int cmdiad_gemm_qkv(const uint16_t* A, const uint16_t* W, const float* bias, int B, int T, int C,
+ * vt_out [B,H,64,Tp] bf16 (V transposed); Tp = T rounded up to 64; padding is never written.
+ * row_scale [B*T] f32 or NULL (ABI 3): qkv = row_scale[m] * (A . W^T) + bias, the consumer side of the LayerNorm fold
+ * (cmdiad_gemm_args.row_scale). */
+int cmdiad_gemm_qkv(const uint16_t* A, const uint16_t* W, const float* bias, const float* row_scale, int B, int T, int C,
                     uint16_t* q_out, uint16_t* k_out, uint16_t* vt_out, cmdiad_stream_t stream);
 
 /* softmax(q k^T) v per (image, head) (models/models.py:153-157), flash-style, bf16 MFMA; q as written by
@@ -201,17 +223,26 @@ int cmdiad_upsample_bicubic(const float* in, int B, int h, int w, int C, int ldi
  * models.py:240).  Weights: bf16 [out, in] matrices in nn.Linear layout, f32 biases / LayerNorm parameters (qkv_b may be
  * NULL).  C = 64 H.  q, k [B,H,Tp,64] and vt [B,H,64,Tp] bf16 scratch as in cmdiad_gemm_qkv (padding rows zeroed once by
  * the caller); workspace >= cmdiad_transformer_block_workspace_bytes(B*T, C, hidden).  Sequencing only: LayerNorm ->
- * cmdiad_gemm_qkv -> cmdiad_attention -> cmdiad_gemm_bf16 x3, all on `stream`. */
+ * cmdiad_gemm_qkv -> cmdiad_attention -> cmdiad_gemm_bf16 x3, all on `stream`.
+ * ABI 3: with the folded weights present (qkv_wf ... fc1_bf: gamma o W centred over k as bf16, b + W beta; see
+ * cmdiad_gemm_args.row_scale) the second LayerNorm is folded into proj (producer) and fc1 (consumer), and with
+ *   CMDIAD_BLOCK_PREP_NEXT  fc2 also emits the bf16 rows + statistics of its output (+ pos: the NEXT block's input) into the
+ *                           workspace, which the next call on the same workspace consumes when it is given
+ *   CMDIAD_BLOCK_LN1_READY  (the first LayerNorm is folded into qkv; pos is NOT added again).
+ * A block whose output is read before the next block (Point-MAE's fetch layers) is called without PREP_NEXT. */
 typedef struct {
     const float *ln1_w, *ln1_b, *ln2_w, *ln2_b;
     const uint16_t* qkv_w; const float* qkv_b;
     const uint16_t* proj_w; const float* proj_b;
     const uint16_t* fc1_w; const float* fc1_b;
     const uint16_t* fc2_w; const float* fc2_b;
+    const uint16_t* qkv_wf; const float* qkv_bf;   /* ABI 3: LayerNorm-folded qkv / fc1 (all four or none) */
+    const uint16_t* fc1_wf; const float* fc1_bf;
 } cmdiad_block_weights;
+enum { CMDIAD_BLOCK_LN1_READY = 1, CMDIAD_BLOCK_PREP_NEXT = 2 };
 size_t cmdiad_transformer_block_workspace_bytes(int M, int C, int hidden);
 int cmdiad_transformer_block_fwd(float* x, const float* pos, const cmdiad_block_weights* w, int B, int T, int C, int H,
-                                 int hidden, float eps, uint16_t* q, uint16_t* k, uint16_t* vt, void* workspace,
+                                 int hidden, float eps, int flags, uint16_t* q, uint16_t* k, uint16_t* vt, void* workspace,
                                  size_t workspace_bytes, cmdiad_stream_t stream);
 
 /* Point-MAE Encoder (models/models.py:200-215), eval-mode BatchNorm folded into the convolutions:

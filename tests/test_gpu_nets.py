@@ -24,7 +24,9 @@ def _rel(got, ref):
     return err.mean().item() / scale, err.max().item() / scale
 
 
-def test_vit_b8_forward_vs_oracle():
+@pytest.mark.parametrize("fold", ["0", "1"])   # LayerNorms as launches (default for the ViT) / folded into the products
+def test_vit_b8_forward_vs_oracle(fold, monkeypatch):
+    monkeypatch.setenv("CMDIAD_LN_FOLD", fold)
     sd = nets.synth_state_dict("vit", 31)
     rgb = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(1))
     with torch.no_grad():
@@ -41,8 +43,8 @@ def test_vit_blocks_vs_reference_golden(golden):
     sd = nets.synth_state_dict("vit", 31)
     vit = runtime.PackedViT(sd, device=DEV)
     x = torch.randn(1, 785, 768, generator=torch.Generator().manual_seed(int(g["x_seed"]))).to(DEV).reshape(785, 768).contiguous()
-    for blk in vit.blocks:
-        runtime.transformer_block(x, blk, 1, 785, 12, 1e-6, vit.bufs)
+    for i, blk in enumerate(vit.blocks):   # the LayerNorm fold chained across the blocks, as PackedViT.forward_tokens does
+        runtime.transformer_block(x, blk, 1, 785, 12, 1e-6, vit.bufs, flags=runtime.block_flags(i, len(vit.blocks), "qkv_wf" in blk))
     ref = torch.from_numpy(g["y_sub"])
     mean_rel, max_rel = _rel(x.cpu()[::8, ::4], ref)
     assert mean_rel < 0.015 and max_rel < 0.12, (mean_rel, max_rel)
@@ -62,7 +64,9 @@ def test_pointmae_vs_reference_golden(golden):
     assert mean_rel < 0.015 and max_rel < 0.12, (mean_rel, max_rel)
 
 
-def test_pointmae_full_size_vs_oracle():
+@pytest.mark.parametrize("fold", ["pmae", "0"])   # folded (default for Point-MAE) / LayerNorms as launches
+def test_pointmae_full_size_vs_oracle(fold, monkeypatch):
+    monkeypatch.setenv("CMDIAD_LN_FOLD", fold)
     from cmdiad_amd.synth import synth_cloud
     from oracle import scoring
     sd = nets.synth_state_dict("pointmae", 21)
