@@ -21,14 +21,20 @@ __global__ __launch_bounds__(256) void loss_head_kernel(const float* __restrict_
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= M) return;
+    // output activation (mode >> 8): 0 = GELU (the MLP head's closing activation), 1 = none, 2 = sigmoid of BOTH the output and
+    // the target (the convolutional head with sigmoid=True, hallucination_network.py:136-140)
+    const int out_act = mode >> 8;
+    mode &= 255;
+    auto act = [&](float v) { return out_act == 0 ? gelu_erf(v) : out_act == 1 ? v : 1.0f / (1.0f + __expf(-v)); };
+    auto tgt = [&](float v) { return out_act == 2 ? 1.0f / (1.0f + __expf(-v)) : v; };
     const float* z = z3 + (size_t)row * D;
     const float* t = target + (size_t)row * D;
     float a = 0.f, b = 0.f, c = 0.f;  // l2: a = sum d^2 ; cos: a = y.t, b = y.y, c = t.t ; smooth: a = sum elementwise
     for (int i = lane * 4; i < D; i += 256) {
         const float4 zz = *reinterpret_cast<const float4*>(z + i);
         const float4 tt = *reinterpret_cast<const float4*>(t + i);
-        const float y[4] = {gelu_erf(zz.x), gelu_erf(zz.y), gelu_erf(zz.z), gelu_erf(zz.w)};
-        const float tv[4] = {tt.x, tt.y, tt.z, tt.w};
+        const float y[4] = {act(zz.x), act(zz.y), act(zz.z), act(zz.w)};
+        const float tv[4] = {tgt(tt.x), tgt(tt.y), tgt(tt.z), tgt(tt.w)};
         if (y_out) *reinterpret_cast<float4*>(y_out + (size_t)row * D + i) = make_float4(y[0], y[1], y[2], y[3]);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -56,16 +62,16 @@ __global__ __launch_bounds__(256) void loss_head_kernel(const float* __restrict_
     for (int i = lane * 4; i < D; i += 256) {
         const float4 zz = *reinterpret_cast<const float4*>(z + i);
         const float4 tt = *reinterpret_cast<const float4*>(t + i);
-        const float zv[4] = {zz.x, zz.y, zz.z, zz.w}, tv[4] = {tt.x, tt.y, tt.z, tt.w};
+        const float zv[4] = {zz.x, zz.y, zz.z, zz.w}, tv[4] = {tgt(tt.x), tgt(tt.y), tgt(tt.z), tgt(tt.w)};
         bf16x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float y = gelu_erf(zv[e]);
+            const float y = act(zv[e]);
             float dy;
             if (mode == 0) dy = k0 * (y - tv[e]);
             else if (mode == 1) dy = k0 * tv[e] + k1 * y;
             else { const float d = y - tv[e]; dy = inv_b * (fabsf(d) < 1.0f ? d : (d > 0.f ? 1.0f : -1.0f)); }
-            o[e] = f2bf(dy * gelu_grad(zv[e]));
+            o[e] = f2bf(dy * (out_act == 0 ? gelu_grad(zv[e]) : out_act == 1 ? 1.0f : y * (1.0f - y)));
         }
         *reinterpret_cast<bf16x4*>(dz3 + (size_t)row * D + i) = o;
     }
@@ -170,8 +176,8 @@ unsigned blocks_for(size_t n) { return (unsigned)((n + 255) / 256); }
 extern "C" int cmdiad_loss_head(const float* z3, const float* target, int M, int D, int mode, float inv_b,
                                 float* row_loss, uint16_t* dz3, float* y_out, cmdiad_stream_t stream)
 {
-    CMDIAD_REQUIRE(z3 && target && row_loss && M > 0 && D % 4 == 0 && mode >= 0 && mode <= 2, CMDIAD_ERR_ARG,
-                   "cmdiad_loss_head: bad args");
+    CMDIAD_REQUIRE(z3 && target && row_loss && M > 0 && D % 4 == 0 && mode >= 0 && (mode & 255) <= 2 && (mode >> 8) <= 2, CMDIAD_ERR_ARG,
+                   "cmdiad_loss_head: bad args (mode %d)", mode);
     hipLaunchKernelGGL(loss_head_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, z3, target, M, D, mode, inv_b,
                        row_loss, (bf16_t*)dz3, y_out);
     CMDIAD_CHECK_LAUNCH();

@@ -13,11 +13,15 @@ The other heads of the reference file -- HallucinationCrossModalityConv (72-143)
 ``hallucination_generation`` / ``forward`` signatures.  INFERENCE (``eval()`` or ``no_grad``) runs eval-mode arithmetic
 (BatchNorm running statistics folded into the convolution weights) on the implicit-GEMM convolution kernel
 (cmdiad_conv2d_nhwc_bf16) and cmdiad_upsample_bicubic.  TRAINING (``train()`` with gradients enabled:
-hallucination_network_pretrain.py:106-147 with --train_method HallucinationCrossModalityConv / *FeatureTo*Input*) evaluates the
-module's own torch layers on the GPU -- fp32, batch-statistics BatchNorm, autograd -- so the reference's loop trains these
-heads unchanged; that path is torch's (MIOpen / rocBLAS) kernels, not hand-written HIP: these heads are outside the
-benchmarked hot path.  tests/test_gpu_heads.py checks a three-step Adam loss curve against the reference's own (golden G12).
+hallucination_network_pretrain.py:106-147): HallucinationCrossModalityConv trains on the hand-written path of
+cmdiad_amd/conv_train.py (batch-statistics BatchNorm, bf16 MFMA convolutions forward / data gradient / weight gradient, exposed
+to autograd; CMDIAD_CONV_TRAIN=torch selects the module's own torch layers as the A/B reference); the two feature-to-input heads
+evaluate the module's own torch layers on the GPU -- fp32, autograd, torch's (MIOpen / rocBLAS) kernels -- so the reference's
+loop trains them unchanged.  tests/test_gpu_heads.py checks a three-step Adam loss curve of each head against the reference's
+own (golden G12); tests/test_gpu_conv_train.py the hand-written path against torch autograd.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -158,7 +162,14 @@ class HallucinationCrossModalityConv(_PackedHead):
 
     def forward(self, xyz_feature, rgb_feature, sigmoid, dist_method):
         """hallucination_network.py:133-147 -> (distance_to_xyz_real, distance_to_rgb_real)."""
-        if self._autograd():   # the towers' own layers: batch-statistics BatchNorm, graph for loss.backward()
+        if self._autograd() and os.environ.get("CMDIAD_CONV_TRAIN", "hip") == "hip":
+            # hand-written forward + backward (cmdiad_amd/conv_train.py): batch-statistics BatchNorm, bf16 MFMA convolutions,
+            # exposed to autograd so loss.backward() / Adam of the reference's loop work unchanged
+            from .. import conv_train
+            assert xyz_feature.shape[1:] == (3136, self.xyz_dim) and rgb_feature.shape[1:] == (3136, self.rgb_dim)
+            return (conv_train.tower_loss(self.rgb_conv, rgb_feature, xyz_feature, sigmoid is True),
+                    conv_train.tower_loss(self.xyz_conv, xyz_feature, rgb_feature, sigmoid is True))
+        if self._autograd():   # CMDIAD_CONV_TRAIN=torch: the towers' own torch layers (MIOpen) -- the A/B reference of the above
             dev = self._device()
             xyz_feature, rgb_feature = xyz_feature.to(dev).float(), rgb_feature.to(dev).float()
             xyz_h = feature_reshape_back(self.rgb_conv(feature_reshape(rgb_feature)))

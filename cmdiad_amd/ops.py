@@ -305,6 +305,45 @@ def col_moments(x):
     return mean, acc[1] / rows - mean * mean
 
 
+def bn_relu_fwd(z, scale, shift):
+    """z [M,C] f32 -> relu(z * scale + shift) as bf16 [M,C] (cmdiad_bn_relu_fwd: batch-statistics BatchNorm2d + ReLU)."""
+    _chk(z, torch.float32, "bn_relu.z"); _chk(scale, torch.float32, "bn_relu.scale"); _chk(shift, torch.float32, "bn_relu.shift")
+    M, C = z.shape
+    y = torch.empty((M, C), dtype=torch.bfloat16, device=z.device)
+    _call("cmdiad_bn_relu_fwd", _p(z), _p(scale), _p(shift), M, C, _p(y), _stream())
+    return y
+
+
+def bn_relu_bwd(dy, z, scale, shift, mean, rstd, chunks=64):
+    """Backward of bn_relu_fwd: dy, z [M,C] f32; per-channel f32 vectors -> (dz bf16 [M,C], dgamma [C], dbeta [C])
+    (cmdiad_bn_relu_bwd_reduce -> cmdiad_reduce_slabs x2 -> cmdiad_bn_relu_bwd_apply)."""
+    _chk(dy, torch.float32, "bn_bwd.dy"); _chk(z, torch.float32, "bn_bwd.z")
+    M, C = z.shape
+    p1 = torch.empty((chunks, C), dtype=torch.float32, device=z.device)
+    p2 = torch.empty((chunks, C), dtype=torch.float32, device=z.device)
+    _call("cmdiad_bn_relu_bwd_reduce", _p(dy), _p(z), _p(scale), _p(shift), _p(mean), _p(rstd), M, C, chunks, _p(p1), _p(p2), _stream())
+    dbeta = torch.empty((C,), dtype=torch.float32, device=z.device)
+    dgamma = torch.empty((C,), dtype=torch.float32, device=z.device)
+    _call("cmdiad_reduce_slabs", _p(p1), chunks, C, C, 1.0, _p(dbeta), _stream())
+    _call("cmdiad_reduce_slabs", _p(p2), chunks, C, C, 1.0, _p(dgamma), _stream())
+    dz = torch.empty((M, C), dtype=torch.bfloat16, device=z.device)
+    _call("cmdiad_bn_relu_bwd_apply", _p(dy), _p(z), _p(scale), _p(shift), _p(mean), _p(rstd), _p(dbeta), _p(dgamma), M, C, _p(dz), _stream())
+    return dz, dgamma, dbeta
+
+
+def pad_nhwc(x, rows_multiple=64):
+    """x [B,H,W,C] bf16 -> (buffer [guard + rows + guard, C] bf16, guard, rows): the zero-bordered copy [B,H+2,W+2,C] flattened to
+    rows (zero-padded up to a multiple of rows_multiple), between two zero guards of W+3 rows so that every 3x3 tap's row
+    offset stays inside the buffer (cmdiad_pad_nhwc_bf16)."""
+    _chk(x, torch.bfloat16, "pad.x")
+    B, H, W, C = x.shape
+    guard = W + 3
+    rows = (B * (H + 2) * (W + 2) + rows_multiple - 1) // rows_multiple * rows_multiple
+    buf = torch.zeros((guard + rows + guard, C), dtype=torch.bfloat16, device=x.device)
+    _call("cmdiad_pad_nhwc_bf16", _p(x), B, H, W, C, _p(buf[guard:]), _stream())
+    return buf, guard, rows
+
+
 def moments3(xyz):
     """xyz [rows, 3] f32 -> (mean [3], covariance [3,3]) in float64, biased (cmdiad_moments3)."""
     _chk(xyz, torch.float32, "moments3.xyz")

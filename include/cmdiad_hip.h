@@ -431,9 +431,35 @@ int cmdiad_ocsvm_fit(const float* X, int n, int F, double nu, int max_iter, doub
 
 /* Loss head: y = GELU(z3); mode 0 'l2' sum_rows ||y-t||_2, 1 'cos_dist' sum_rows (1 - cos(y,t)), 2 'smooth_l1'
  * sum of elements (beta 1); row_loss [M] gets the per-row terms (reduce with cmdiad_sum_vector, scale 1/B);
- * dz3 [M,D] bf16 (NULL allowed) = inv_b * dLoss/dz3 (through the output GELU); y_out [M,D] f32 optional. */
+ * dz3 [M,D] bf16 (NULL allowed) = inv_b * dLoss/dz3 (through the output GELU); y_out [M,D] f32 optional.
+ * ABI 3: mode + CMDIAD_LOSS_OUT_NONE = no output activation (y = z3), mode + CMDIAD_LOSS_OUT_SIGMOID = sigmoid of the output AND
+ * of the target -- the convolutional head's two losses (hallucination_network.py:136-147). */
+enum { CMDIAD_LOSS_OUT_NONE = 256, CMDIAD_LOSS_OUT_SIGMOID = 512 };
 int cmdiad_loss_head(const float* z3, const float* target, int M, int D, int mode, float inv_b,
                      float* row_loss, uint16_t* dz3, float* y_out, cmdiad_stream_t stream);
+
+/* ---- training side of the convolutional FtoF head (models/hallucination_network.py:72-147: conv3x3 -> BatchNorm2d -> ReLU x3,
+ * conv3x3 per direction; hallucination_network_pretrain.py:106-147 trains it in train() mode = BatchNorm on batch statistics).
+ * Activations are NHWC flattened to [M = B*H*W, C].  Convolution forward and data gradient: cmdiad_conv2d_nhwc_bf16 (the latter on
+ * flipped, transposed weights); weight gradient: cmdiad_gemm_tn_bf16 per filter tap over cmdiad_pad_nhwc_bf16 copies. ---- */
+
+/* y = relu(z * scale[c] + shift[c]) as bf16: BatchNorm (scale = gamma / sqrt(var + eps), shift = beta - mean * scale, batch
+ * statistics from cmdiad_col_moments) + ReLU, nn.Sequential(..., BatchNorm2d, ReLU, ...) of hallucination_network.py:80-90.  C % 8 == 0. */
+int cmdiad_bn_relu_fwd(const float* z, const float* scale, const float* shift, size_t M, int C, uint16_t* y, cmdiad_stream_t stream);
+/* Backward of the same pair (autograd of hallucination_network_pretrain.py:146): with g = dy where z * scale + shift > 0 else 0 and
+ * xhat = (z - mean) * rstd:  part_dbeta / part_dgamma [chunks][C] = column sums of g / g * xhat over `chunks` row ranges (add them
+ * with cmdiad_reduce_slabs: fixed order), then dz = scale * (g - dbeta / M - xhat * dgamma / M) as bf16. */
+int cmdiad_bn_relu_bwd_reduce(const float* dy, const float* z, const float* scale, const float* shift, const float* mean,
+                              const float* rstd, size_t M, int C, int chunks, float* part_dbeta, float* part_dgamma,
+                              cmdiad_stream_t stream);
+int cmdiad_bn_relu_bwd_apply(const float* dy, const float* z, const float* scale, const float* shift, const float* mean,
+                             const float* rstd, const float* dbeta, const float* dgamma, size_t M, int C, uint16_t* dz,
+                             cmdiad_stream_t stream);
+/* x [B,H,W,C] bf16 -> the interior of out [B,H+2,W+2,C] (border untouched: the caller zero-fills out once).  In that layout the
+ * (ky, kx) tap of a 3x3 convolution with padding 1 is the row offset (ky-1)*(W+2) + (kx-1): the weight gradient of a tap is
+ * one [M',N]^T [M',C] product of the padded output gradient with the shifted padded input.  C % 8 == 0. */
+int cmdiad_pad_nhwc_bf16(const uint16_t* x, int B, int H, int W, int C, uint16_t* out, cmdiad_stream_t stream);
+
 /* out[i] = scale * sum_s slabs[s*stride + i] in fixed order (split-K partials, column partials). n, stride % 4 == 0 */
 int cmdiad_reduce_slabs(const float* slabs, int S, size_t n, size_t stride, float scale, float* out,
                         cmdiad_stream_t stream);

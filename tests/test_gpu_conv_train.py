@@ -1,0 +1,162 @@
+"""Hand-written training path of the convolutional FtoF head (cmdiad_amd/conv_train.py, csrc/conv_train.hip; the reference's
+models/hallucination_network.py:72-147 trained by hallucination_network_pretrain.py:106-147 in train() mode) against torch
+autograd in float64 on the same bf16-rounded operands: the BatchNorm + ReLU pair forward and backward, the weight gradient by
+filter tap, the data gradient, a whole tower (loss, all ten gradients, running statistics).  The three-step Adam curve of the
+REFERENCE's own module is tests/test_gpu_heads.py::test_head_training_follows_the_reference_loss_curve[conv_ftof] (golden G12),
+which runs through this path."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from cmdiad_amd import conv_train, ops  # noqa: E402
+
+DEV = "cuda"
+
+
+def _bf(t):
+    return t.bfloat16().float()
+
+
+def _cos(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a @ b) / (a.norm() * b.norm()))
+
+
+@pytest.mark.parametrize("M,C", [(3136 * 2, 768), (1000, 64), (77, 8)])
+def test_batchnorm_relu_forward_and_backward(M, C):
+    g = torch.Generator().manual_seed(M + C)
+    z = (torch.randn(M, C, generator=g) * 1.5 + 0.3).double().requires_grad_(True)
+    gamma, beta = (1 + 0.2 * torch.randn(C, generator=g)).double(), (0.1 * torch.randn(C, generator=g)).double()
+    gamma.requires_grad_(True); beta.requires_grad_(True)
+    dy = torch.randn(M, C, generator=g).double()
+    y = F.relu(F.batch_norm(z, None, None, gamma, beta, training=True, eps=1e-5))
+    y.backward(dy)
+    zd = z.detach().float().to(DEV)
+    mean64, var64 = ops.col_moments(zd)
+    np.testing.assert_allclose(mean64.cpu().numpy(), z.detach().mean(0).numpy(), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(var64.cpu().numpy(), z.detach().var(0, unbiased=False).numpy(), rtol=1e-5)
+    rstd = (1.0 / torch.sqrt(var64 + 1e-5))
+    scale = (gamma.detach().to(DEV) * rstd).float()
+    shift = (beta.detach().to(DEV) - mean64 * scale.double()).float()
+    got = ops.bn_relu_fwd(zd, scale, shift)
+    np.testing.assert_allclose(got.float().cpu().numpy(), y.detach().numpy(), rtol=8e-3, atol=8e-3)   # bf16 output
+    dz, dgamma, dbeta = ops.bn_relu_bwd(dy.float().to(DEV), zd, scale, shift, mean64.float(), rstd.float())
+    np.testing.assert_allclose(dgamma.cpu().numpy(), gamma.grad.numpy(), rtol=2e-3, atol=2e-3 * float(gamma.grad.abs().mean()))
+    np.testing.assert_allclose(dbeta.cpu().numpy(), beta.grad.numpy(), rtol=2e-3, atol=2e-3 * float(beta.grad.abs().mean()))
+    np.testing.assert_allclose(dz.float().cpu().numpy(), z.grad.numpy(), rtol=1e-2, atol=1e-2 * float(z.grad.abs().mean()))
+
+
+@pytest.mark.parametrize("B,H,W,C,N", [(2, 56, 56, 768, 768), (3, 9, 7, 64, 72), (1, 5, 5, 128, 8), (16, 6, 6, 64, 64)])
+def test_weight_and_data_gradient_of_a_3x3_convolution(B, H, W, C, N):
+    g = torch.Generator().manual_seed(B + H + C + N)
+    x = _bf(torch.randn(B, C, H, W, generator=g)).double()
+    w = _bf(torch.randn(N, C, 3, 3, generator=g) / (9 * C) ** 0.5).double().requires_grad_(True)
+    dz = _bf(torch.randn(B, N, H, W, generator=g)).double()
+    x.requires_grad_(True)
+    F.conv2d(x, w, None, padding=1).backward(dz)
+    M = B * H * W
+    x_rows = x.detach().permute(0, 2, 3, 1).reshape(M, C).contiguous().float().to(DEV).bfloat16()
+    dz_rows = dz.permute(0, 2, 3, 1).reshape(M, N).contiguous().float().to(DEV).bfloat16()
+    dw = conv_train._wgrad(dz_rows, x_rows, B, H, W)
+    scale = float(w.grad.abs().mean())
+    assert dw.shape == (N, C, 3, 3)
+    np.testing.assert_allclose(dw.cpu().numpy(), w.grad.numpy(), rtol=2e-3, atol=2e-3 * scale)
+    if N % 64 == 0:   # the data gradient is a convolution with N input channels
+        dx, _ = ops.conv2d_nhwc(dz_rows.view(B, H, W, N), conv_train._conv_w_dgrad(w.detach().float().to(DEV)), C,
+                                want_f32=True, want_bf16=False)
+        ref = x.grad.permute(0, 2, 3, 1)
+        np.testing.assert_allclose(dx.cpu().numpy(), ref.numpy(), rtol=2e-3, atol=2e-3 * float(ref.abs().mean()))
+
+
+def _tower(cin, width, gen):
+    layers = []
+    for i in range(4):
+        conv = nn.Conv2d(cin if i == 0 else width, width, 3, padding=1, bias=False)
+        with torch.no_grad():
+            conv.weight.copy_(torch.randn(conv.weight.shape, generator=gen) * (2.0 / (9 * conv.in_channels)) ** 0.5)
+        layers.append(conv)
+        if i < 3:
+            bn = nn.BatchNorm2d(width)
+            with torch.no_grad():
+                bn.weight.copy_(1 + 0.2 * torch.randn(width, generator=gen)); bn.bias.copy_(0.1 * torch.randn(width, generator=gen))
+            layers += [bn, nn.ReLU()]
+    return nn.Sequential(*layers)
+
+
+@pytest.mark.parametrize("B,side,C,sigmoid", [(2, 12, 128, False), (3, 8, 64, True), (2, 56, 768, False)])
+def test_tower_loss_and_gradients_vs_torch_autograd(B, side, C, sigmoid):
+    """One direction of the head: loss, the ten parameter gradients and the BatchNorm running statistics against the same
+    nn.Sequential under torch autograd in float64 (CPU).  The reference rounds its forward GEMM operands to bf16 where the GPU path
+    does (straight-through), so both sides open the same ReLUs -- against an un-rounded forward ~0.2 % of the ReLU masks differ,
+    which alone is sqrt(0.002) = 4-5 % of gradient norm per stage (measured: cosine 0.994-0.997 after three stages).  What remains is
+    the bf16 rounding of the output gradients: cosine > 0.999 per gradient tensor."""
+    gen = torch.Generator().manual_seed(B * side + C)
+    rt = torch.float64 if C < 768 else torch.float32      # (the full-size tower in float64 on the host would take minutes)
+    ref = _tower(C, C, gen).to(rt).train()
+    mine = _tower(C, C, torch.Generator().manual_seed(B * side + C)).to(DEV).train()
+    T = side * side
+    x, t = torch.randn(B, T, C, generator=gen), torch.randn(B, T, C, generator=gen)
+
+    def rb(v):   # value rounded to bf16 where the GPU path rounds (GEMM operands), gradient passed straight through
+        return v + (v.detach().float().bfloat16().to(v.dtype) - v.detach())
+
+    h = rb(x.to(rt).transpose(1, 2).reshape(B, C, side, side))
+    for m in ref:
+        if isinstance(m, nn.Conv2d):
+            h = F.conv2d(h, rb(m.weight), None, padding=1)
+        elif isinstance(m, nn.BatchNorm2d):
+            h = m(h)
+        else:
+            h = rb(F.relu(h))
+    h = h.reshape(B, C, T).transpose(1, 2)
+    a, b = (torch.sigmoid(h), torch.sigmoid(t.to(rt))) if sigmoid else (h, t.to(rt))
+    d = torch.linalg.norm(a - b, dim=2)
+    ref_loss = d.sum() / d.shape[0]
+    ref_loss.backward()
+    loss = conv_train.tower_loss(mine, x.to(DEV), t.to(DEV), sigmoid)
+    assert loss.requires_grad
+    np.testing.assert_allclose(float(loss.detach()), float(ref_loss.detach()), rtol=3e-3)
+    loss.backward()
+    report = {}
+    for (name, p), q in zip(mine.named_parameters(), ref.parameters()):
+        assert p.grad is not None and p.grad.shape == q.grad.shape, name
+        report[name] = (_cos(p.grad.cpu(), q.grad), float((p.grad.cpu().double() - q.grad.double()).norm() / q.grad.double().norm()))
+    assert all(c > 0.999 and rel < 0.05 for c, rel in report.values()), report
+    for (name, u), v in zip(mine.named_buffers(), ref.buffers()):
+        if u.dtype.is_floating_point:
+            np.testing.assert_allclose(u.cpu().numpy(), v.double().numpy(), rtol=5e-3, atol=5e-4, err_msg=name)
+        else:
+            assert int(u) == int(v) == 1, name
+    with torch.no_grad():   # no graph, no statistics update
+        l2 = conv_train.tower_loss(mine, x.to(DEV), t.to(DEV), sigmoid)
+    assert not l2.requires_grad
+
+
+def test_head_module_routes_training_through_the_hip_path(monkeypatch):
+    """HallucinationCrossModalityConv.forward in train() mode: the hand-written path (default) and the module's own torch layers
+    (CMDIAD_CONV_TRAIN=torch, fp32 operands) give the same two losses, running statistics and -- up to the ReLU masks that bf16
+    operands flip (see above: cosine 0.994-0.997 for the deepest layer) -- gradients."""
+    from cmdiad_amd.models import hallucination_network as hn
+    from oracle import heads
+    res = {}
+    gen = torch.Generator().manual_seed(9)
+    a, b = torch.randn(2, 3136, 768, generator=gen), torch.randn(2, 3136, 768, generator=gen)
+    for mode in ("hip", "torch"):
+        monkeypatch.setenv("CMDIAD_CONV_TRAIN", mode)
+        m = hn.HallucinationCrossModalityConv(None, 768, 768)
+        m.load_state_dict(heads.synth_head_state_dict("conv_ftof", 41))
+        m.to(DEV).train()
+        lx, lr = m(a, b, False, "l2")
+        (lx + lr).backward()
+        res[mode] = (float(lx.detach()), float(lr.detach()), {k: p.grad.clone() for k, p in m.named_parameters()},
+                     {k: v.clone() for k, v in m.named_buffers()})
+    np.testing.assert_allclose(res["hip"][:2], res["torch"][:2], rtol=3e-3)
+    for k, gq in res["torch"][2].items():
+        assert _cos(res["hip"][2][k], gq) > 0.99, k
+    for k, v in res["torch"][3].items():
+        if v.dtype.is_floating_point:
+            np.testing.assert_allclose(res["hip"][3][k].cpu().numpy(), v.cpu().numpy(), rtol=5e-3, atol=5e-4, err_msg=k)
