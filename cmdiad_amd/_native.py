@@ -87,6 +87,7 @@ SIGNATURES = {
     "cmdiad_score_tail": [P, P, P, P, I, I, I, U32, P, P],
     "cmdiad_score_final": [P, P, I, I, P, P],
     "cmdiad_coreset_greedy": [P, I, I, I, I, P, P, SZ, P],
+    "cmdiad_sparse_project_f32": [P, SZ, I, P, P, P, I, P, P],
     "cmdiad_normalize_cast": [P, SZ, I, F, F, P, P, P, I, P],
     "cmdiad_im2col_patch8": [P, I, I, P, P],
     "cmdiad_vit_assemble": [P, P, P, I, I, I, P, P],

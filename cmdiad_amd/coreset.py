@@ -20,3 +20,30 @@ def greedy_coreset(z, n_select, coreset_dtype="FP16"):
     nat.check(nat.lib().cmdiad_coreset_greedy(ops._p(z), n, d, n_select, 0, ops._p(out), ops._p(ws), wsb, ops._stream()),
               "cmdiad_coreset_greedy")
     return out
+
+
+def sparse_random_projection(z_lib, eps=0.9, random_state=None):
+    """z_lib [n,d] f32 cuda -> SparseRandomProjection(eps=eps, random_state=random_state).fit_transform(z_lib) [n, n_comp] f32, on the
+    device and bit-identical to the host's (features.py:360-371).  scikit-learn FITS the transformer -- the Johnson-Lindenstrauss
+    dimension for n samples and the random sparse matrix, from its own generator -- on a zero-strided stand-in with the library's
+    shape (the fit never looks at values); the TRANSFORM is cmdiad_sparse_project_f32.  Raises ValueError as scikit-learn does when
+    eps asks for more components than there are features."""
+    import numpy as np
+    from sklearn import random_projection
+    n, d = z_lib.shape
+    tr = random_projection.SparseRandomProjection(eps=eps, random_state=random_state)
+    tr.fit(np.lib.stride_tricks.as_strided(np.zeros((1,), dtype=np.float32), shape=(n, d), strides=(0, 0), writeable=False))
+    comp = tr.components_.tocsr()
+    comp.sort_indices()
+    if comp.dtype != np.float32:
+        raise RuntimeError(f"SparseRandomProjection.components_ is {comp.dtype}: the float32 arithmetic of the device transform "
+                           "would not match this scikit-learn")
+    dev = z_lib.device
+    indptr = torch.from_numpy(comp.indptr.astype(np.int32)).to(dev)
+    indices = torch.from_numpy(comp.indices.astype(np.int32)).to(dev)
+    data = torch.from_numpy(comp.data.astype(np.float32)).to(dev)
+    z = z_lib.float().contiguous()
+    out = torch.empty((n, comp.shape[0]), dtype=torch.float32, device=dev)
+    nat.check(nat.lib().cmdiad_sparse_project_f32(ops._p(z), n, d, ops._p(indptr), ops._p(indices), ops._p(data), comp.shape[0],
+                                                  ops._p(out), ops._stream()), "cmdiad_sparse_project_f32")
+    return out

@@ -55,7 +55,7 @@ def method_class(args):
 
 # ------------------------------------------------------------------------------------------------ assignment
 def class_cost(n_train, n_test, f_coreset=0.1, libraries=2, rows_per_image=3136, t_image=2.0e-3, t_row_round=1.18e-10,
-               t_proj_row=7.0e-6, t_svm_row=1.0e-7):
+               t_proj_row=1.0e-6, t_svm_row=1.0e-7):
     """Estimated seconds one GPU (and its host thread) spends on a class: two passes over the train images (memory bank,
     late-fusion bank) and one over the test images at ``t_image`` each; per library the sparse random projection on the host
     (``t_proj_row`` per library row) and a greedy coreset of f*rows rounds each scanning all rows (csrc/coreset.hip: 90 us per

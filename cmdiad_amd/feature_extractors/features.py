@@ -358,12 +358,15 @@ class Features(torch.nn.Module):
         from .. import coreset
         print(f"   Fitting random projections. Start dim = {z_lib.shape}.")
         try:
-            transformer = random_projection.SparseRandomProjection(eps=eps, random_state=self.random_state)
-            z = torch.tensor(transformer.fit_transform(z_lib.detach().cpu().numpy()))
+            if os.environ.get("CMDIAD_PROJECT_HOST", "0") == "1":   # the reference's host transform (A/B runs, parity tests)
+                transformer = random_projection.SparseRandomProjection(eps=eps, random_state=self.random_state)
+                z = torch.tensor(transformer.fit_transform(z_lib.detach().cpu().numpy()))
+            else:   # fitted by scikit-learn, transformed on the device: bit-identical (coreset.sparse_random_projection)
+                z = coreset.sparse_random_projection(z_lib.detach().to(self.device), eps, self.random_state)
             print(f"   DONE.                 Transformed dim = {z.shape}.")
         except ValueError:
             print("   Error: could not project vectors. Please increase `eps`.")
-            z = z_lib.detach().cpu()
+            z = z_lib.detach()
         if self.args.dist_method_coreset != "l2":
             raise NotImplementedError("only dist_method_coreset='l2' is implemented")
         return coreset.greedy_coreset(z.to(self.device), n, coreset_dtype).cpu()

@@ -360,6 +360,15 @@ size_t cmdiad_coreset_workspace_bytes(int n, int d, int n_select);
 int cmdiad_coreset_greedy(const float* z32, int n, int d, int n_select, int first_idx, int64_t* idx_out,
                           void* workspace, size_t workspace_bytes, cmdiad_stream_t stream);
 
+/* Sparse random projection in front of the coreset selection (features.py:360-371: SparseRandomProjection.fit_transform): out [n,
+ * n_comp] = X [n,d] . components^T with `components` [n_comp,d] in CSR (int32 indptr / sorted indices, f32 data: the fitted
+ * transformer's components_, ABI 3).  Per output element the products are added one by one in the order of the row's non-zeros,
+ * each product and each sum rounded to float32 -- the arithmetic of the scipy routine sklearn calls, so out is bit-identical to the
+ * host transform.  d <= 4096. */
+int cmdiad_sparse_project_f32(const float* X, size_t n, int d, const int* indptr, const int* indices, const float* data, int n_comp,
+                              float* out, cmdiad_stream_t stream);
+
+
 /* ---------------------------------------------------------------------------------------------
  * Small fused element-wise / layout kernels
  * ------------------------------------------------------------------------------------------- */

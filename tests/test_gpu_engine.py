@@ -196,6 +196,25 @@ def test_coreset_vs_reference_golden(golden):
     np.testing.assert_array_equal(sel.numpy(), g["idx"])
 
 
+@pytest.mark.parametrize("n,d,eps,seed", [(5003, 768, 0.9, 3), (20000, 1152, 0.9, 0), (777, 256, 0.95, 11), (9, 2048, 0.9, 5)])
+def test_sparse_random_projection_on_device_is_bit_identical_to_sklearn(n, d, eps, seed):
+    """features.py:360-363: SparseRandomProjection(eps, random_state).fit_transform on the host against
+    coreset.sparse_random_projection (scikit-learn fits, cmdiad_sparse_project_f32 transforms): same shape, same bits."""
+    from sklearn import random_projection
+    from cmdiad_amd import coreset
+    z = torch.randn(n, d, generator=torch.Generator().manual_seed(n + d))
+    want = random_projection.SparseRandomProjection(eps=eps, random_state=seed).fit_transform(z.numpy())
+    got = coreset.sparse_random_projection(z.to(DEV), eps, seed)
+    assert got.dtype == torch.float32 and tuple(got.shape) == want.shape
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+
+
+def test_sparse_random_projection_raises_like_sklearn_when_eps_is_too_small():
+    from cmdiad_amd import coreset
+    with pytest.raises(ValueError):   # the Johnson-Lindenstrauss dimension for eps = 0.1 exceeds 64 features
+        coreset.sparse_random_projection(torch.randn(1000, 64).to(DEV), 0.1, 0)
+
+
 def test_late_fusion_fit_on_device_equals_sklearn(weights, monkeypatch):
     """features.py:352-358 with CMDIAD_OCSVM_DEVICE=1: the drop-in's two one-class SVMs are fitted by cmdiad_ocsvm_fit and equal
     scikit-learn fitted on the same s_lib / s_map_lib rows bit for bit (score maps of 2 train samples: 100 352 rows)."""
