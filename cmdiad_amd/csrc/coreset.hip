@@ -17,6 +17,7 @@
 // load instruction of a wave is one contiguous 1 KiB piece and a row's sum of squares lives in ONE lane: no cross-lane
 // reduction per row (round 1's wave-per-row form spent a 6-step butterfly per 668 bytes and reached 2.3 TB/s).
 #include <hip/hip_fp16.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -31,6 +32,12 @@ __device__ __forceinline__ float sq_diff_acc(unsigned a, unsigned b, float acc)
     return acc + (x * x + y * y);
 }
 
+// EARLY: partial-distance termination, exact.  The squares are non-negative and accumulated in fp32, so a row's partial sum
+// never decreases, and sqrt and the fp16 rounding are monotone: once fp16(sqrt(partial)) >= min_d[row], the full distance cannot be
+// below min_d[row] either and the row's minimum stays as it is.  Every eight dimension pairs the wave votes; when all of its 256
+// rows are settled it stops reading (the remaining 1 KiB pieces of its rows are never fetched).  Late in a selection most rows sit
+// close to some centre and far from the newest one, so most waves leave after a fraction of the dimensions.
+template <bool EARLY>
 __global__ __launch_bounds__(256) void coreset_round_kernel(const __half* __restrict__ z, const uint4* __restrict__ zT, int n, int n4,
                                                             int d2, __half* __restrict__ min_d,
                                                             const unsigned long long* __restrict__ best_prev,
@@ -48,6 +55,33 @@ __global__ __launch_bounds__(256) void coreset_round_kernel(const __half* __rest
     if (q < n4) {
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
         const uint4* src = zT + q;
+        __half md[4];
+        *reinterpret_cast<uint2*>(md) = *reinterpret_cast<const uint2*>(min_d + (size_t)q * 4);
+        if constexpr (EARLY) {
+            int c = 0;
+            for (; c + 8 <= d2; c += 8) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const uint4 v = src[(size_t)(c + e) * n4];
+                    const unsigned pv = s_piv[c + e];
+                    s0 = sq_diff_acc(v.x, pv, s0);
+                    s1 = sq_diff_acc(v.y, pv, s1);
+                    s2 = sq_diff_acc(v.z, pv, s2);
+                    s3 = sq_diff_acc(v.w, pv, s3);
+                }
+                const bool settled = !__hlt(__float2half(sqrtf(s0)), md[0]) && !__hlt(__float2half(sqrtf(s1)), md[1]) &&
+                                     !__hlt(__float2half(sqrtf(s2)), md[2]) && !__hlt(__float2half(sqrtf(s3)), md[3]);
+                if (__all(settled)) { c = d2; break; }   // wave-uniform: every row of the wave keeps its minimum
+            }
+            for (; c < d2; ++c) {
+                const uint4 v = src[(size_t)c * n4];
+                const unsigned pv = s_piv[c];
+                s0 = sq_diff_acc(v.x, pv, s0);
+                s1 = sq_diff_acc(v.y, pv, s1);
+                s2 = sq_diff_acc(v.z, pv, s2);
+                s3 = sq_diff_acc(v.w, pv, s3);
+            }
+        } else {
 #pragma unroll 8
         for (int c = 0; c < d2; ++c) {
             const uint4 v = src[(size_t)c * n4];
@@ -57,9 +91,8 @@ __global__ __launch_bounds__(256) void coreset_round_kernel(const __half* __rest
             s2 = sq_diff_acc(v.z, pv, s2);
             s3 = sq_diff_acc(v.w, pv, s3);
         }
+        }
         const float ss[4] = {s0, s1, s2, s3};
-        __half md[4];
-        *reinterpret_cast<uint2*>(md) = *reinterpret_cast<const uint2*>(min_d + (size_t)q * 4);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = q * 4 + r;
@@ -155,9 +188,14 @@ extern "C" int cmdiad_coreset_greedy(const float* z32, int n, int d, int n_selec
     }
     hipLaunchKernelGGL(coreset_init_kernel, dim3(2048), dim3(256), 0, s, z32, n, n4, d, first_idx, z16, zT, min_d);
     const int grid = (n4 + 255) / 256;
-    for (int r = 0; r + 1 < n_select; ++r)
-        hipLaunchKernelGGL(coreset_round_kernel, dim3(grid), dim3(256), 0, s, z16, (const uint4*)zT, n, n4, d / 2, min_d,
-                           r == 0 ? nullptr : best + (r - 1), best + r, first_idx);
+    const char* ee = getenv("CMDIAD_CORESET_EARLY");   // =0: every row reads all its dimensions every round (A/B runs; read per call)
+    const bool early = !(ee && ee[0] == '0');
+    for (int r = 0; r + 1 < n_select; ++r) {
+        if (early) hipLaunchKernelGGL(coreset_round_kernel<true>, dim3(grid), dim3(256), 0, s, z16, (const uint4*)zT, n, n4, d / 2, min_d,
+                                      r == 0 ? nullptr : best + (r - 1), best + r, first_idx);
+        else hipLaunchKernelGGL(coreset_round_kernel<false>, dim3(grid), dim3(256), 0, s, z16, (const uint4*)zT, n, n4, d / 2, min_d,
+                                r == 0 ? nullptr : best + (r - 1), best + r, first_idx);
+    }
     hipLaunchKernelGGL(coreset_decode_kernel, dim3((n_select + 255) / 256), dim3(256), 0, s, best, n_select, first_idx,
                        idx_out);
     CMDIAD_CHECK_LAUNCH();

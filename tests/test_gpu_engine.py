@@ -185,6 +185,23 @@ def test_greedy_coreset_matches_fp16_restatement():
     np.testing.assert_array_equal(sel.numpy(), np.array(ref))
 
 
+def test_coreset_early_termination_keeps_every_pick(monkeypatch):
+    """The partial-distance early exit of the round kernel (a wave stops reading its rows' dimensions once every row's partial
+    distance has reached its current minimum) is exact: same picks as the full scan on clustered rows with exact duplicates
+    (the structure of a patch library: background patches repeat, neighbouring patches are close)."""
+    from cmdiad_amd import coreset
+    g = torch.Generator().manual_seed(17)
+    centres = torch.randn(40, 334, generator=g) * 3
+    z = centres[torch.randint(0, 40, (30000,), generator=g)] + 0.3 * torch.randn(30000, 334, generator=g)
+    z[5000:9000] = z[4999]                 # a run of identical rows
+    z[20000:20300] = 0.0
+    picks = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("CMDIAD_CORESET_EARLY", mode)
+        picks[mode] = coreset.greedy_coreset(z.to(DEV), 1500).cpu()
+    assert torch.equal(picks["1"], picks["0"]) and len(set(picks["1"].tolist())) == 1500
+
+
 def test_coreset_vs_reference_golden(golden):
     """get_coreset_idx_randomp (host sparse projection + cmdiad_coreset_greedy) against the selection the REFERENCE's
     own function made on the same rows (tests/golden/g9_coreset.npz, features.py:360-425)."""
