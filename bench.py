@@ -461,6 +461,45 @@ def train_step_leg(dev, steps=50, warm=10):
                 tokens_per_s=round(32 * 3136 / dt, 0))
 
 
+def conv_head_train_leg(dev, batch=8, steps=6, warm=2):
+    """one training step of the convolutional FtoF head (HallucinationCrossModalityConv: per direction conv3x3 ->
+    batch-statistics BatchNorm -> ReLU three times + conv3x3, hallucination_network.py:72-147) -- both directions, forward + l2 loss +
+    backward + Adam -- on the hand-written path of cmdiad_amd/conv_train.py.  FLOPs: 2 towers x (4 forward + 3 data-gradient + 4
+    weight-gradient convolutions) x 2 M 768 (9 768), M = batch x 3136 positions."""
+    import torch
+    from cmdiad_amd.models.hallucination_network import HallucinationCrossModalityConv
+    torch.manual_seed(3407)
+    net = HallucinationCrossModalityConv(None, 768, 768).to(dev).train()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+    g = torch.Generator(device=dev).manual_seed(3407)
+    a, b = torch.randn(batch, 3136, 768, generator=g, device=dev), torch.randn(batch, 3136, 768, generator=g, device=dev)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        lx, lr_ = net(a, b, False, "l2")
+        (lx + lr_).backward()
+        opt.step()
+        return lx, lr_
+
+    first = None
+    for i in range(warm):
+        lx, lr_ = step()
+        first = first if first is not None else float(lx.detach() + lr_.detach())
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        lx, lr_ = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    last = float(lx.detach() + lr_.detach())
+    assert last == last and last < first, (first, last)
+    tflop = 2 * 11 * 2.0 * batch * 3136 * 768 * 9 * 768 / 1e12
+    return dict(what="row f4: HallucinationCrossModalityConv training step (both directions: forward, l2 loss, backward, Adam), "
+                     "hand-written HIP forward + backward (cmdiad_amd/conv_train.py), batch-statistics BatchNorm",
+                batch=batch, ms_per_step=round(dt * 1e3, 2), tflop_per_step=round(tflop, 2), achieved_TFLOPs=round(tflop / dt, 1),
+                steps=steps, warmup=warm, loss_first=round(first, 1), loss_last=round(last, 1))
+
+
 def var_n_leg(st, dev, steps=8, warm=3):
     """SURVEY 8(d) var-N regime: every cloud keeps a different share of the image -- foreground 35 ... 65 % of the 224 x 224 pixels
     (N ~ 17.5 k ... 32.6 k points) -- instead of the fixed 24 576 points of the headline batches: the same predictor, ragged
@@ -716,6 +755,7 @@ def main():
         if group is None:
             extras["var_n"] = var_n_leg(st, dev)
             extras["train_step"] = train_step_leg(dev)
+            extras["conv_head_train_step"] = conv_head_train_leg(dev)
         # configs[4] as a config (bounded): the class loop with the classes dealt to the ranks, metrics gathered at the end
         extras["mtfi_classes"] = mtfi_classes(dev, group, rank, world, "all", args.class_scale, args.class_test)
 

@@ -33,6 +33,18 @@ def test_bench_single_gpu_line():
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
 
 
+def test_bench_default_line_carries_the_secondary_legs():
+    """The driver's command (no flags beyond steps): besides the headline, configs[2] (distillation training step), the conv head's
+    training step (row f4), the variable-N leg and the class loop ride in the same JSON line."""
+    d = _run({})
+    t, ct = d["train_step"], d["conv_head_train_step"]
+    assert t["ms_per_step"] > 0 and t["loss_last_timed"] < t["loss_first_timed"]
+    assert ct["batch"] == 8 and ct["achieved_TFLOPs"] > 100 and ct["loss_last"] < ct["loss_first"]
+    assert d["var_n"]["value"] > 100 and d["h2d_inclusive"]["value"] > 100 and d["every_row_searched"]["value"] > 100
+    assert d.get("cpu_baseline") is None or d["cpu_baseline"]["value"] > 0
+    assert len(d["mtfi_classes"]["per_class"]) == 10
+
+
 def test_bench_distributed_path_on_one_gpu():
     d = _run({"CMDIAD_FORCE_DIST": "1"})
     s = d["sharded_search"]
