@@ -61,10 +61,14 @@ SIGNATURES = {
     "cmdiad_transformer_block_fwd": [P, P, POINTER(BlockWeights), I, I, I, I, I, F, I, P, P, P, P, SZ, P],
     "cmdiad_layernorm": [P, P, P, P, F, I, I, P, P, I, P, P, P],
     "cmdiad_loss_head": [P, P, I, I, I, F, P, P, P, P],
-    "cmdiad_bn_relu_fwd": [P, P, P, SZ, I, P, P],
-    "cmdiad_bn_relu_bwd_reduce": [P, P, P, P, P, P, SZ, I, I, P, P, P],
-    "cmdiad_bn_relu_bwd_apply": [P, P, P, P, P, P, P, P, SZ, I, P, P],
+    "cmdiad_bn_affine": [P, P, P, P, SZ, D, I, P, P, P, P, P, P, P],
+    "cmdiad_bn_relu_fwd": [P, P, P, P, I, SZ, I, P, P, P],
+    "cmdiad_bn_relu_bwd_reduce": [P, P, P, P, P, P, I, SZ, I, I, P, P, P],
+    "cmdiad_bn_partials_sum": [P, P, I, I, P, P, P],
+    "cmdiad_bn_relu_bwd_apply": [P, P, P, P, P, P, P, P, I, SZ, I, P, P],
     "cmdiad_pad_nhwc_bf16": [P, I, I, I, I, P, P],
+    "cmdiad_relu_bwd_bf16": [P, P, SZ, P, P, P],
+    "cmdiad_upsample_bicubic_bwd": [P, I, I, I, I, I, I, P, P, P],
     "cmdiad_reduce_slabs": [P, I, SZ, SZ, F, P, P],
     "cmdiad_sum_vector": [P, SZ, F, P, P],
     "cmdiad_colsum_bf16": [P, I, I, I, P, P],

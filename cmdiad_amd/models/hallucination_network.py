@@ -213,7 +213,11 @@ class HallucinationRGBFeatureToXYZInputMLP(_PackedHead):
     def forward(self, rgb_feature, xyz):
         """hallucination_network.py:174-182."""
         rgb_feature = rgb_feature.reshape(rgb_feature.shape[0], rgb_feature.shape[1], -1)
-        if self._autograd():
+        if self._autograd() and os.environ.get("CMDIAD_CONV_TRAIN", "hip") == "hip":   # hand-written forward + backward
+            from .. import conv_train
+            assert rgb_feature.shape[1:] == (3136, self.rgb_dim) and xyz.shape[2:] == (224, 224)
+            return conv_train.ftoi_mlp_loss(self, rgb_feature, xyz)
+        if self._autograd():   # CMDIAD_CONV_TRAIN=torch: the module's own torch layers, the A/B reference of the above
             dev = self._device()
             x = self.mlp(self.rgb_norm(rgb_feature.to(dev).float())).transpose(1, 2)
             h = nn.functional.interpolate(x.reshape(x.shape[0], x.shape[1], 56, 56), size=(224, 224), mode='bicubic')
@@ -243,7 +247,11 @@ class HallucinationFeatureToInputConv(_PackedHead):
 
     def forward(self, feature, img):
         """hallucination_network.py:211-220."""
-        if self._autograd():
+        if self._autograd() and os.environ.get("CMDIAD_CONV_TRAIN", "hip") == "hip":   # hand-written forward + backward
+            from .. import conv_train
+            assert feature.shape[1:] == (3136, self.dim) and img.shape[1:] == (3, 224, 224)
+            return conv_train.ftoi_conv_loss(self, feature, img)
+        if self._autograd():   # CMDIAD_CONV_TRAIN=torch: the module's own torch layers, the A/B reference of the above
             dev = self._device()
             f = feature.to(dev).float().transpose(1, 2)
             h = self.conv1(f.reshape(f.shape[0], f.shape[1], 56, 56))

@@ -7,9 +7,13 @@ StageModule / BasicBlock / transition code of that file is commented out or neve
 
 SURVEY 8f row f4: same constructor, state_dict keys and method signatures.  Inference (``eval()`` / ``no_grad``): eval-mode
 arithmetic with BatchNorm folded, on cmdiad_conv_stem + cmdiad_conv2d_nhwc_bf16 (cmdiad_amd.runtime.PackedHRNet).  Training
-(``train()`` with gradients: --train_method *InputTo*FeatureHRNET): the module's own torch layers on the GPU (fp32,
-batch-statistics BatchNorm, autograd; MIOpen kernels, not hand-written HIP -- outside the benchmarked hot path), golden G12.
+(``train()`` with gradients: --train_method *InputTo*FeatureHRNET): by default the module's own torch layers on the GPU (fp32,
+batch-statistics BatchNorm, autograd; MIOpen kernels), golden G12; CMDIAD_HRNET_TRAIN=hip selects the hand-written forward +
+backward of cmdiad_amd/conv_train.py (same golden, tests/test_gpu_conv_train.py) -- built and parity-green, but host-bound at
+~1 000 launches per step and slower than the torch layers, hence opt-in.
 """
+import os
+
 import torch
 from torch import nn
 
@@ -69,7 +73,13 @@ class HRNet(_PackedHead):
 
     def forward(self, img, feature):
         """hrnet.py:290-299."""
-        if self._autograd():
+        # hand-written forward + backward (cmdiad_amd/conv_train.py): parity-green but OPT-IN -- ~1 000 small launches per step make it
+        # host-bound (24-40 ms against 12.5 ms on the torch layers at batch 8, 54 against 39 at batch 32; profiles/r3_notes.md)
+        if self._autograd() and os.environ.get("CMDIAD_HRNET_TRAIN", "torch") == "hip":
+            from .. import conv_train
+            assert tuple(img.shape[1:]) == (3, 224, 224) and tuple(feature.shape[1:]) == (3136, self.final_layer.out_channels)
+            return conv_train.hrnet_loss(self, img, feature)
+        if self._autograd():   # default: the module's own torch layers (MIOpen / rocBLAS, autograd)
             dev = self._device()
             x = torch.relu(self.bn1(self.conv1(img.to(dev).float())))
             x = torch.relu(self.bn2(self.conv2(x)))

@@ -305,30 +305,57 @@ def col_moments(x):
     return mean, acc[1] / rows - mean * mean
 
 
-def bn_relu_fwd(z, scale, shift):
-    """z [M,C] f32 -> relu(z * scale + shift) as bf16 [M,C] (cmdiad_bn_relu_fwd: batch-statistics BatchNorm2d + ReLU)."""
+def bn_relu_fwd(z, scale, shift, residual=None, relu=True, want_bf16=True, want_f32=False):
+    """z [M,C] f32 -> z * scale + shift (+ residual) (ReLU) as bf16 [M,C] (and / or f32): batch-statistics BatchNorm2d + ReLU
+    (cmdiad_bn_relu_fwd).  Returns the bf16 tensor, or (bf16 | None, f32) when want_f32."""
     _chk(z, torch.float32, "bn_relu.z"); _chk(scale, torch.float32, "bn_relu.scale"); _chk(shift, torch.float32, "bn_relu.shift")
+    _chk(residual, torch.float32, "bn_relu.residual")
     M, C = z.shape
-    y = torch.empty((M, C), dtype=torch.bfloat16, device=z.device)
-    _call("cmdiad_bn_relu_fwd", _p(z), _p(scale), _p(shift), M, C, _p(y), _stream())
-    return y
+    y = torch.empty((M, C), dtype=torch.bfloat16, device=z.device) if want_bf16 else None
+    y32 = torch.empty((M, C), dtype=torch.float32, device=z.device) if want_f32 else None
+    _call("cmdiad_bn_relu_fwd", _p(z), _p(scale), _p(shift), _p(residual), 1 if relu else 0, M, C, _p(y), _p(y32), _stream())
+    return (y, y32) if want_f32 else y
 
 
-def bn_relu_bwd(dy, z, scale, shift, mean, rstd, chunks=64):
-    """Backward of bn_relu_fwd: dy, z [M,C] f32; per-channel f32 vectors -> (dz bf16 [M,C], dgamma [C], dbeta [C])
-    (cmdiad_bn_relu_bwd_reduce -> cmdiad_reduce_slabs x2 -> cmdiad_bn_relu_bwd_apply)."""
+def bn_relu_bwd(dy, z, scale, shift, mean, rstd, chunks=None, masked=True):
+    """Backward of bn_relu_fwd: dy, z [M,C] f32; per-channel f32 vectors -> (dz bf16 [M,C], dgamma [C], dbeta [C]).  masked=False:
+    the layer had no ReLU of its own (dy already carries the mask of the ReLU after the residual sum).
+    (cmdiad_bn_relu_bwd_reduce -> cmdiad_bn_partials_sum -> cmdiad_bn_relu_bwd_apply)."""
     _chk(dy, torch.float32, "bn_bwd.dy"); _chk(z, torch.float32, "bn_bwd.z")
     M, C = z.shape
+    if chunks is None:   # ~256 rows per workgroup (64 columns x 4 row lanes each), at most 256 row ranges
+        chunks = max(16, min(256, (M + 255) // 256))
+    mk = 1 if masked else 0
     p1 = torch.empty((chunks, C), dtype=torch.float32, device=z.device)
     p2 = torch.empty((chunks, C), dtype=torch.float32, device=z.device)
-    _call("cmdiad_bn_relu_bwd_reduce", _p(dy), _p(z), _p(scale), _p(shift), _p(mean), _p(rstd), M, C, chunks, _p(p1), _p(p2), _stream())
+    _call("cmdiad_bn_relu_bwd_reduce", _p(dy), _p(z), _p(scale), _p(shift), _p(mean), _p(rstd), mk, M, C, chunks, _p(p1), _p(p2), _stream())
     dbeta = torch.empty((C,), dtype=torch.float32, device=z.device)
     dgamma = torch.empty((C,), dtype=torch.float32, device=z.device)
-    _call("cmdiad_reduce_slabs", _p(p1), chunks, C, C, 1.0, _p(dbeta), _stream())
-    _call("cmdiad_reduce_slabs", _p(p2), chunks, C, C, 1.0, _p(dgamma), _stream())
+    _call("cmdiad_bn_partials_sum", _p(p1), _p(p2), chunks, C, _p(dbeta), _p(dgamma), _stream())
     dz = torch.empty((M, C), dtype=torch.bfloat16, device=z.device)
-    _call("cmdiad_bn_relu_bwd_apply", _p(dy), _p(z), _p(scale), _p(shift), _p(mean), _p(rstd), _p(dbeta), _p(dgamma), M, C, _p(dz), _stream())
+    _call("cmdiad_bn_relu_bwd_apply", _p(dy), _p(z), _p(scale), _p(shift), _p(mean), _p(rstd), _p(dbeta), _p(dgamma), mk, M, C, _p(dz),
+          _stream())
     return dz, dgamma, dbeta
+
+
+def relu_bwd(dx, y, want_bf16=True, want_f32=False):
+    """dx f32, y bf16 (the ReLU output), same shape -> dx where y > 0 else 0, as bf16 (and / or f32) (cmdiad_relu_bwd_bf16)."""
+    _chk(dx, torch.float32, "relu_bwd.dx"); _chk(y, torch.bfloat16, "relu_bwd.y")
+    assert dx.shape == y.shape
+    dz = torch.empty(y.shape, dtype=torch.bfloat16, device=y.device) if want_bf16 else None
+    dz32 = torch.empty(y.shape, dtype=torch.float32, device=y.device) if want_f32 else None
+    _call("cmdiad_relu_bwd_bf16", _p(dx), _p(y), dx.numel(), _p(dz), _p(dz32), _stream())
+    return (dz, dz32) if want_f32 else dz
+
+
+def upsample_bicubic_bwd(grad_out, h, w):
+    """grad_out [B,H,W,C] f32 NHWC -> gradient of the [B,h,w,C] input of upsample_bicubic (cmdiad_upsample_bicubic_bwd)."""
+    _chk(grad_out, torch.float32, "bicubic_bwd.grad_out")
+    B, H, W, C = grad_out.shape
+    tmp = torch.empty((B, H, w, C), dtype=torch.float32, device=grad_out.device)
+    out = torch.empty((B, h, w, C), dtype=torch.float32, device=grad_out.device)
+    _call("cmdiad_upsample_bicubic_bwd", _p(grad_out), B, H, W, C, h, w, _p(tmp), _p(out), _stream())
+    return out
 
 
 def pad_nhwc(x, rows_multiple=64):

@@ -452,22 +452,42 @@ int cmdiad_loss_head(const float* z3, const float* target, int M, int D, int mod
  * Activations are NHWC flattened to [M = B*H*W, C].  Convolution forward and data gradient: cmdiad_conv2d_nhwc_bf16 (the latter on
  * flipped, transposed weights); weight gradient: cmdiad_gemm_tn_bf16 per filter tap over cmdiad_pad_nhwc_bf16 copies. ---- */
 
-/* y = relu(z * scale[c] + shift[c]) as bf16: BatchNorm (scale = gamma / sqrt(var + eps), shift = beta - mean * scale, batch
- * statistics from cmdiad_col_moments) + ReLU, nn.Sequential(..., BatchNorm2d, ReLU, ...) of hallucination_network.py:80-90.  C % 8 == 0. */
-int cmdiad_bn_relu_fwd(const float* z, const float* scale, const float* shift, size_t M, int C, uint16_t* y, cmdiad_stream_t stream);
-/* Backward of the same pair (autograd of hallucination_network_pretrain.py:146): with g = dy where z * scale + shift > 0 else 0 and
- * xhat = (z - mean) * rstd:  part_dbeta / part_dgamma [chunks][C] = column sums of g / g * xhat over `chunks` row ranges (add them
- * with cmdiad_reduce_slabs: fixed order), then dz = scale * (g - dbeta / M - xhat * dgamma / M) as bf16. */
+/* The constants of one batch-statistics BatchNorm from the float64 column sums of cmdiad_col_moments (sum, sumsq [C]) over `rows`
+ * rows: mean64 / var64 [C] (biased variance; the caller's running-statistics update), scale = gamma / sqrt(var + eps),
+ * shift = beta - mean * scale, mean, rstd as f32 [C]. */
+int cmdiad_bn_affine(const double* sum, const double* sumsq, const float* gamma, const float* beta, size_t rows, double eps, int C,
+                     double* mean64, double* var64, float* scale, float* shift, float* mean, float* rstd, cmdiad_stream_t stream);
+/* y = z * scale[c] + shift[c] (+ residual [M,C] f32) (ReLU when relu != 0) as bf16 and / or f32 (NULL = not wanted): BatchNorm
+ * (scale = gamma / sqrt(var + eps), shift = beta - mean * scale, batch statistics from cmdiad_col_moments) + ReLU,
+ * nn.Sequential(..., BatchNorm2d, ReLU, ...) of hallucination_network.py:80-90; with the residual: bn3 + identity + ReLU of
+ * Bottleneck.forward (hrnet.py:38-42).  C % 8 == 0. */
+int cmdiad_bn_relu_fwd(const float* z, const float* scale, const float* shift, const float* residual, int relu, size_t M, int C,
+                       uint16_t* y, float* y_f32, cmdiad_stream_t stream);
+/* Backward of the same (autograd of hallucination_network_pretrain.py:146): with g = dy where z * scale + shift > 0 else 0
+ * (masked != 0: the layer's own ReLU) or g = dy (masked == 0: no ReLU of its own -- the caller has applied the mask of the
+ * ReLU after the residual sum) and xhat = (z - mean) * rstd:  part_dbeta / part_dgamma [chunks][C] = column sums of g /
+ * g * xhat over `chunks` row ranges; cmdiad_bn_partials_sum adds them (fixed order) into dbeta / dgamma [C]; then
+ * dz = scale * (g - dbeta / M - xhat * dgamma / M) as bf16 (per-channel vectors 16-byte aligned, C % 4 == 0). */
 int cmdiad_bn_relu_bwd_reduce(const float* dy, const float* z, const float* scale, const float* shift, const float* mean,
-                              const float* rstd, size_t M, int C, int chunks, float* part_dbeta, float* part_dgamma,
+                              const float* rstd, int masked, size_t M, int C, int chunks, float* part_dbeta, float* part_dgamma,
                               cmdiad_stream_t stream);
+int cmdiad_bn_partials_sum(const float* part_dbeta, const float* part_dgamma, int chunks, int C, float* dbeta, float* dgamma,
+                           cmdiad_stream_t stream);
 int cmdiad_bn_relu_bwd_apply(const float* dy, const float* z, const float* scale, const float* shift, const float* mean,
-                             const float* rstd, const float* dbeta, const float* dgamma, size_t M, int C, uint16_t* dz,
+                             const float* rstd, const float* dbeta, const float* dgamma, int masked, size_t M, int C, uint16_t* dz,
                              cmdiad_stream_t stream);
 /* x [B,H,W,C] bf16 -> the interior of out [B,H+2,W+2,C] (border untouched: the caller zero-fills out once).  In that layout the
  * (ky, kx) tap of a 3x3 convolution with padding 1 is the row offset (ky-1)*(W+2) + (kx-1): the weight gradient of a tap is
  * one [M',N]^T [M',C] product of the padded output gradient with the shifted padded input.  C % 8 == 0. */
 int cmdiad_pad_nhwc_bf16(const uint16_t* x, int B, int H, int W, int C, uint16_t* out, cmdiad_stream_t stream);
+/* Backward pieces of the feature-to-input convolutional head (hallucination_network.py:185-220; trained by
+ * hallucination_network_pretrain.py:106-147).  relu_bwd: dz = dx where the saved ReLU OUTPUT y (bf16) is positive, else 0, as bf16
+ * and / or f32 (n elements, n % 4 == 0).  upsample_bicubic_bwd: adjoint of F.interpolate(mode='bicubic', align_corners=False) (:204):
+ * grad_out f32 NHWC [B,H,W,C] -> grad_in f32 [B,h,w,C]; tmp f32 [B,H,w,C]; gathering passes, no atomics.  C % 4 == 0. */
+int cmdiad_relu_bwd_bf16(const float* dx, const uint16_t* y, size_t n, uint16_t* dz, float* dz_f32, cmdiad_stream_t stream);
+int cmdiad_upsample_bicubic_bwd(const float* grad_out, int B, int H, int W, int C, int h, int w, float* tmp, float* grad_in,
+                                cmdiad_stream_t stream);
+
 
 /* out[i] = scale * sum_s slabs[s*stride + i] in fixed order (split-K partials, column partials). n, stride % 4 == 0 */
 int cmdiad_reduce_slabs(const float* slabs, int S, size_t n, size_t stride, float scale, float* out,

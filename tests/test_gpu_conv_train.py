@@ -160,3 +160,113 @@ def test_head_module_routes_training_through_the_hip_path(monkeypatch):
     for k, v in res["torch"][3].items():
         if v.dtype.is_floating_point:
             np.testing.assert_allclose(res["hip"][3][k].cpu().numpy(), v.cpu().numpy(), rtol=5e-3, atol=5e-4, err_msg=k)
+
+
+@pytest.mark.parametrize("B,h,H,C", [(2, 56, 224, 384), (1, 7, 28, 8), (2, 5, 13, 4), (1, 9, 9, 4)])
+def test_bicubic_upsampling_adjoint_vs_torch(B, h, H, C):
+    """cmdiad_upsample_bicubic_bwd against autograd through F.interpolate(mode='bicubic', align_corners=False) in float64:
+    the x4 case of the heads, other ratios, border clamping, identity size."""
+    g = torch.Generator().manual_seed(B + h + H + C)
+    x = torch.randn(B, C, h, h, generator=g).double().requires_grad_(True)
+    go = torch.randn(B, C, H, H, generator=g)
+    F.interpolate(x, size=(H, H), mode="bicubic", align_corners=False).backward(go.double())
+    got = ops.upsample_bicubic_bwd(go.permute(0, 2, 3, 1).contiguous().to(DEV), h, h)
+    ref = x.grad.permute(0, 2, 3, 1)
+    np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=1e-4 * float(ref.abs().mean()))
+
+
+def test_relu_backward_from_the_saved_output():
+    g = torch.Generator().manual_seed(4)
+    y = torch.relu(torch.randn(1000, 64, generator=g)).bfloat16()
+    dx = torch.randn(1000, 64, generator=g)
+    got = ops.relu_bwd(dx.to(DEV), y.to(DEV))
+    want = torch.where(y.float() > 0, dx, torch.zeros_like(dx)).bfloat16()
+    assert torch.equal(got.cpu(), want)
+
+
+def test_feature_to_input_conv_head_trains_on_the_hip_path(monkeypatch):
+    """HallucinationFeatureToInputConv.forward in train() mode: hand-written path (default) against the module's own torch layers
+    (CMDIAD_CONV_TRAIN=torch, fp32): loss 3e-3, gradient cosines (ReLU masks flip under bf16 operands: > 0.99)."""
+    from cmdiad_amd.models import hallucination_network as hn
+    from oracle import heads
+    gen = torch.Generator().manual_seed(12)
+    f, img = torch.randn(2, 3136, 768, generator=gen), torch.randn(2, 3, 224, 224, generator=gen)
+    res = {}
+    for mode in ("hip", "torch"):
+        monkeypatch.setenv("CMDIAD_CONV_TRAIN", mode)
+        m = hn.HallucinationFeatureToInputConv(None, 768)
+        m.load_state_dict(heads.synth_head_state_dict("ftoi_conv", 41))
+        m.to(DEV).train()
+        loss = m(f, img)
+        assert loss.requires_grad
+        loss.backward()
+        res[mode] = (float(loss.detach()), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+    np.testing.assert_allclose(res["hip"][0], res["torch"][0], rtol=3e-3)
+    assert set(res["hip"][1]) == set(res["torch"][1]) == {f"conv{i}.{w}" for i in range(1, 5) for w in ("weight", "bias")}
+    for k, gq in res["torch"][1].items():
+        assert res["hip"][1][k].shape == gq.shape and _cos(res["hip"][1][k], gq) > 0.99, (k, _cos(res["hip"][1][k], gq))
+
+
+@pytest.mark.parametrize("depth_only", [False, True])
+def test_feature_to_input_mlp_head_trains_on_the_hip_path(depth_only, monkeypatch):
+    """HallucinationRGBFeatureToXYZInputMLP.forward in train() mode (3 output channels, and 1 with --estimate_depth): hand-written
+    path against the module's own torch layers (fp32): loss 3e-3, every gradient cosine > 0.995 (GELU is smooth: no mask flips)."""
+    import types
+    from cmdiad_amd.models import hallucination_network as hn
+    from oracle import heads
+    gen = torch.Generator().manual_seed(13)
+    f = torch.randn(2, 3136, 768, generator=gen)
+    img = torch.randn(2, 1 if depth_only else 3, 224, 224, generator=gen)
+    res = {}
+    for mode in ("hip", "torch"):
+        monkeypatch.setenv("CMDIAD_CONV_TRAIN", mode)
+        torch.manual_seed(5)
+        m = hn.HallucinationRGBFeatureToXYZInputMLP(types.SimpleNamespace(estimate_depth=depth_only), 768)
+        if not depth_only:
+            m.load_state_dict(heads.synth_head_state_dict("ftoi_mlp", 41))
+        m.to(DEV).train()
+        loss = m(f, img)
+        assert loss.requires_grad
+        loss.backward()
+        res[mode] = (float(loss.detach()), {k: p.grad.clone() for k, p in m.named_parameters()})
+    np.testing.assert_allclose(res["hip"][0], res["torch"][0], rtol=3e-3)
+    for k, gq in res["torch"][1].items():
+        c = _cos(res["hip"][1][k], gq)
+        assert res["hip"][1][k].shape == gq.shape and c > 0.995, (k, c)
+
+
+def test_hrnet_trunk_trains_on_the_hip_path(monkeypatch):
+    """models.hrnet.HRNet.forward in train() mode (stem, twelve Bottlenecks, final 1x1; 39 batch-statistics BatchNorms): hand-written
+    path against the module's own torch layers (fp32): loss 3e-3, running statistics, and the gradient of every parameter the
+    forward uses -- cosine > 0.999 at the final layer, > 0.98 in the last Bottleneck, falling with depth as bf16 operands flip
+    ~0.2 % of every ReLU mask on the way down (36 ReLUs between the loss and the stem: 1 - 36 x 0.002 / 2 = 0.964; measured 0.96-0.97
+    at the stem)."""
+    from cmdiad_amd.models.hrnet import HRNet
+    from oracle import heads
+    gen = torch.Generator().manual_seed(21)
+    img, feat = torch.randn(2, 3, 224, 224, generator=gen), torch.randn(2, 3136, 768, generator=gen)
+    res = {}
+    for mode in ("hip", "torch"):
+        monkeypatch.setenv("CMDIAD_HRNET_TRAIN", mode)      # (opt-in for this head: the hand-written path is host-bound, see hrnet.py)
+        m = HRNet(512, 768, 0.1)
+        m.load_state_dict(heads.synth_head_state_dict("hrnet", 41))
+        m.to(DEV).train()
+        loss = m(img, feat)
+        assert loss.requires_grad
+        loss.backward()
+        res[mode] = (float(loss.detach()), {k: (None if p.grad is None else p.grad.clone()) for k, p in m.named_parameters()},
+                     {k: v.clone() for k, v in m.named_buffers()})
+    np.testing.assert_allclose(res["hip"][0], res["torch"][0], rtol=3e-3)
+    cos = {}
+    for k, gq in res["torch"][1].items():
+        gh = res["hip"][1][k]
+        assert (gh is None) == (gq is None), k                      # layer4 is constructed but never run: no gradient on either side
+        if gq is not None:
+            assert gh.shape == gq.shape, k
+            cos[k] = _cos(gh, gq)
+    assert cos["final_layer.weight"] > 0.999 and cos["final_layer.bias"] > 0.999, cos
+    assert min(v for k, v in cos.items() if k.startswith("layer3.3")) > 0.98, cos
+    assert min(cos.values()) > 0.93, cos
+    for k, v in res["torch"][2].items():
+        if v.dtype.is_floating_point and not k.startswith("layer4."):
+            np.testing.assert_allclose(res["hip"][2][k].cpu().numpy(), v.cpu().numpy(), rtol=1e-2, atol=2e-3, err_msg=k)

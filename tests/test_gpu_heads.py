@@ -122,14 +122,18 @@ def test_head_repacks_after_weight_update():
         assert not m(tok, torch.zeros(1, 3, 224, 224, device=DEV)).requires_grad
 
 
-@pytest.mark.parametrize("kind", ["ftoi_mlp", "ftoi_conv", "hrnet", "conv_ftof"])
-def test_head_training_follows_the_reference_loss_curve(kind, golden):
+@pytest.mark.parametrize("kind", ["ftoi_mlp", "ftoi_conv", "hrnet", "hrnet_hip", "conv_ftof"])
+def test_head_training_follows_the_reference_loss_curve(kind, golden, monkeypatch):
     """hallucination_network_pretrain.py:106-147 for the conv / feature-to-input / HRNet heads: three Adam steps (lr 1e-3) in
     train() mode from the synthetic weights on one seeded batch of two, against the same three steps of the REFERENCE's own
     modules on the CPU (tests/golden/g12_heads_train.npz, make_golden.py g12): the loss before every step, and sum / abs-sum of
-    every tensor of the state_dict afterwards (weights, biases, BatchNorm running statistics).  fp32 on both sides; the
-    convolution algorithms differ (MIOpen vs the CPU's), hence the tolerances."""
+    every tensor of the state_dict afterwards (weights, biases, BatchNorm running statistics).  The conv FtoF and the two
+    feature-to-input heads run their hand-written forward + backward (cmdiad_amd/conv_train.py: bf16 GEMM operands, fp32
+    accumulation); the HRNet trunk runs the module's torch layers by default and the hand-written path as "hrnet_hip"."""
     from cmdiad_amd.models.hrnet import HRNet
+    if kind == "hrnet_hip":   # the same golden through the opt-in hand-written path of the HRNet trunk (the other heads default to theirs)
+        monkeypatch.setenv("CMDIAD_HRNET_TRAIN", "hip")
+        kind = "hrnet"
     g12 = golden("g12_heads_train.npz")
     gen = torch.Generator().manual_seed(int(g12["input_seed"]))
     a, b = torch.randn(2, 3136, 768, generator=gen), torch.randn(2, 3136, 768, generator=gen)
