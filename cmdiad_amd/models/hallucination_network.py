@@ -13,12 +13,11 @@ The other heads of the reference file -- HallucinationCrossModalityConv (72-143)
 ``hallucination_generation`` / ``forward`` signatures.  INFERENCE (``eval()`` or ``no_grad``) runs eval-mode arithmetic
 (BatchNorm running statistics folded into the convolution weights) on the implicit-GEMM convolution kernel
 (cmdiad_conv2d_nhwc_bf16) and cmdiad_upsample_bicubic.  TRAINING (``train()`` with gradients enabled:
-hallucination_network_pretrain.py:106-147): HallucinationCrossModalityConv trains on the hand-written path of
-cmdiad_amd/conv_train.py (batch-statistics BatchNorm, bf16 MFMA convolutions forward / data gradient / weight gradient, exposed
-to autograd; CMDIAD_CONV_TRAIN=torch selects the module's own torch layers as the A/B reference); the two feature-to-input heads
-evaluate the module's own torch layers on the GPU -- fp32, autograd, torch's (MIOpen / rocBLAS) kernels -- so the reference's
-loop trains them unchanged.  tests/test_gpu_heads.py checks a three-step Adam loss curve of each head against the reference's
-own (golden G12); tests/test_gpu_conv_train.py the hand-written path against torch autograd.
+hallucination_network_pretrain.py:106-147): all three train on the hand-written paths of cmdiad_amd/conv_train.py (batch-statistics
+BatchNorm, bf16 MFMA convolutions / GEMMs forward, data gradient and weight gradient, bicubic adjoint; exposed to autograd so the
+reference's loop runs unchanged); CMDIAD_CONV_TRAIN=torch selects the modules' own torch layers (fp32, MIOpen / rocBLAS) as the A/B
+reference.  tests/test_gpu_heads.py checks a three-step Adam loss curve of each head against the reference's own (golden G12);
+tests/test_gpu_conv_train.py the hand-written paths against torch autograd.
 """
 import os
 
