@@ -7,10 +7,11 @@ StageModule / BasicBlock / transition code of that file is commented out or neve
 
 SURVEY 8f row f4: same constructor, state_dict keys and method signatures.  Inference (``eval()`` / ``no_grad``): eval-mode
 arithmetic with BatchNorm folded, on cmdiad_conv_stem + cmdiad_conv2d_nhwc_bf16 (cmdiad_amd.runtime.PackedHRNet).  Training
-(``train()`` with gradients: --train_method *InputTo*FeatureHRNET): by default the module's own torch layers on the GPU (fp32,
-batch-statistics BatchNorm, autograd; MIOpen kernels), golden G12; CMDIAD_HRNET_TRAIN=hip selects the hand-written forward +
-backward of cmdiad_amd/conv_train.py (same golden, tests/test_gpu_conv_train.py) -- built and parity-green, but host-bound at
-~1 000 launches per step and slower than the torch layers, hence opt-in.
+(``train()`` with gradients: --train_method *InputTo*FeatureHRNET): the hand-written forward + backward of
+cmdiad_amd/conv_train.py from batch 16 up (the reference's default batch is 64; 1.4x the torch layers at batch 32), the module's own
+torch layers on the GPU (fp32, batch-statistics BatchNorm, autograd; MIOpen kernels) below that, where the hand-written path's
+~500 launches per step are not hidden yet; CMDIAD_HRNET_TRAIN=hip / torch forces one.  Both follow golden G12
+(tests/test_gpu_heads.py) and agree with each other (tests/test_gpu_conv_train.py).
 """
 import os
 
@@ -73,13 +74,15 @@ class HRNet(_PackedHead):
 
     def forward(self, img, feature):
         """hrnet.py:290-299."""
-        # hand-written forward + backward (cmdiad_amd/conv_train.py): parity-green but OPT-IN -- ~1 000 small launches per step make it
-        # host-bound (24-40 ms against 12.5 ms on the torch layers at batch 8, 54 against 39 at batch 32; profiles/r3_notes.md)
-        if self._autograd() and os.environ.get("CMDIAD_HRNET_TRAIN", "torch") == "hip":
+        # hand-written forward + backward (cmdiad_amd/conv_train.py) from batch 16 up: 27.4 ms against 38.6 ms on the torch layers at
+        # batch 32, but 14.4 against 11.9 at batch 8, where its ~500 launches per step are not yet hidden (profiles/r3_notes.md).
+        # CMDIAD_HRNET_TRAIN = auto (default) | hip | torch.
+        mode = os.environ.get("CMDIAD_HRNET_TRAIN", "auto")
+        if self._autograd() and (mode == "hip" or (mode == "auto" and img.shape[0] >= 16)):
             from .. import conv_train
             assert tuple(img.shape[1:]) == (3, 224, 224) and tuple(feature.shape[1:]) == (3136, self.final_layer.out_channels)
             return conv_train.hrnet_loss(self, img, feature)
-        if self._autograd():   # default: the module's own torch layers (MIOpen / rocBLAS, autograd)
+        if self._autograd():   # small batches (or CMDIAD_HRNET_TRAIN=torch): the module's own torch layers (MIOpen / rocBLAS, autograd)
             dev = self._device()
             x = torch.relu(self.bn1(self.conv1(img.to(dev).float())))
             x = torch.relu(self.bn2(self.conv2(x)))

@@ -129,9 +129,9 @@ def test_head_training_follows_the_reference_loss_curve(kind, golden, monkeypatc
     modules on the CPU (tests/golden/g12_heads_train.npz, make_golden.py g12): the loss before every step, and sum / abs-sum of
     every tensor of the state_dict afterwards (weights, biases, BatchNorm running statistics).  The conv FtoF and the two
     feature-to-input heads run their hand-written forward + backward (cmdiad_amd/conv_train.py: bf16 GEMM operands, fp32
-    accumulation); the HRNet trunk runs the module's torch layers by default and the hand-written path as "hrnet_hip"."""
+    accumulation); the HRNet trunk runs the module's torch layers at this batch size and the hand-written path as "hrnet_hip"."""
     from cmdiad_amd.models.hrnet import HRNet
-    if kind == "hrnet_hip":   # the same golden through the opt-in hand-written path of the HRNet trunk (the other heads default to theirs)
+    if kind == "hrnet_hip":   # the same golden through the hand-written path of the HRNet trunk (its default from batch 16 up)
         monkeypatch.setenv("CMDIAD_HRNET_TRAIN", "hip")
         kind = "hrnet"
     g12 = golden("g12_heads_train.npz")

@@ -12,6 +12,8 @@ m = HRNet(512, 768, 0.1); m.load_state_dict(heads.synth_head_state_dict("hrnet",
 opt = torch.optim.Adam(m.parameters(), lr=1e-4)
 def step():
     opt.zero_grad(); loss = m(img, feat); loss.backward(); opt.step(); return loss
-step(); torch.cuda.synchronize(); t0 = time.perf_counter()
-for _ in range(3): step()
-torch.cuda.synchronize(); print(f"hrnet training step, batch {B}: {(time.perf_counter() - t0) / 3 * 1e3:.1f} ms")
+W, K = int(os.environ.get("WARM", "1")), int(os.environ.get("STEPS", "3"))   # (the first steps grow the caching allocator: WARM=5 for timings)
+for _ in range(W): step()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(K): step()
+torch.cuda.synchronize(); print(f"hrnet training step, batch {B}, {os.environ['CMDIAD_HRNET_TRAIN']}: {(time.perf_counter() - t0) / K * 1e3:.1f} ms")
