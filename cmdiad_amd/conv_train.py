@@ -14,6 +14,8 @@ over the tower's ten parameters, so the reference trainer's ``loss.backward()`` 
             copies, in which a tap's shift is a row offset ; dx_l = conv3x3(dz_l, W_l flipped and transposed) fp32 ;
             (dz_{l-1}, dgamma, dbeta) = BatchNorm + ReLU backward (cmdiad_bn_relu_bwd_*).
 The BatchNorm running statistics are updated as torch does (momentum 0.1, unbiased variance, num_batches_tracked)."""
+import os
+
 import torch
 
 from . import _native as nat
@@ -39,9 +41,11 @@ def _conv_w_dgrad(w):
 
 def _split_for(rows, n1, n2):
     """Slices of the token dimension for a weight-gradient product whose output is only a few 128 x 128 tiles: enough workgroups to
-    fill the chip (>= 256), at least two 64-row steps per slice."""
+    fill the chip (~512: two co-resident workgroups per CU; 36 tiles x 8 slices = 288 left the 768 x 768 products of the conv head at
+    505 TFLOP/s), at least two 64-row steps per slice."""
     tiles = ((n1 + 127) // 128) * ((n2 + 127) // 128)
-    return int(max(1, min(max(SPLIT_K, 256 // tiles), rows // 128, 64)))
+    target = int(os.environ.get("CMDIAD_WGRAD_BLOCKS", "512"))     # two co-resident workgroups per CU
+    return int(max(1, min(max(1, target // tiles), rows // 128, 64)))
 
 
 def _wgrad(dz, x, B, H, W):
