@@ -623,3 +623,44 @@ def test_class_sharded_evaluate_propagates_a_rank_failure_world2_gloo(tmp_path):
     assert all(p.returncode == 0 for p in procs), outs
     for o in outs:
         assert "RAISED class-sharded evaluation failed on rank 1: ValueError: cloud has 7 valid points" in o, o
+
+
+def test_layernorm_fold_weights_and_chain_flags():
+    """Host logic of the LayerNorm fold (runtime.ln_fold / block_flags): folded weights reproduce LayerNorm -> Linear in float64 for any
+    row mean; a block prepares the next block's first LayerNorm unless its output is read in between or it is the last."""
+    import numpy as np
+    import torch
+    from cmdiad_amd import ops, runtime
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(50, 384, generator=g) * 2 + 5).double()
+    W, b = torch.randn(96, 384, generator=g), torch.randn(96, generator=g)
+    gamma, beta = 1 + 0.3 * torch.randn(384, generator=g), 0.2 * torch.randn(384, generator=g)
+    Wf, bf = runtime.ln_fold(W, b, gamma, beta)
+    assert torch.allclose(Wf.double().sum(1), torch.zeros(96, dtype=torch.float64), atol=1e-4)     # centred over k
+    ref = torch.nn.functional.layer_norm(x, (384,), gamma.double(), beta.double(), 1e-5) @ W.double().T + b.double()
+    rstd = 1.0 / torch.sqrt(x.var(dim=1, unbiased=False) + 1e-5)
+    np.testing.assert_allclose((rstd[:, None] * (x @ Wf.double().T) + bf.double()).numpy(), ref.numpy(), rtol=1e-5, atol=1e-5)
+    Wn, bn = runtime.ln_fold(W, None, gamma, beta)                                                  # qkv without bias (Point-MAE)
+    np.testing.assert_allclose(bn.numpy(), (W.double() @ beta.double()).float().numpy(), rtol=1e-6)
+    R, P = ops.BLOCK_LN1_READY, ops.BLOCK_PREP_NEXT
+    assert [runtime.block_flags(i, 4, True) for i in range(4)] == [P, R | P, R | P, R]
+    assert [runtime.block_flags(i, 12, True, (3, 7, 11)) for i in range(12)] == [P, R | P, R | P, R, P, R | P, R | P, R, P, R | P, R | P, R]
+    assert [runtime.block_flags(i, 4, False) for i in range(4)] == [0, 0, 0, 0]
+    for v, want in (("0", (False, False)), ("1", (True, True)), ("pmae", (False, True)), ("vit", (True, False))):
+        os.environ["CMDIAD_LN_FOLD"] = v
+        try:
+            assert (runtime.ln_fold_enabled("vit"), runtime.ln_fold_enabled("pmae")) == want
+        finally:
+            del os.environ["CMDIAD_LN_FOLD"]
+    assert (runtime.ln_fold_enabled("vit"), runtime.ln_fold_enabled("pmae")) == (False, True)      # the default
+
+
+def test_weight_gradient_row_slices():
+    """conv_train._split_for: slices of the token dimension for few-tile weight-gradient products -- about two workgroups per CU,
+    never more slices than pairs of 64-row steps, at most 64."""
+    from cmdiad_amd import conv_train
+    assert conv_train._split_for(107648, 768, 768) == 14          # 36 tiles x 14 = 504 workgroups
+    assert conv_train._split_for(25088, 128, 128) == 64           # one tile: capped
+    assert conv_train._split_for(25088, 512, 128) == 64           # four tiles: 256 workgroups at the cap
+    assert conv_train._split_for(256, 128, 128) == 2 and conv_train._split_for(64, 64, 64) == 1
+    assert conv_train._split_for(100352, 1920, 1920) == 2         # 225 tiles: already enough workgroups
