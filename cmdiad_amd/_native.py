@@ -78,6 +78,7 @@ SIGNATURES = {
     "cmdiad_gemm_groupmax": [P, P, P, I, I, I, I, P, P, P],
     "cmdiad_l2_min_keys": [P, P, P, P, I, I, I, U32, P, I, P],
     "cmdiad_l2_min_keys_counted": [P, P, P, I, P, P, I, I, U32, P, I, P],
+    "cmdiad_l2_min_keys_segments": [P, P, P, I, I, P, P, I, I, U32, P, I, P],
     "cmdiad_rows_dedup_plan": [P, P, I, I, P, P, P, P, P, P, P],
     "cmdiad_keys_expand": [P, P, I, P, P],
     "cmdiad_rows_expand_f32": [P, P, I, I, P, P],

@@ -66,21 +66,35 @@ __device__ __forceinline__ unsigned dpp_max_u32(unsigned v)
     return ab > cd ? ab : cd;
 }
 
-template <int kThreads, int PPT>
-__global__ __launch_bounds__(kThreads) void fps_pk_kernel(const float* __restrict__ xyz,
-                                                          const int32_t* __restrict__ n_valid, int N, int G,
-                                                          int32_t* __restrict__ idx_out,
-                                                          float* __restrict__ center_out)
+__device__ __forceinline__ unsigned dpp_min_u32(unsigned v)
+{
+    unsigned o;
+    o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false); v = o < v ? o : v;
+    o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false); v = o < v ? o : v;
+    o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false); v = o < v ? o : v;
+    o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false); v = o < v ? o : v;
+    const unsigned a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    const unsigned c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    const unsigned ab = a < b ? a : b, cd = c < d ? c : d;
+    return ab < cd ? ab : cd;
+}
+
+// The round, for the first PPT * kThreads points of a cloud in registers.  TAIL: the cloud continues beyond the register file of
+// the CU -- the next `lds_cap` points (coordinates + running minimum, 16 bytes each) live in LDS, whatever is left is re-read from
+// global memory every round with its running minimum in `temp` (L2-resident) -- so a cloud of up to 28 672 + 9 728 points never
+// leaves the CU and the largest cloud of the 224 x 224 grid (50 176) streams a quarter of its points instead of all of them.
+// A thread owns the same tail points in every round, so neither tier needs a barrier of its own.  Tail points have higher
+// indices than every register point: the winner is taken from the register slots first, from the tail (lowest index among the
+// lanes whose tail maximum IS the wave maximum) only when no register slot matches -- the tie rule (lowest index) holds.
+template <int kThreads, int PPT, bool TAIL>
+__device__ __forceinline__ void fps_pk_body(const float* __restrict__ p, const int n, const int G, int32_t* __restrict__ out,
+                                            float* __restrict__ cen, float4* __restrict__ lds_pts, const int lds_cap,
+                                            float* __restrict__ temp)
 {
     static_assert(PPT % 2 == 0, "two points per packed operation");
-    constexpr int kWaves = kThreads / 64, H = PPT / 2;
+    constexpr int kWaves = kThreads / 64, H = PPT / 2, R = PPT * kThreads;
     __shared__ unsigned long long s_key[2][kWaves];
-    const int b = blockIdx.x;
     const int tid = threadIdx.x;
-    const int n = n_valid ? n_valid[b] : N;
-    const float* p = xyz + (size_t)b * N * 3;
-    int32_t* out = idx_out + (size_t)b * G;
-    float* cen = center_out ? center_out + (size_t)b * G * 3 : nullptr;
 
     f32x2 px[H], py[H], pz[H], t[H];  // slot s = 2h + e holds point s * kThreads + tid
 #pragma unroll
@@ -94,6 +108,21 @@ __global__ __launch_bounds__(kThreads) void fps_pk_kernel(const float* __restric
             const float mag = (x * x + y * y) + z * z;
             t[h][e] = (k < n && !(mag <= 1e-3f)) ? 1e10f : -__builtin_inff();
         }
+    const int n_lds = TAIL ? min(max(n - R, 0), lds_cap) : 0;   // points R .. R + n_lds - 1 in LDS
+    const int g0 = R + n_lds;                                    // points g0 .. n - 1 stay in global memory
+    if constexpr (TAIL) {
+        for (int e = tid; e < n_lds; e += kThreads) {
+            const int k = R + e;
+            const float x = p[k * 3 + 0], y = p[k * 3 + 1], z = p[k * 3 + 2];
+            const float mag = (x * x + y * y) + z * z;
+            lds_pts[e] = float4{x, y, z, !(mag <= 1e-3f) ? 1e10f : -__builtin_inff()};
+        }
+        for (int k = g0 + tid; k < n; k += kThreads) {
+            const float x = p[k * 3 + 0], y = p[k * 3 + 1], z = p[k * 3 + 2];
+            const float mag = (x * x + y * y) + z * z;
+            temp[k] = !(mag <= 1e-3f) ? 1e10f : -__builtin_inff();
+        }
+    }
 
     int old = 0;
     if (tid == 0 && G > 0) {
@@ -118,7 +147,25 @@ __global__ __launch_bounds__(kThreads) void fps_pk_kernel(const float* __restric
             t[h][1] = __uint_as_float((unsigned)c);
             best = max(best, max(a, c));
         }
-        const unsigned wbits = dpp_max_u32((unsigned)best);
+        int tb = -1, ti = 0;   // tail: this lane's largest running minimum (bits; -1 = none) and the LOWEST index that attains it
+        if constexpr (TAIL) {
+            for (int e = tid; e < n_lds; e += kThreads) {
+                const float4 q = lds_pts[e];
+                const float dx = q.x - x1, dy = q.y - y1, dz = q.z - z1;
+                const float d = (dx * dx + dy * dy) + dz * dz;
+                const int a = min((int)__float_as_uint(d), (int)__float_as_uint(q.w));
+                lds_pts[e].w = __uint_as_float((unsigned)a);
+                if (a > tb) { tb = a; ti = R + e; }
+            }
+            for (int k = g0 + tid; k < n; k += kThreads) {
+                const float dx = p[k * 3] - x1, dy = p[k * 3 + 1] - y1, dz = p[k * 3 + 2] - z1;
+                const float d = (dx * dx + dy * dy) + dz * dz;
+                const int a = min((int)__float_as_uint(d), (int)__float_as_uint(temp[k]));
+                temp[k] = __uint_as_float((unsigned)a);
+                if (a > tb) { tb = a; ti = k; }
+            }
+        }
+        const unsigned wbits = dpp_max_u32((unsigned)max(best, tb));
         // lowest slot, then lowest lane, whose running minimum IS the wave maximum (none if the wave holds no valid point).
         // Eight slots at a time with an early exit: the lane masks of one chunk fit the scalar registers.
         int slot = -1;
@@ -144,6 +191,9 @@ __global__ __launch_bounds__(kThreads) void fps_pk_kernel(const float* __restric
         if (slot >= 0) {
             const int besti = slot * kThreads + (tid & ~63) + (__ffsll((long long)lanes) - 1);
             key = ((unsigned long long)wbits << 32) | (0xFFFFFFFFu - (unsigned)besti);
+        } else if constexpr (TAIL) {   // wave-uniform: no register slot holds the wave maximum
+            const unsigned cand = dpp_min_u32(tb == (int)wbits ? (unsigned)ti : 0xFFFFFFFFu);
+            if (cand != 0xFFFFFFFFu) key = ((unsigned long long)wbits << 32) | (0xFFFFFFFFu - cand);
         }
         const int buf = j & 1;
         if ((tid & 63) == 0) s_key[buf][tid >> 6] = key;
@@ -162,6 +212,41 @@ __global__ __launch_bounds__(kThreads) void fps_pk_kernel(const float* __restric
     }
 }
 
+template <int kThreads, int PPT>
+__global__ __launch_bounds__(kThreads) void fps_pk_kernel(const float* __restrict__ xyz,
+                                                          const int32_t* __restrict__ n_valid, int N, int G,
+                                                          int32_t* __restrict__ idx_out,
+                                                          float* __restrict__ center_out)
+{
+    const int b = blockIdx.x;
+    fps_pk_body<kThreads, PPT, false>(xyz + (size_t)b * N * 3, n_valid ? n_valid[b] : N, G, idx_out + (size_t)b * G,
+                                      center_out ? center_out + (size_t)b * G * 3 : nullptr, nullptr, 0, nullptr);
+}
+
+// Ragged batches and clouds beyond the register file: every cloud takes the path ITS OWN point count needs (the padded batch
+// maximum used to pick one kernel for all 32 clouds -- a single cloud above 28 672 points sent the whole batch through the
+// memory-resident loop, bench.py `var_n`): 40 / 48 / 56 points per lane in registers, and above 28 672 points the tiers of
+// fps_pk_body.  512 threads (two waves per SIMD, 256 VGPRs) in every branch; dynamic LDS = the LDS tier (16 bytes per point).
+constexpr int kRaggedThreads = 512;
+constexpr int kMaxLdsPoints = 9728;   // 152 KiB of the CU's 160 KiB
+__global__ __launch_bounds__(kRaggedThreads) void fps_ragged_kernel(const float* __restrict__ xyz,
+                                                                    const int32_t* __restrict__ n_valid, int N, int G,
+                                                                    int lds_cap, float* __restrict__ temp_ws,
+                                                                    int32_t* __restrict__ idx_out, float* __restrict__ center_out)
+{
+    extern __shared__ __attribute__((aligned(16))) float4 fps_lds[];
+    const int b = blockIdx.x;
+    const int n = __builtin_amdgcn_readfirstlane(n_valid ? n_valid[b] : N);
+    const float* p = xyz + (size_t)b * N * 3;
+    int32_t* out = idx_out + (size_t)b * G;
+    float* cen = center_out ? center_out + (size_t)b * G * 3 : nullptr;
+    if (n <= kRaggedThreads * 40) fps_pk_body<kRaggedThreads, 40, false>(p, n, G, out, cen, nullptr, 0, nullptr);
+    else if (n <= kRaggedThreads * 48) fps_pk_body<kRaggedThreads, 48, false>(p, n, G, out, cen, nullptr, 0, nullptr);
+    else if (n <= kRaggedThreads * 56) fps_pk_body<kRaggedThreads, 56, false>(p, n, G, out, cen, nullptr, 0, nullptr);
+    else fps_pk_body<kRaggedThreads, 56, true>(p, n, G, out, cen, fps_lds, lds_cap, temp_ws ? temp_ws + (size_t)b * N : nullptr);
+}
+
+#ifdef CMDIAD_AB_VARIANTS  // the first answer to clouds beyond the register file (every point re-read per round): test-only build
 // Fallback for clouds that do not fit the register file of one CU (N > 24*1024): running min in
 // a caller-provided global workspace (L2-resident), coordinates re-read every round.
 __global__ __launch_bounds__(kThreads) void fps_mem_kernel(const float* __restrict__ xyz,
@@ -221,11 +306,14 @@ __global__ __launch_bounds__(kThreads) void fps_mem_kernel(const float* __restri
     }
 }
 
+#endif  // CMDIAD_AB_VARIANTS
+
 }  // namespace
 
 extern "C" size_t cmdiad_fps_workspace_bytes(int B, int N)
 {
-    return N > kMaxRegPoints ? (size_t)B * (size_t)N * sizeof(float) : 0;
+    // running minima of the points beyond the register + LDS tiers of fps_ragged_kernel (indexed by point: B * N floats)
+    return N > kMaxRegPoints + kMaxLdsPoints ? (size_t)B * (size_t)N * sizeof(float) : 0;
 }
 
 extern "C" int cmdiad_fps(const float* xyz, const int32_t* n_valid, int B, int N, int G, int32_t* idx_out,
@@ -236,20 +324,43 @@ extern "C" int cmdiad_fps(const float* xyz, const int32_t* n_valid, int B, int N
     if (B == 0 || G == 0) return CMDIAD_OK;
     hipStream_t s = (hipStream_t)stream;
 #ifdef CMDIAD_AB_VARIANTS
-    // test-only build: CMDIAD_FPS_PK=0 selects the first formulation (A/B runs and the parity tests; read per call)
+    // test-only build: CMDIAD_FPS_PK=0 selects the first formulation (A/B runs and the parity tests; read per call),
+    // CMDIAD_FPS_RAGGED=0 the dispatch on the padded length with the memory-resident loop above 28 672 points
     const char* e = getenv("CMDIAD_FPS_PK");
     const bool pk = !(e && e[0] == '0');
+    const char* er = getenv("CMDIAD_FPS_RAGGED");
+    const bool ragged_ok = !(er && er[0] == '0');
 #define FPS_LAUNCH(T, P)                                                                                                      \
     do {                                                                                                                      \
         if (pk) hipLaunchKernelGGL((fps_pk_kernel<T, P>), dim3(B), dim3(T), 0, s, xyz, n_valid, N, G, idx_out, center_out);   \
         else hipLaunchKernelGGL((fps_reg_kernel<T, P>), dim3(B), dim3(T), 0, s, xyz, n_valid, N, G, idx_out, center_out);     \
     } while (0)
 #else
+    const bool ragged_ok = true;
 #define FPS_LAUNCH(T, P) hipLaunchKernelGGL((fps_pk_kernel<T, P>), dim3(B), dim3(T), 0, s, xyz, n_valid, N, G, idx_out, center_out)
 #endif
     // 1024 threads (4 waves/SIMD, 128 VGPRs) hold 16 points per lane; larger clouds use 512 threads
     // (2 waves/SIMD, 256 VGPRs): the register file of ONE CU bounds the resident cloud at ~28k points.
-    if (N <= 1024 * 4) FPS_LAUNCH(1024, 4);
+    // Per-cloud lengths (n_valid) above 16 384 padded points, and every cloud above 28 672: fps_ragged_kernel.
+    const bool ragged = ragged_ok && N > 1024 * 16 && (n_valid != nullptr || N > kMaxRegPoints);
+    if (ragged) {
+        const int lds_cap = N > kMaxRegPoints ? (N - kMaxRegPoints < kMaxLdsPoints ? N - kMaxRegPoints : kMaxLdsPoints) : 0;
+        const size_t need = cmdiad_fps_workspace_bytes(B, N);
+        CMDIAD_REQUIRE(need == 0 || (workspace && workspace_bytes >= need), CMDIAD_ERR_WORKSPACE,
+                       "cmdiad_fps: N=%d needs %zu workspace bytes", N, need);
+        static bool attr = false;
+        if (!attr) {
+            if (hipFuncSetAttribute((const void*)fps_ragged_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    kMaxLdsPoints * (int)sizeof(float4)) != hipSuccess) {
+                cmdiad_set_error("cmdiad_fps: hipFuncSetAttribute failed");
+                return CMDIAD_ERR_LAUNCH;
+            }
+            attr = true;
+        }
+        hipLaunchKernelGGL(fps_ragged_kernel, dim3(B), dim3(kRaggedThreads), (size_t)lds_cap * sizeof(float4), s, xyz, n_valid, N, G,
+                           lds_cap, need ? (float*)workspace : nullptr, idx_out, center_out);
+    }
+    else if (N <= 1024 * 4) FPS_LAUNCH(1024, 4);
     else if (N <= 1024 * 8) FPS_LAUNCH(1024, 8);
     else if (N <= 1024 * 16) FPS_LAUNCH(1024, 16);
     else if (N <= 512 * 40) FPS_LAUNCH(512, 40);
@@ -257,9 +368,14 @@ extern "C" int cmdiad_fps(const float* xyz, const int32_t* n_valid, int B, int N
     else if (N <= 512 * 56) FPS_LAUNCH(512, 56);
 #undef FPS_LAUNCH
     else {
-        CMDIAD_REQUIRE(workspace && workspace_bytes >= cmdiad_fps_workspace_bytes(B, N), CMDIAD_ERR_WORKSPACE,
-                       "cmdiad_fps: N=%d needs %zu workspace bytes", N, cmdiad_fps_workspace_bytes(B, N));
+#ifdef CMDIAD_AB_VARIANTS
+        const size_t need = (size_t)B * (size_t)N * sizeof(float);
+        CMDIAD_REQUIRE(workspace && workspace_bytes >= need, CMDIAD_ERR_WORKSPACE, "cmdiad_fps: N=%d needs %zu workspace bytes", N, need);
         hipLaunchKernelGGL(fps_mem_kernel, dim3(B), dim3(kThreads), 0, s, xyz, n_valid, N, G, (float*)workspace, idx_out, center_out);
+#else
+        cmdiad_set_error("cmdiad_fps: unreachable dispatch (N=%d)", N);
+        return CMDIAD_ERR_ARG;
+#endif
     }
     CMDIAD_CHECK_LAUNCH();
     return CMDIAD_OK;

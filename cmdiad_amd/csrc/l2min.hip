@@ -34,15 +34,27 @@ struct L2Params {
     unsigned* diag;    // test-only build: in-kernel stamps of one workgroup (l2_min_pp3_kernel<F16, true>), else null
     int diag_wg;
     const int* q_count;   // device-resident number of live query rows (<= Q), or null: cmdiad_l2_min_keys_counted
+    const int* seg_counts;  // cmdiad_l2_min_keys_segments: live rows of each of n_seg query segments (device), or null
+    int n_seg, seg_stride;  // segment w = query rows [w * seg_stride, w * seg_stride + min(seg_counts[w], seg_stride))
 };
 
 // Live query rows known only on the device (the compacted query set of cmdiad_rows_dedup_plan): the grid is sized for Q, every
 // block reads the count once and the blocks of query tiles beyond it leave.
 // Returns the number of workgroups that have work: the XCD remap must run over THAT count -- it hands every XCD a contiguous range
 // of (query tile, library range) blocks, so a remap over the launched grid would leave the live query tiles to the first XCDs only.
+// With segments (cmdiad_l2_min_keys_segments: the gathered query sets of W ranks, each compacted on its own rank, laid out at a
+// fixed stride) the live query tiles of ALL segments form one tile list: p.nq_tiles = sum of ceil(count[w] / BM).
 template <int BM>
 __device__ __forceinline__ int live_rows(GlobalTile& A, L2Params& p)
 {
+    if (p.seg_counts) {
+        int tiles = 0;
+        for (int w = 0; w < p.n_seg; ++w) tiles += (min(max(__builtin_amdgcn_readfirstlane(p.seg_counts[w]), 0), p.seg_stride) + BM - 1) / BM;
+        p.nq_tiles = tiles;
+        const int qg = min(p.qgroup, max(tiles, 1));
+        p.qgroup = qg;
+        return (tiles + qg - 1) / qg * qg * p.splits;
+    }
     if (!p.q_count) return gridDim.x;
     const int q = __builtin_amdgcn_readfirstlane(*p.q_count);
     p.Q = q;
@@ -51,6 +63,26 @@ __device__ __forceinline__ int live_rows(GlobalTile& A, L2Params& p)
     const int qg = min(p.qgroup, max(p.nq_tiles, 1));   // the launcher's clamp of qgroup, for the live tile count
     p.qgroup = qg;
     return (p.nq_tiles + qg - 1) / qg * qg * p.splits;
+}
+
+// First query row of live tile `qt`.  Plain / counted launches: qt * BM.  Segments: the tile's segment is found by walking the
+// (<= 64) counts again; p.Q / A.rows become the END of that segment's live rows, which is all the kernels use them for (the row
+// clamp of a partial tile, the norm fetch and the final atomics).
+template <int BM>
+__device__ __forceinline__ int tile_first_row(GlobalTile& A, L2Params& p, int qt)
+{
+    if (!p.seg_counts) return qt * BM;
+    int before = 0, w = 0, cnt = 0;
+    for (; w < p.n_seg; ++w) {
+        cnt = min(max(__builtin_amdgcn_readfirstlane(p.seg_counts[w]), 0), p.seg_stride);
+        const int t = (cnt + BM - 1) / BM;
+        if (qt < before + t) break;
+        before += t;
+    }
+    const int end = w * p.seg_stride + cnt;
+    p.Q = end;
+    A.rows = end;
+    return w * p.seg_stride + (qt - before) * BM;
 }
 
 template <class S, bool F16>
@@ -74,7 +106,7 @@ __global__ __launch_bounds__(S::THREADS, S::WAVES_PER_SIMD) void l2_min_kernel(G
     const int nt0 = split * per;
     const int ntc = min(per, p.n_bank_tiles - nt0);
     if (ntc <= 0) return;
-    const int m0 = qt * S::BM;
+    const int m0 = tile_first_row<S::BM>(A, p, qt);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave / S::WN, wc = wave % S::WN;
 
@@ -166,7 +198,7 @@ __global__ __launch_bounds__(512, 1) void l2_min_pp3_kernel(GlobalTile A, Global
     const int nt0 = split * per;
     const int ntc = min(per, p.n_bank_tiles - nt0);
     if (ntc <= 0) return;
-    const int m0 = qt * S::BM;
+    const int m0 = tile_first_row<S::BM>(A, p, qt);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int KT = p.D / BK, T_total = ntc * KT;
@@ -586,9 +618,29 @@ template <bool F16> struct L2Kernel<SPingPong3, F16> { static constexpr auto fn 
 template <bool F16> struct L2Kernel<SPingPong4, F16> { static constexpr auto fn = l2_min_pp4_kernel<F16>; };
 #endif
 
+// Optional device-side row counts of a launch: one live count for the whole query set (counted) or one per segment.
+struct L2Live {
+    const int* q_count = nullptr;
+    const int* seg_counts = nullptr;
+    int n_seg = 0, seg_stride = 0;
+};
+
+// Library ranges per query tile of the segments launch (the W-way row-sharded search: W x the query tiles of one rank against
+// 1/W of the library).  Measured on the bagel library at W = 1 / 2 / 4 / 8 (299 / 150 / 74 / 38 library tiles, 213 live query
+// tiles per segment; tools/l2_segments_sweep.sh, profiles/r4_notes.md): ranges of ~15 tiles as in the single-library launch, but
+// never fewer than 8 ranges -- a group of 4 query tiles x 8 ranges is what one XCD's 32 CUs hold at a time, with fewer ranges its
+// L2 has to keep more query tiles than it can (W = 8: 1 range 6.35 ms, 8 ranges 5.96 ms) -- and ranges of at least 4 tiles.
+static int segment_splits(int nbt)
+{
+    int sp = nbt / 15;
+    sp = sp < 8 ? 8 : (sp > 20 ? 20 : sp);
+    const int most = nbt / 4 < 1 ? 1 : nbt / 4;
+    return sp > most ? most : sp;
+}
+
 template <class S, bool F16>
 int launch_l2(const uint16_t* q, const float* q_sqnorm, const uint16_t* bank, const float* bank_sqnorm, int Q, int Nb,
-              int D, uint32_t row_offset, unsigned long long* keys, hipStream_t stream, const int* q_count = nullptr)
+              int D, uint32_t row_offset, unsigned long long* keys, hipStream_t stream, const L2Live& live = L2Live())
 {
     static bool attr = false;
     if (!attr) {
@@ -598,11 +650,14 @@ int launch_l2(const uint16_t* q, const float* q_sqnorm, const uint16_t* bank, co
         }
         attr = true;
     }
-    const int nq = (Q + S::BM - 1) / S::BM, nbt = (Nb + S::BN - 1) / S::BN;
+    // segments: the launch is sized for every segment's cap (seg_stride rows); Q = n_seg * seg_stride
+    const int nq = live.seg_counts ? live.n_seg * ((live.seg_stride + S::BM - 1) / S::BM) : (Q + S::BM - 1) / S::BM;
+    const int nbt = (Nb + S::BN - 1) / S::BN;
     // enough blocks to fill the chip a few times over, but long bank ranges per block so the running
     // min stays in registers and the per-block atomics stay negligible
     static const int env_splits = getenv("CMDIAD_L2_SPLITS") ? atoi(getenv("CMDIAD_L2_SPLITS")) : 0;
     static const int env_qgroup = getenv("CMDIAD_L2_QGROUP") ? atoi(getenv("CMDIAD_L2_QGROUP")) : 0;
+    const char* env_seg_splits = getenv("CMDIAD_L2_SEG_SPLITS");   // read per call: tools/l2_segments.py sweeps it
     // measured on the bagel xyz library (profiles/r1_notes.md): 8 bank ranges for the 8-wave shapes; the 4-wave wide
     // shape gains another 5 % from 16-32 (shorter ranges, better tail balance), as long as a range keeps >= 4 tiles.
     // Round 3 (profiles/r3_notes.md, the two-group kernel on the de-duplicated 54 401 rows): 20 ranges of 15 tiles 5.40 ms against
@@ -610,17 +665,19 @@ int launch_l2(const uint16_t* q, const float* q_sqnorm, const uint16_t* bank, co
     // tail to balance; all 100 352 rows: within 1 % from 15 to 50 ranges.
     int splits = env_splits > 0 ? env_splits : 8;
     if (env_splits <= 0 && S::BM == 256 && !std::is_same<S, S2x2>::value) splits = nbt / 4 < 1 ? 1 : (nbt / 4 > 20 ? 20 : nbt / 4);
+    if (live.seg_counts && S::BM == 256) splits = env_seg_splits && atoi(env_seg_splits) > 0 ? atoi(env_seg_splits) : segment_splits(nbt);
     splits = splits > nbt ? nbt : splits;
     int qgroup = env_qgroup > 0 ? env_qgroup : 4;
     qgroup = qgroup > nq ? nq : qgroup;
     GlobalTile A{(const bf16_t*)q, D, Q}, W{(const bf16_t*)bank, D, Nb};
-    L2Params p{Q, Nb, D, q_sqnorm, bank_sqnorm, row_offset, keys, nq, nbt, splits, qgroup, nullptr, -1, q_count};
+    L2Params p{Q, Nb, D, q_sqnorm, bank_sqnorm, row_offset, keys, nq, nbt, splits, qgroup, nullptr, -1, live.q_count,
+               live.seg_counts, live.n_seg, live.seg_stride};
     const int ngroups = (nq + qgroup - 1) / qgroup;
     hipLaunchKernelGGL((L2Kernel<S, F16>::fn), dim3(ngroups * qgroup * splits), dim3(S::THREADS), S::LDS_BYTES, stream, A, W, p);
     return CMDIAD_OK;
 }
 
-static int l2_min_keys_impl(const uint16_t* q, const float* q_sqnorm, const int* q_count, const uint16_t* bank,
+static int l2_min_keys_impl(const uint16_t* q, const float* q_sqnorm, const L2Live& q_count, const uint16_t* bank,
                            const float* bank_sqnorm, int Q, int Nb, int D, uint32_t row_offset,
                            unsigned long long* keys, int dtype, cmdiad_stream_t stream)
 {
@@ -637,6 +694,7 @@ static int l2_min_keys_impl(const uint16_t* q, const float* q_sqnorm, const int*
     const char* env_tile = getenv("CMDIAD_L2_TILE");
     const int force = env_tile ? atoi(env_tile) : -1;
     int tile = force >= 0 ? force : (Q >= 512 ? 5 : 0);
+    if (q_count.seg_counts && tile != 0) tile = 5;    // segments exist for the production shapes only
 #ifndef CMDIAD_AB_VARIANTS
     if (tile != 0 && tile != 5) {
         cmdiad_set_error("cmdiad_l2_min_keys: CMDIAD_L2_TILE=%d names an A/B variant that only the test build (make ab) contains", tile);
@@ -695,7 +753,7 @@ extern "C" int cmdiad_l2_min_keys(const uint16_t* q, const float* q_sqnorm, cons
                                   const float* bank_sqnorm, int Q, int Nb, int D, uint32_t row_offset,
                                   unsigned long long* keys, int dtype, cmdiad_stream_t stream)
 {
-    return l2_min_keys_impl(q, q_sqnorm, nullptr, bank, bank_sqnorm, Q, Nb, D, row_offset, keys, dtype, stream);
+    return l2_min_keys_impl(q, q_sqnorm, L2Live(), bank, bank_sqnorm, Q, Nb, D, row_offset, keys, dtype, stream);
 }
 
 extern "C" int cmdiad_l2_min_keys_counted(const uint16_t* q, const float* q_sqnorm, const int* q_count, int Q_max,
@@ -703,7 +761,23 @@ extern "C" int cmdiad_l2_min_keys_counted(const uint16_t* q, const float* q_sqno
                                           uint32_t row_offset, unsigned long long* keys, int dtype, cmdiad_stream_t stream)
 {
     CMDIAD_REQUIRE(q_count, CMDIAD_ERR_ARG, "cmdiad_l2_min_keys_counted: null count");
-    return l2_min_keys_impl(q, q_sqnorm, q_count, bank, bank_sqnorm, Q_max, Nb, D, row_offset, keys, dtype, stream);
+    L2Live live;
+    live.q_count = q_count;
+    return l2_min_keys_impl(q, q_sqnorm, live, bank, bank_sqnorm, Q_max, Nb, D, row_offset, keys, dtype, stream);
+}
+
+extern "C" int cmdiad_l2_min_keys_segments(const uint16_t* q, const float* q_sqnorm, const int* seg_counts, int n_seg,
+                                           int seg_stride, const uint16_t* bank, const float* bank_sqnorm, int Nb, int D,
+                                           uint32_t row_offset, unsigned long long* keys, int dtype, cmdiad_stream_t stream)
+{
+    CMDIAD_REQUIRE(seg_counts, CMDIAD_ERR_ARG, "cmdiad_l2_min_keys_segments: null counts");
+    CMDIAD_REQUIRE(n_seg >= 1 && n_seg <= 64 && seg_stride >= 0 && (long long)n_seg * seg_stride < (1ll << 31), CMDIAD_ERR_ARG,
+                   "cmdiad_l2_min_keys_segments: need 1 <= n_seg <= 64 (n_seg=%d) and n_seg * seg_stride < 2^31", n_seg);
+    L2Live live;
+    live.seg_counts = seg_counts;
+    live.n_seg = n_seg;
+    live.seg_stride = seg_stride;
+    return l2_min_keys_impl(q, q_sqnorm, live, bank, bank_sqnorm, n_seg * seg_stride, Nb, D, row_offset, keys, dtype, stream);
 }
 
 #ifdef CMDIAD_AB_VARIANTS

@@ -110,6 +110,12 @@ class _HipSearch:
         return ops.l2_min_keys(q16, q_sq, bank.bf16, bank.sqnorm, keys, bank.row_offset)
 
     @staticmethod
+    def search_segments(q_all, s_all, counts, cap, bank, keys_all):
+        """Every rank's live rows (segment w = rows [w * cap, w * cap + counts[w]), counts on the device) against this rank's
+        shard: ONE launch over the live query tiles of all segments (cmdiad_l2_min_keys_segments)."""
+        return ops.l2_min_keys_segments(q_all, s_all, counts, cap, bank.bf16, bank.sqnorm, keys_all, bank.row_offset)
+
+    @staticmethod
     def expand(keys_compact, slot, out):
         return ops.keys_expand(keys_compact, slot, out)
 
@@ -120,32 +126,65 @@ class ShardedSearch:
     can put step i + 1's exchange under step i's distance GEMM (bench.py `sharded_search`):
 
       gather(q16, q_sq): the repeated background row of the rank's own queries is removed locally (csrc/dedup.hip): `count`
-              live rows; the ranks exchange their counts (W int32 -- the one host read of the step, it sizes the exchange);
-              all-gather of the first cap = max(count) rows (rounded up to 256) of every rank's compacted queries + norms:
-              about half of the 154 MB per rank that gathering every row takes (45 % of a batch's patches have no
-              foreground pixel);
-      gemm(): per rank segment, the distance GEMM over that rank's live rows against this rank's shard (global rows via
-              row_offset) -- no collective;
+              live rows; the ranks exchange their counts (W int32, they STAY on the device); all-gather of the first `cap` rows
+              of every rank's compacted queries + norms: about half of the 154 MB per rank that gathering every row takes
+              (45 % of a batch's patches have no foreground pixel);
+      gemm(): ONE launch: the distance GEMM over the live rows of all W segments against this rank's shard (global rows via
+              row_offset), the live counts read on the device -- no collective, no host read;
       reduce(): ONE integer-MIN all-reduce of the packed (distance, global row) keys, then the rank's own segment is expanded
               back to one key per original row -> keys [Q] int64.
 
-    `stats` (a dict) receives the bytes this rank received in the gather, the live counts and cap."""
+    `cap_rows`: how many rows of every rank travel.
+      "exact": every gather() reads the W counts on the host (one synchronisation per step) and takes cap = max(count) rounded up
+               to 256 rows;
+      "auto" (default): the FIRST gather() does that once and keeps cap = max(count) * (1 + slack) (rounded up to 256) for the
+               following steps -- no host read in steady state.  A step whose live rows exceed the cap on ANY rank cannot be
+               answered from what was gathered: `overflow` (a device flag, the same on every rank because it is computed from the
+               all-gathered counts) says so, and the caller checks it (`overflowed()`: a host read) wherever it synchronises with the
+               step's results anyway, then calls `regrow()` and repeats the step;
+      an int:  that many rows (Q = no compaction, never overflows).
 
-    def __init__(self, bank, group, impl=_HipSearch, stats=None):
+    `stats` (a dict) receives the bytes this rank received in the gather, the live counts (of the last host read) and cap."""
+
+    def __init__(self, bank, group, impl=_HipSearch, stats=None, cap_rows="auto", slack=0.06):
         import torch.distributed as td
         self.bank, self.group, self.impl, self.stats = bank, group, impl, stats
         self.world, self.rank = td.get_world_size(group), td.get_rank(group)
         self.plan = None
+        if not (cap_rows in ("auto", "exact") or (isinstance(cap_rows, int) and cap_rows > 0)):
+            raise ValueError(f"cap_rows must be 'auto', 'exact' or a positive row count, not {cap_rows!r}")
+        self.cap_rows, self.slack = cap_rows, float(slack)
+        self.cap = None              # rows of every rank that travel (sticky in "auto" mode)
+        self.counts = None           # live rows per rank at the last host read
+        self.host_reads = 0
+        self.overflow = None
+
+    def regrow(self):
+        """Forget the sticky cap: the next gather() reads the live counts on the host again."""
+        self.cap = None
+
+    def overflowed(self):
+        """True when the last gather()'s live rows did not fit the cap on some rank (host read; identical on every rank)."""
+        return self.overflow is not None and bool(self.overflow.item())
 
     def gather(self, q16, q_sq):
         import torch.distributed as td
         Q, D = q16.shape
         self.Q = Q
         self.plan = self.impl.plan(q16, q_sq, self.plan)
-        counts_t = torch.empty((self.world,), dtype=torch.int32, device=q16.device)
+        counts_t = self.counts_dev = torch.empty((self.world,), dtype=torch.int32, device=q16.device)
         td.all_gather_into_tensor(counts_t, self.plan.count.view(1), group=self.group)
-        self.counts = [int(c) for c in counts_t.cpu().tolist()]
-        cap = self.cap = min(Q, (max(self.counts) + 255) // 256 * 256)
+        if isinstance(self.cap_rows, int):
+            cap = min(Q, (self.cap_rows + 255) // 256 * 256)
+        elif self.cap_rows == "exact" or self.cap is None or self.cap > Q:
+            self.counts = [int(c) for c in counts_t.cpu().tolist()]        # the one host read (every step / the first step)
+            self.host_reads += 1
+            grow = 1.0 if self.cap_rows == "exact" else 1.0 + self.slack
+            cap = min(Q, (int(math.ceil(max(self.counts) * grow)) + 255) // 256 * 256)
+        else:
+            cap = self.cap
+        self.cap = cap
+        self.overflow = counts_t.max() > cap
         self.q_all = torch.empty((self.world * cap, D), dtype=q16.dtype, device=q16.device)
         self.s_all = torch.empty((self.world * cap,), dtype=torch.float32, device=q16.device)
         td.all_gather_into_tensor(self.q_all.view(torch.uint8), self.plan.q16[:cap].view(torch.uint8), group=self.group)   # raw bytes: gloo has no bf16
@@ -153,6 +192,7 @@ class ShardedSearch:
         if self.stats is not None:
             row = D * q16.element_size() + 4
             self.stats.update(world=self.world, rows_per_rank=Q, live_rows=self.counts, gathered_rows_per_rank=cap,
+                              host_reads=self.host_reads,
                               gather_bytes_received=(self.world - 1) * cap * row,
                               gather_bytes_received_without_compaction=(self.world - 1) * Q * row,
                               reduce_bytes=self.world * cap * 8)
@@ -162,23 +202,25 @@ class ShardedSearch:
         cap = self.cap
         self.keys_all = torch.full((self.world * cap,), KEY_EMPTY, dtype=torch.int64, device=self.q_all.device)
         with (timer if timer is not None else _Null()):
-            for w in range(self.world):
-                n = self.counts[w]
-                if n > 0:
-                    self.impl.search(self.q_all[w * cap:w * cap + n], self.s_all[w * cap:w * cap + n], self.bank,
-                                     self.keys_all[w * cap:w * cap + n])
+            self.impl.search_segments(self.q_all, self.s_all, self.counts_dev, cap, self.bank, self.keys_all)
         return self
 
     def reduce(self):
         cap = self.cap
         keys_all = merge_shard_keys(self.keys_all, self.group)
-        return self.impl.expand(keys_all[self.rank * cap:(self.rank + 1) * cap].contiguous(), self.plan.slot,
-                                torch.empty((self.Q,), dtype=torch.int64, device=keys_all.device))
+        mine = keys_all[self.rank * cap:(self.rank + 1) * cap]
+        if cap < self.Q:
+            # slot[] names compacted rows up to count - 1, and count is known on the device only: in a step that overflowed the
+            # cap the expansion must still read inside its buffer (such rows get "no candidate"; `overflow` tells the caller)
+            kc = torch.full((self.Q,), KEY_EMPTY, dtype=torch.int64, device=keys_all.device)
+            kc[:cap] = mine
+            mine = kc
+        return self.impl.expand(mine.contiguous(), self.plan.slot, torch.empty((self.Q,), dtype=torch.int64, device=keys_all.device))
 
 
 def sharded_min_keys(q16, q_sq, bank, group, plan=None, timer=None, stats=None, impl=_HipSearch):
-    """ShardedSearch's three stages in line -> (keys [Q] int64, plan)."""
-    s = ShardedSearch(bank, group, impl, stats)
+    """ShardedSearch's three stages in line, the cap read per call ("exact") -> (keys [Q] int64, plan)."""
+    s = ShardedSearch(bank, group, impl, stats, cap_rows="exact")
     s.plan = plan
     keys = s.gather(q16, q_sq).gemm(timer).reduce()
     return keys, s.plan

@@ -107,14 +107,14 @@ def run_class(args, data, weights=None, method=None, extractor=None):
     count = getattr(args, "max_sample", 500)
     sec = {}
 
-    def loop(it, call):
+    def loop(it, call, limit=count):
         t0 = time.perf_counter()
         n = flag = 0
         for item in it:
             call(item)
             n += 1
             flag += 1
-            if flag > count:                                 # cmdiad_runner.py:50-52: stops AFTER max_sample + 1 samples
+            if limit is not None and flag > limit:           # cmdiad_runner.py:50-52, 64-66: the two TRAIN loops stop AFTER max_sample + 1 samples
                 break
         return n, t0
 
@@ -133,7 +133,7 @@ def run_class(args, data, weights=None, method=None, extractor=None):
         method.run_late_fusion()
         sec["late_fusion"] = time.perf_counter() - t0
     with torch.no_grad():
-        n_test, t0 = loop(test_items, lambda it: method.predict(*it))
+        n_test, t0 = loop(test_items, lambda it: method.predict(*it), limit=None)   # cmdiad_runner.py:80-85: every test sample, no cut-off
         # the drop-in defers predict() into micro-batches; reading a result attribute completes them (multiple_features._MethodBase)
         assert len(method.image_preds) == n_test
         torch.cuda.synchronize()

@@ -469,6 +469,21 @@ def l2_min_keys_counted(q16, q_sq, count, bank16, bank_sq, keys, row_offset=0):
     return keys
 
 
+def l2_min_keys_segments(q16, q_sq, seg_counts, seg_stride, bank16, bank_sq, keys, row_offset=0):
+    """l2_min_keys over the segments [w * seg_stride, w * seg_stride + seg_counts[w]) of q16 (seg_counts: device int32 [n_seg]):
+    ONE launch over the live query tiles of all segments (include/cmdiad_hip.h)."""
+    Q, D = q16.shape
+    if q16.dtype != bank16.dtype:
+        raise TypeError("l2_min_keys_segments: queries and bank must share the 16-bit dtype")
+    _chk(seg_counts, torch.int32, "l2_min_keys_segments.seg_counts")
+    n_seg = seg_counts.shape[0]
+    if n_seg * seg_stride != Q or keys.shape[0] < Q:
+        raise ValueError(f"l2_min_keys_segments: {n_seg} segments of {seg_stride} rows != {Q} query rows (keys: {keys.shape[0]})")
+    _call("cmdiad_l2_min_keys_segments", _p(q16), _p(q_sq), _p(seg_counts), n_seg, seg_stride, _p(bank16), _p(bank_sq),
+          bank16.shape[0], D, row_offset, _p(keys), 1 if q16.dtype == torch.float16 else 0, _stream())
+    return keys
+
+
 def rows_expand_f32(rows_compact, slot, out=None):
     """out[q] = rows_compact[slot[q]] (f32 rows): per-row results computed on the compacted rows, back on every original row."""
     _chk(rows_compact, torch.float32, "rows_expand.rows"); _chk(slot, torch.int32, "rows_expand.slot")

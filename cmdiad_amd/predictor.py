@@ -61,10 +61,14 @@ class _NoTimer:
 
 
 class Ticket:
-    """One submitted batch: wait() -> (image scores [B] f64, pixel maps [B, gt, gt] f64) as numpy arrays."""
+    """One submitted batch: wait() -> (image scores [B] f64, pixel maps [B, gt, gt] f64) as numpy arrays.
+    `flag` / `redo` (row-sharded search only): a pinned int32 that the step set to non-zero when some rank's live query rows did
+    not fit the sticky gather cap (engine.ShardedSearch) -- the step's keys are then incomplete and wait() repeats the batch through
+    `redo` (the same decision on every rank: the flag is computed from the all-gathered counts)."""
 
-    def __init__(self, host_s, host_m, event, gt):
+    def __init__(self, host_s, host_m, event, gt, flag=None, redo=None):
         self._s, self._m, self._ev, self._gt = host_s, host_m, event, gt
+        self._flag, self._redo = flag, redo
         self._out = None
 
     @property
@@ -76,8 +80,11 @@ class Ticket:
         if self._out is None:
             self._ev.synchronize()
             B = self._s.shape[0]
-            self._out = (self._s.numpy().reshape(B).copy(), self._m.numpy().reshape(B, self._gt, self._gt).copy())
-            self._s = self._m = None
+            if self._flag is not None and int(self._flag.item()) != 0:
+                self._out = self._redo()
+            else:
+                self._out = (self._s.numpy().reshape(B).copy(), self._m.numpy().reshape(B, self._gt, self._gt).copy())
+            self._s = self._m = self._flag = self._redo = None
         return self._out
 
 
@@ -110,6 +117,8 @@ class BatchPredictor:
         # host ring: the step's FINAL outputs (image score, pixel map), f64 as sklearn's score_samples returns them
         self.ring = [(torch.empty((batch, 1), dtype=torch.float64, pin_memory=True),
                       torch.empty((batch, gt_size * gt_size), dtype=torch.float64, pin_memory=True)) for _ in range(ring)]
+        # row-sharded search: one pinned flag per ring slot ("this step's live rows exceeded the gather cap on some rank")
+        self.flag_ring = [torch.zeros((1,), dtype=torch.int32, pin_memory=True) for _ in range(ring)] if group is not None else None
         self.slot = 0
         self.tickets = [None] * ring     # the ticket that aliases each pinned slot (submit refuses to overwrite an unread one)
         self.step_no = 0
@@ -117,10 +126,14 @@ class BatchPredictor:
         self.static = {}
         # exact removal of the repeated background rows in front of the xyz search (csrc/dedup.hip); CMDIAD_DEDUP=0 searches every row
         self.dedup = os.environ.get("CMDIAD_DEDUP", "1") != "0"
+        # row-sharded search: rows of every rank that travel per step -- "auto" (sticky cap, no host read in steady state) | "exact"
+        self.shard_cap = os.environ.get("CMDIAD_SHARD_CAP", "auto")
         self.live_rows = torch.zeros((1,), dtype=torch.int64, device=dev)   # rows actually searched, summed over the xyz searches
         self.xyz_searches = 0
         self._raw_norm = None
-        self.shard_stats = {}        # per library: what the last row-sharded search exchanged (engine.sharded_min_keys)
+        self.shard_stats = {}        # per library: what the last row-sharded search exchanged (engine.ShardedSearch)
+        self.step_flags = []         # device flags of the current step's row-sharded searches ("live rows exceeded the gather cap")
+        self.redone = 0              # steps repeated because of such a flag
         self.inputs = [self._new_inputs() for _ in range(2 if use_graph else 1)]
 
     def _new_inputs(self):
@@ -213,12 +226,15 @@ class BatchPredictor:
             B, Q, D = q.shape
             if self.group is not None and self.dedup:
                 # row-sharded library: compact locally, all-gather the live rows only (engine.sharded_min_keys)
+                # one ShardedSearch per (library, buffer set): its gather cap is sticky, so a steady-state step reads nothing on the host
                 st = self.shard_stats.setdefault(name, {})
-                k, plan = eng.sharded_min_keys(q16, qsq, bank, self.group, plan=self.static.get(f"plan_{name}_{buf}"),
-                                               timer=self.timers.get(name), stats=st)
-                self.static[f"plan_{name}_{buf}"] = plan
+                ss = self.static.get(f"ss_{name}_{buf}")
+                if ss is None:
+                    ss = self.static[f"ss_{name}_{buf}"] = eng.ShardedSearch(bank, self.group, stats=st, cap_rows=self.shard_cap)
+                k = ss.gather(q16, qsq).gemm(self.timers.get(name)).reduce()
+                self.step_flags.append(ss.overflow)
                 if name == "xyz":
-                    self.live_rows += sum(st["live_rows"])
+                    self.live_rows += ss.counts_dev.sum()
                     self.xyz_searches += 1
                 keys[name] = k
                 continue
@@ -287,6 +303,7 @@ class BatchPredictor:
                 torch.cuda.synchronize()
                 sets.append(dict(g1=g1, g2=g2, qs=qs, k=k, out=out, done=None))
             self.sets = sets
+            self.step_flags = []      # the rehearsal's row-sharded searches are not a step
         except Exception as exc:  # capture is an optimisation, never a requirement
             print(f"[cmdiad_amd.predictor] HIP graph capture unavailable ({type(exc).__name__}: {exc}); running eagerly",
                   file=sys.stderr)
@@ -369,10 +386,11 @@ class BatchPredictor:
                 s_dev, maps_dev = st["out"]
                 host_s.copy_(s_dev, non_blocking=True)
                 host_m.copy_(maps_dev, non_blocking=True)
+                flag = self._flag_to_host()
                 ev = torch.cuda.Event()
                 ev.record()
             st["done"] = ev
-            return self._ticket(host_s, host_m, ev)
+            return self._ticket(host_s, host_m, ev, flag, rgb, pcs)
         inp = self.inputs[0]
         self.step_no += 1
         self._load_inputs(inp, rgb, pcs)
@@ -382,12 +400,43 @@ class BatchPredictor:
         s_dev, maps_dev = self.stage2(qs, self.search(qs, 0))
         host_s.copy_(s_dev, non_blocking=True)
         host_m.copy_(maps_dev, non_blocking=True)
+        flag = self._flag_to_host()
         ev = torch.cuda.Event()
         ev.record()
-        return self._ticket(host_s, host_m, ev)
+        return self._ticket(host_s, host_m, ev, flag, rgb, pcs)
 
-    def _ticket(self, host_s, host_m, ev):
-        t = Ticket(host_s, host_m, ev, self.gt)
+    def _flag_to_host(self):
+        """Row-sharded search: OR of this step's overflow flags -> the pinned flag of the step's ring slot (asynchronous)."""
+        if self.flag_ring is None or not self.step_flags:
+            self.step_flags = []
+            return None
+        dev_flag = torch.stack(self.step_flags).any().to(torch.int32).view(1)
+        self.step_flags = []
+        host = self.flag_ring[(self.slot - 1) % len(self.ring)]
+        host.copy_(dev_flag, non_blocking=True)
+        return host
+
+    def _redo(self, rgb, pcs):
+        """A step whose live query rows exceeded the sticky gather cap on some rank: its keys are incomplete.  Every rank sees the
+        same flag, so every rank repeats the batch here, in the same place of its submit / wait sequence: drain the device, let the
+        searches read the live counts again (a larger cap from now on), run the batch eagerly."""
+        torch.cuda.synchronize()
+        self.redone += 1
+        for k, v in self.static.items():
+            if k.startswith("ss_"):
+                v.regrow()
+        inp = self.inputs[0]
+        self._load_inputs(inp, rgb, pcs)
+        qs = self.stage1(inp)
+        inp["free"] = torch.cuda.Event()
+        inp["free"].record()
+        s_dev, maps_dev = self.stage2(qs, self.search(qs, 0))
+        self.step_flags = []
+        B = s_dev.shape[0]
+        return s_dev.cpu().numpy().reshape(B).copy(), maps_dev.cpu().numpy().reshape(B, self.gt, self.gt).copy()
+
+    def _ticket(self, host_s, host_m, ev, flag=None, rgb=None, pcs=None):
+        t = Ticket(host_s, host_m, ev, self.gt, flag, (lambda: self._redo(rgb, pcs)) if flag is not None else None)
         self.tickets[(self.slot - 1) % len(self.ring)] = t
         return t
 

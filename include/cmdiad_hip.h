@@ -36,7 +36,8 @@ const char* cmdiad_last_error(void);
 int cmdiad_abi_version(void); /* 2: cmdiad_reweight_scan's limits and workspace changed (see there); cmdiad_gemm_args gained m_count
                                  3: LayerNorm fold -- cmdiad_gemm_args gained row_scale / ln_xb / ln_part / add2, cmdiad_gemm_qkv gained
                                     row_scale, cmdiad_block_weights the folded weights, cmdiad_transformer_block_fwd its flags;
-                                    cmdiad_ln_stats_finalize is new */
+                                    cmdiad_ln_stats_finalize is new
+                                 4: cmdiad_l2_min_keys_segments is new */
 /* 1 when the library is the test-only build that also contains the superseded kernel formulations (A/B references). */
 int cmdiad_has_ab_variants(void);
 
@@ -281,6 +282,16 @@ int cmdiad_l2_min_keys(const uint16_t* q, const float* q_sqnorm, const uint16_t*
 int cmdiad_l2_min_keys_counted(const uint16_t* q, const float* q_sqnorm, const int* q_count, int Q_max, const uint16_t* bank,
                                const float* bank_sqnorm, int Nb, int D, uint32_t row_offset, unsigned long long* keys, int dtype,
                                cmdiad_stream_t stream);
+
+/* The same search over n_seg query SEGMENTS laid out at a fixed stride -- the row-sharded search of SURVEY 8(e): the gathered,
+ * separately compacted query sets of the W ranks of a node against THIS rank's library shard (what features.py:186-190,227 do on
+ * one device, per shard).  Segment w = rows [w * seg_stride, w * seg_stride + min(seg_counts[w], seg_stride)) of q / q_sqnorm /
+ * keys ([n_seg * seg_stride] each); seg_counts [n_seg] int32 lives on the device, so no host read sizes the launch: ONE launch
+ * walks the live query tiles of all segments as one tile list (XCD-aware mapping over the live blocks), instead of one launch per
+ * segment.  1 <= n_seg <= 64. */
+int cmdiad_l2_min_keys_segments(const uint16_t* q, const float* q_sqnorm, const int* seg_counts, int n_seg, int seg_stride,
+                                const uint16_t* bank, const float* bank_sqnorm, int Nb, int D, uint32_t row_offset,
+                                unsigned long long* keys, int dtype, cmdiad_stream_t stream);
 
 /* Exact removal of repeated query rows in front of the search.  Every patch of the 56 x 56 grid without a foreground pixel under
  * it is the same vector ((0 - mean) / std in every column; features.py:169-184, multiple_features.py:976-977) and the reference's

@@ -1,0 +1,200 @@
+"""GPU: BASELINE configs[3] -- the patch-library search with the library's rows sharded W ways -- at its real shard shapes on ONE
+device ("fake world"): the W shards are searched in turn through exactly what one rank of a W-rank node
+executes (engine.Bank shards + cmdiad_l2_min_keys_segments over the W gathered, separately compacted query sets), the integer MIN
+over the shards stands in for the all_reduce(MIN), and the result must equal the single-library keys bit for bit
+(features.py:186-190,227 on one device).  Plus the segments launch against its definition on small ragged shapes."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from cmdiad_amd import engine as eng  # noqa: E402
+from cmdiad_amd import ops  # noqa: E402
+
+DEV = "cuda"
+
+
+def _segments_case(counts, stride, Nb, D, dtype, seed):
+    g = torch.Generator().manual_seed(seed)
+    W = len(counts)
+    bank = torch.randn(Nb, D, generator=g).to(DEV)
+    q = torch.randn(W * stride, D, generator=g).to(DEV)
+    k = min(64, W * stride, Nb)
+    q[:k] = bank[:k]                          # self-matches: exact zeros
+    b16, _, bsq = ops.normalize_cast(bank, dtype=dtype)
+    q16, _, qsq = ops.normalize_cast(q, dtype=dtype)
+    cnt = torch.tensor(counts, dtype=torch.int32, device=DEV)
+    got = ops.l2_min_keys_segments(q16, qsq, cnt, stride, b16, bsq, ops.new_keys(W * stride, DEV), 7)
+    want = ops.new_keys(W * stride, DEV)
+    for w, n in enumerate(counts):
+        n = max(0, min(n, stride))
+        if n:
+            lo = w * stride
+            ops.l2_min_keys(q16[lo:lo + n].contiguous(), qsq[lo:lo + n].contiguous(), b16, bsq, want[lo:lo + n], 7)
+    return got, want
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("counts,stride,Nb", [
+    ((700, 0, 513, 1), 768, 1300),            # ragged, an empty segment, partial tiles, library with a partial last tile
+    ((1024, 1024), 1024, 512),                # full segments, whole tiles
+    ((300, 900, 2000), 1024, 777),            # a count ABOVE the stride is cut to the stride (rows beyond were not gathered)
+    ((5,), 256, 256),                         # one short segment: the 128 x 128 kernel's path (Q < 512)
+    ((0, 0), 512, 600),                       # nothing live: no key is touched
+    ((260, 250, 255, 257, 1, 256, 511, 3), 512, 2048),   # eight segments
+])
+def test_segments_launch_equals_one_launch_per_segment(counts, stride, Nb, dtype):
+    got, want = _segments_case(counts, stride, Nb, 768, dtype, seed=sum(counts) + Nb)
+    assert torch.equal(got, want)
+    for w, n in enumerate(counts):            # rows at and beyond a segment's live count are neither searched nor written
+        assert bool((got[w * stride + min(n, stride):(w + 1) * stride] == eng.KEY_EMPTY).all())
+
+
+def _query_sets(W, Q, D, bg_share, seed):
+    """W batches of Q rows, a share of each the repeated background row -> their dedup plans (each rank compacts its own)."""
+    plans, fulls = [], []
+    for w in range(W):
+        g = torch.Generator(device=DEV).manual_seed(seed + w)
+        q = torch.randn(Q, D, generator=g, device=DEV)
+        bg = torch.rand(Q, generator=g, device=DEV) < bg_share * (0.8 + 0.4 * w / max(W - 1, 1))   # ragged live counts
+        q[bg] = -0.3
+        q16, _, qsq = ops.normalize_cast(q)
+        del q
+        plans.append(ops.rows_dedup_plan(q16, qsq))
+        fulls.append((q16, qsq))
+    return plans, fulls
+
+
+@pytest.mark.parametrize("cls_rows", [76518, 113209], ids=["bagel", "peach"])
+@pytest.mark.parametrize("W", [2, 4, 8])
+def test_fake_world_full_size_sharded_search_equals_single_library(W, cls_rows):
+    """Full size: W ranks x 32 images (100 352 query rows each, ~46 % background), bagel (76 518 rows: 9 600-row shards of 38 tiles
+    at W = 8) and peach (113 209 rows).  For every rank r: ONE segments launch of all W ranks' live rows against shard r; MIN
+    over r; expansion per rank -- equal to that rank's de-duplicated search of the whole library, which the dedup tests pin to
+    the search of every row."""
+    Q, D = 32 * 3136, 768
+    gb = torch.Generator(device=DEV).manual_seed(4321 + cls_rows)
+    full = torch.randn(cls_rows, D, generator=gb, device=DEV)
+    plans, _ = _query_sets(W, Q, D, 0.46, seed=1000 * W)
+    counts = [int(p.count.item()) for p in plans]
+    assert len(set(counts)) > 1                                             # ragged
+    cap = min(Q, (max(counts) + 255) // 256 * 256)
+    q_all = torch.cat([p.q16[:cap] for p in plans])
+    s_all = torch.cat([p.q_sq[:cap] for p in plans])
+    cnt = torch.tensor(counts, dtype=torch.int32, device=DEV)
+    merged = ops.new_keys(W * cap, DEV)
+    covered = 0
+    for r in range(W):
+        bank = eng.Bank(full, r, W)
+        assert bank.row_offset == covered and bank.bf16.shape[0] % 256 == 0
+        covered += bank.shard_rows
+        keys = eng._HipSearch.search_segments(q_all, s_all, cnt, cap, bank, ops.new_keys(W * cap, DEV))
+        merged = torch.minimum(merged, keys)                                # the all_reduce(MIN) of the packed keys
+        del bank, keys
+    assert covered == cls_rows
+    whole = eng.Bank(full, 0, 1)
+    for w in range(W):
+        p = plans[w]
+        ref_c = ops.l2_min_keys_counted(p.q16, p.q_sq, p.count, whole.bf16, whole.sqnorm, ops.new_keys(Q, DEV))
+        seg = merged[w * cap:w * cap + counts[w]]
+        assert torch.equal(seg, ref_c[:counts[w]]), f"rank {w}: sharded keys differ from the single-library keys"
+        assert bool((merged[w * cap + counts[w]:(w + 1) * cap] == eng.KEY_EMPTY).all())
+        out = ops.keys_expand(merged[w * cap:(w + 1) * cap].contiguous(), p.slot, torch.empty((Q,), dtype=torch.int64, device=DEV)) \
+            if cap == Q else None
+        if out is not None:
+            assert torch.equal(out, ops.keys_expand(ref_c, p.slot, torch.empty_like(out)))
+    idx = (merged[:counts[0]] & 0xFFFFFFFF)
+    assert int(idx.max()) < cls_rows                                        # no key names a pad row
+
+
+def _world_of_one():
+    import torch.distributed as td
+    _world_of_one()
+    return td.group.WORLD
+
+
+def test_pipeline_repeats_a_step_whose_live_rows_exceed_the_sticky_cap():
+    """BatchPredictor with the row-sharded search (RCCL, world of one): batches of sparse clouds set a small sticky gather cap;
+    a batch of dense clouds then has more live query rows than the cap -- the step's flag reaches the ticket, wait() repeats the
+    batch with a re-read cap, and every batch's scores and maps equal the unsharded predictor's, bit for bit."""
+    import importlib.util
+    import os
+    import torch.distributed as td
+    from cmdiad_amd.predictor import BatchPredictor
+    from cmdiad_amd.synth import synth_cloud, synth_rgb
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    group = _world_of_one()
+    try:
+        st = bench.build_state(torch.device("cuda", 0))
+        B, n_max = 8, 34000
+
+        def batch(seed, frac):
+            return (torch.cat([synth_rgb(seed + i) for i in range(B)]).to(DEV),
+                    torch.cat([synth_cloud(seed + i, frac) for i in range(B)]).to(DEV))
+
+        sparse_a, sparse_b, dense = batch(10, 0.36), batch(30, 0.37), batch(50, 0.64)
+        mk = lambda g: BatchPredictor(st["engine"], st["bank_xyz"], st["bank_second"], st["stats"], st["det"], st["seg"], batch=B,
+                                      n_max=n_max, group=g)
+        ref, sh = mk(None), mk(group)
+        order = [sparse_a, sparse_b, sparse_a, dense, dense, sparse_b]
+        want = [ref.predict_batch(*b) for b in order]
+        got = []
+        pending = []
+        for b in order:                                   # pipelined: two tickets outstanding, as bench.run_steps drives it
+            if len(pending) == 2:
+                got.append(pending.pop(0).wait())
+            pending.append(sh.submit(*b))
+        got += [t.wait() for t in pending]
+        assert sh.redone >= 1, "the dense batch must have overflowed the cap set by the sparse ones"
+        assert sh.redone <= 2
+        for (gs, gm), (ws, wm) in zip(got, want):
+            assert np.array_equal(gs, ws) and np.array_equal(gm, wm)
+    finally:
+        td.destroy_process_group()
+
+
+def test_sharded_search_object_world_of_one_rccl_sticky_cap_and_overflow():
+    """engine.ShardedSearch through RCCL with a world of one rank: the sticky cap ("auto") reads the counts on the host once,
+    a later batch with MORE live rows than the cap raises the device flag, regrow() + the repeated step is exact again."""
+    import os
+    import socket
+    import torch.distributed as td
+    if not td.is_initialized():
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+        td.init_process_group("nccl", device_id=torch.device("cuda", 0))
+    try:
+        Q, D, Nb = 4096, 768, 3000
+        g = torch.Generator().manual_seed(5)
+        lib = torch.randn(Nb, D, generator=g).to(DEV)
+        bank = eng.Bank(lib, 0, 1)
+
+        def batch(bg_share, seed):
+            gq = torch.Generator().manual_seed(seed)
+            q = torch.randn(Q, D, generator=gq)
+            q[torch.rand(Q, generator=gq) < bg_share] = -0.3
+            return ops.normalize_cast(q.to(DEV))
+
+        def single(q16, qsq):
+            return ops.l2_min_keys(q16, qsq, bank.bf16, bank.sqnorm, ops.new_keys(Q, DEV))
+
+        ss = eng.ShardedSearch(bank, td.group.WORLD, cap_rows="auto", slack=0.02)
+        for i in range(3):
+            q16, _, qsq = batch(0.6, 100 + i)
+            keys = ss.gather(q16, qsq).gemm().reduce()
+            assert torch.equal(keys, single(q16, qsq)) and not ss.overflowed()
+        assert ss.host_reads == 1 and ss.cap < Q
+        q16, _, qsq = batch(0.1, 200)                                       # far more live rows than the cap
+        bad = ss.gather(q16, qsq).gemm().reduce()
+        assert ss.overflowed() and ss.host_reads == 1
+        assert not torch.equal(bad, single(q16, qsq))                       # the flag is what tells: these keys are incomplete
+        ss.regrow()
+        keys = ss.gather(q16, qsq).gemm().reduce()
+        assert torch.equal(keys, single(q16, qsq)) and not ss.overflowed() and ss.host_reads == 2
+    finally:
+        td.destroy_process_group()

@@ -85,6 +85,53 @@ def test_fps_mostly_skipped_and_all_skipped_clouds(fps_variant):
     assert (idx == 0).all()
 
 
+def _dense_cloud(n, seed):
+    """n distinct points of a bumpy sheet (as the organised clouds: |p|^2 ~ 0.25, far outside the skip radius)."""
+    rs = np.random.RandomState(seed)
+    xy = (rs.rand(n, 2).astype(np.float32) - 0.5) * 0.2
+    z = (0.5 + 0.03 * np.sin(25 * xy[:, 0]) * np.cos(31 * xy[:, 1]) + 1e-4 * rs.randn(n)).astype(np.float32)
+    return np.concatenate([xy, z[:, None]], 1).astype(np.float32)
+
+
+def test_fps_ragged_batch_every_cloud_takes_its_own_path():
+    """csrc/fps.hip fps_ragged_kernel: per-cloud dispatch on n_valid (not on the padded batch maximum).  One batch holds clouds
+    for every branch -- 40 / 48 / 56 points per lane in registers (with the bucket boundaries), registers + the LDS tier (28 673
+    ... 38 400 points), registers + LDS + the global tier (above) -- and each must equal the oracle's FPS of that cloud alone;
+    bench.py's `var_n` shape (one 30 k-point cloud among 24 k-point clouds) is the second batch."""
+    for sizes, G in (((17000, 20480, 20481, 24576, 28672, 28673, 32614, 38400, 38401, 44000), 160),
+                     ((24576, 24576, 30011, 24576), 1024)):
+        N = (max(sizes) + 255) // 256 * 256
+        xyz = np.zeros((len(sizes), N, 3), np.float32)
+        clouds = []
+        for i, n in enumerate(sizes):
+            c = _dense_cloud(n, 40 + i)
+            c[n // 2] = 0.001                     # one skipped point per cloud (|p|^2 <= 1e-3)
+            if n > 28672:
+                c[n - 5] = c[3]                   # an exact duplicate in the TAIL tiers of a register point: ties -> lowest index
+            clouds.append(c)
+            xyz[i, :n] = c
+        nv = torch.tensor(sizes, dtype=torch.int32, device=DEV)
+        idx, cen = ops.fps(torch.from_numpy(xyz).to(DEV), G, n_valid=nv)
+        for i, c in enumerate(clouds):
+            ref_idx, ref_cen = ok.fps(c[None], G)
+            np.testing.assert_array_equal(idx[i].cpu().numpy(), ref_idx[0], err_msg=f"cloud of {sizes[i]} points")
+            np.testing.assert_array_equal(cen[i].cpu().numpy(), ref_cen[0])
+
+
+def test_fps_tail_tiers_hold_the_farthest_points():
+    """A cloud whose farthest points all lie beyond the register tier (indices >= 28 672): most winners then come from the LDS
+    and global tiers, including exact ties between tail points (lowest index wins) and with register points."""
+    n = 41000
+    c = _dense_cloud(n, 77)
+    c[:28672, :2] *= 0.05                         # the register tier is a small patch in the middle, the rest surrounds it
+    c[40000:40200] = c[30000:30200]               # exact duplicates inside the tail: LDS tier vs global tier
+    idx, cen = ops.fps(torch.from_numpy(c[None]).to(DEV), 300)
+    ref_idx, ref_cen = ok.fps(c[None], 300)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ref_idx)
+    np.testing.assert_array_equal(cen.cpu().numpy(), ref_cen)
+    assert (ref_idx >= 28672).mean() > 0.5 and (ref_idx >= 38400).any()
+
+
 @pytest.fixture(params=["1", "0"], ids=["wave", "block"])
 def knn_variant(request, monkeypatch):
     """Both formulations of the kNN grouping (knn_group.hip: a wave owns its centres with an in-register sorting network, and

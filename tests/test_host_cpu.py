@@ -17,7 +17,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_cabi_library_loads_and_exports_every_declared_symbol():
     from cmdiad_amd import _native as nat
     L = nat.lib()
-    assert L.cmdiad_abi_version() == 3
+    assert L.cmdiad_abi_version() == 4
     hdr = open(os.path.join(REPO, "include", "cmdiad_hip.h")).read()
     declared = set(re.findall(r"\b(cmdiad_[a-z0-9_]+)\s*\(", hdr))
     bound = set(nat.SIGNATURES) | set(nat.SIZE_QUERIES) | {"cmdiad_last_error", "cmdiad_abi_version", "cmdiad_has_ab_variants"}
@@ -156,6 +156,36 @@ def test_feature_ring_reproduces_dataloader_order(tmp_path):
         assert rng_after == torch.rand(1).item()
 
 
+
+def _free_port():
+    """A TCP port nobody listens on right now (the hard-coded rendezvous ports of earlier rounds collide on a shared box)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def _run_gloo(script_text, tmp_path, world=2, timeout=240, extra_env=None):
+    """Starts `world` ranks of a worker script (one process each, gloo rendezvous on 127.0.0.1 and a free port), waits for all of
+    them and returns their outputs; asserts that every rank exited with 0."""
+    script = tmp_path / "w.py"
+    script.write_text(script_text)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(world), OMP_NUM_THREADS="1")
+    env.update(extra_env or {})
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(world)]
+    outs = []
+    try:
+        for pr in procs:
+            outs.append(pr.communicate(timeout=timeout)[0].decode())
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    assert all(pr.returncode == 0 for pr in procs), outs
+    return outs
+
+
 _GLOO_WORKER = r"""
 import os, sys
 sys.path.insert(0, {repo!r})
@@ -191,13 +221,7 @@ print("rank", rank, "ok")
 
 
 def test_sharded_merge_world2_gloo(tmp_path):
-    script = tmp_path / "w.py"
-    script.write_text(_GLOO_WORKER.format(repo=REPO))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2")
-    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
-                              stderr=subprocess.STDOUT) for r in range(2)]
-    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
-    assert all(p.returncode == 0 for p in procs), outs
+    _run_gloo(_GLOO_WORKER.format(repo=REPO), tmp_path)
 
 
 def test_isa_lint_main_loops():
@@ -472,13 +496,7 @@ def test_class_sharded_evaluate_world2_gloo(tmp_path):
     all_gather_object BOTH ranks hold the dictionary -- and the main.py table -- a single rank produces."""
     import json
     from cmdiad_amd import evaluate as ev
-    script = tmp_path / "w.py"
-    script.write_text(_GLOO_EVAL_WORKER.format(repo=REPO))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", WORLD_SIZE="2")
-    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
-                              stderr=subprocess.STDOUT) for r in range(2)]
-    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
-    assert all(p.returncode == 0 for p in procs), outs
+    outs = _run_gloo(_GLOO_EVAL_WORKER.format(repo=REPO), tmp_path, timeout=240)
     recs = [json.loads([ln for ln in o.splitlines() if ln.startswith("RESULT ")][-1][7:]) for o in outs]
     recs.sort(key=lambda r: r["rank"])
     assert sorted(recs[0]["calls"] + recs[1]["calls"]) == sorted(ev.MVTEC3D_TRAIN) and not set(recs[0]["calls"]) & set(recs[1]["calls"])
@@ -544,20 +562,31 @@ class TorchSearch:      # stand-in for the HIP kernels behind engine.sharded_min
         return keys
 
     @staticmethod
+    def search_segments(q_all, s_all, counts, cap, bank, keys_all):
+        for w, n in enumerate(counts.tolist()):       # host tensors here: reading the counts costs nothing
+            n = min(n, cap)
+            if n:
+                TorchSearch.search(q_all[w * cap:w * cap + n], s_all[w * cap:w * cap + n], bank, keys_all[w * cap:w * cap + n])
+        return keys_all
+
+    @staticmethod
     def expand(kc, slot, out):
         out.copy_(kc[slot.long()])
         return out
 
 
 g = torch.Generator().manual_seed(21)
-Nb, D, Q = 1500, 16, 700
+Nb, D, Q = int(os.environ.get("T_NB", "1500")), 16, 700
 lib = torch.randn(Nb, D, generator=g).half()                   # the same library on every rank; each keeps its row shard
 lib_sq = lib.float().pow(2).sum(1)
 lo, hi = eng.shard_range(Nb, rank, world)
+if os.environ.get("T_EXPECT_EMPTY_LAST") == "1" and rank == world - 1:
+    assert lo == hi == Nb                                      # 128-row aligned shards: the last rank holds NO library row
 bank = types.SimpleNamespace(bf16=lib[lo:hi], sqnorm=lib_sq[lo:hi], row_offset=lo)
 gq = torch.Generator().manual_seed(100 + rank)                 # every rank's own queries, with its own share of background rows
 q = torch.randn(Q, D, generator=gq).half()
-bg = torch.rand(Q, generator=gq) < (0.35 + 0.2 * rank)
+share = 0.35 + 0.2 * rank if world == 2 else 0.2 + 0.55 * rank / (world - 1)   # ragged: 20 % ... 75 % background rows at world 8
+bg = torch.rand(Q, generator=gq) < share
 q[bg] = torch.full((D,), -0.25).half()
 q_sq = q.float().pow(2).sum(1)
 stats = {{}}
@@ -568,9 +597,31 @@ want = pack(v, i)
 assert torch.equal(keys, want), (keys != want).nonzero().flatten()[:8]
 live = int(plan.count)
 assert live == int((~bg).sum()) + 1 and stats["live_rows"][rank] == live
-assert stats["gathered_rows_per_rank"] == min(Q, (max(stats["live_rows"]) + 255) // 256 * 256) < Q
-assert stats["gather_bytes_received"] < 0.8 * stats["gather_bytes_received_without_compaction"]
-assert TorchSearch.searched == sum(stats["live_rows"])       # every rank searched the live rows of all ranks, nothing else
+assert stats["gathered_rows_per_rank"] == min(Q, (max(stats["live_rows"]) + 255) // 256 * 256)
+if world == 2:
+    assert stats["gathered_rows_per_rank"] < Q and stats["gather_bytes_received"] < 0.8 * stats["gather_bytes_received_without_compaction"]
+assert TorchSearch.searched == (sum(stats["live_rows"]) if hi > lo else 0)   # the live rows of all ranks, nothing else (nothing at all on an empty shard)
+
+# steady state ("auto"): ONE host read for three steps; then a batch with more live rows than the sticky cap raises the flag
+# on every rank, the repeated step (after regrow()) is exact again
+ss = eng.ShardedSearch(bank, td.group.WORLD, impl=TorchSearch, cap_rows="auto", slack=0.0)
+for step in range(3):
+    k2 = ss.gather(q, q_sq).gemm().reduce()
+    assert torch.equal(k2, want) and not ss.overflowed()
+assert ss.host_reads == 1
+q_more = q.clone()
+if rank == 0:
+    q_more[bg] = torch.randn(int(bg.sum()), D, generator=gq).half()     # rank 0's background rows become live rows
+qm_sq = q_more.float().pow(2).sum(1)
+cap_before = ss.cap
+ss.gather(q_more, qm_sq).gemm().reduce()
+grew = int(ss.counts_dev.max()) > cap_before
+assert ss.overflowed() == grew and ss.host_reads == 1
+if grew:
+    ss.regrow()
+    k3 = ss.gather(q_more, qm_sq).gemm().reduce()
+    v3, i3 = d2_of(q_more, qm_sq, lib, lib_sq).min(1)
+    assert torch.equal(k3, pack(v3, i3)) and not ss.overflowed() and ss.host_reads == 2 and ss.cap > cap_before
 td.barrier()
 td.destroy_process_group()
 print("rank", rank, "ok", stats["live_rows"], stats["gathered_rows_per_rank"])
@@ -581,13 +632,16 @@ def test_compact_then_gather_equals_gather_then_search_world2_gloo(tmp_path):
     """engine.sharded_min_keys on a gloo group of two ranks with a torch stand-in for the kernels: removing each rank's repeated
     background row BEFORE the all-gather (only the live rows + a per-rank count travel) returns, for every original row, the
     key that searching every row of every rank against the whole library returns -- ties to the lowest global row included."""
-    script = tmp_path / "w.py"
-    script.write_text(_GLOO_COMPACT_WORKER.format(repo=REPO))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29561", WORLD_SIZE="2")
-    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
-                              stderr=subprocess.STDOUT) for r in range(2)]
-    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
-    assert all(p.returncode == 0 for p in procs), outs
+    outs = _run_gloo(_GLOO_COMPACT_WORKER.format(repo=REPO), tmp_path, timeout=240)
+
+
+def test_compact_then_gather_world8_gloo_ragged_counts_and_an_empty_shard(tmp_path):
+    """The same on a gloo world of EIGHT (BASELINE configs[3]'s rank count): ragged live counts (20 % ... 75 % background rows per
+    rank), and a library so short (800 rows -> seven 128-row shards) that the last rank's shard is EMPTY -- its keys stay
+    KEY_EMPTY and lose the MIN reduce."""
+    outs = _run_gloo(_GLOO_COMPACT_WORKER.format(repo=REPO), tmp_path, world=8, timeout=600,
+                     extra_env={"T_NB": "800", "T_EXPECT_EMPTY_LAST": "1"})
+    assert all("ok" in o for o in outs), outs
 
 
 _GLOO_EVAL_FAIL_WORKER = r"""
@@ -614,13 +668,7 @@ td.destroy_process_group()
 def test_class_sharded_evaluate_propagates_a_rank_failure_world2_gloo(tmp_path):
     """A rank whose class loop raises still reaches the gather, and EVERY rank then raises naming the rank and the cause -- no
     rank is left waiting in the collective until it times out."""
-    script = tmp_path / "w.py"
-    script.write_text(_GLOO_EVAL_FAIL_WORKER.format(repo=REPO))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29573", WORLD_SIZE="2")
-    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
-                              stderr=subprocess.STDOUT) for r in range(2)]
-    outs = [p.communicate(timeout=120)[0].decode() for p in procs]
-    assert all(p.returncode == 0 for p in procs), outs
+    outs = _run_gloo(_GLOO_EVAL_FAIL_WORKER.format(repo=REPO), tmp_path, timeout=120)
     for o in outs:
         assert "RAISED class-sharded evaluation failed on rank 1: ValueError: cloud has 7 valid points" in o, o
 
