@@ -365,11 +365,12 @@ class BatchPredictor:
             st["g1"].replay()
             inp["free"] = torch.cuda.Event()
             inp["free"].record()
-            # MTFI workload: the searches go to the second stream as well and run beside the NEXT step's extraction, which without
-            # a ViT beside it leaves the chip idle while FPS walks its chain on 32 CUs (25.9 -> 23.5 ms).  With the ViT in stage 1
-            # the same move gains 2.5 % of the step and doubles the measured duration of the distance GEMM (it shares the chip):
-            # off there, so that roofline.launch_ms stays the kernel's own time.  CMDIAD_SEARCH_POST=0 / 1 forces either.
-            search_on_post = os.environ.get("CMDIAD_SEARCH_POST", "1" if self.workload == "mtfi" else "0") == "1"
+            # The library searches go to the second stream as well and run beside the NEXT step's extraction.  MTFI workload: without
+            # a ViT beside it the extraction leaves the chip idle while FPS walks its chain on 32 CUs (25.9 -> 23.5 ms).  With the
+            # ViT in stage 1 the same move gains 2.5 % of the step (23.5 -> 22.9 ms); the distance GEMM then shares the chip, so its
+            # duration inside the pipeline says little about the kernel -- bench.py times the same launch again, alone, for
+            # `roofline.launch_ms`.  CMDIAD_SEARCH_POST=0 keeps the searches on the main stream.
+            search_on_post = os.environ.get("CMDIAD_SEARCH_POST", "1") == "1"
             if not search_on_post:
                 keys = self.search(st["qs"], which)
                 for n, k in keys.items():

@@ -109,8 +109,15 @@ def test_fake_world_full_size_sharded_search_equals_single_library(W, cls_rows):
 
 
 def _world_of_one():
+    import os
+    import socket
     import torch.distributed as td
-    _world_of_one()
+    if not td.is_initialized():
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+        td.init_process_group("nccl", device_id=torch.device("cuda", 0))
     return td.group.WORLD
 
 
@@ -159,15 +166,8 @@ def test_pipeline_repeats_a_step_whose_live_rows_exceed_the_sticky_cap():
 def test_sharded_search_object_world_of_one_rccl_sticky_cap_and_overflow():
     """engine.ShardedSearch through RCCL with a world of one rank: the sticky cap ("auto") reads the counts on the host once,
     a later batch with MORE live rows than the cap raises the device flag, regrow() + the repeated step is exact again."""
-    import os
-    import socket
     import torch.distributed as td
-    if not td.is_initialized():
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0))
-            port = sk.getsockname()[1]
-        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
-        td.init_process_group("nccl", device_id=torch.device("cuda", 0))
+    _world_of_one()
     try:
         Q, D, Nb = 4096, 768, 3000
         g = torch.Generator().manual_seed(5)

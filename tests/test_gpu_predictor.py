@@ -142,8 +142,9 @@ def test_predict_batch_b32_vs_oracle(weights, cpu_ex, gpu_engine, monkeypatch):
     every = p_all.predict_batch(rgb, pcs)
     assert not p_all.dedup and int(p_all.live_rows.item()) == B * 3136 * p_all.xyz_searches
     assert np.array_equal(every[0], outs["graph"][0]) and np.array_equal(every[1], outs["graph"][1])
-    # the searches on the second stream, beside the next step's extraction (the MTFI workload's default): same outputs
-    monkeypatch.setenv("CMDIAD_SEARCH_POST", "1")
+    # the searches on the MAIN stream (CMDIAD_SEARCH_POST=0; the default runs them on the second stream, beside the next step's
+    # extraction): same outputs
+    monkeypatch.setenv("CMDIAD_SEARCH_POST", "0")
     p_post = BatchPredictor(gpu_engine, bank_xyz, bank_rgb, stats, det, seg, lambdas=(1.0, 1.0, 0.1, 0.1), batch=B, use_graph=True)
     tickets = [p_post.submit(rgb, pcs) for _ in range(2)]      # two steps in flight: both buffer sets, searches overlapping stage 1
     monkeypatch.delenv("CMDIAD_SEARCH_POST")
