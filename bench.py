@@ -58,6 +58,7 @@ CLASS_TRAIN = {"bagel": 244, "cable_gland": 223, "carrot": 286, "cookie": 210, "
 PEAK_BF16_TFLOPS = 2500.0           # dense bf16 / fp16 MFMA, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 ROTATE = 4                          # distinct input batches rotated through the timed region
+DEFECT_SEVERITY = 0.35              # synthetic defects of the class loop: hard enough that I-AUROC is not saturated (synth.SyntheticClass)
 
 
 def class_rows(name):
@@ -682,7 +683,7 @@ def mtfi_classes(dev, group, rank, world, classes="all", scale=0.05, n_test=20, 
                sharpen_pointmae({k: v.detach() for k, v in PointTransformer().state_dict().items()}),
                {k: v.detach() for k, v in HallucinationCrossModalityNetwork(None, 768, 768).state_dict().items()})
     names = "all" if classes == "all" else [c for c in classes.split(",") if c]
-    data = ev.synthetic_mvtec3d(names, scale=scale, n_test=n_test)
+    data = ev.synthetic_mvtec3d(names, scale=scale, n_test=n_test, severity=DEFECT_SEVERITY)
     a = ev.mtfi_args(f_coreset=f_coreset)
     import contextlib
     import warnings
@@ -712,7 +713,8 @@ def mtfi_classes(dev, group, rank, world, classes="all", scale=0.05, n_test=20, 
                 job_images_per_s=round(n_images / wall, 2),
                 per_class={c: {**{m: round(v[m], 4) for m in ev.METRICS}, "rank": v["rank"], "n_train": v["n_train"],
                                "n_test": v["n_test"], "seconds": v["seconds"], "library_rows": v["library_rows"]} for c, v in pc.items()},
-                mean={m: res["table"][m]["Mean"] for m in ev.METRICS})
+                mean={m: res["table"][m]["Mean"] for m in ev.METRICS}, defect_severity=DEFECT_SEVERITY,
+                host_fit_overlapped=os.environ.get("CMDIAD_EVAL_OVERLAP", "1") != "0" and world < len(pc))
 
 
 

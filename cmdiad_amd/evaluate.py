@@ -14,6 +14,7 @@ communication needed to agree on it.
 Everything below the protocol calls is the drop-in classes of ``feature_extractors/multiple_features.py`` (HIP kernels);
 this module holds no arithmetic of its own.
 """
+import os
 import time
 import types
 
@@ -84,31 +85,40 @@ def lpt_assign(costs, world):
 
 
 # ------------------------------------------------------------------------------------------------ one class
-def run_class(args, data, weights=None, method=None, extractor=None):
-    """fit + evaluate of ONE class, in the reference's order (cmdiad_runner.py:33-107):
-    add_sample_to_mem_bank over the train loader -> run_coreset -> (memory_bank == 'multiple')
-    add_sample_to_late_fusion_mem_bank over the train loader again -> run_late_fusion -> predict over the test loader ->
-    calculate_metrics.  ``data``: an object with ``name``, ``train()`` yielding (sample, label) and ``test()`` yielding
-    (sample, mask, label, rgb_path) -- the reference's loaders, or synth.SyntheticClass.  ``weights`` (optional):
-    (ViT state_dict, Point-MAE state_dict, fusion state_dict | None) loaded into the fresh method object (offline stand-in
-    for the checkpoints).  ``extractor`` (optional): the frozen backbones (``Features.deep_feature_extractor``) of an earlier
-    class on this rank -- every other piece of state (banks, statistics, SVMs, result lists) is the fresh object's.
-    Returns the class's metrics (unrounded), image counts, seconds per phase, and the extractor under "_extractor"."""
-    from .utils.utils import set_seeds
-    if method is None:
-        _, cls = method_class(args)
-        method = cls(args, shared_extractor=extractor)      # a fresh object per class, as main.py:23
-    if weights is not None and extractor is None:
-        method.deep_feature_extractor.rgb_backbone.load_state_dict(weights[0])
-        method.deep_feature_extractor.xyz_backbone.load_state_dict(weights[1])
-    if weights is not None and len(weights) > 2 and weights[2] is not None and getattr(method, "fusion", None) is not None:
-        method.fusion.load_state_dict(weights[2])
-    set_seeds(0)
-    count = getattr(args, "max_sample", 500)
-    sec = {}
+class ClassRun:
+    """fit + evaluate of ONE class, in the reference's order (cmdiad_runner.py:33-107), cut into the three stages a rank can
+    overlap ACROSS classes (the order inside a class never changes):
 
-    def loop(it, call, limit=count):
-        t0 = time.perf_counter()
+      fit_device():  add_sample_to_mem_bank over the train loader -> run_coreset -> (memory_bank == 'multiple')
+                     add_sample_to_late_fusion_mem_bank over the train loader again, scored on the GPU   [device-bound]
+      fit_host():    run_late_fusion: the two scikit-learn SGDOneClassSVM fits of features.py:352-358 -- 8-9 s of ONE host core
+                     per full-size class, during which the GPU has nothing to do for THIS class             [host-bound]
+      predict():     predict over the test loader -> calculate_metrics.
+
+    ``data``: an object with ``name``, ``train()`` yielding (sample, label) and ``test()`` yielding (sample, mask, label,
+    rgb_path) -- the reference's loaders, or synth.SyntheticClass.  ``weights`` (optional): (ViT state_dict, Point-MAE
+    state_dict, fusion state_dict | None) loaded into the fresh method object (offline stand-in for the checkpoints).
+    ``extractor`` (optional): the frozen backbones (``Features.deep_feature_extractor``) of an earlier class on this rank --
+    every other piece of state (banks, statistics, SVMs, result lists) is the fresh object's."""
+
+    def __init__(self, args, data, weights=None, method=None, extractor=None):
+        from .utils.utils import set_seeds
+        if method is None:
+            _, cls = method_class(args)
+            method = cls(args, shared_extractor=extractor)      # a fresh object per class, as main.py:23
+        if weights is not None and extractor is None:
+            method.deep_feature_extractor.rgb_backbone.load_state_dict(weights[0])
+            method.deep_feature_extractor.xyz_backbone.load_state_dict(weights[1])
+        if weights is not None and len(weights) > 2 and weights[2] is not None and getattr(method, "fusion", None) is not None:
+            method.fusion.load_state_dict(weights[2])
+        set_seeds(0)
+        self.args, self.data, self.method = args, data, method
+        self.count = getattr(args, "max_sample", 500)
+        self.sec, self.phases = {}, []
+        self.multiple = getattr(args, "memory_bank", "multiple") == "multiple"
+        self.n_train = self.n_test = 0
+
+    def _loop(self, it, call, limit):
         n = flag = 0
         for item in it:
             call(item)
@@ -116,36 +126,128 @@ def run_class(args, data, weights=None, method=None, extractor=None):
             flag += 1
             if limit is not None and flag > limit:           # cmdiad_runner.py:50-52, 64-66: the two TRAIN loops stop AFTER max_sample + 1 samples
                 break
-        return n, t0
+        return n
 
-    # the loaders are drained first (the reference's DataLoader workers prefetch beside the model; a synthetic class generates its
-    # samples on this thread): "load" is reported on its own and the phase timings below are the method's
-    t0 = time.perf_counter()
-    train_items = list(data.train())
-    test_items = list(data.test())
-    sec["load"] = time.perf_counter() - t0
-    n_train, t0 = loop(train_items, lambda it: method.add_sample_to_mem_bank(it[0], class_name=data.name))
-    method.run_coreset()
-    torch.cuda.synchronize()
-    sec["memory_bank_and_coreset"] = time.perf_counter() - t0
-    if getattr(args, "memory_bank", "multiple") == "multiple":
-        _, t0 = loop(train_items, lambda it: method.add_sample_to_late_fusion_mem_bank(it[0]))
-        method.run_late_fusion()
-        sec["late_fusion"] = time.perf_counter() - t0
-    with torch.no_grad():
-        n_test, t0 = loop(test_items, lambda it: method.predict(*it), limit=None)   # cmdiad_runner.py:80-85: every test sample, no cut-off
-        # the drop-in defers predict() into micro-batches; reading a result attribute completes them (multiple_features._MethodBase)
-        assert len(method.image_preds) == n_test
+    def fit_device(self):
+        m, data = self.method, self.data
+        # the loaders are drained first (the reference's DataLoader workers prefetch beside the model; a synthetic class generates its
+        # samples on this thread): "load" is reported on its own and the phase timings below are the method's
+        t0 = time.perf_counter()
+        self.train_items = list(data.train())
+        self.test_items = list(data.test())
+        self.sec["load"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        self.n_train = self._loop(self.train_items, lambda it: m.add_sample_to_mem_bank(it[0], class_name=data.name), self.count)
+        m.run_coreset()
         torch.cuda.synchronize()
-        sec["predict"] = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    method.calculate_metrics()
-    sec["metrics"] = time.perf_counter() - t0
-    out = {m: float(getattr(method, m)) for m in METRICS}
-    out.update(n_train=n_train, n_test=n_test, seconds={k: round(v, 3) for k, v in sec.items()},
-               library_rows={k: int(getattr(method, f"patch_{k}_lib").shape[0]) for k in ("xyz", "rgb", "fusion")
-                             if torch.is_tensor(getattr(method, f"patch_{k}_lib", None))})
-    out["_extractor"] = method.deep_feature_extractor
+        self.sec["memory_bank_and_coreset"] = time.perf_counter() - t0
+        self.phases += ["memory_bank", "coreset"]
+        if self.multiple:
+            t0 = time.perf_counter()
+            self._loop(self.train_items, lambda it: m.add_sample_to_late_fusion_mem_bank(it[0]), self.count)
+            flush = getattr(m, "_flush", None)               # the drop-in defers the samples into micro-batches: score them now (GPU)
+            if flush is not None:
+                flush("late")
+            torch.cuda.synchronize()
+            self.sec["late_fusion_bank"] = time.perf_counter() - t0
+            self.phases.append("late_fusion_bank")
+        self.train_items = None
+        return self
+
+    def host_fit_is_host_only(self):
+        """True when fit_host() touches no GPU state (scikit-learn fits): it may then run on a worker thread."""
+        from sklearn.base import BaseEstimator
+        m = self.method
+        return self.multiple and all(isinstance(getattr(m, f, None), BaseEstimator) for f in ("detect_fuser", "seg_fuser"))
+
+    def fit_host(self):
+        if self.multiple:
+            t0 = time.perf_counter()
+            self.method.run_late_fusion()
+            self.sec["late_fusion_fit"] = time.perf_counter() - t0
+            self.sec["late_fusion"] = self.sec["late_fusion_bank"] + self.sec["late_fusion_fit"]
+            self.phases.append("late_fusion_fit")
+        return self
+
+    def predict(self):
+        m = self.method
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            self.n_test = self._loop(self.test_items, lambda it: m.predict(*it), None)   # cmdiad_runner.py:80-85: every test sample, no cut-off
+            # the drop-in defers predict() into micro-batches; reading a result attribute completes them (multiple_features._MethodBase)
+            assert len(m.image_preds) == self.n_test
+            torch.cuda.synchronize()
+            self.sec["predict"] = time.perf_counter() - t0
+        self.phases.append("predict")
+        t0 = time.perf_counter()
+        m.calculate_metrics()
+        self.sec["metrics"] = time.perf_counter() - t0
+        self.phases.append("metrics")
+        self.test_items = None
+        return self
+
+    def result(self):
+        m = self.method
+        out = {k: float(getattr(m, k)) for k in METRICS}
+        out.update(n_train=self.n_train, n_test=self.n_test, seconds={k: round(v, 3) for k, v in self.sec.items()},
+                   phases=list(self.phases),
+                   library_rows={k: int(getattr(m, f"patch_{k}_lib").shape[0]) for k in ("xyz", "rgb", "fusion")
+                                 if torch.is_tensor(getattr(m, f"patch_{k}_lib", None))})
+        out["_extractor"] = m.deep_feature_extractor
+        return out
+
+
+def run_class(args, data, weights=None, method=None, extractor=None):
+    """The three stages of ClassRun in line.  Returns the class's metrics (unrounded), image counts, seconds per phase, the
+    phase order, and the extractor under "_extractor"."""
+    return ClassRun(args, data, weights, method, extractor).fit_device().fit_host().predict().result()
+
+
+def run_classes_overlapped(args, datasets, names, weights=None, log=None):
+    """The classes `names` of one rank with the host-bound stage of class k (the two one-class-SVM fits: one host core, no GPU)
+    on a worker THREAD beside the device-bound stage of class k + 1 (memory bank, coreset, late-fusion bank):
+
+        fit_device(c0) | fit_host(c0) on the worker || fit_device(c1) | join | predict(c0) | fit_host(c1) || fit_device(c2) | ...
+
+    Inside a class the reference's order is untouched (cmdiad_runner.py:33-107); classes are independent of each other (a fresh
+    method object per class, main.py:23; the worker uses no global RNG: SGDOneClassSVM(random_state=42), features.py:114-115), so
+    every number equals the in-line run's.  No fork, no second GPU process: scikit-learn's SGD loop releases the GIL."""
+    import threading
+    out, extractor = {}, None
+    pending = None            # (ClassRun, thread | None, error list)
+
+    def finish(p):
+        run, th, err = p
+        if th is not None:
+            th.join()
+        if err:
+            raise err[0]
+        if th is None:
+            run.fit_host()
+        res = run.predict().result()
+        res.pop("_extractor")
+        out[run.data.name] = res
+        if log is not None:
+            log(f"class {run.data.name}: " + ", ".join(f"{m} {res[m]:.3f}" for m in METRICS) + f" {res['seconds']}")
+
+    for cls in names:
+        run = ClassRun(args, datasets[cls], weights=weights, extractor=extractor)
+        extractor = run.method.deep_feature_extractor
+        run.fit_device()
+        if pending is not None:
+            finish(pending)
+        th, err = None, []
+        if run.host_fit_is_host_only():
+            def work(r=run, e=err):
+                try:
+                    r.fit_host()
+                except BaseException as exc:      # re-raised on the main thread at the join
+                    e.append(exc)
+            th = threading.Thread(target=work, name=f"late-fusion-fit-{cls}", daemon=True)
+            th.start()
+        pending = (run, th, err)
+    if pending is not None:
+        finish(pending)
     return out
 
 
@@ -180,8 +282,14 @@ def evaluate_classes(args, datasets, group=None, weights=None, costs=None, log=N
     extractor = None
     error = None
     t0 = time.perf_counter()
+    overlap = runner is None and os.environ.get("CMDIAD_EVAL_OVERLAP", "1") != "0" and len(assignment[rank]) > 1
     try:
-        for cls in assignment[rank]:
+        if overlap:   # the host SVM fits of class k beside the device work of class k + 1 (run_classes_overlapped)
+            mine = run_classes_overlapped(args, datasets, assignment[rank], weights=weights,
+                                          log=(lambda msg: log(f"[rank {rank}] {msg}")) if log is not None else None)
+            for cls in mine:
+                mine[cls]["rank"] = rank
+        for cls in ([] if overlap else assignment[rank]):
             if runner is None:
                 mine[cls] = run_class(args, datasets[cls], weights=weights, extractor=extractor)
                 extractor = mine[cls].pop("_extractor")          # the frozen backbones stay on the rank; everything else is per class
@@ -217,8 +325,9 @@ def evaluate_classes(args, datasets, group=None, weights=None, costs=None, log=N
                 estimated_cost_s={c: round(float(costs[c]), 3) for c in datasets}, rank_seconds=rank_seconds, world=world)
 
 
-def synthetic_mvtec3d(classes="all", scale=1.0, n_train=None, n_test=None):
-    """{class: synth.SyntheticClass} with the MVTec 3D-AD split sizes times ``scale`` (or fixed ``n_train`` / ``n_test``)."""
+def synthetic_mvtec3d(classes="all", scale=1.0, n_train=None, n_test=None, severity=1.0):
+    """{class: synth.SyntheticClass} with the MVTec 3D-AD split sizes times ``scale`` (or fixed ``n_train`` / ``n_test``);
+    ``severity``: strength of the planted defects (synth.SyntheticClass)."""
     from .synth import SyntheticClass
     names = list(MVTEC3D_TRAIN) if classes == "all" else [c for c in classes if c]
     out = {}
@@ -227,5 +336,5 @@ def synthetic_mvtec3d(classes="all", scale=1.0, n_train=None, n_test=None):
             raise ValueError(f"unknown MVTec 3D-AD class {c!r}")
         tr = n_train if n_train is not None else max(2, int(round(MVTEC3D_TRAIN[c] * scale)))
         te = n_test if n_test is not None else max(4, int(round(MVTEC3D_TEST[c] * scale)))
-        out[c] = SyntheticClass(c, tr, te, index=list(MVTEC3D_TRAIN).index(c))
+        out[c] = SyntheticClass(c, tr, te, index=list(MVTEC3D_TRAIN).index(c), severity=severity)
     return out

@@ -12,6 +12,7 @@ the HIP kernels behind ``Features``.
 """
 import math
 import os
+import warnings
 
 import numpy as np
 import torch
@@ -159,8 +160,10 @@ class _MethodBase(Features):
         try:
             try:
                 self._run_items(kind, items, drain, flight)
-            except Exception:
-                if len(items) <= 1:
+            except Exception as exc:
+                # only a failure of the NEW samples' batch is retried sample by sample; anything else (completing the batch that was
+                # in flight, recording results) is not tied to one sample and must surface as it is
+                if len(items) <= 1 or not getattr(exc, "_cmdiad_new_batch", False):
                     raise
                 for k, it in enumerate(items):
                     try:
@@ -168,17 +171,25 @@ class _MethodBase(Features):
                     except Exception:
                         q[kind] = items[k + 1:] + q[kind]
                         raise
+                # every sample went through on its own: the results are complete, but the batch-level failure is worth knowing
+                warnings.warn(f"a micro-batch of {len(items)} '{kind}' samples failed as a batch ({exc!r}) and succeeded sample by sample")
         finally:
             self.__dict__["_flushing"] = False
 
     def _run_items(self, kind, items, drain, flight):
+        def new_batch(fn, *a, **k):
+            try:
+                return fn(*a, **k)
+            except Exception as exc:
+                exc._cmdiad_new_batch = True       # nothing of this call has been recorded yet: safe to retry per sample
+                raise
         if kind == "fit":
             if items:
-                self._fit_batch(items)
+                new_batch(self._fit_batch, items)
             return
         new = None
         if items:
-            new = (self._score_batch(items if kind == "late" else [it[0] for it in items], test=(kind == "predict")), items)
+            new = (new_batch(self._score_batch, items if kind == "late" else [it[0] for it in items], test=(kind == "predict")), items)
         if kind in flight:
             self._complete(kind, *flight.pop(kind))
         if new is not None:

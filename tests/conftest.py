@@ -34,3 +34,23 @@ def need_ab_variants(what):
     from cmdiad_amd import _native as nat
     if not nat.lib().cmdiad_has_ab_variants():
         pytest.skip(f"{what}: A/B variant, only in the test build (make -C cmdiad_amd/csrc ab; CMDIAD_TEST_AB=1)")
+
+
+def pmap(fn, items, workers=4, total=None):
+    """fn over items on `workers` host threads, results in order.  For the CPU-oracle loops of the GPU parity tests: one oracle
+    `predict` is ~2 s on 32 host threads and does not scale beyond that (bench.py cpu_baseline), while the GPU box has 128 -- the
+    torch CPU operators and the ctypes calls into the C oracle release the GIL, so `workers` samples run side by side, each on its
+    share of the cores (`total`: samples in flight over all nested pmap levels; at most 32 threads each).  (Test infrastructure
+    only; the oracle's arithmetic is untouched: every sample is still computed alone.)"""
+    import concurrent.futures as cf
+    import torch
+    items = list(items)
+    if workers <= 1 or len(items) <= 1:
+        return [fn(it) for it in items]
+    before = torch.get_num_threads()
+    torch.set_num_threads(max(1, min(32, (os.cpu_count() or workers) // (total or workers))))
+    try:
+        with cf.ThreadPoolExecutor(max_workers=workers) as ex:
+            return list(ex.map(fn, items))
+    finally:
+        torch.set_num_threads(before)

@@ -19,6 +19,7 @@ from cmdiad_amd import evaluate as ev  # noqa: E402
 from cmdiad_amd.synth import SyntheticClass  # noqa: E402
 from cmdiad_amd.utils.au_pro_util import calculate_au_pro  # noqa: E402
 from oracle import nets, pipeline  # noqa: E402
+from conftest import pmap  # noqa: E402
 
 
 def _oracle_class(cpu_ex, sd_h, data, lambdas, f_coreset, random_state):
@@ -29,12 +30,13 @@ def _oracle_class(cpu_ex, sd_h, data, lambdas, f_coreset, random_state):
     from sklearn.metrics import roc_auc_score
     cpu = pipeline.CpuOneHallucination(cpu_ex, sd_h, "xyz", lambdas=lambdas, f_coreset=f_coreset, random_state=random_state)
     trip = cpu.fit([(s[0], s[1]) for s, _ in data.train()])
-    rows = [cpu.score(*t)[:2] for t in trip]               # the train samples again (cmdiad_runner.py:58-66): same patches
+    rows = pmap(lambda t: cpu.score(*t)[:2], trip, 2, total=4)      # the train samples again (cmdiad_runner.py:58-66): same patches
     det = linear_model.SGDOneClassSVM(random_state=42, nu=0.5, max_iter=1000).fit(torch.cat([r[0] for r in rows], 0).numpy())
     seg = linear_model.SGDOneClassSVM(random_state=42, nu=0.5, max_iter=1000).fit(torch.cat([r[1] for r in rows], 0).numpy())
     img, pix, labels, masks = [], [], [], []
-    for sample, mask, label, _ in data.test():
-        s, s_map = cpu.predict(sample[0], sample[1])[:2]
+    tests = list(data.test())
+    preds = pmap(lambda it: cpu.predict(it[0][0], it[0][1])[:2], tests, 2, total=4)     # (two classes run side by side: 4 samples at a time)
+    for (s, s_map), (sample, mask, label, _) in zip(preds, tests):
         img.append(float(det.score_samples(s.numpy())[0]))
         pix.append(seg.score_samples(s_map.numpy()).reshape(224, 224))
         labels.append(int(label[0]))
@@ -49,19 +51,24 @@ def test_mtfi_class_loop_auroc_vs_oracle(monkeypatch):
     """Two synthetic classes x (4 train, 20 test of which 6 anomalous) through cmdiad_amd.evaluate.evaluate_classes
     (drop-in RGBorXYZWithOneHallucination, main modality xyz, the whole five-call protocol on the GPU: memory bank, statistics,
     coreset, late-fusion bank, both one-class-SVM fits, predict, metrics) against the oracle's class loop, every fit done
-    independently on each side: |dI-AUROC| <= 1e-2, |dP-AUROC| <= 1e-2, |dAU-PRO| <= 2e-2 per class, and the table's Mean
-    column.  f_coreset = 0.1 as in the reference's runs (with 1.0 every late-fusion sample is its own nearest neighbour and
-    the SVMs are fitted on zeros).  The greedy coreset is chaotic in the last bit of its input (its own parity gate is G9), so
-    the oracle's picks are handed to the GPU side; the drop-in's OWN selection on its bf16 features must overlap them."""
+    independently on each side.  f_coreset = 0.1 as in the reference's runs (with 1.0 every late-fusion sample is its own nearest
+    neighbour and the SVMs are fitted on zeros).  Defects at severity 0.35: the oracle's I-AUROC is 0.88 on both classes -- normal
+    and anomalous image scores interleave, so the ranking is sensitive to the scorer (round 3's defects gave 1.000 everywhere).
+
+    Pass 1: the greedy coreset is chaotic in the last bit of its input (its own parity gate is G9), so the oracle's picks are
+    handed to the GPU side -- everything else is the GPU's: |dI-AUROC| <= 1.25e-2 (ONE of the 84 (normal, anomalous) pairs may
+    swap: 0.0119), |dP-AUROC| <= 1e-2, |dAU-PRO| <= 2e-2; the drop-in's OWN selection on its bf16 features must overlap the
+    oracle's.  Pass 2: the whole loop again with the drop-in's OWN coreset picks, nothing patched: |dI-/P-AUROC| <= 2e-2,
+    |dAU-PRO| <= 3e-2."""
     from cmdiad_amd.feature_extractors import multiple_features as mf
     weights = (nets.synth_state_dict("vit", 31), nets.sharpen_pointmae(nets.synth_state_dict("pointmae", 21)),
                nets.synth_state_dict("halluc", 51))
     cpu_ex = pipeline.CpuExtractor(weights[0], weights[1])
-    data = {"bagel": SyntheticClass("bagel", 4, 20, index=0), "rope": SyntheticClass("rope", 4, 20, index=8)}
+    data = {"bagel": SyntheticClass("bagel", 4, 20, index=0, severity=0.35), "rope": SyntheticClass("rope", 4, 20, index=8, severity=0.35)}
     assert sum(int(l[0]) for _, _, l, _ in data["bagel"].test()) == 6
     a = ev.mtfi_args(f_coreset=0.1, random_state=3)
     lam = (a.xyz_s_lambda, a.xyz_smap_lambda, a.fusion_s_lambda, a.fusion_smap_lambda)
-    refs = {cls: _oracle_class(cpu_ex, weights[2], d, lam, a.f_coreset, a.random_state) for cls, d in data.items()}
+    refs = dict(zip(data, pmap(lambda d: _oracle_class(cpu_ex, weights[2], d, lam, a.f_coreset, a.random_state), data.values(), 2, total=4)))
     queue = [pk for cls in ("bagel", "rope") for pk in refs[cls]["picks"]]      # run_coreset: main library, then fusion
     own = []
     inner = mf.RGBorXYZWithOneHallucination.get_coreset_idx_randomp
@@ -70,29 +77,38 @@ def test_mtfi_class_loop_auroc_vs_oracle(monkeypatch):
         own.append(inner(self, *args, **kw))
         return torch.as_tensor(queue[len(own) - 1]).long()
 
-    monkeypatch.setattr(mf.RGBorXYZWithOneHallucination, "get_coreset_idx_randomp", picker)
-    res = ev.evaluate_classes(a, data, weights=weights, log=print)
+    def check(res, tol_i, tol_p, tol_pro, tag):
+        assert res["method"] == "WithHallucination" and list(res["per_class"]) == ["bagel", "rope"]
+        assert res["assignment"] == [["bagel", "rope"]] and res["world"] == 1          # equal costs: ties by name
+        for cls, ref in refs.items():
+            got = res["per_class"][cls]
+            print(f"[{tag}] {cls}: I-AUROC {got['image_rocauc']:.4f} (oracle {ref['image_rocauc']:.4f}); P-AUROC {got['pixel_rocauc']:.4f} "
+                  f"(oracle {ref['pixel_rocauc']:.4f}); AU-PRO {got['au_pro']:.4f} (oracle {ref['au_pro']:.4f}); "
+                  f"oracle det coef {ref['det'].coef_.ravel()} seg coef {ref['seg'].coef_.ravel()}")
+            assert got["n_train"] == 4 and got["n_test"] == 20
+            assert got["library_rows"] == {"xyz": 1254, "rgb": 4 * 784, "fusion": 1254}
+            assert got["phases"] == ["memory_bank", "coreset", "late_fusion_bank", "late_fusion_fit", "predict", "metrics"]
+            assert abs(got["image_rocauc"] - ref["image_rocauc"]) <= tol_i, (tag, cls)
+            assert abs(got["pixel_rocauc"] - ref["pixel_rocauc"]) <= tol_p, (tag, cls)
+            assert abs(got["au_pro"] - ref["au_pro"]) <= tol_pro, (tag, cls)
+
+    with monkeypatch.context() as mp:
+        mp.setattr(mf.RGBorXYZWithOneHallucination, "get_coreset_idx_randomp", picker)
+        res = ev.evaluate_classes(a, data, weights=weights, log=print)
     assert len(own) == 4
     for o, pk in zip(own, queue):
         assert len(o) == len(pk) == int(0.1 * 4 * 3136) and len(set(o.tolist()) & set(torch.as_tensor(pk).tolist())) > 0.5 * len(pk)
-    assert res["method"] == "WithHallucination" and list(res["per_class"]) == ["bagel", "rope"]
-    assert res["assignment"] == [["bagel", "rope"]] and res["world"] == 1          # equal costs: ties by name
+    check(res, 1.25e-2, 1e-2, 2e-2, "oracle's coreset picks")
     for cls, ref in refs.items():
-        got = res["per_class"][cls]
-        print(f"{cls}: I-AUROC {got['image_rocauc']:.4f} (oracle {ref['image_rocauc']:.4f}); P-AUROC {got['pixel_rocauc']:.4f} "
-              f"(oracle {ref['pixel_rocauc']:.4f}); AU-PRO {got['au_pro']:.4f} (oracle {ref['au_pro']:.4f}); "
-              f"oracle det coef {ref['det'].coef_.ravel()} seg coef {ref['seg'].coef_.ravel()}")
-        assert got["n_train"] == 4 and got["n_test"] == 20
-        assert got["library_rows"] == {"xyz": 1254, "rgb": 4 * 784, "fusion": 1254}
-        assert abs(got["image_rocauc"] - ref["image_rocauc"]) <= 1e-2, cls
-        assert abs(got["pixel_rocauc"] - ref["pixel_rocauc"]) <= 1e-2, cls
-        assert abs(got["au_pro"] - ref["au_pro"]) <= 2e-2, cls
-        # the synthetic defects (a rough 28 x 28-pixel dent, synth.SyntheticClass) leave a ~50 % margin between the image scores of
-        # normal and anomalous samples on the oracle, so the image-level ranking does not hinge on a 2 % score difference
-        assert ref["pixel_rocauc"] > 0.9 and ref["image_rocauc"] > 0.95, "the synthetic anomalies must be detectable, or parity says nothing"
+        # hard enough that the image-level metric is NOT saturated, easy enough that the defects are still found pixel-wise
+        assert 0.85 <= ref["image_rocauc"] <= 0.97, (cls, ref["image_rocauc"])
+        assert ref["pixel_rocauc"] > 0.85, (cls, ref["pixel_rocauc"])
     t = res["table"]["image_rocauc"]
     assert t["Method"] == "WithHallucination" and set(t) == {"Method", "Bagel", "Rope", "Mean"}
     assert t["Mean"] == round((t["Bagel"] + t["Rope"]) / 2, 3)
+    # pass 2: nothing patched -- the drop-in selects its own coresets from its own bf16 features
+    res_own = ev.evaluate_classes(a, data, weights=weights, log=print)
+    check(res_own, 2e-2, 2e-2, 3e-2, "own coreset picks")
 
 
 def test_bench_evaluate_mode_through_rccl_world_of_one():

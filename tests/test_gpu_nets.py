@@ -153,3 +153,62 @@ def test_pointmae_batch_statistics_bn_vs_reference_golden(golden):
     mu, cov = ops.moments3(p3)
     np.testing.assert_allclose(mu.cpu().numpy(), p3.double().mean(0).cpu().numpy(), atol=1e-12)
     np.testing.assert_allclose(cov.cpu().numpy(), torch.cov(p3.double().T, correction=0).cpu().numpy(), rtol=1e-7, atol=1e-14)
+
+
+# ------------------------------------------------------------------------------------------ operand-rounded fp64 oracle
+def _tight(got, ref):
+    """(mean, max) |error| relative to the mean absolute feature value, against the operand-rounded float64 oracle."""
+    scale = ref.abs().mean().item()
+    err = (got.double() - ref).abs()
+    return err.mean().item() / scale, err.max().item() / scale
+
+
+def test_vit_b8_forward_vs_operand_rounded_fp64_oracle(monkeypatch):
+    """ViT-B/8 at full size, B = 2, against oracle/nets_rounded.py: float64 with every product operand rounded to bf16 where the
+    kernels round it.  What is left is accumulation order, the exp2 / GELU approximations and the odd last-bit rounding flip:
+    max |err| <= 3e-3 of the feature scale (the fp32-oracle test next to this one allows 12 %) -- a wrong bias on one output
+    column (0.02 of the scale with these weights) or a mis-scaled head fails here."""
+    from oracle import nets_rounded as nr
+    monkeypatch.setenv("CMDIAD_LN_FOLD", "0")          # the LayerNorms as launches: LN(x) is what gets rounded (nets_rounded's model)
+    sd = nets.synth_state_dict("vit", 31)
+    rgb = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        ref = nr.vit_forward_rounded(sd, rgb)
+    got = runtime.PackedViT(sd, device=DEV).forward(rgb.to(DEV)).cpu()
+    mean_rel, max_rel = _tight(got, ref)
+    print(f"ViT-B/8 vs operand-rounded fp64: mean {mean_rel:.2e}, max {max_rel:.2e} of the feature scale")
+    assert mean_rel < 3e-4 and max_rel < 3e-3, (mean_rel, max_rel)
+    # the test has teeth: the same comparison with ONE bias element of one block moved by 0.02 must fail
+    sd_bad = dict(sd)
+    b = sd["blocks.7.mlp.fc2.bias"].clone()
+    b[123] += 0.02
+    sd_bad["blocks.7.mlp.fc2.bias"] = b
+    bad = runtime.PackedViT(sd_bad, device=DEV).forward(rgb.to(DEV)).cpu()
+    assert _tight(bad, ref)[1] > 3e-3
+
+
+def test_pointmae_full_size_vs_operand_rounded_fp64_oracle(monkeypatch):
+    """Point-MAE (encoder + transformer) at full size, B = 2 clouds of different size, same method: FPS / kNN indices from the C
+    oracle (bit-exact with the kernels), then tokens and features against the operand-rounded float64 restatement."""
+    from cmdiad_amd.synth import synth_cloud
+    from oracle import nets_rounded as nr
+    from oracle import scoring
+    monkeypatch.setenv("CMDIAD_LN_FOLD", "0")
+    sd = nets.synth_state_dict("pointmae", 21)
+    pm = runtime.PackedPointMAE(sd, device=DEV)
+    for seed, frac in ((2, 0.3), (5, 0.45)):
+        pc, _ = scoring.unorganize_no_zeros(synth_cloud(seed, frac))
+        xyz = np.ascontiguousarray(pc[0].T.numpy())[None]
+        feats, center, ori_idx, center_idx = pm.forward(torch.from_numpy(xyz).to(DEV))
+        cidx, cen = ok.fps(xyz, 1024)
+        idx, nb = ok.knn_group(xyz, cen, 128)
+        np.testing.assert_array_equal(ori_idx.cpu().numpy(), idx)
+        tok_gpu = pm.encode(torch.from_numpy(nb).to(DEV)).cpu().view(1, 1024, -1)
+        with torch.no_grad():
+            tok = nr.pointmae_encoder_rounded(sd, torch.from_numpy(nb))
+            ref = nr.pointmae_transformer_rounded(sd, tok, torch.from_numpy(cen))
+        t_mean, t_max = _tight(tok_gpu, tok)
+        f_mean, f_max = _tight(feats.transpose(1, 2).cpu(), ref)
+        print(f"Point-MAE vs operand-rounded fp64: tokens mean {t_mean:.2e} max {t_max:.2e}; features mean {f_mean:.2e} max {f_max:.2e}")
+        assert t_mean < 3e-4 and t_max < 3e-3, (t_mean, t_max)
+        assert f_mean < 3e-4 and f_max < 3e-3, (f_mean, f_max)

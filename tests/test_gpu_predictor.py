@@ -19,6 +19,7 @@ from cmdiad_amd import runtime  # noqa: E402
 from cmdiad_amd.predictor import BatchPredictor  # noqa: E402
 from cmdiad_amd.synth import synth_cloud, synth_rgb  # noqa: E402
 from oracle import nets, pipeline  # noqa: E402
+from conftest import pmap  # noqa: E402
 
 DEV = "cuda"
 
@@ -112,12 +113,9 @@ def test_predict_batch_b32_vs_oracle(weights, cpu_ex, gpu_engine, monkeypatch):
     samples = [synth_sample(i, anomalous=(i % 3 == 0 and i < 30)) for i in range(B)]
     labels = np.array([int(s[2].any()) for s in samples])
     assert labels.sum() == 10
-    ref_img, ref_pix = [], []
-    for rgb, pc, _ in samples:
-        s, s_map, _, _ = cpu.predict(rgb, pc)
-        ref_img.append(float(det.score_samples(s.numpy())[0]))
-        ref_pix.append(seg.score_samples(s_map.numpy()).reshape(224, 224))
-    ref_img, ref_pix = np.array(ref_img), np.stack(ref_pix)
+    ref = pmap(lambda smp: cpu.predict(smp[0], smp[1])[:2], samples)          # the oracle, four samples at a time on the host cores
+    ref_img = np.array([float(det.score_samples(s.numpy())[0]) for s, _ in ref])
+    ref_pix = np.stack([seg.score_samples(s_map.numpy()).reshape(224, 224) for _, s_map in ref])
 
     bank_xyz, bank_rgb = eng.Bank(cpu.xyz_lib.to(DEV)), eng.Bank(cpu.rgb_lib.to(DEV))
     stats = dict(xyz_mean=float(cpu.xyz_mean), xyz_std=float(cpu.xyz_std), rgb_mean=float(cpu.rgb_mean), rgb_std=float(cpu.rgb_std))
@@ -194,12 +192,9 @@ def test_mtfi_batch_vs_oracle(weights, cpu_ex, gpu_engine, monkeypatch):
     samples = [synth_sample(i, anomalous=(i % 3 == 0)) for i in range(B)]
     labels = np.array([int(s[2].any()) for s in samples])
     assert labels.sum() == 8
-    ref_img, ref_pix = [], []
-    for rgb, pc, _ in samples:
-        s, s_map = cpu.predict(rgb, pc)[:2]
-        ref_img.append(float(det.score_samples(s.numpy())[0]))
-        ref_pix.append(seg.score_samples(s_map.numpy()).reshape(224, 224))
-    ref_img, ref_pix = np.array(ref_img), np.stack(ref_pix)
+    ref = pmap(lambda smp: cpu.predict(smp[0], smp[1])[:2], samples)
+    ref_img = np.array([float(det.score_samples(s.numpy())[0]) for s, _ in ref])
+    ref_pix = np.stack([seg.score_samples(s_map.numpy()).reshape(224, 224) for _, s_map in ref])
     stats = dict(xyz_mean=float(cpu.mean), xyz_std=float(cpu.std), rgb_mean=float(cpu.mean), rgb_std=float(cpu.std))
     p = BatchPredictor(gpu_engine, eng.Bank(cpu.main_lib.to(DEV)), eng.Bank(cpu.fus_lib.to(DEV)), stats, det, seg,
                        lambdas=(1.0, 1.0, 1.0, 1.0), batch=B, workload="mtfi",

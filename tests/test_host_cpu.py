@@ -712,3 +712,95 @@ def test_weight_gradient_row_slices():
     assert conv_train._split_for(25088, 512, 128) == 64           # four tiles: 256 workgroups at the cap
     assert conv_train._split_for(256, 128, 128) == 2 and conv_train._split_for(64, 64, 64) == 1
     assert conv_train._split_for(100352, 1920, 1920) == 2         # 225 tiles: already enough workgroups
+
+
+# ------------------------------------------------------------------------------------------------ class loop: stages, cut-off, overlap
+class _FakeMethod:
+    """Protocol stand-in for a drop-in method class (cmdiad_runner.py:16-31): records (class, call, thread) and costs nothing."""
+    log = []
+
+    def __init__(self, args, shared_extractor=None):
+        from sklearn.linear_model import SGDOneClassSVM
+        self.deep_feature_extractor = shared_extractor or object()
+        self.detect_fuser, self.seg_fuser = SGDOneClassSVM(), SGDOneClassSVM()    # scikit-learn estimators: a host-only fit
+        self.image_preds, self.name = [], None
+
+    def _note(self, what):
+        import threading
+        _FakeMethod.log.append((self.name, what, threading.current_thread() is threading.main_thread()))
+
+    def add_sample_to_mem_bank(self, sample, class_name=None):
+        self.name = class_name
+        self._note("bank")
+
+    def run_coreset(self):
+        self._note("coreset")
+
+    def add_sample_to_late_fusion_mem_bank(self, sample):
+        self._note("late")
+
+    def run_late_fusion(self):
+        import time
+        self._note("fit_begin")
+        time.sleep(0.3)
+        self._note("fit_end")
+
+    def predict(self, sample, mask, label, rgb_path):
+        self.image_preds.append(0.0)
+        self._note("predict")
+
+    def calculate_metrics(self):
+        self._note("metrics")
+        self.image_rocauc = self.pixel_rocauc = self.au_pro = self.au_pro_001 = 0.5
+
+
+def _fake_eval(monkeypatch):
+    from cmdiad_amd import evaluate as ev
+    _FakeMethod.log = []
+    monkeypatch.setattr(ev, "method_class", lambda a: ("WithHallucination", _FakeMethod))
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    return ev
+
+
+def test_max_sample_cuts_the_train_loops_only(monkeypatch):
+    """cmdiad_runner.py:43-66 stop the two TRAIN loops after max_sample + 1 samples; cmdiad_runner.py:80-85 predicts EVERY test
+    sample (round 3 truncated the test loop too: metrics on a truncated test set)."""
+    ev = _fake_eval(monkeypatch)
+    data = ev.synthetic_mvtec3d(["carrot"], n_train=5, n_test=4)["carrot"]
+    res = ev.run_class(ev.mtfi_args(max_sample=1), data)
+    calls = [c for _, c, _ in _FakeMethod.log]
+    assert calls.count("bank") == 2 and calls.count("late") == 2 and calls.count("predict") == 4
+    assert res["n_train"] == 2 and res["n_test"] == 4
+    assert res["phases"] == ["memory_bank", "coreset", "late_fusion_bank", "late_fusion_fit", "predict", "metrics"]
+
+
+def test_overlapped_class_schedule_keeps_every_class_in_order(monkeypatch):
+    """evaluate.run_classes_overlapped: the host one-class-SVM fits of class k run on a worker thread beside the device stage of
+    class k + 1; inside every class the reference's phase order (cmdiad_runner.py:33-107) is untouched, predict(k) waits for
+    fit(k), and the results equal the in-line loop's."""
+    ev = _fake_eval(monkeypatch)
+    data = ev.synthetic_mvtec3d(["bagel", "peach", "tire"], n_train=2, n_test=3)
+    names = ["peach", "bagel", "tire"]
+    out = ev.run_classes_overlapped(ev.mtfi_args(), data, names)
+    log = list(_FakeMethod.log)
+    want = ["bank", "bank", "coreset", "late", "late", "fit_begin", "fit_end", "predict", "predict", "predict", "metrics"]
+    for cls in names:
+        assert [c for n, c, _ in log if n == cls] == want, cls                     # per class: the reference's order
+        assert out[cls]["phases"] == ["memory_bank", "coreset", "late_fusion_bank", "late_fusion_fit", "predict", "metrics"]
+    assert all(main for _, c, main in log if not c.startswith("fit"))              # device stages + predict: the main thread
+    assert not any(main for _, c, main in log if c.startswith("fit"))              # the SVM fits: the worker
+    pos = {(n, c): i for i, (n, c, _) in enumerate(log)}                           # (last occurrence)
+    first = {}
+    for i, (n, c, _) in enumerate(log):
+        first.setdefault((n, c), i)
+    # the fit of class k overlaps the device stage of class k + 1, and predict(k) follows both
+    assert first[("peach", "fit_begin")] < first[("bagel", "bank")] < pos[("peach", "fit_end")]
+    assert pos[("bagel", "late")] < first[("peach", "predict")] and pos[("peach", "fit_end")] < first[("peach", "predict")]
+    assert first[("bagel", "fit_begin")] < first[("tire", "bank")] and pos[("tire", "fit_end")] < first[("tire", "predict")]
+    _FakeMethod.log = []
+    inline = {c: ev.run_class(ev.mtfi_args(), data[c]) for c in names}
+    for c in names:
+        a, b = dict(out[c]), dict(inline[c])
+        for d in (a, b):
+            d.pop("seconds"), d.pop("_extractor", None)
+        assert a == b
