@@ -197,6 +197,17 @@ class ClassRun:
         return out
 
 
+def _limit_host_threads():
+    """torch's CPU operators (staging the micro-batches, a synthetic class generating its samples: operators on ~150 k elements)
+    run on an OpenMP pool of one thread per core whose idle threads SPIN between operators.  On a 128-thread host that pool makes
+    those small operators 20x slower than 8 threads do (a synthetic class of 61 + 20 images: 2.5 s -> 0.13 s to generate) and
+    slows the single-threaded SGD fit on the worker thread down by 2.5x (1.8 -> 4.3 s).  The host side of the class loop never
+    needs more than a few threads: CMDIAD_EVAL_HOST_THREADS (default 8).  Returns the previous count."""
+    before = torch.get_num_threads()
+    torch.set_num_threads(max(1, min(before, int(os.environ.get("CMDIAD_EVAL_HOST_THREADS", "8")))))
+    return before
+
+
 def run_class(args, data, weights=None, method=None, extractor=None):
     """The three stages of ClassRun in line.  Returns the class's metrics (unrounded), image counts, seconds per phase, the
     phase order, and the extractor under "_extractor"."""
@@ -215,6 +226,7 @@ def run_classes_overlapped(args, datasets, names, weights=None, log=None):
     import threading
     out, extractor = {}, None
     pending = None            # (ClassRun, thread | None, error list)
+    threads_before = _limit_host_threads()
 
     def finish(p):
         run, th, err = p
@@ -230,24 +242,27 @@ def run_classes_overlapped(args, datasets, names, weights=None, log=None):
         if log is not None:
             log(f"class {run.data.name}: " + ", ".join(f"{m} {res[m]:.3f}" for m in METRICS) + f" {res['seconds']}")
 
-    for cls in names:
-        run = ClassRun(args, datasets[cls], weights=weights, extractor=extractor)
-        extractor = run.method.deep_feature_extractor
-        run.fit_device()
+    try:
+        for cls in names:
+            run = ClassRun(args, datasets[cls], weights=weights, extractor=extractor)
+            extractor = run.method.deep_feature_extractor
+            run.fit_device()
+            if pending is not None:
+                finish(pending)
+            th, err = None, []
+            if run.host_fit_is_host_only():
+                def work(r=run, e=err):
+                    try:
+                        r.fit_host()
+                    except BaseException as exc:      # re-raised on the main thread at the join
+                        e.append(exc)
+                th = threading.Thread(target=work, name=f"late-fusion-fit-{cls}", daemon=True)
+                th.start()
+            pending = (run, th, err)
         if pending is not None:
             finish(pending)
-        th, err = None, []
-        if run.host_fit_is_host_only():
-            def work(r=run, e=err):
-                try:
-                    r.fit_host()
-                except BaseException as exc:      # re-raised on the main thread at the join
-                    e.append(exc)
-            th = threading.Thread(target=work, name=f"late-fusion-fit-{cls}", daemon=True)
-            th.start()
-        pending = (run, th, err)
-    if pending is not None:
-        finish(pending)
+    finally:
+        torch.set_num_threads(threads_before)
     return out
 
 
@@ -283,6 +298,7 @@ def evaluate_classes(args, datasets, group=None, weights=None, costs=None, log=N
     error = None
     t0 = time.perf_counter()
     overlap = runner is None and os.environ.get("CMDIAD_EVAL_OVERLAP", "1") != "0" and len(assignment[rank]) > 1
+    threads_before = _limit_host_threads() if runner is None else None
     try:
         if overlap:   # the host SVM fits of class k beside the device work of class k + 1 (run_classes_overlapped)
             mine = run_classes_overlapped(args, datasets, assignment[rank], weights=weights,
@@ -302,6 +318,9 @@ def evaluate_classes(args, datasets, group=None, weights=None, costs=None, log=N
         if group is None:
             raise
         error = f"{type(exc).__name__}: {exc}"
+    finally:
+        if threads_before is not None:
+            torch.set_num_threads(threads_before)
     mine_s = time.perf_counter() - t0
     parts = [(rank, mine, mine_s, error)]
     if group is not None:

@@ -555,8 +555,8 @@ class TorchSearch:      # stand-in for the HIP kernels behind engine.sharded_min
 
     @staticmethod
     def search(q16, q_sq, bank, keys):
-        TorchSearch.searched += q16.shape[0]
         if bank.bf16.shape[0]:
+            TorchSearch.searched += q16.shape[0]
             v, i = d2_of(q16, q_sq, bank.bf16, bank.sqnorm).min(1)
             keys.copy_(torch.minimum(keys, pack(v, i + bank.row_offset)))
         return keys
