@@ -22,3 +22,11 @@ for pass in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "l2:TCC_HIT_sum TCC_MISS_sum" 
     echo "pass $name rc=$?"
 done
 du -sh "$OUT"
+# stand-alone kernels: one kernel trace + FETCH / WRITE passes of the two HBM-bound kernels
+export STANDALONE_WORK_DIR="$OUT"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/standalone" -- python3 tools/standalone_kernels.py > "$OUT/standalone.log" 2>&1
+echo "standalone trace rc=$?"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/standalone_pmc/fetch" -- python3 tools/standalone_kernels.py hbm > "$OUT/standalone_fetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/standalone_pmc/write" -- python3 tools/standalone_kernels.py hbm > "$OUT/standalone_write.log" 2>&1
+echo "standalone pmc rc=$?"
+du -sh "$OUT"

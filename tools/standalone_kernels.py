@@ -1,0 +1,108 @@
+#!/usr/bin/env python3
+"""Every kernel of DESIGN.md section 4 that the pipelined bench trace cannot time on its own, launched ALONE at the bench shapes
+(batch 32, bagel-sized libraries), for a kernel trace and for counter passes:
+
+    rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r4/standalone -- python3 tools/standalone_kernels.py
+    rocprofv3 --pmc FETCH_SIZE  --output-format csv -d gpurun_out/prof_r4/standalone_pmc/fetch -- python3 tools/standalone_kernels.py hbm
+    rocprofv3 --pmc WRITE_SIZE  --output-format csv -d gpurun_out/prof_r4/standalone_pmc/write -- python3 tools/standalone_kernels.py hbm
+    python tools/standalone_summary.py gpurun_out/prof_r4/standalone gpurun_out/prof_r4/standalone_pmc > profiles/r4_standalone.md
+
+`hbm`: only the two HBM-bound kernels whose bytes are the claim (re-weighting scan, coreset round).  The algorithmic work of
+every launch is written to standalone_work.json next to the trace (kernel-name prefix -> bytes / flops per launch)."""
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cmdiad_amd import coreset, ops  # noqa: E402
+from cmdiad_amd.runtime import fold_pointmae_encoder  # noqa: E402
+from cmdiad_amd.synth import synth_cloud, synth_cloud_fixed_n  # noqa: E402
+
+DEV = "cuda"
+only_hbm = len(sys.argv) > 1 and sys.argv[1] == "hbm"
+B, G, K, D = 32, 1024, 128, 768
+g = torch.Generator().manual_seed(0)
+work = {}
+
+
+def sync():
+    torch.cuda.synchronize()
+
+
+# ---- re-weighting scan (features.py:235-254): 32 probes, the fp32 library streamed once
+for name, rows in (("xyz", 76518), ("rgb", 19129)):
+    bank = torch.randn(rows, D, generator=g).to(DEV)
+    blk = ops.bank_block16(bank)
+    probes = bank[:32].contiguous()
+    for _ in range(30):
+        ops.reweight_scan(probes, bank, blk)
+    sync()
+    work[f"reweight_scan_mfma_kernel/{rows}"] = dict(bytes=rows * D * 4, what=f"re-weighting scan, {name} library {rows} x 768 fp32, 32 probes", match_rows=rows)
+    del bank, blk
+# ---- greedy coreset round (features.py:401-420): 765 184 x 334 fp16 rows per round
+n, d = 765184, 334
+z = torch.randn(n, d, device=DEV)
+coreset.greedy_coreset(z, 5)
+sync()
+coreset.greedy_coreset(z, 201)
+sync()
+work["coreset_round_kernel"] = dict(bytes=n * d * 2, what="greedy coreset round, 765 184 x 334 fp16 (bagel xyz)")
+del z
+if not only_hbm:
+    # ---- farthest point sampling + kNN grouping (models/models.py:70-113)
+    pcs = torch.cat([synth_cloud_fixed_n(1000 + i, 24576) for i in range(B)]).to(DEV)
+    xyz, nz, pix2pt, nv = ops.unorganize(pcs, 24576)
+    for _ in range(6):
+        idx, cen = ops.fps(xyz, G, nv)
+    sync()
+    work["fps_ragged_kernel/fixed"] = dict(evals=B * G * 24576, bytes=B * (24576 * 12 + G * 16), what="FPS, 32 clouds x 24 576 points, 1024 samples (latency-bound: distance evaluations/s)")
+    for _ in range(6):
+        ops.knn_group(xyz, cen, K, nv)
+    sync()
+    work["knn_wave_kernel"] = dict(evals=B * G * 24576, bytes=B * (24576 * 12 + G * 12 + G * K * 20), what="kNN grouping, 1024 centres x 128 neighbours per cloud")
+    import numpy as np
+    rs = np.random.RandomState(8)
+    fr = (0.35 + 0.30 * rs.rand(B)) / 0.85
+    pcs_v = torch.cat([synth_cloud(7000 + i, float(fr[i])) for i in range(B)]).to(DEV)
+    xyz_v, _, _, nv_v = ops.unorganize(pcs_v, None)
+    for _ in range(6):
+        ops.fps(xyz_v, G, nv_v)
+    sync()
+    work["fps_ragged_kernel/var"] = dict(evals=int(G * nv_v.sum().item()), what=f"FPS, ragged batch ({int(nv_v.min())} ... {int(nv_v.max())} points, padded {xyz_v.shape[1]})")
+    # ---- Point-MAE encoder (models/models.py:200-215)
+    from oracle import nets  # noqa: E402  (synthetic weights only)
+    w = fold_pointmae_encoder(nets.synth_state_dict("pointmae", 21), "encoder.", DEV)
+    nb = (torch.randn(B * G * K, 3, generator=g) * 0.01).to(DEV)
+    for _ in range(6):
+        h2, _, g16 = ops.encoder_stage1(nb, w["w1b1"], w["W2"], w["b2"], B * G, K)
+        gb, _ = ops.gemm(g16, w["W3a"], bias=w["b3"], want_f32=True, want_bf16=False)
+        ops.encoder_tail(h2, gb, w["W3b"], w["W4"], w["b4"], B * G, K)
+    sync()
+    pts = B * G * K
+    work["encoder_stage1_persist_kernel"] = dict(flops=2.0 * pts * (3 * 128 + 128 * 256), bytes=pts * (12 + 512), what="encoder stage 1: conv1 + conv2 + group max, h2 written as bf16")
+    work["encoder_tail_persist_kernel"] = dict(flops=2.0 * pts * (256 * 512 + 512 * 384), bytes=pts * 512, what="encoder tail: conv3 (per-point half) + ReLU + conv4 + group max")
+    del nb, h2
+    # ---- implicit-GEMM convolution of the distillation heads (hallucination_network.py:72-143)
+    x = torch.randn(B, 56, 56, 768, generator=g).to(DEV).bfloat16()
+    wc = (torch.randn(768, 9 * 768, generator=g) / (9 * 768) ** 0.5).to(DEV).bfloat16()
+    out = torch.empty(B, 56, 56, 768, device=DEV, dtype=torch.bfloat16)
+    for _ in range(6):
+        ops.conv2d_nhwc(x, wc, 768, 3, 1, act=ops.ACT_RELU, out_bf16=out, want_bf16=False)
+    sync()
+    work["conv_igemm_kernel"] = dict(flops=2.0 * B * 3136 * 768 * 9 * 768, what="3x3 convolution 768 -> 768 on the 56 x 56 token grid, batch 32")
+    del x, out
+    # ---- weight-gradient product of the trainer (pretrain.py:148-154)
+    M = B * 3136
+    P = torch.randn(M, 1920, generator=g).to(DEV).bfloat16()
+    Q = torch.randn(M, 1920, generator=g).to(DEV).bfloat16()
+    for _ in range(6):
+        ops.gemm_tn(P, Q, split_k=8, want_colsum=True)
+    sync()
+    work["gemm_tn_kernel"] = dict(flops=2.0 * M * 1920 * 1920, what="dW = sum_m P[m,:]^T Q[m,:], 1920 x 1920 x 100 352, split-K 8")
+out_dir = os.environ.get("STANDALONE_WORK_DIR", "gpurun_out")
+os.makedirs(out_dir, exist_ok=True)
+if not only_hbm:      # (the counter passes repeat a subset: they must not overwrite the full table)
+    json.dump(work, open(os.path.join(out_dir, "standalone_work.json"), "w"), indent=1)
+print("done", sorted(work))

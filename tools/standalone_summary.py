@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""profiles/rN_standalone.md from the traces of tools/standalone_kernels.py:
+    python tools/standalone_summary.py <kernel-trace dir> [<pmc dir>] [standalone_work.json] > profiles/r4_standalone.md
+Per kernel (and grid, where one kernel runs at two sizes): launches, mean duration from rocprofv3's kernel trace, the algorithmic
+bytes / FLOPs of one launch (tools/standalone_kernels.py) and the fraction of the peak that bounds it (8 TB/s HBM, 2.5 PFLOP/s
+dense 16-bit MFMA; /opt/skills/guides/MI355X_MICROARCH.md); with a PMC directory also the fabric-side bytes per launch
+(2 x FETCH_SIZE -- gfx950 tallies the 128-byte requests of 16-B-per-lane loads at 64 bytes -- and WRITE_SIZE, KiB -> bytes)."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+trace_dir = sys.argv[1]
+pmc_dir = sys.argv[2] if len(sys.argv) > 2 and os.path.isdir(sys.argv[2]) else None
+work_file = next((a for a in sys.argv[2:] if a.endswith(".json")), os.path.join("gpurun_out", "standalone_work.json"))
+work = json.load(open(work_file))
+
+
+def short(name):
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].split("<")[0]
+    if name.startswith("_ZN"):              # a name the profiler did not demangle: keep the identifier inside it
+        import re
+        m = re.search(r"\d+([a-z][a-z0-9_]*kernel)", name)
+        name = m.group(1) if m else name
+    return name
+
+
+dur = collections.defaultdict(list)
+for f in glob.glob(os.path.join(trace_dir, "**", "*kernel_trace.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        dur[(short(r["Kernel_Name"]), int(r["Grid_Size_X"]) * max(int(r.get("Grid_Size_Y", 1) or 1), 1))].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+pmc = collections.defaultdict(lambda: collections.defaultdict(list))
+if pmc_dir:
+    for f in glob.glob(os.path.join(pmc_dir, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            pmc[(short(r["Kernel_Name"]), int(r["Grid_Size"]))][r["Counter_Name"]].append(float(r["Counter_Value"]))
+
+print("| kernel | grid (threads) | launches | mean us | algorithmic work per launch | achieved | fraction of peak | fabric bytes per launch (PMC) | what |")
+print("|---|---|---|---|---|---|---|---|---|")
+for key, spec in work.items():
+    kname = key.split("/")[0]
+    cands = sorted(((k, v) for k, v in dur.items() if kname in k[0]), key=lambda kv: -kv[0][1])
+    if not cands:
+        print(f"| `{kname}` | - | 0 | - | - | - | - | - | {spec['what']} (not in the trace) |")
+        continue
+    if "/" in key:                          # the same kernel at two sizes: xyz / rgb library, fixed / ragged batch
+        tag = key.split("/")[1]
+        cands = [cands[0]] if tag in ("76518", "fixed") else [cands[-1]]
+        if tag in ("fixed", "var"):         # same grid (32 blocks): split by launch order (the fixed-N batch runs first)
+            k, v = cands[0]
+            half = len(v) // 2
+            cands = [(k, v[:half] if tag == "fixed" else v[half:])]
+    (k, v) = cands[0]
+    v = v[1:] if len(v) > 2 else v           # the first launch of a kernel pays code loading
+    us = sum(v) / len(v)
+    if "flops" in spec:
+        ach, frac, unit = spec["flops"] / us / 1e6, spec["flops"] / us / 1e6 / 2500.0, "TFLOP/s"
+        algo = f"{spec['flops'] / 1e9:.1f} GFLOP"
+    elif "evals" in spec and "bytes" not in spec or kname.startswith("fps") or kname.startswith("knn"):
+        ach, frac, unit = spec["evals"] / us / 1e3, None, "G distance evals/s"
+        algo = f"{spec['evals'] / 1e6:.0f} M distance evaluations" + (f", {spec['bytes'] / 1e6:.1f} MB" if "bytes" in spec else "")
+    else:
+        ach, frac, unit = spec["bytes"] / us / 1e3, spec["bytes"] / us / 1e3 / 8000.0, "GB/s"
+        algo = f"{spec['bytes'] / 1e6:.1f} MB"
+    fab = "-"
+    c = pmc.get(k)
+    if c:
+        parts = []
+        if "FETCH_SIZE" in c:
+            parts.append(f"fetch {2 * 1024 * sum(c['FETCH_SIZE']) / len(c['FETCH_SIZE']) / 1e6:.1f} MB")
+        if "WRITE_SIZE" in c:
+            parts.append(f"write {1024 * sum(c['WRITE_SIZE']) / len(c['WRITE_SIZE']) / 1e6:.1f} MB")
+        fab = ", ".join(parts)
+    print(f"| `{k[0]}` | {k[1]} | {len(v)} | {us:.1f} | {algo} | {ach:.1f} {unit} | {'%.3f' % frac if frac is not None else '-'} | {fab} | {spec['what']} |")
