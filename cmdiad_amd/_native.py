@@ -50,6 +50,8 @@ SIGNATURES = {
     "cmdiad_interp_gather": [P, P, P, P, I, I, I, I, P, P],
     "cmdiad_xyz_patch_fused": [P, P, P, P, I, I, I, I, I, I, F, F, P, P, P],
     "cmdiad_gemm_bf16": [POINTER(GemmArgs), P],
+    "cmdiad_gemm_streamk_bf16": [POINTER(GemmArgs), P, SZ, P],
+    "cmdiad_gemm_streamk_eligible": [I, I, I],
     "cmdiad_gemm_qkv": [P, P, P, P, I, I, I, P, P, P, P],
     "cmdiad_ln_stats_finalize": [P, I, I, F, P, P, P],
     "cmdiad_gemm_tn_bf16": [P, I, P, I, I, I, I, I, P, I, P, P],
@@ -107,6 +109,7 @@ SIGNATURES = {
     "cmdiad_transpose_bf16": [P, I, I, P, P],
 }
 SIZE_QUERIES = {
+    "cmdiad_gemm_streamk_workspace_bytes": [],
     "cmdiad_fps_workspace_bytes": [I, I],
     "cmdiad_reweight_workspace_bytes": [I, I],
     "cmdiad_bank_block16_floats": [I, I],

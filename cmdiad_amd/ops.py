@@ -166,6 +166,33 @@ def gemm(A, W, bias=None, act=ACT_NONE, residual=None, group_bias=None, group_ro
     return out_f32, out_bf16
 
 
+_streamk_ws = {}
+
+
+def gemm_streamk_eligible(M, N, K):
+    return bool(nat.lib().cmdiad_gemm_streamk_eligible(M, N, K))
+
+
+def gemm_streamk(A, W, bias, residual, out_f32=None):
+    """out_f32 = A[M,K] . W[N,K]^T + bias + residual (in place when out_f32 is residual) on the stream-K kernel
+    (cmdiad_gemm_streamk_bf16; bit-identical to gemm()).  The workspace (64 MiB of hand-over slots + counters, zeroed once) is kept
+    per device and stream."""
+    _chk(A, torch.bfloat16, "gemm_streamk.A"); _chk(W, torch.bfloat16, "gemm_streamk.W")
+    _chk(bias, torch.float32, "gemm_streamk.bias"); _chk(residual, torch.float32, "gemm_streamk.residual")
+    M, K = A.shape
+    N = W.shape[0]
+    if out_f32 is None:
+        out_f32 = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    key = (A.device.index, int(_stream() or 0))
+    ws = _streamk_ws.get(key)
+    if ws is None:
+        ws = _streamk_ws[key] = torch.zeros((nat.lib().cmdiad_gemm_streamk_workspace_bytes(),), dtype=torch.uint8, device=A.device)
+    a = nat.GemmArgs(_p(A), K, _p(W), K, M, N, K, _p(bias), None, 1, ACT_NONE, _p(residual), N, _p(out_f32), N, None, 0, None, None, 1,
+                     None, None, None, 0, None, None, 0)
+    _call("cmdiad_gemm_streamk_bf16", ctypes.byref(a), _p(ws), ws.numel(), _stream())
+    return out_f32
+
+
 def ln_stats_finalize(part, M, chunks, eps, rstd=None, want_mean=False):
     """part [chunks, M, 2] f32 (gemm(..., ln_part=)) -> rstd [M rounded up to 256] f32 (first M valid) (, mean [M])."""
     _chk(part, torch.float32, "ln_stats.part")

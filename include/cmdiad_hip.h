@@ -37,7 +37,7 @@ int cmdiad_abi_version(void); /* 2: cmdiad_reweight_scan's limits and workspace 
                                  3: LayerNorm fold -- cmdiad_gemm_args gained row_scale / ln_xb / ln_part / add2, cmdiad_gemm_qkv gained
                                     row_scale, cmdiad_block_weights the folded weights, cmdiad_transformer_block_fwd its flags;
                                     cmdiad_ln_stats_finalize is new
-                                 4: cmdiad_l2_min_keys_segments is new */
+                                 4: cmdiad_l2_min_keys_segments, cmdiad_gemm_streamk_* are new */
 /* 1 when the library is the test-only build that also contains the superseded kernel formulations (A/B references). */
 int cmdiad_has_ab_variants(void);
 
@@ -136,6 +136,18 @@ typedef struct {
     const float* add2; int ld_add2;  /* second f32 addend [M,N] (the next block's positional embedding, models.py:240), or NULL */
 } cmdiad_gemm_args;
 int cmdiad_gemm_bf16(const cmdiad_gemm_args* args, cmdiad_stream_t stream);
+
+/* Stream-K form of the in-place residual products of a transformer block (x = x + fc2(...), models/models.py:126-132,177-180):
+ * out_f32 = A . W^T + bias + residual with N % 256 == 0, for shapes whose 256 x 256 tile count is between one and two per CU
+ * (ViT-B/8's N = 768 products at batch 32: 297 tiles on 256 CUs).  The (tile, k-tile) list is cut into one contiguous range per
+ * CU; a tile shared by two blocks is finished IN ORDER (the second block starts from the first one's parked accumulators), so the
+ * result is bit-identical to cmdiad_gemm_bf16's.  Takes the cmdiad_gemm_args of the residual form only (A, W, bias, residual,
+ * out_f32; everything else unset).  workspace: cmdiad_gemm_streamk_workspace_bytes() bytes, ZERO-INITIALISED once by the caller
+ * and then left to the library (slots + hand-over counters; the kernel leaves the counters at zero again); one launch at a time
+ * per workspace.  cmdiad_gemm_streamk_eligible(M, N, K) -> 1 when the shape qualifies. */
+size_t cmdiad_gemm_streamk_workspace_bytes(void);
+int cmdiad_gemm_streamk_eligible(int M, int N, int K);
+int cmdiad_gemm_streamk_bf16(const cmdiad_gemm_args* a, void* workspace, size_t workspace_bytes, cmdiad_stream_t stream);
 
 /* LayerNorm statistics from the producer's chunk partials (nn.LayerNorm inside Block, models/models.py:170,175): part
  * [chunks][M][2] as written through cmdiad_gemm_args.ln_part -> rstd[m] = 1 / sqrt(var_m + eps) over the chunks * 64 columns

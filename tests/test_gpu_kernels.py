@@ -275,6 +275,31 @@ def test_gemm_persistent_256_tile_matches_128_tile(monkeypatch):
         np.testing.assert_allclose(got["pp3"][2].cpu().numpy(), (ref + bias.double() + res.double()).numpy(), rtol=1e-4, atol=1e-4)
 
 
+def test_gemm_streamk_matches_128_tile_bit_for_bit():
+    """cmdiad_gemm_streamk_bf16 (csrc/gemm_sk.hip: the (tile, k-tile) list of the N = 768 residual products cut into one range
+    per CU, tiles shared by two blocks finished in order through parked accumulators) against cmdiad_gemm_bf16's 128 x 128
+    kernel on ViT-B/8's batch-32 shapes: fc2 (K = 3072), proj (K = 768), ragged and whole last M tile, in place on the residual
+    stream -- identical bits, launch after launch on one workspace (the hand-over counters return to zero)."""
+    g = torch.Generator().manual_seed(91)
+    for M, N, K in ((32 * 785, 768, 3072), (32 * 785, 768, 768), (100 * 256, 768, 1536), (24000, 1024, 1024)):
+        assert ops.gemm_streamk_eligible(M, N, K), (M, N, K)
+        dA = (torch.randn(M, K, generator=g)).to(DEV).bfloat16()
+        dW = (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV).bfloat16()
+        bias, res = torch.randn(N, generator=g).to(DEV), torch.randn(M, N, generator=g).to(DEV)
+        want = res.clone()
+        ops.gemm(dA, dW, bias=bias, residual=want, out_f32=want, want_bf16=False)
+        for rep in range(3):
+            x = res.clone()
+            ops.gemm_streamk(dA, dW, bias, x, out_f32=x)                    # in place, as the transformer block runs it
+            assert torch.equal(x, want), (M, N, K, rep, float((x - want).abs().max()))
+        out = ops.gemm_streamk(dA, dW, bias, res)                           # separate output buffer
+        assert torch.equal(out, want)
+        ref = dA[:512].double() @ dW.double().T + bias.double() + res[:512].double()
+        np.testing.assert_allclose(want[:512].cpu().double().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-4)
+    for M, N, K in ((2 * 785, 768, 3072), (32 * 785, 384, 1536), (32 * 785, 3072, 768), (70000, 768, 768)):
+        assert not ops.gemm_streamk_eligible(M, N, K)                       # too few tiles / N % 256 / two or more tiles per CU
+
+
 def test_gemm_identity_asymmetric_layout():
     # A = I against an asymmetric W catches any row/column swap in the accumulator mapping
     K = 128

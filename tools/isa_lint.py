@@ -98,7 +98,7 @@ def lint(src):
 
 
 def main():
-    srcs = sys.argv[1:] or [os.path.join(ROOT, "cmdiad_amd", "csrc", f) for f in ("gemm.hip", "l2min.hip", "conv.hip", "encoder_tail.hip")]
+    srcs = sys.argv[1:] or [os.path.join(ROOT, "cmdiad_amd", "csrc", f) for f in ("gemm.hip", "gemm_sk.hip", "l2min.hip", "conv.hip", "encoder_tail.hip")]
     rc = 0
     for src in srcs:
         bad = lint(src)
