@@ -58,7 +58,7 @@ CLASS_TRAIN = {"bagel": 244, "cable_gland": 223, "carrot": 286, "cookie": 210, "
 PEAK_BF16_TFLOPS = 2500.0           # dense bf16 / fp16 MFMA, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 ROTATE = 4                          # distinct input batches rotated through the timed region
-DEFECT_SEVERITY = 0.35              # synthetic defects of the class loop: hard enough that I-AUROC is not saturated (synth.SyntheticClass)
+DEFECT_SEVERITY = float(os.environ.get("CMDIAD_DEFECT_SEVERITY", "0.22"))   # synthetic defects of the class loop: hard enough that I-AUROC is not saturated (synth.SyntheticClass)
 
 
 def class_rows(name):

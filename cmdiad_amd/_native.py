@@ -94,9 +94,11 @@ SIGNATURES = {
     "cmdiad_score_tail": [P, P, P, P, I, I, I, U32, P, P],
     "cmdiad_score_final": [P, P, I, I, P, P],
     "cmdiad_coreset_greedy": [P, I, I, I, I, P, P, SZ, P],
+    "cmdiad_coreset_greedy_f32": [P, I, I, I, I, P, P, SZ, P],
     "cmdiad_sparse_project_f32": [P, SZ, I, P, P, P, I, P, P],
     "cmdiad_normalize_cast": [P, SZ, I, F, F, P, P, P, I, P],
     "cmdiad_im2col_patch8": [P, I, I, P, P],
+    "cmdiad_im2col3x3_bf16": [P, I, I, I, I, I, I, P, P],
     "cmdiad_vit_assemble": [P, P, P, I, I, I, P, P],
     "cmdiad_bilinear_up": [P, I, I, I, P, P],
     "cmdiad_ball_query": [P, P, P, I, I, I, F, I, P, P],
@@ -114,6 +116,7 @@ SIZE_QUERIES = {
     "cmdiad_reweight_workspace_bytes": [I, I],
     "cmdiad_bank_block16_floats": [I, I],
     "cmdiad_coreset_workspace_bytes": [I, I, I],
+    "cmdiad_coreset_f32_workspace_bytes": [I, I, I],
     "cmdiad_blur8_lds_bytes": [I, I],
     "cmdiad_ocsvm_fit_workspace_bytes": [I, I],
     "cmdiad_rows_dedup_workspace_bytes": [I],

@@ -134,10 +134,20 @@ class _TowerLoss(torch.autograd.Function):
         return (None,) * 6 + tuple(gr * g for gr in ctx.grads)
 
 
+def _check_bn(bns):
+    """The hand-written BatchNorm forward / backward is the affine batch-statistics form with eps = EPS (nn.BatchNorm2d's default,
+    what every BatchNorm of the reference's heads is constructed with): anything else must not be trained silently differently."""
+    for bn in bns:
+        if not bn.affine or abs(float(bn.eps) - EPS) > 1e-12:
+            raise NotImplementedError(f"hand-written BatchNorm training path: affine BatchNorm2d with eps = {EPS} only (got eps = {bn.eps}, "
+                                      f"affine = {bn.affine}); use the module's torch layers (CMDIAD_HRNET_TRAIN=torch / CMDIAD_CONV_TRAIN=torch)")
+
+
 def tower_params(tower):
     convs = [m for m in tower if isinstance(m, torch.nn.Conv2d)]
     bns = [m for m in tower if isinstance(m, torch.nn.BatchNorm2d)]
     assert len(convs) == 4 and len(bns) == 3 and all(c.bias is None and c.kernel_size == (3, 3) for c in convs)
+    _check_bn(bns)
     out = []
     for l in range(3):
         out += [convs[l].weight, bns[l].weight, bns[l].bias]
@@ -418,9 +428,7 @@ def hrnet_forward_backward(img, feature, P, batch, need_grad=True):
 
     # stem
     H1 = (img.shape[-1] + 1) // 2
-    cols = torch.nn.functional.unfold(img, 3, padding=1, stride=2).transpose(1, 2).reshape(B * H1 * H1, 27)
-    cols64 = torch.zeros((cols.shape[0], 64), dtype=torch.bfloat16, device=dev)
-    cols64[:, :27] = cols.to(torch.bfloat16)
+    cols64 = ops.im2col3x3(img.contiguous(), stride=2, ld=64)       # [B*112*112, 64] bf16: 27 columns (c, ky, kx) + zero padding
     W1 = torch.zeros((64, 64), dtype=torch.float32, device=dev)
     W1[:, :27] = P["conv1.weight"].reshape(64, 27)
     z1, _ = ops.gemm(cols64, ops.cast_bf16(W1), want_f32=True, want_bf16=False)
@@ -445,6 +453,7 @@ def hrnet_forward_backward(img, feature, P, batch, need_grad=True):
             _, identity = bn(b + ".downsample.1", zd, relu=False, want_f32=True)
         else:
             identity = x32
+        assert identity is not None, f"{b}: a stage's first bottleneck must widen its identity (downsample), hrnet.py:167-171"
         x16, x32 = bn(b + ".bn3", zc3, residual=identity, relu=True, want_f32=True)
         saved[b] = (xin, t1, t2, x16)
     Wf = _w1x1(P["final_layer.weight"])
@@ -531,6 +540,7 @@ def hrnet_loss(module, img, feature):
     """module: models.hrnet.HRNet (c = 512); img [B,3,224,224], feature [B,3136,768] -> its training loss (hrnet.py:290-299),
     differentiable w.r.t. every parameter its forward uses (layer4 is constructed but never run: no gradient, as in the reference)."""
     names, params = zip(*[(n, p) for n, p in module.named_parameters() if not n.startswith("layer4.")])
+    _check_bn([m for n, m in module.named_modules() if isinstance(m, torch.nn.BatchNorm2d) and not n.startswith("layer4.")])
     dev = params[0].device
     img, feature = img.to(dev).float().contiguous(), feature.to(dev).float().contiguous()
     need = torch.is_grad_enabled() and any(p.requires_grad for p in params)

@@ -7,10 +7,17 @@ from . import ops
 
 def greedy_coreset(z, n_select, coreset_dtype="FP16"):
     """z [n,d] f32 cuda (randomly projected library) -> selected row indices [n_select] int64 (cuda)."""
-    if coreset_dtype != "FP16":
-        raise NotImplementedError("cmdiad_amd implements coreset_dtype='FP16' (the reference default)")
+    if coreset_dtype not in ("FP16", "TF32"):
+        raise NotImplementedError(f"coreset_dtype {coreset_dtype!r}: the reference knows 'FP16' and 'TF32' (features.py:386-393)")
     z = z.float().contiguous()
     n, d = z.shape
+    if coreset_dtype == "TF32":      # the fp32 scan (allow_tf32 changes matrix products only: the loop has none)
+        out = torch.empty((n_select,), dtype=torch.int64, device=z.device)
+        wsb = nat.lib().cmdiad_coreset_f32_workspace_bytes(n, d, n_select)
+        ws = torch.empty((wsb + 7) // 8, dtype=torch.int64, device=z.device)
+        nat.check(nat.lib().cmdiad_coreset_greedy_f32(ops._p(z), n, d, n_select, 0, ops._p(out), ops._p(ws), wsb, ops._stream()),
+                  "cmdiad_coreset_greedy_f32")
+        return out
     if d % 2:
         z = torch.nn.functional.pad(z, (0, 1))
         d += 1

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void coreset_round_kernel(const __half* __rest
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int last = best_prev ? (int)(0xFFFFFFFFu - (unsigned)(*best_prev & 0xFFFFFFFFull)) : first_idx;
     const unsigned* zl = reinterpret_cast<const unsigned*>(z + (size_t)last * (2 * d2));
-    for (int c = threadIdx.x; c < d2; c += 256) s_piv[c] = zl[c];
+    for (int c = threadIdx.x; c < 512; c += 256) s_piv[c] = c < d2 ? zl[c] : 0u;   // (zero beyond d2: the padded tail of the last chunk)
     __syncthreads();
     unsigned long long best = 0ull;
     const int q = blockIdx.x * 256 + threadIdx.x;        // this thread's group of four rows
@@ -57,40 +57,46 @@ __global__ __launch_bounds__(256) void coreset_round_kernel(const __half* __rest
         const uint4* src = zT + q;
         __half md[4];
         *reinterpret_cast<uint2*>(md) = *reinterpret_cast<const uint2*>(min_d + (size_t)q * 4);
-        if constexpr (EARLY) {
-            int c = 0;
-            for (; c + 8 <= d2; c += 8) {
+        // Chunks of eight dimension pairs, DOUBLE-BUFFERED: the next chunk's eight 16-byte loads are issued before the current
+        // chunk is summed (and, with EARLY, voted on), so a wave always has 8-16 KiB in flight -- with the loads of a chunk issued
+        // only after the previous chunk's vote the three waves per SIMD of this grid left the memory pipe idle between chunks
+        // (109 us per round at 765 184 x 334; profiles/r4_notes.md).  The sum per row runs over c in the same order as before.
+        const int nchunk = (d2 + 7) / 8;
+        uint4 buf[2][8];
+        auto fetch = [&](int ch, uint4 (&dst)[8]) __attribute__((always_inline)) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const uint4 v = src[(size_t)(c + e) * n4];
-                    const unsigned pv = s_piv[c + e];
-                    s0 = sq_diff_acc(v.x, pv, s0);
-                    s1 = sq_diff_acc(v.y, pv, s1);
-                    s2 = sq_diff_acc(v.z, pv, s2);
-                    s3 = sq_diff_acc(v.w, pv, s3);
-                }
+            for (int e = 0; e < 8; ++e) {
+                const int c = ch * 8 + e;
+                dst[e] = c < d2 ? src[(size_t)c * n4] : uint4{0u, 0u, 0u, 0u};
+            }
+        };
+        auto sum = [&](int ch, const uint4 (&v)[8]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const unsigned pv = s_piv[ch * 8 + e];
+                s0 = sq_diff_acc(v[e].x, pv, s0);
+                s1 = sq_diff_acc(v[e].y, pv, s1);
+                s2 = sq_diff_acc(v[e].z, pv, s2);
+                s3 = sq_diff_acc(v[e].w, pv, s3);
+            }
+        };
+        fetch(0, buf[0]);
+        for (int ch = 0; ch < nchunk; ch += 2) {
+            if (ch + 1 < nchunk) fetch(ch + 1, buf[1]);
+            sum(ch, buf[0]);
+            if constexpr (EARLY) {
                 const bool settled = !__hlt(__float2half(sqrtf(s0)), md[0]) && !__hlt(__float2half(sqrtf(s1)), md[1]) &&
                                      !__hlt(__float2half(sqrtf(s2)), md[2]) && !__hlt(__float2half(sqrtf(s3)), md[3]);
-                if (__all(settled)) { c = d2; break; }   // wave-uniform: every row of the wave keeps its minimum
+                if (__all(settled)) break;   // wave-uniform: every row of the wave keeps its minimum
             }
-            for (; c < d2; ++c) {
-                const uint4 v = src[(size_t)c * n4];
-                const unsigned pv = s_piv[c];
-                s0 = sq_diff_acc(v.x, pv, s0);
-                s1 = sq_diff_acc(v.y, pv, s1);
-                s2 = sq_diff_acc(v.z, pv, s2);
-                s3 = sq_diff_acc(v.w, pv, s3);
+            if (ch + 1 >= nchunk) break;
+            if (ch + 2 < nchunk) fetch(ch + 2, buf[0]);
+            sum(ch + 1, buf[1]);
+            if constexpr (EARLY) {
+                const bool settled = !__hlt(__float2half(sqrtf(s0)), md[0]) && !__hlt(__float2half(sqrtf(s1)), md[1]) &&
+                                     !__hlt(__float2half(sqrtf(s2)), md[2]) && !__hlt(__float2half(sqrtf(s3)), md[3]);
+                if (__all(settled)) break;
             }
-        } else {
-#pragma unroll 8
-        for (int c = 0; c < d2; ++c) {
-            const uint4 v = src[(size_t)c * n4];
-            const unsigned pv = s_piv[c];
-            s0 = sq_diff_acc(v.x, pv, s0);
-            s1 = sq_diff_acc(v.y, pv, s1);
-            s2 = sq_diff_acc(v.z, pv, s2);
-            s3 = sq_diff_acc(v.w, pv, s3);
-        }
         }
         const float ss[4] = {s0, s1, s2, s3};
 #pragma unroll
@@ -150,6 +156,102 @@ __global__ __launch_bounds__(256) void coreset_init_kernel(const float* __restri
     }
 }
 
+// coreset_dtype 'TF32' (features.py:390-391, main.py:151): torch.backends.cuda.matmul.allow_tf32 only changes matrix products, and
+// the loop has none -- the branch is the same greedy selection on the UNROUNDED fp32 rows: dist = sqrt(sum (z_i - z_last)^2) in fp32
+// (torch's fp32 norm; its summation order is not specified: "parity unpinned" beyond the golden's size), fp32 running minimum.
+// Same layout idea: zT32[c][row] (one float per dimension, a thread owns four consecutive rows: 16-byte loads, 1 KiB per wave
+// instruction), the pivot row in LDS, the exact partial-distance exit (sums of squares never decrease, sqrt is monotone).
+__global__ __launch_bounds__(256) void coreset_round_f32_kernel(const float* __restrict__ z, const float4* __restrict__ zT, int n, int n4,
+                                                                int d, float* __restrict__ min_d,
+                                                                const unsigned long long* __restrict__ best_prev,
+                                                                unsigned long long* __restrict__ best_cur, int first_idx)
+{
+    __shared__ float s_piv[1024];
+    __shared__ unsigned long long s_key[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int last = best_prev ? (int)(0xFFFFFFFFu - (unsigned)(*best_prev & 0xFFFFFFFFull)) : first_idx;
+    const float* zl = z + (size_t)last * d;
+    for (int c = threadIdx.x; c < d; c += 256) s_piv[c] = zl[c];
+    __syncthreads();
+    unsigned long long best = 0ull;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q < n4) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        const float4* src = zT + q;
+        float4 md = *reinterpret_cast<const float4*>(min_d + (size_t)q * 4);
+        int c = 0;
+        for (; c + 8 <= d; c += 8) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float4 v = src[(size_t)(c + e) * n4];
+                const float pv = s_piv[c + e];
+                const float d0 = v.x - pv, d1 = v.y - pv, d2 = v.z - pv, d3 = v.w - pv;
+                s0 += d0 * d0; s1 += d1 * d1; s2 += d2 * d2; s3 += d3 * d3;
+            }
+            const bool settled = !(sqrtf(s0) < md.x) && !(sqrtf(s1) < md.y) && !(sqrtf(s2) < md.z) && !(sqrtf(s3) < md.w);
+            if (__all(settled)) { c = d; break; }
+        }
+        for (; c < d; ++c) {
+            const float4 v = src[(size_t)c * n4];
+            const float pv = s_piv[c];
+            const float d0 = v.x - pv, d1 = v.y - pv, d2 = v.z - pv, d3 = v.w - pv;
+            s0 += d0 * d0; s1 += d1 * d1; s2 += d2 * d2; s3 += d3 * d3;
+        }
+        const float ss[4] = {s0, s1, s2, s3};
+        float m4[4] = {md.x, md.y, md.z, md.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = q * 4 + r;
+            const float dist = sqrtf(ss[r]);
+            const float nm = dist < m4[r] ? dist : m4[r];
+            m4[r] = nm;
+            if (row < n) {
+                const unsigned long long k = ((unsigned long long)__float_as_uint(nm) << 32) | (0xFFFFFFFFu - (unsigned)row);
+                best = k > best ? k : best;
+            }
+        }
+        *reinterpret_cast<float4*>(min_d + (size_t)q * 4) = float4{m4[0], m4[1], m4[2], m4[3]};
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const unsigned long long o = shfl_xor_u64(best, m);
+        best = o > best ? o : best;
+    }
+    if (lane == 0) s_key[wave] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long m = s_key[0];
+        for (int w = 1; w < 4; ++w) m = s_key[w] > m ? s_key[w] : m;
+        atomicMax(best_cur, m);
+    }
+}
+
+__global__ __launch_bounds__(256) void coreset_init_f32_kernel(const float* __restrict__ z32, int n, int n4, int d, int first_idx,
+                                                               float* __restrict__ zT, float* __restrict__ min_d)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* zl = z32 + (size_t)first_idx * d;
+    const size_t tstride = (size_t)n4 * 4;   // floats between consecutive dimensions of zT
+    for (int row = blockIdx.x * 4 + wave; row < n4 * 4; row += gridDim.x * 4) {
+        if (row >= n) {
+            for (int c = lane; c < d; c += 64) zT[(size_t)c * tstride + row] = 0.f;
+            if (lane == 0) min_d[row] = 0.f;
+            continue;
+        }
+        const float* zr = z32 + (size_t)row * d;
+        float s = 0.0f;
+        for (int c = lane; c < d; c += 64) {
+            const float v = zr[c];
+            const float df = v - zl[c];
+            s += df * df;
+            zT[(size_t)c * tstride + row] = v;
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+        if (lane == 0) min_d[row] = sqrtf(s);
+    }
+}
+
 __global__ void coreset_decode_kernel(const unsigned long long* __restrict__ best, int n_sel, int first_idx,
                                       int64_t* __restrict__ out)
 {
@@ -166,6 +268,40 @@ extern "C" size_t cmdiad_coreset_workspace_bytes(int n, int d, int n_select)
 {
     const size_t n4 = ((size_t)n + 3) / 4;
     return up256((size_t)n * d * 2) + up256(n4 * 4 * (size_t)d * 2) + up256(n4 * 4 * 2) + (size_t)(n_select > 0 ? n_select : 1) * 8;
+}
+
+extern "C" size_t cmdiad_coreset_f32_workspace_bytes(int n, int d, int n_select)
+{
+    const size_t n4 = ((size_t)n + 3) / 4;
+    return up256(n4 * 4 * (size_t)d * 4) + up256(n4 * 4 * 4) + (size_t)(n_select > 0 ? n_select : 1) * 8;
+}
+
+// coreset_dtype 'TF32': the selection on the fp32 rows (see coreset_round_f32_kernel); the pivot row is read from z32 itself.
+extern "C" int cmdiad_coreset_greedy_f32(const float* z32, int n, int d, int n_select, int first_idx, int64_t* idx_out,
+                                         void* workspace, size_t workspace_bytes, cmdiad_stream_t stream)
+{
+    CMDIAD_REQUIRE(z32 && idx_out && n > 0 && d > 0 && n_select > 0 && n_select <= n && d <= 1024, CMDIAD_ERR_ARG,
+                   "cmdiad_coreset_greedy_f32: bad args (need d <= 1024)");
+    CMDIAD_REQUIRE(workspace && workspace_bytes >= cmdiad_coreset_f32_workspace_bytes(n, d, n_select), CMDIAD_ERR_WORKSPACE,
+                   "cmdiad_coreset_greedy_f32: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    const int n4 = (n + 3) / 4;
+    float* zT = (float*)ws;
+    float* min_d = (float*)(ws + up256((size_t)n4 * 4 * d * 4));
+    unsigned long long* best = (unsigned long long*)((char*)min_d + up256((size_t)n4 * 4 * 4));
+    if (hipMemsetAsync(best, 0, (size_t)n_select * 8, s) != hipSuccess) {
+        cmdiad_set_error("cmdiad_coreset_greedy_f32: memset failed");
+        return CMDIAD_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL(coreset_init_f32_kernel, dim3(2048), dim3(256), 0, s, z32, n, n4, d, first_idx, zT, min_d);
+    const int grid = (n4 + 255) / 256;
+    for (int r = 0; r + 1 < n_select; ++r)
+        hipLaunchKernelGGL(coreset_round_f32_kernel, dim3(grid), dim3(256), 0, s, z32, (const float4*)zT, n, n4, d, min_d,
+                           r == 0 ? nullptr : best + (r - 1), best + r, first_idx);
+    hipLaunchKernelGGL(coreset_decode_kernel, dim3((n_select + 255) / 256), dim3(256), 0, s, best, n_select, first_idx, idx_out);
+    CMDIAD_CHECK_LAUNCH();
+    return CMDIAD_OK;
 }
 
 extern "C" int cmdiad_coreset_greedy(const float* z32, int n, int d, int n_select, int first_idx, int64_t* idx_out,

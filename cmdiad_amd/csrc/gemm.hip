@@ -1022,7 +1022,7 @@ extern "C" int cmdiad_gemm_bf16(const cmdiad_gemm_args* a, cmdiad_stream_t strea
     const bool extras = a->out_pre_bf16 || a->dact_of;
     int rc;
 #ifdef CMDIAD_AB_VARIANTS
-    const int wide = a->m_count ? 0 : wide_choice(a->M, a->N, a->K, !extras && !a->residual && a->ldo16 % 4 == 0, split);
+    const int wide = a->m_count ? 0 : wide_choice(a->M, a->N, a->K, !extras && !a->residual && !a->row_scale && !ln_out && a->ldo16 % 4 == 0, split);   // (the wide kernels know neither row_scale nor the LayerNorm outputs)
     if (wide) {
 #define CMDIAD_WIDE(NJ, ACT) launch_wide<WideShape<NJ>>(gemm_std_wide_kernel<NJ, ACT>, a->M, a->N, a->K, p, A, W, s)
         if (wide == 8) rc = a->act == CMDIAD_ACT_GELU ? CMDIAD_WIDE(8, CMDIAD_ACT_GELU) : a->act == CMDIAD_ACT_RELU ? CMDIAD_WIDE(8, CMDIAD_ACT_RELU) : CMDIAD_WIDE(8, CMDIAD_ACT_NONE);

@@ -77,6 +77,34 @@ __global__ __launch_bounds__(256) void im2col_patch8_kernel(const float* __restr
     *reinterpret_cast<bf16x8*>(patches + pi * 192 + c * 64 + dy * 8) = o;
 }
 
+// 3 x 3 im2col with padding 1 (the stem convolution of the HRNet trunk as a GEMM, hrnet.py:152: Conv2d(3, 64, 3, stride 2, padding 1)):
+// img [B,C,H,W] f32 -> cols [B*Ho*Wo, ld] bf16 with column k = c * 9 + ky * 3 + kx (torch.nn.functional.unfold's order = the
+// flattened conv weight [N, C, 3, 3]), columns C * 9 .. ld - 1 zero.  One thread per (output pixel, 8 columns).
+__global__ __launch_bounds__(256) void im2col3x3_kernel(const float* __restrict__ img, int B, int C, int H, int W, int stride,
+                                                        int Ho, int Wo, int ld, bf16_t* __restrict__ cols)
+{
+    const int chunks = ld / 8;
+    const size_t total = (size_t)B * Ho * Wo * chunks;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int ch = (int)(i % chunks);
+    const size_t pix = i / chunks;
+    const int ox = (int)(pix % Wo), oy = (int)((pix / Wo) % Ho), b = (int)(pix / ((size_t)Wo * Ho));
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = ch * 8 + e;
+        float v = 0.0f;
+        if (k < C * 9) {
+            const int c = k / 9, ky = (k % 9) / 3, kx = k % 3;
+            const int y = oy * stride + ky - 1, x = ox * stride + kx - 1;
+            if (y >= 0 && y < H && x >= 0 && x < W) v = img[(((size_t)b * C + c) * H + y) * W + x];
+        }
+        o[e] = f2bf(v);
+    }
+    *reinterpret_cast<bf16x8*>(cols + pix * ld + ch * 8) = o;
+}
+
 // tokens[b][0] = cls + pos[0]; tokens[b][1+i] = patch_out[b][i] + pos[1+i]
 __global__ __launch_bounds__(256) void vit_assemble_kernel(const float* __restrict__ patch_out, const float* __restrict__ cls,
                                                            const float* __restrict__ pos, int B, int P, int C,
@@ -242,6 +270,18 @@ extern "C" int cmdiad_im2col_patch8(const float* rgb, int B, int S, uint16_t* pa
     const size_t total = (size_t)B * (S / 8) * (S / 8) * 24;
     hipLaunchKernelGGL(im2col_patch8_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, rgb, B, S,
                        (bf16_t*)patches);
+    CMDIAD_CHECK_LAUNCH();
+    return CMDIAD_OK;
+}
+
+extern "C" int cmdiad_im2col3x3_bf16(const float* img, int B, int C, int H, int W, int stride, int ld, uint16_t* cols, cmdiad_stream_t stream)
+{
+    CMDIAD_REQUIRE(img && cols && B > 0 && C > 0 && H > 0 && W > 0 && (stride == 1 || stride == 2) && ld % 8 == 0 && ld >= C * 9 &&
+                       ((uintptr_t)cols & 15) == 0, CMDIAD_ERR_ARG, "cmdiad_im2col3x3_bf16: bad args (need ld %% 8 == 0, ld >= 9 C, stride 1 | 2)");
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    const size_t total = (size_t)B * Ho * Wo * (ld / 8);
+    hipLaunchKernelGGL(im2col3x3_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, img, B, C, H, W, stride, Ho, Wo, ld,
+                       (bf16_t*)cols);
     CMDIAD_CHECK_LAUNCH();
     return CMDIAD_OK;
 }

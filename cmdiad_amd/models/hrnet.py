@@ -78,7 +78,13 @@ class HRNet(_PackedHead):
         # batch 32, but 14.4 against 11.9 at batch 8, where its ~500 launches per step are not yet hidden (profiles/r3_notes.md).
         # CMDIAD_HRNET_TRAIN = auto (default) | hip | torch.
         mode = os.environ.get("CMDIAD_HRNET_TRAIN", "auto")
-        if self._autograd() and (mode == "hip" or (mode == "auto" and img.shape[0] >= 16)):
+        if mode == "auto" and self._autograd():
+            # decided ONCE per module, from the first training batch: a short last batch of an epoch must not switch a run between
+            # the bf16 hand-written path and the fp32 torch layers (different numerics inside one training run)
+            if getattr(self, "_train_path", None) is None:
+                self._train_path = "hip" if img.shape[0] >= 16 else "torch"
+            mode = self._train_path
+        if self._autograd() and mode == "hip":
             from .. import conv_train
             assert tuple(img.shape[1:]) == (3, 224, 224) and tuple(feature.shape[1:]) == (3136, self.final_layer.out_channels)
             return conv_train.hrnet_loss(self, img, feature)

@@ -259,6 +259,16 @@ def conv2d_nhwc(x, W, N, ksize=3, stride=1, bias=None, act=ACT_NONE, residual=No
     return out_f32, out_bf16
 
 
+def im2col3x3(img, stride=2, ld=64):
+    """img [B,C,H,W] f32 -> [B*Ho*Wo, ld] bf16, column c * 9 + ky * 3 + kx (padding 1; zero beyond 9 C): cmdiad_im2col3x3_bf16."""
+    _chk(img, torch.float32, "im2col3x3.img")
+    B, C, H, W = img.shape
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    cols = torch.empty((B * Ho * Wo, ld), dtype=torch.bfloat16, device=img.device)
+    _call("cmdiad_im2col3x3_bf16", _p(img), B, C, H, W, stride, ld, _p(cols), _stream())
+    return cols
+
+
 def conv_stem(x, w, bias, stride=2):
     """x [B,Cin<=4,H,W] f32 NCHW, w [Cout,Cin,3,3] f32 (BatchNorm folded), bias [Cout] -> ReLU(conv) as bf16 NHWC."""
     _chk(x, torch.float32, "stem.x"); _chk(w, torch.float32, "stem.w"); _chk(bias, torch.float32, "stem.bias")

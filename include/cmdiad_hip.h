@@ -37,7 +37,7 @@ int cmdiad_abi_version(void); /* 2: cmdiad_reweight_scan's limits and workspace 
                                  3: LayerNorm fold -- cmdiad_gemm_args gained row_scale / ln_xb / ln_part / add2, cmdiad_gemm_qkv gained
                                     row_scale, cmdiad_block_weights the folded weights, cmdiad_transformer_block_fwd its flags;
                                     cmdiad_ln_stats_finalize is new
-                                 4: cmdiad_l2_min_keys_segments, cmdiad_gemm_streamk_* are new */
+                                 4: cmdiad_l2_min_keys_segments, cmdiad_gemm_streamk_*, cmdiad_coreset_greedy_f32, cmdiad_im2col3x3_bf16 are new */
 /* 1 when the library is the test-only build that also contains the superseded kernel formulations (A/B references). */
 int cmdiad_has_ab_variants(void);
 
@@ -382,6 +382,12 @@ int cmdiad_score_final(const float* s_star, const float* knn_d, int B, int D, fl
 size_t cmdiad_coreset_workspace_bytes(int n, int d, int n_select);
 int cmdiad_coreset_greedy(const float* z32, int n, int d, int n_select, int first_idx, int64_t* idx_out,
                           void* workspace, size_t workspace_bytes, cmdiad_stream_t stream);
+/* coreset_dtype 'TF32' (features.py:390-391; main.py:151): the same selection on the UNROUNDED fp32 rows -- allow_tf32 only touches
+ * matrix products and the loop has none, so the reference's branch is an fp32 scan: dist = sqrt(sum (z_i - z_last)^2) in fp32, fp32
+ * running minimum, first arg-max.  d <= 1024 (any parity). */
+size_t cmdiad_coreset_f32_workspace_bytes(int n, int d, int n_select);
+int cmdiad_coreset_greedy_f32(const float* z32, int n, int d, int n_select, int first_idx, int64_t* idx_out, void* workspace,
+                              size_t workspace_bytes, cmdiad_stream_t stream);
 
 /* Sparse random projection in front of the coreset selection (features.py:360-371: SparseRandomProjection.fit_transform): out [n,
  * n_comp] = X [n,d] . components^T with `components` [n_comp,d] in CSR (int32 indptr / sorted indices, f32 data: the fitted
@@ -404,6 +410,10 @@ int cmdiad_normalize_cast(const float* x, size_t rows, int D, float mean, float 
 /* ViT patch embedding as a GEMM operand: rgb [B,3,S,S] f32 -> patches [B*(S/8)^2, 192] bf16 with
  * k = (c, dy, dx) matching conv weight [768,3,8,8] flattened (timm PatchEmbed, models/models.py:41). */
 int cmdiad_im2col_patch8(const float* rgb, int B, int S, uint16_t* patches, cmdiad_stream_t stream);
+/* 3 x 3 im2col with padding 1 and stride 1 | 2 (hrnet.py:152, the trunk's stem convolution as a GEMM in the hand-written training
+ * step): img [B,C,H,W] f32 -> cols [B*Ho*Wo, ld] bf16, column c * 9 + ky * 3 + kx (the order of the flattened Conv2d weight and of
+ * torch.nn.functional.unfold), columns 9 C .. ld - 1 zero.  ld % 8 == 0, ld >= 9 C. */
+int cmdiad_im2col3x3_bf16(const float* img, int B, int C, int H, int W, int stride, int ld, uint16_t* cols, cmdiad_stream_t stream);
 
 /* tokens[b][0] = cls + pos[0]; tokens[b][1+i] = patch_out[b][i] + pos[1+i]  (timm _pos_embed,
  * models/models.py:42).  patch_out [B*P, C] f32, tokens [B*(P+1), C] f32. */

@@ -344,6 +344,25 @@ def golden_halluc_depth2():
     np.savez_compressed(os.path.join(HERE, "g5b_halluc_depth2.npz"), samples_seed=54, weights_seed=53, **out)
 
 
+def golden_coreset_tf32():
+    """G9b: get_coreset_idx_randomp with coreset_dtype='TF32' (features.py:390-391: an fp32 scan -- allow_tf32 touches matrix
+    products only), the hard-coded "cuda" redirected to the CPU as for G9."""
+    _install_stubs()
+    sys.path.insert(0, REF)
+    from feature_extractors import features as rfeat
+    g = torch.Generator().manual_seed(92)
+    z = torch.randn(2500, 768, generator=g)
+    orig_to = torch.Tensor.to
+    torch.Tensor.to = lambda self, *a, **k: orig_to(self, *[("cpu" if (isinstance(x, str) and x == "cuda") else x) for x in a], **k)
+    try:
+        fake = _ns(args=_ns(dist_method_coreset="l2"), random_state=0)
+        sel = rfeat.Features.get_coreset_idx_randomp(fake, z, n=250, eps=0.9, coreset_dtype="TF32")
+    finally:
+        torch.Tensor.to = orig_to
+    np.savez_compressed(os.path.join(HERE, "g9b_coreset_tf32.npz"), z_seed=92, rows=2500, dim=768, n=250, eps=0.9, random_state=0,
+                        idx=sel.numpy().astype(np.int64))
+
+
 def main():
     _install_stubs()
     sys.path.insert(0, REF)
@@ -617,6 +636,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "g9_coreset.npz"), z_seed=91, rows=2500, dim=768, n=250, eps=0.9, random_state=0,
                         idx=sel.numpy().astype(np.int64))
 
+    golden_coreset_tf32()
     golden_heads()
     golden_methods()
 

@@ -213,6 +213,29 @@ def test_coreset_vs_reference_golden(golden):
     np.testing.assert_array_equal(sel.numpy(), g["idx"])
 
 
+def test_coreset_tf32_vs_reference_golden(golden):
+    """coreset_dtype='TF32' (features.py:390-391, main.py:151 -- in the reference an fp32 scan): cmdiad_coreset_greedy_f32 against
+    the selection the reference's own function made with that setting (tests/golden/g9b_coreset_tf32.npz), and against a float64
+    restatement of the greedy rule on a larger set (every pick attains the largest running minimum to fp32 accuracy)."""
+    from cmdiad_amd import coreset
+    from cmdiad_amd.feature_extractors.features import Features
+    g = golden("g9b_coreset_tf32.npz")
+    z = torch.randn(int(g["rows"]), int(g["dim"]), generator=torch.Generator().manual_seed(int(g["z_seed"])))
+    fake = types.SimpleNamespace(args=types.SimpleNamespace(dist_method_coreset="l2"), random_state=int(g["random_state"]), device=DEV)
+    sel = Features.get_coreset_idx_randomp(fake, z, n=int(g["n"]), eps=float(g["eps"]), coreset_dtype="TF32")
+    np.testing.assert_array_equal(sel.numpy(), g["idx"])
+    zz = torch.randn(30001, 333, generator=torch.Generator().manual_seed(5))          # odd d, n % 4 != 0
+    picks = coreset.greedy_coreset(zz.to(DEV), 400, "TF32").cpu()
+    assert picks[0] == 0 and len(set(picks.tolist())) == 400
+    z64 = zz.double()
+    min_d = torch.linalg.norm(z64 - z64[0:1], dim=1)
+    for i in picks[1:].tolist():                   # the greedy rule in float64: each pick is an arg-max of the running minimum
+        assert float(min_d[i]) >= float(min_d.max()) * (1 - 1e-5)
+        min_d = torch.minimum(min_d, torch.linalg.norm(z64 - z64[i:i + 1], dim=1))
+    with pytest.raises(NotImplementedError):
+        coreset.greedy_coreset(zz.to(DEV), 4, "BF16")
+
+
 @pytest.mark.parametrize("n,d,eps,seed", [(5003, 768, 0.9, 3), (20000, 1152, 0.9, 0), (777, 256, 0.95, 11), (9, 2048, 0.9, 5)])
 def test_sparse_random_projection_on_device_is_bit_identical_to_sklearn(n, d, eps, seed):
     """features.py:360-363: SparseRandomProjection(eps, random_state).fit_transform on the host against

@@ -30,12 +30,12 @@ def _oracle_class(cpu_ex, sd_h, data, lambdas, f_coreset, random_state):
     from sklearn.metrics import roc_auc_score
     cpu = pipeline.CpuOneHallucination(cpu_ex, sd_h, "xyz", lambdas=lambdas, f_coreset=f_coreset, random_state=random_state)
     trip = cpu.fit([(s[0], s[1]) for s, _ in data.train()])
-    rows = pmap(lambda t: cpu.score(*t)[:2], trip, 2, total=4)      # the train samples again (cmdiad_runner.py:58-66): same patches
+    rows = pmap(lambda t: cpu.score(*t)[:2], trip, 4, total=8)      # the train samples again (cmdiad_runner.py:58-66): same patches
     det = linear_model.SGDOneClassSVM(random_state=42, nu=0.5, max_iter=1000).fit(torch.cat([r[0] for r in rows], 0).numpy())
     seg = linear_model.SGDOneClassSVM(random_state=42, nu=0.5, max_iter=1000).fit(torch.cat([r[1] for r in rows], 0).numpy())
     img, pix, labels, masks = [], [], [], []
     tests = list(data.test())
-    preds = pmap(lambda it: cpu.predict(it[0][0], it[0][1])[:2], tests, 2, total=4)     # (two classes run side by side: 4 samples at a time)
+    preds = pmap(lambda it: cpu.predict(it[0][0], it[0][1])[:2], tests, 4, total=8)     # (two classes run side by side: 8 samples at a time)
     for (s, s_map), (sample, mask, label, _) in zip(preds, tests):
         img.append(float(det.score_samples(s.numpy())[0]))
         pix.append(seg.score_samples(s_map.numpy()).reshape(224, 224))
@@ -71,7 +71,7 @@ def test_mtfi_class_loop_auroc_vs_oracle(monkeypatch):
     assert sum(int(l[0]) for _, _, l, _ in data["bagel"].test()) == 6
     a = ev.mtfi_args(f_coreset=0.1, random_state=3)
     lam = (a.xyz_s_lambda, a.xyz_smap_lambda, a.fusion_s_lambda, a.fusion_smap_lambda)
-    refs = dict(zip(data, pmap(lambda d: _oracle_class(cpu_ex, weights[2], d, lam, a.f_coreset, a.random_state), data.values(), 2, total=4)))
+    refs = dict(zip(data, pmap(lambda d: _oracle_class(cpu_ex, weights[2], d, lam, a.f_coreset, a.random_state), data.values(), 2, total=8)))
     queue = [pk for cls in ("bagel", "rope") for pk in refs[cls]["picks"]]      # run_coreset: main library, then fusion
     own = []
     inner = mf.RGBorXYZWithOneHallucination.get_coreset_idx_randomp

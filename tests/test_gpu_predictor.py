@@ -113,7 +113,7 @@ def test_predict_batch_b32_vs_oracle(weights, cpu_ex, gpu_engine, monkeypatch):
     samples = [synth_sample(i, anomalous=(i % 3 == 0 and i < 30)) for i in range(B)]
     labels = np.array([int(s[2].any()) for s in samples])
     assert labels.sum() == 10
-    ref = pmap(lambda smp: cpu.predict(smp[0], smp[1])[:2], samples)          # the oracle, four samples at a time on the host cores
+    ref = pmap(lambda smp: cpu.predict(smp[0], smp[1])[:2], samples, 8)       # the oracle, eight samples at a time on the host cores
     ref_img = np.array([float(det.score_samples(s.numpy())[0]) for s, _ in ref])
     ref_pix = np.stack([seg.score_samples(s_map.numpy()).reshape(224, 224) for _, s_map in ref])
 
@@ -192,7 +192,7 @@ def test_mtfi_batch_vs_oracle(weights, cpu_ex, gpu_engine, monkeypatch):
     samples = [synth_sample(i, anomalous=(i % 3 == 0)) for i in range(B)]
     labels = np.array([int(s[2].any()) for s in samples])
     assert labels.sum() == 8
-    ref = pmap(lambda smp: cpu.predict(smp[0], smp[1])[:2], samples)
+    ref = pmap(lambda smp: cpu.predict(smp[0], smp[1])[:2], samples, 8)
     ref_img = np.array([float(det.score_samples(s.numpy())[0]) for s, _ in ref])
     ref_pix = np.stack([seg.score_samples(s_map.numpy()).reshape(224, 224) for _, s_map in ref])
     stats = dict(xyz_mean=float(cpu.mean), xyz_std=float(cpu.std), rgb_mean=float(cpu.mean), rgb_std=float(cpu.std))
