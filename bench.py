@@ -623,7 +623,7 @@ def conv_head_train_leg(dev, batch=8, steps=6, warm=2):
                 steps=steps, warmup=warm, loss_first=round(first, 1), loss_last=round(last, 1))
 
 
-def var_n_leg(st, dev, steps=8, warm=3):
+def var_n_leg(st, dev, steps=16, warm=8):
     """SURVEY 8(d) var-N regime: every cloud keeps a different share of the image -- foreground 35 ... 65 % of the 224 x 224 pixels
     (N ~ 17.5 k ... 32.6 k points) -- instead of the fixed 24 576 points of the headline batches: the same predictor, ragged
     point counts inside a batch of 32 (padded to the largest, per-sample lengths on the device), and a DIFFERENT share of
