@@ -26,14 +26,29 @@ class Bank:
       shard for the queries of ALL ranks and the per-shard minima are combined with one integer-MIN
       all-reduce of packed (distance, global row) keys over RCCL/xGMI."""
 
-    def __init__(self, rows_f32, rank=0, world=1):
+    def __init__(self, rows_f32, rank=0, world=1, replicate_f32=True):
+        """replicate_f32=False: this rank keeps ONLY its row shard of the fp32 library (and of the block16 copy) as well -- the
+        partitioning of SURVEY 8(e) to the letter.  The exact re-score and the re-weighting step (features.py:235-290) then need
+        four small collectives per scored batch (score_patches_from_keys with `group`): who owns a row contributes it.  The default
+        replicates the fp32 rows (<= 700 MB for the largest MVTec-3D class: 0.25 % of 288 GB) and needs none."""
         assert rows_f32.is_cuda and rows_f32.dtype == torch.float32
-        self.f32 = rows_f32.contiguous()
-        n = self.f32.shape[0]
+        n = rows_f32.shape[0]
         lo, hi = shard_range(n, rank, world)
         self.row_offset, self.rank, self.world = lo, rank, world
         self.shard_rows = hi - lo
-        b16, _, sq = ops.normalize_cast(self.f32[lo:hi])
+        self.total_rows = n
+        self.f32_sharded = not replicate_f32      # (a world of one takes the collective path too: that is how one GPU tests it)
+        if hi > lo:
+            b16, _, sq = ops.normalize_cast(rows_f32[lo:hi].contiguous())
+        else:       # an empty shard (fewer rows than 128 x (world - 1)): nothing to search, its keys stay KEY_EMPTY
+            b16 = torch.empty((0, rows_f32.shape[1]), dtype=ops.SEARCH_DTYPE, device=rows_f32.device)
+            sq = torch.empty((0,), dtype=torch.float32, device=rows_f32.device)
+        if self.f32_sharded:
+            self.f32 = rows_f32[lo:hi].clone() if hi > lo else torch.zeros((1, rows_f32.shape[1]), dtype=torch.float32, device=rows_f32.device)
+            self.f32_offset, self.f32_rows = lo, hi - lo          # (an empty shard keeps one dummy row that no index can name)
+        else:
+            self.f32 = rows_f32.contiguous()
+            self.f32_offset, self.f32_rows = 0, n
         # The distance GEMM's production kernel takes whole 256-row library tiles and hands the last n % 256 rows to a second,
         # much less efficient launch (76 518 = 298 x 256 + 230).  Pad the SEARCH operand to a tile boundary with rows that cannot
         # win -- all-zero rows whose squared norm is +inf, so d2 = (|q|^2 + inf) - 2 * 0 = inf never passes `d2 < best` -- and the
@@ -54,7 +69,8 @@ class Bank:
 
     @property
     def rows(self):
-        return self.f32.shape[0]
+        """rows of the WHOLE library (the fp32 copy holds all of them unless f32_sharded)"""
+        return self.total_rows
 
 
 def shard_range(n, rank, world):
@@ -243,7 +259,7 @@ def score_patches(patch32, bank, dims, gt_size=224, group=None):
     q16, _, qsq = ops.normalize_cast(flat)
     if group is not None and os.environ.get("CMDIAD_DEDUP", "1") != "0":
         keys, _ = sharded_min_keys(q16, qsq, bank, group)      # compact locally, gather the live rows only
-        return score_patches_from_keys(patch32, keys, bank, dims, gt_size)
+        return score_patches_from_keys(patch32, keys, bank, dims, gt_size, group)
     q_all, s_all = gather_queries(q16, qsq, group)
     keys = ops.new_keys(q_all.shape[0], dev)
     if os.environ.get("CMDIAD_DEDUP", "1") != "0":
@@ -256,11 +272,80 @@ def score_patches(patch32, bank, dims, gt_size=224, group=None):
     keys = merge_shard_keys(keys, group)
     if group is not None:
         keys = keys[bank.rank * B * Q:(bank.rank + 1) * B * Q].contiguous()
-    return score_patches_from_keys(patch32, keys, bank, dims, gt_size)
+    return score_patches_from_keys(patch32, keys, bank, dims, gt_size, group)
 
 
-def score_patches_from_keys(patch32, keys, bank, dims, gt_size=224):
-    """Everything after the (merged) nearest-neighbour keys: exact re-score, s*, re-weighting, score map."""
+def _sharded_score_steps(patch32, keys, bank, dims, gt_size):
+    """score_patches_from_keys for a library whose fp32 rows are SHARDED too (Bank(replicate_f32=False)); SURVEY 8(e)'s re-weight
+    step, features.py:225-290 per shard.  A generator: every `yield (kind, tensor)` is one collective over the ranks and receives its
+    result -- "sum": element-wise sum (exactly one rank, the owner of the row in question, contributes a non-zero value, so the sum
+    is exact); "gather": [W, *shape] of every rank's tensor.  Driven by real collectives (`_drive_collectives`) or, on one device,
+    by a lock-step loop over W generators (tests/test_gpu_fakeworld.py).
+      1. exact fp32 distance to the winning row: computed by the rank that owns it                      -> sum   [B*Q] f32
+      2. s* = max over a sample's patches; m_star = the winning row of that patch: sent by its owner       -> sum   [B, D] f32
+      3. re-weighting scan of the LOCAL rows: three smallest (distance, global row) keys per probe         -> gather [W, B, 3] keys,
+         merged by integer order (ties -> lowest global row, as the single-library scan)
+      4. || m_test - row || for the 2nd and 3rd of them: computed by the owners of those rows              -> sum   [B, 2] f32"""
+    B, Q, D = patch32.shape
+    dev = patch32.device
+    flat = patch32.reshape(B * Q, D)
+    off, nloc = bank.f32_offset, bank.f32_rows
+    min_val = torch.zeros((B * Q,), dtype=torch.float32, device=dev)
+    scratch_idx = torch.full((B * Q,), -1, dtype=torch.int64, device=dev)
+    ops.l2_rescore(flat, bank.f32, keys, min_val, scratch_idx, off) if nloc else None
+    min_val = yield ("sum", min_val)
+    min_idx = torch.where(keys == KEY_EMPTY, torch.full_like(keys, -1), keys & 0xFFFFFFFF)       # global rows, known everywhere
+    s_star = torch.empty((B,), dtype=torch.float32, device=dev)
+    s_idx = torch.empty((B,), dtype=torch.int32, device=dev)
+    m_test = torch.empty((B, D), dtype=torch.float32, device=dev)
+    m_star = torch.zeros((B, D), dtype=torch.float32, device=dev)
+    st = ops._stream()
+    _call("cmdiad_score_head", ops._p(min_val), ops._p(min_idx), ops._p(flat), ops._p(bank.f32), B, Q, D, nloc, off,
+          ops._p(s_star), ops._p(s_idx), ops._p(m_test), ops._p(m_star), st)
+    m_star = yield ("sum", m_star)
+    if nloc:
+        top3_local = ops.reweight_scan(m_star, bank.f32, bank.blk16, row_offset=off)
+    else:
+        top3_local = torch.full((B, 3), KEY_EMPTY, dtype=torch.int64, device=dev)
+    everyone = yield ("gather", top3_local)                                                      # [W, B, 3]
+    top3 = everyone.permute(1, 0, 2).reshape(B, -1).sort(1).values[:, :3].contiguous()           # keys are non-negative int64
+    knn_d = torch.zeros((B, 2), dtype=torch.float32, device=dev)
+    _call("cmdiad_score_tail", ops._p(s_star), ops._p(m_test), ops._p(top3), ops._p(bank.f32), B, D, nloc, off, ops._p(knn_d), st)
+    knn_d = yield ("sum", knn_d)
+    s = torch.empty((B,), dtype=torch.float32, device=dev)
+    _call("cmdiad_score_final", ops._p(s_star), ops._p(knn_d), B, D, ops._p(s), st)
+    s_map = ops.bilinear_up(min_val.view(B, dims[0], dims[1]), gt_size)
+    return dict(min_val=min_val.view(B, Q), min_idx=min_idx.view(B, Q), s_idx=s_idx, s_star=s_star, s=s,
+                s_map_pre=s_map, top3=top3, knn_d=knn_d)
+
+
+def _drive_collectives(gen, group):
+    """Runs a `_sharded_score_steps` generator over a torch.distributed group (RCCL on the GPUs, gloo in the CPU tests)."""
+    import torch.distributed as td
+    world = td.get_world_size(group)
+    try:
+        kind, t = next(gen)
+        while True:
+            if kind == "sum":
+                td.all_reduce(t, op=td.ReduceOp.SUM, group=group)
+                res = t
+            else:
+                t = t.contiguous()
+                flat = torch.empty((world * t.shape[0], *t.shape[1:]), dtype=t.dtype, device=t.device)   # (gloo wants the concatenated shape)
+                td.all_gather_into_tensor(flat, t, group=group)
+                res = flat.view(world, *t.shape)
+            kind, t = gen.send(res)
+    except StopIteration as done:
+        return done.value
+
+
+def score_patches_from_keys(patch32, keys, bank, dims, gt_size=224, group=None):
+    """Everything after the (merged) nearest-neighbour keys: exact re-score, s*, re-weighting, score map.  `group` is needed only
+    when the library's fp32 rows are sharded as well (Bank(replicate_f32=False))."""
+    if getattr(bank, "f32_sharded", False):
+        if group is None:
+            raise ValueError("score_patches_from_keys: the library's fp32 rows are sharded -- the process group is needed")
+        return _drive_collectives(_sharded_score_steps(patch32, keys, bank, dims, gt_size), group)
     B, Q, D = patch32.shape
     dev = patch32.device
     flat = patch32.reshape(B * Q, D)

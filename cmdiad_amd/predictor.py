@@ -128,6 +128,9 @@ class BatchPredictor:
         self.dedup = os.environ.get("CMDIAD_DEDUP", "1") != "0"
         # row-sharded search: rows of every rank that travel per step -- "auto" (sticky cap, no host read in steady state) | "exact"
         self.shard_cap = os.environ.get("CMDIAD_SHARD_CAP", "auto")
+        self.stage2_eager = bool(getattr(bank_xyz, "f32_sharded", False) or getattr(bank_second, "f32_sharded", False))
+        if self.stage2_eager and group is None:
+            raise ValueError("BatchPredictor: a library with sharded fp32 rows (Bank(replicate_f32=False)) needs the process group")
         self.live_rows = torch.zeros((1,), dtype=torch.int64, device=dev)   # rows actually searched, summed over the xyz searches
         self.xyz_searches = 0
         self._raw_norm = None
@@ -273,9 +276,9 @@ class BatchPredictor:
     def stage2(self, qs, keys):
         lam = self.lambdas
         gt = self.gt
-        rx = eng.score_patches_from_keys(qs["xyz"][0], keys["xyz"].contiguous(), self.bank_xyz, (56, 56), gt)
+        rx = eng.score_patches_from_keys(qs["xyz"][0], keys["xyz"].contiguous(), self.bank_xyz, (56, 56), gt, self.group)
         side = (56, 56) if self.workload == "mtfi" else (28, 28)
-        rr = eng.score_patches_from_keys(qs["rgb"][0], keys["rgb"].contiguous(), self.bank_second, side, gt)
+        rr = eng.score_patches_from_keys(qs["rgb"][0], keys["rgb"].contiguous(), self.bank_second, side, gt, self.group)
         s = torch.stack([rx["s"], rr["s"]], 1)                                   # [B,2]
         maps = torch.stack([rx["s_map_pre"], rr["s_map_pre"]], 1).contiguous()   # [B,2,gt,gt]
         B = maps.shape[0]
@@ -297,9 +300,13 @@ class BatchPredictor:
                 g1.replay()
                 keys = self.search(qs, s)
                 k = {n: v.contiguous() for n, v in keys.items()}
-                g2 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g2):
+                g2 = None
+                if self.stage2_eager:       # fp32 rows sharded too: the scoring tail holds collectives and runs eagerly
                     out = self.stage2(qs, k)
+                else:
+                    g2 = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g2):
+                        out = self.stage2(qs, k)
                 torch.cuda.synchronize()
                 sets.append(dict(g1=g1, g2=g2, qs=qs, k=k, out=out, done=None))
             self.sets = sets
@@ -383,7 +390,10 @@ class BatchPredictor:
                     for n, k in keys.items():
                         if k.data_ptr() != st["k"][n].data_ptr():
                             st["k"][n].copy_(k)
-                st["g2"].replay()
+                if st["g2"] is not None:
+                    st["g2"].replay()
+                else:
+                    st["out"] = self.stage2(st["qs"], st["k"])
                 s_dev, maps_dev = st["out"]
                 host_s.copy_(s_dev, non_blocking=True)
                 host_m.copy_(maps_dev, non_blocking=True)

@@ -198,3 +198,90 @@ def test_sharded_search_object_world_of_one_rccl_sticky_cap_and_overflow():
         assert torch.equal(keys, single(q16, qsq)) and not ss.overflowed() and ss.host_reads == 2
     finally:
         td.destroy_process_group()
+
+
+def _lockstep(gens):
+    """Drives W `_sharded_score_steps` generators (one per fake rank) in lock step on one device: the stand-in for the collectives."""
+    W = len(gens)
+    reqs = [next(g) for g in gens]
+    out = [None] * W
+    while any(o is None for o in out):
+        kind = reqs[0][0]
+        assert all(k == kind for k, _ in reqs)
+        if kind == "sum":
+            tot = reqs[0][1].clone()
+            for _, t in reqs[1:]:
+                tot += t
+            res = [tot.clone() for _ in range(W)]
+        else:
+            stack = torch.stack([t for _, t in reqs])
+            res = [stack] * W
+        nxt = []
+        for r, g in enumerate(gens):
+            try:
+                nxt.append(g.send(res[r]))
+            except StopIteration as done:
+                out[r] = done.value
+        reqs = nxt
+    return out
+
+
+@pytest.mark.parametrize("W,rows", [(2, 20000), (4, 20000), (8, 9000), (4, 300)])
+def test_fake_world_sharded_fp32_library_reweight_equals_single_library(W, rows):
+    """SURVEY 8(e)'s re-weight step with the fp32 rows sharded as well (engine.Bank(replicate_f32=False)): exact re-score, s*,
+    m_star hand-over, per-shard top-3 + merge, the two re-weighting distances -- W fake ranks in lock step on one device against
+    the single-library `score_patches_from_keys` (features.py:225-290): every output identical, bit for bit, on every rank;
+    duplicates of the winning row in DIFFERENT shards (ties -> lowest global row), and (W = 4, 300 rows) an EMPTY last shard."""
+    B, Q, D = 6, 784, 768
+    g = torch.Generator().manual_seed(100 + W)
+    lib = torch.randn(rows, D, generator=g)
+    lib[rows - 5] = lib[7]                                   # exact duplicates across shards
+    lib[rows // 2 + 3] = lib[7]
+    patch = lib[torch.randint(0, rows, (B * Q,), generator=g)] + 0.4 * torch.randn(B * Q, D, generator=g)
+    patch[5] = lib[7]                                        # a query that IS the duplicated row
+    patch = patch.view(B, Q, D).to(DEV)
+    whole = eng.Bank(lib.to(DEV))
+    q16, _, qsq = ops.normalize_cast(patch.reshape(B * Q, D))
+    keys = ops.l2_min_keys(q16, qsq, whole.bf16, whole.sqnorm, ops.new_keys(B * Q, DEV))
+    want = eng.score_patches_from_keys(patch, keys, whole, (28, 28))
+    banks = [eng.Bank(lib.to(DEV), r, W, replicate_f32=False) for r in range(W)]
+    assert sum(b.f32_rows for b in banks) == rows and all(b.f32_sharded for b in banks)
+    if rows == 300:
+        assert banks[-1].f32_rows == 0                        # 128-row aligned shards: 300 rows leave the fourth rank nothing
+    got = _lockstep([eng._sharded_score_steps(patch, keys, b, (28, 28), 224) for b in banks])
+    for r, res in enumerate(got):
+        for k in ("min_val", "min_idx", "s_idx", "s_star", "top3", "knn_d", "s", "s_map_pre"):
+            assert torch.equal(res[k], want[k]), (r, k)
+    assert int(want["min_idx"].view(-1)[5]) == 7              # the duplicated row: lowest global row wins
+
+
+def test_pipeline_with_sharded_fp32_library_through_rccl_world_of_one():
+    """BatchPredictor on libraries whose fp32 rows are sharded too (the scoring tail then runs eagerly with its four collectives),
+    through RCCL with a world of one: scores and maps equal the replicated-library predictor's, bit for bit."""
+    import importlib.util
+    import os
+    import torch.distributed as td
+    from cmdiad_amd.predictor import BatchPredictor
+    from cmdiad_amd.synth import synth_cloud_fixed_n, synth_rgb
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    group = _world_of_one()
+    try:
+        st = bench.build_state(torch.device("cuda", 0))
+        B = 4
+        rgb = torch.cat([synth_rgb(70 + i) for i in range(B)]).to(DEV)
+        pcs = torch.cat([synth_cloud_fixed_n(70 + i, 24576) for i in range(B)]).to(DEV)
+        ref = BatchPredictor(st["engine"], st["bank_xyz"], st["bank_second"], st["stats"], st["det"], st["seg"], batch=B, n_max=24576)
+        want = ref.predict_batch(rgb, pcs)
+        bx = eng.Bank(st["bank_xyz"].f32, 0, 1, replicate_f32=False)
+        br = eng.Bank(st["bank_second"].f32, 0, 1, replicate_f32=False)
+        sh = BatchPredictor(st["engine"], bx, br, st["stats"], st["det"], st["seg"], batch=B, n_max=24576, group=group)
+        assert sh.stage2_eager
+        for _ in range(3):                                    # both buffer sets
+            got = sh.predict_batch(rgb, pcs)
+            assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+        with pytest.raises(ValueError):
+            BatchPredictor(st["engine"], bx, br, st["stats"], st["det"], st["seg"], batch=B, n_max=24576, group=None)
+    finally:
+        td.destroy_process_group()

@@ -804,3 +804,43 @@ def test_overlapped_class_schedule_keeps_every_class_in_order(monkeypatch):
         for d in (a, b):
             d.pop("seconds"), d.pop("_extractor", None)
         assert a == b
+
+
+_GLOO_DRIVE_WORKER = r"""
+import sys
+sys.path.insert(0, {repo!r})
+import torch
+import torch.distributed as td
+from cmdiad_amd import engine as eng
+td.init_process_group("gloo")
+rank, world = td.get_rank(), td.get_world_size()
+
+
+def steps():
+    # the contract of engine._sharded_score_steps: "sum" -> element-wise sum over the ranks (one owner, zeros elsewhere),
+    # "gather" -> [W, *shape] of every rank's tensor
+    owned = torch.zeros(6)
+    owned[rank::world] = torch.arange(6, dtype=torch.float32)[rank::world] + 1.0      # every element has exactly one owner
+    total = yield ("sum", owned)
+    assert torch.equal(total, torch.arange(6, dtype=torch.float32) + 1.0)
+    mine = torch.tensor([[10 * rank + 3, 10 * rank + 1, 10 * rank + 2]], dtype=torch.int64)   # per-rank top-3 keys of one probe
+    everyone = yield ("gather", mine)
+    assert everyone.shape == (world, 1, 3)
+    merged = everyone.permute(1, 0, 2).reshape(1, -1).sort(1).values[:, :3]
+    assert merged.tolist() == [[1, 2, 3]]
+    return "done"
+
+
+assert eng._drive_collectives(steps(), td.group.WORLD) == "done"
+td.barrier()
+td.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_sharded_reweight_exchange_protocol_world2_gloo(tmp_path):
+    """engine._drive_collectives (what runs engine._sharded_score_steps over RCCL: SURVEY 8(e)'s re-weight step on a library whose
+    fp32 rows are sharded) on a gloo world of two: "sum" is an all_reduce(SUM), "gather" an all-gather into [W, ...]; the generator's
+    return value comes back.  The arithmetic of the steps themselves is checked on the GPU (tests/test_gpu_fakeworld.py)."""
+    outs = _run_gloo(_GLOO_DRIVE_WORKER.format(repo=REPO), tmp_path)
+    assert all("ok" in o for o in outs), outs
