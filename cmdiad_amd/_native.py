@@ -95,6 +95,9 @@ SIGNATURES = {
     "cmdiad_score_final": [P, P, I, I, P, P],
     "cmdiad_coreset_greedy": [P, I, I, I, I, P, P, SZ, P],
     "cmdiad_coreset_greedy_f32": [P, I, I, I, I, P, P, SZ, P],
+    "cmdiad_coreset_prepare": [P, I, I, I, P, SZ, P],
+    "cmdiad_coreset_round": [P, I, I, I, I, P, I, P, P],
+    "cmdiad_coreset_decode": [P, I, I, P, P],
     "cmdiad_sparse_project_f32": [P, SZ, I, P, P, P, I, P, P],
     "cmdiad_normalize_cast": [P, SZ, I, F, F, P, P, P, I, P],
     "cmdiad_im2col_patch8": [P, I, I, P, P],

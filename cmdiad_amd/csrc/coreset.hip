@@ -41,8 +41,9 @@ template <bool EARLY>
 __global__ __launch_bounds__(256) void coreset_round_kernel(const __half* __restrict__ z, const uint4* __restrict__ zT, int n, int n4,
                                                             int d2, __half* __restrict__ min_d,
                                                             const unsigned long long* __restrict__ best_prev,
-                                                            unsigned long long* __restrict__ best_cur, int first_idx)
+                                                            unsigned long long* __restrict__ best_cur, int first_idx, int q_begin, int q_end)
 {
+    // [q_begin, q_end): the groups of four rows this launch scans -- all of them, or one rank's row shard (cmdiad_coreset_round)
     __shared__ unsigned s_piv[512];
     __shared__ unsigned long long s_key[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -51,8 +52,8 @@ __global__ __launch_bounds__(256) void coreset_round_kernel(const __half* __rest
     for (int c = threadIdx.x; c < 512; c += 256) s_piv[c] = c < d2 ? zl[c] : 0u;   // (zero beyond d2: the padded tail of the last chunk)
     __syncthreads();
     unsigned long long best = 0ull;
-    const int q = blockIdx.x * 256 + threadIdx.x;        // this thread's group of four rows
-    if (q < n4) {
+    const int q = q_begin + blockIdx.x * 256 + threadIdx.x;        // this thread's group of four rows
+    if (q < q_end) {
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
         const uint4* src = zT + q;
         __half md[4];
@@ -270,6 +271,58 @@ extern "C" size_t cmdiad_coreset_workspace_bytes(int n, int d, int n_select)
     return up256((size_t)n * d * 2) + up256(n4 * 4 * (size_t)d * 2) + up256(n4 * 4 * 2) + (size_t)(n_select > 0 ? n_select : 1) * 8;
 }
 
+// Row-sharded selection (SURVEY 8e "fit-time sharding"): every rank holds the whole projected library (the pivot row of a round can be
+// any row) but SCANS only its row range; per round one packed-key all_reduce(MAX) of 8 bytes between the ranks (the caller's: RCCL /
+// gloo) turns the per-rank winners into the global one, which is the next round's pivot.  prepare = the first pass of
+// cmdiad_coreset_greedy (fp16 copies, transposed layout, distances to row first_idx); round = one scan of rows [row_lo, row_hi);
+// keys[r] = (fp32 bits of the winning running minimum) << 32 | ~row -- exactly what the single-device loop chains internally, so the
+// picks are identical.  row_lo % 4 == 0.
+extern "C" int cmdiad_coreset_prepare(const float* z32, int n, int d, int first_idx, void* workspace, size_t workspace_bytes,
+                                      cmdiad_stream_t stream)
+{
+    CMDIAD_REQUIRE(z32 && n > 0 && d > 0 && d % 2 == 0 && d <= 1024 && first_idx >= 0 && first_idx < n, CMDIAD_ERR_ARG,
+                   "cmdiad_coreset_prepare: bad args (need d even, d <= 1024)");
+    CMDIAD_REQUIRE(workspace && workspace_bytes >= cmdiad_coreset_workspace_bytes(n, d, 1), CMDIAD_ERR_WORKSPACE,
+                   "cmdiad_coreset_prepare: workspace too small");
+    char* ws = (char*)workspace;
+    const int n4 = (n + 3) / 4;
+    __half* z16 = (__half*)ws;
+    __half* zT = (__half*)(ws + up256((size_t)n * d * 2));
+    __half* min_d = (__half*)((char*)zT + up256((size_t)n4 * 4 * d * 2));
+    hipLaunchKernelGGL(coreset_init_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, z32, n, n4, d, first_idx, z16, zT, min_d);
+    CMDIAD_CHECK_LAUNCH();
+    return CMDIAD_OK;
+}
+
+extern "C" int cmdiad_coreset_round(void* workspace, int n, int d, int row_lo, int row_hi, const unsigned long long* pivot_key,
+                                    int first_idx, unsigned long long* best_out, cmdiad_stream_t stream)
+{
+    CMDIAD_REQUIRE(workspace && best_out && n > 0 && d > 0 && d % 2 == 0 && d <= 1024 && row_lo >= 0 && row_lo <= row_hi && row_hi <= n &&
+                       row_lo % 4 == 0, CMDIAD_ERR_ARG, "cmdiad_coreset_round: bad args (row_lo %% 4 == 0, 0 <= row_lo <= row_hi <= n)");
+    if (row_lo == row_hi) return CMDIAD_OK;     // an empty shard proposes nothing: its key stays 0 and loses the MAX
+    char* ws = (char*)workspace;
+    const int n4 = (n + 3) / 4;
+    __half* z16 = (__half*)ws;
+    __half* zT = (__half*)(ws + up256((size_t)n * d * 2));
+    __half* min_d = (__half*)((char*)zT + up256((size_t)n4 * 4 * d * 2));
+    const int q0 = row_lo / 4, q1 = (row_hi + 3) / 4;
+    // rows of the last group beyond row_hi belong to the next rank (or are padding): the shard boundaries are 4-row aligned except
+    // at n itself, where the kernel's `row < n` test applies
+    CMDIAD_REQUIRE(row_hi % 4 == 0 || row_hi == n, CMDIAD_ERR_ARG, "cmdiad_coreset_round: row_hi must be a multiple of 4 or n");
+    hipLaunchKernelGGL(coreset_round_kernel<true>, dim3((q1 - q0 + 255) / 256), dim3(256), 0, (hipStream_t)stream, z16, (const uint4*)zT, n, n4,
+                       d / 2, min_d, pivot_key, best_out, first_idx, q0, q1);
+    CMDIAD_CHECK_LAUNCH();
+    return CMDIAD_OK;
+}
+
+extern "C" int cmdiad_coreset_decode(const unsigned long long* keys, int n_select, int first_idx, int64_t* idx_out, cmdiad_stream_t stream)
+{
+    CMDIAD_REQUIRE(keys && idx_out && n_select > 0, CMDIAD_ERR_ARG, "cmdiad_coreset_decode: bad args");
+    hipLaunchKernelGGL(coreset_decode_kernel, dim3((n_select + 255) / 256), dim3(256), 0, (hipStream_t)stream, keys, n_select, first_idx, idx_out);
+    CMDIAD_CHECK_LAUNCH();
+    return CMDIAD_OK;
+}
+
 extern "C" size_t cmdiad_coreset_f32_workspace_bytes(int n, int d, int n_select)
 {
     const size_t n4 = ((size_t)n + 3) / 4;
@@ -328,9 +381,9 @@ extern "C" int cmdiad_coreset_greedy(const float* z32, int n, int d, int n_selec
     const bool early = !(ee && ee[0] == '0');
     for (int r = 0; r + 1 < n_select; ++r) {
         if (early) hipLaunchKernelGGL(coreset_round_kernel<true>, dim3(grid), dim3(256), 0, s, z16, (const uint4*)zT, n, n4, d / 2, min_d,
-                                      r == 0 ? nullptr : best + (r - 1), best + r, first_idx);
+                                      r == 0 ? nullptr : best + (r - 1), best + r, first_idx, 0, n4);
         else hipLaunchKernelGGL(coreset_round_kernel<false>, dim3(grid), dim3(256), 0, s, z16, (const uint4*)zT, n, n4, d / 2, min_d,
-                                r == 0 ? nullptr : best + (r - 1), best + r, first_idx);
+                                r == 0 ? nullptr : best + (r - 1), best + r, first_idx, 0, n4);
     }
     hipLaunchKernelGGL(coreset_decode_kernel, dim3((n_select + 255) / 256), dim3(256), 0, s, best, n_select, first_idx,
                        idx_out);

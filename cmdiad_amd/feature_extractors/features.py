@@ -369,4 +369,8 @@ class Features(torch.nn.Module):
             z = z_lib.detach()
         if self.args.dist_method_coreset != "l2":
             raise NotImplementedError("only dist_method_coreset='l2' is implemented")
+        group = getattr(self, "coreset_group", None)
+        if group is not None and coreset_dtype == "FP16":
+            # row-sharded selection (fit-time sharding): every rank of the group must make this call with the same library
+            return coreset.greedy_coreset_sharded(z.to(self.device), n, group).cpu()
         return coreset.greedy_coreset(z.to(self.device), n, coreset_dtype).cpu()

@@ -37,7 +37,7 @@ int cmdiad_abi_version(void); /* 2: cmdiad_reweight_scan's limits and workspace 
                                  3: LayerNorm fold -- cmdiad_gemm_args gained row_scale / ln_xb / ln_part / add2, cmdiad_gemm_qkv gained
                                     row_scale, cmdiad_block_weights the folded weights, cmdiad_transformer_block_fwd its flags;
                                     cmdiad_ln_stats_finalize is new
-                                 4: cmdiad_l2_min_keys_segments, cmdiad_gemm_streamk_*, cmdiad_coreset_greedy_f32, cmdiad_im2col3x3_bf16 are new */
+                                 4: cmdiad_l2_min_keys_segments, cmdiad_gemm_streamk_*, cmdiad_coreset_greedy_f32, cmdiad_coreset_prepare / _round / _decode, cmdiad_im2col3x3_bf16 are new */
 /* 1 when the library is the test-only build that also contains the superseded kernel formulations (A/B references). */
 int cmdiad_has_ab_variants(void);
 
@@ -385,6 +385,15 @@ int cmdiad_coreset_greedy(const float* z32, int n, int d, int n_select, int firs
 /* coreset_dtype 'TF32' (features.py:390-391; main.py:151): the same selection on the UNROUNDED fp32 rows -- allow_tf32 only touches
  * matrix products and the loop has none, so the reference's branch is an fp32 scan: dist = sqrt(sum (z_i - z_last)^2) in fp32, fp32
  * running minimum, first arg-max.  d <= 1024 (any parity). */
+/* Row-sharded selection (fit-time sharding): every rank holds the projected library and scans its own row range; between
+ * rounds the caller all-reduces (MAX) the 8-byte packed winner keys of the ranks.  prepare: the first pass (workspace:
+ * cmdiad_coreset_workspace_bytes(n, d, 1)); round: rows [row_lo, row_hi) (row_lo % 4 == 0; row_hi % 4 == 0 or == n) against the pivot
+ * named by *pivot_key (NULL: row first_idx), winner into *best_out with atomic max (the caller zeroes it first); decode: keys[r] of
+ * rounds 0 .. n_select - 2 -> idx_out[0] = first_idx, idx_out[r + 1] = row of keys[r].  Picks identical to cmdiad_coreset_greedy. */
+int cmdiad_coreset_prepare(const float* z32, int n, int d, int first_idx, void* workspace, size_t workspace_bytes, cmdiad_stream_t stream);
+int cmdiad_coreset_round(void* workspace, int n, int d, int row_lo, int row_hi, const unsigned long long* pivot_key, int first_idx,
+                         unsigned long long* best_out, cmdiad_stream_t stream);
+int cmdiad_coreset_decode(const unsigned long long* keys, int n_select, int first_idx, int64_t* idx_out, cmdiad_stream_t stream);
 size_t cmdiad_coreset_f32_workspace_bytes(int n, int d, int n_select);
 int cmdiad_coreset_greedy_f32(const float* z32, int n, int d, int n_select, int first_idx, int64_t* idx_out, void* workspace,
                               size_t workspace_bytes, cmdiad_stream_t stream);

@@ -285,3 +285,40 @@ def test_pipeline_with_sharded_fp32_library_through_rccl_world_of_one():
             BatchPredictor(st["engine"], bx, br, st["stats"], st["det"], st["seg"], batch=B, n_max=24576, group=None)
     finally:
         td.destroy_process_group()
+
+
+@pytest.mark.parametrize("W", [2, 4, 8])
+def test_fake_world_row_sharded_coreset_selection_equals_single_device(W):
+    """SURVEY 8(e) fit-time sharding: every fake rank scans its 4-row aligned range of the projected library per round and proposes a
+    packed (running minimum, row) key; the MAX over the ranks is the next pivot (cmdiad_coreset_prepare / _round / _decode).  The
+    picks equal cmdiad_coreset_greedy's, pick for pick -- including duplicate rows in different shards (ties -> lowest row)."""
+    from cmdiad_amd import coreset
+    g = torch.Generator().manual_seed(7)
+    n, d, n_sel = 20003, 334, 300
+    z = torch.randn(n, d, generator=g)
+    z[15000] = z[40]
+    z[19999] = z[40]                                        # duplicates across shards
+    z = z.to(DEV)
+    want = coreset.greedy_coreset(z, n_sel).cpu()
+    ranks = [coreset._HipRounds(z) for _ in range(W)]
+    bounds = [coreset.shard_rows(n, r, W) for r in range(W)]
+    assert bounds[0][0] == 0 and bounds[-1][1] == n and all(b[0] % 4 == 0 for b in bounds)
+    keys = torch.zeros((n_sel - 1,), dtype=torch.int64, device=DEV)
+    for r in range(n_sel - 1):
+        mine = torch.zeros((W,), dtype=torch.int64, device=DEV)
+        for w in range(W):
+            ranks[w].round(bounds[w][0], bounds[w][1], keys[r - 1:r] if r else None, mine[w:w + 1])
+        keys[r] = mine.max()                                # the all_reduce(MAX)
+    got = ranks[0].decode(keys, n_sel).cpu()
+    assert torch.equal(got, want)
+
+
+def test_row_sharded_coreset_through_rccl_world_of_one():
+    import torch.distributed as td
+    from cmdiad_amd import coreset
+    group = _world_of_one()
+    try:
+        z = torch.randn(9001, 200, generator=torch.Generator().manual_seed(3)).to(DEV)
+        assert torch.equal(coreset.greedy_coreset_sharded(z, 120, group).cpu(), coreset.greedy_coreset(z, 120).cpu())
+    finally:
+        td.destroy_process_group()

@@ -844,3 +844,64 @@ def test_sharded_reweight_exchange_protocol_world2_gloo(tmp_path):
     return value comes back.  The arithmetic of the steps themselves is checked on the GPU (tests/test_gpu_fakeworld.py)."""
     outs = _run_gloo(_GLOO_DRIVE_WORKER.format(repo=REPO), tmp_path)
     assert all("ok" in o for o in outs), outs
+
+
+_GLOO_CORESET_WORKER = r"""
+import sys
+sys.path.insert(0, {repo!r})
+import torch
+import torch.distributed as td
+from cmdiad_amd import coreset
+td.init_process_group("gloo")
+rank, world = td.get_rank(), td.get_world_size()
+
+
+class TorchRounds:      # stand-in for the HIP kernels behind coreset.greedy_coreset_sharded (same contracts, host tensors):
+    # features.py:372-425 with coreset_dtype 'FP16' -- difference rounded to half, norm accumulated in float, result rounded to half
+    def __init__(self, z):
+        self.n, self.d = z.shape
+        self.z = z.half()
+        self.min_d = torch.linalg.norm(z - z[0:1], dim=1).half()
+
+    def round(self, lo, hi, pivot_key, out_key):
+        last = 0 if pivot_key is None else int(0xFFFFFFFF - (int(pivot_key[0]) & 0xFFFFFFFF))
+        if hi == lo:
+            return
+        dist = torch.linalg.norm((self.z[lo:hi] - self.z[last:last + 1]).float(), dim=1).half()
+        self.min_d[lo:hi] = torch.minimum(dist, self.min_d[lo:hi])
+        m = self.min_d[lo:hi].float()
+        i = int(torch.argmax(m))                                       # first occurrence = lowest row
+        key = (int(m[i].view(torch.int32)) << 32) | (0xFFFFFFFF - (lo + i))
+        out_key[0] = max(int(out_key[0]), key)
+
+    def decode(self, keys, n_select):
+        return torch.tensor([0] + [0xFFFFFFFF - (int(k) & 0xFFFFFFFF) for k in keys[:n_select - 1]])
+
+
+g = torch.Generator().manual_seed(13)
+z = torch.randn(1003, 40, generator=g)
+z[900] = z[5]                                                          # a duplicate in another shard
+got = coreset.greedy_coreset_sharded(z, 60, td.group.WORLD, impl=TorchRounds)
+# the reference's loop in one process (features.py:372-425)
+zh, min_d, last, want = z.half(), torch.linalg.norm(z - z[0:1], dim=1).half(), 0, [0]
+for _ in range(59):
+    min_d = torch.minimum(torch.linalg.norm((zh - zh[last:last + 1]).float(), dim=1).half(), min_d)
+    last = int(torch.argmax(min_d.float()))
+    min_d[last] = 0
+    want.append(last)
+assert got.tolist() == want, (got.tolist()[:10], want[:10])
+lo, hi = coreset.shard_rows(1003, rank, world)
+assert lo % 4 == 0 and (hi % 4 == 0 or hi == 1003)
+td.barrier()
+td.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_row_sharded_coreset_exchange_gloo(tmp_path, world):
+    """coreset.greedy_coreset_sharded on a gloo group (torch stand-in for the scan kernel): per round every rank scans its own
+    4-row aligned range and ONE all_reduce(MAX) of the packed (running minimum, ~row) key picks the pivot -- the selection equals
+    the reference's single loop (features.py:372-425), ties between duplicate rows in different shards included."""
+    outs = _run_gloo(_GLOO_CORESET_WORKER.format(repo=REPO), tmp_path, world=world)
+    assert all("ok" in o for o in outs), outs
