@@ -44,6 +44,11 @@ constexpr unsigned long long kInf = ~0ull;
 // ascending order are those of the oracle bit for bit, whatever the visiting order.
 // ------------------------------------------------------------------------------------------------
 constexpr int kStepPts = 128;     // points per streaming step (two per lane)
+#ifdef CMDIAD_KNN_SCALAR
+constexpr bool kKnnScalar = true;    // timing-only build: one centre per arithmetic instruction (the form before round 4)
+#else
+constexpr bool kKnnScalar = false;
+#endif
 
 __device__ __forceinline__ unsigned long long shfl_u64(unsigned long long v, int src)
 {
@@ -202,10 +207,29 @@ __global__ __launch_bounds__(kWaves * 64) void knn_wave_kernel(const float* __re
             const bool inb = k < n;
             float x = 0.f, y = 0.f, z = 0.f;
             if (inb) { x = p[k * 3 + 0]; y = p[k * 3 + 1]; z = p[k * 3 + 2]; }
+            // two centres per arithmetic instruction (v_pk_add_f32 / v_pk_mul_f32 are IEEE per element: the same single roundings
+            // in the same order as the scalar form, so the keys do not change): 8 packed operations per pair instead of 16
+            float dist[kWaveCentres];
+            if constexpr (kWaveCentres >= 2 && !kKnnScalar) {
+                const f32x2 X = {x, x}, Y = {y, y}, Z = {z, z};
+#pragma unroll
+                for (int pr = 0; pr < kWaveCentres / 2; ++pr) {
+                    const f32x2 dx = X - f32x2{cx[2 * pr], cx[2 * pr + 1]}, dy = Y - f32x2{cy[2 * pr], cy[2 * pr + 1]},
+                                dz = Z - f32x2{cz[2 * pr], cz[2 * pr + 1]};
+                    const f32x2 d2 = (dx * dx + dy * dy) + dz * dz;
+                    dist[2 * pr] = d2[0];
+                    dist[2 * pr + 1] = d2[1];
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < kWaveCentres; ++c) {
+                    const float dx = x - cx[c], dy = y - cy[c], dz = z - cz[c];
+                    dist[c] = (dx * dx + dy * dy) + dz * dz;
+                }
+            }
 #pragma unroll
             for (int c = 0; c < kWaveCentres; ++c) {
-                const float dx = x - cx[c], dy = y - cy[c], dz = z - cz[c];
-                const float d = (dx * dx + dy * dy) + dz * dz;
+                const float d = dist[c];
                 const unsigned long long key = pack_key(d, (unsigned)k);
                 const bool pass = inb && key < tau[c];
                 const unsigned long long m = __ballot(pass);
