@@ -101,9 +101,11 @@ __device__ __forceinline__ void fps_pk_body(const float* __restrict__ p, const i
     for (int h = 0; h < H; ++h)
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
+            // unconditional loads of a clamped index: a load under a lane mask is followed by a full wait, PPT round trips one after
+            // the other in front of the first round; these go out together (slots past the cloud's end are masked by t = -inf)
             const int k = (2 * h + e) * kThreads + tid;
-            float x = 0.f, y = 0.f, z = 0.f;
-            if (k < n) { x = p[k * 3 + 0]; y = p[k * 3 + 1]; z = p[k * 3 + 2]; }
+            const int kk = max(min(k, n - 1), 0);
+            const float x = p[kk * 3 + 0], y = p[kk * 3 + 1], z = p[kk * 3 + 2];
             px[h][e] = x; py[h][e] = y; pz[h][e] = z;
             const float mag = (x * x + y * y) + z * z;
             t[h][e] = (k < n && !(mag <= 1e-3f)) ? 1e10f : -__builtin_inff();

@@ -49,6 +49,11 @@ constexpr bool kKnnScalar = true;    // timing-only build: one centre per arithm
 #else
 constexpr bool kKnnScalar = false;
 #endif
+#ifdef CMDIAD_KNN_BRANCH_PER_CENTRE
+constexpr bool kKnnBranchPerCentre = true;   // timing-only build: no common branch in front of the per-centre ones
+#else
+constexpr bool kKnnBranchPerCentre = false;
+#endif
 
 __device__ __forceinline__ unsigned long long shfl_u64(unsigned long long v, int src)
 {
@@ -166,12 +171,14 @@ __global__ __launch_bounds__(kWaves * 64) void knn_wave_kernel(const float* __re
 
     float cx[kWaveCentres], cy[kWaveCentres], cz[kWaveCentres];
     unsigned long long ta[kWaveCentres], tb[kWaveCentres], tau[kWaveCentres];
+    unsigned tau_hi[kWaveCentres];   // high word of tau (the distance bits of the K-th best), wave-uniform
     int cnt[kWaveCentres];
 #pragma unroll
     for (int c = 0; c < kWaveCentres; ++c) {
         const float* cc = center + ((size_t)b * G + min(g0 + c, G - 1)) * 3;
         cx[c] = cc[0]; cy[c] = cc[1]; cz[c] = cc[2];
         ta[c] = tb[c] = tau[c] = kInf;
+        tau_hi[c] = 0xFFFFFFFFu;
         cnt[c] = 0;
     }
     auto prune = [&](int c) {
@@ -182,8 +189,8 @@ __global__ __launch_bounds__(kWaves * 64) void knn_wave_kernel(const float* __re
         merge128(ta[c], tb[c], ca, cb, lane);
         const unsigned long long kth = K <= 64 ? ta[c] : tb[c];   // element K-1 = (r, lane) = ((K-1) >> 6, (K-1) & 63)
         tau[c] = shfl_u64(kth, (K - 1) & 63);
-        tau[c] = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(tau[c] >> 32)) << 32) |
-                 __builtin_amdgcn_readfirstlane((unsigned)tau[c]);
+        tau_hi[c] = __builtin_amdgcn_readfirstlane((unsigned)(tau[c] >> 32));
+        tau[c] = ((unsigned long long)tau_hi[c] << 32) | __builtin_amdgcn_readfirstlane((unsigned)tau[c]);
         cnt[c] = 0;
     };
 
@@ -196,17 +203,24 @@ __global__ __launch_bounds__(kWaves * 64) void knn_wave_kernel(const float* __re
         while (bb) { const int t = a % bb; a = bb; bb = t; }
         if (a == 1) break;
     }
+    // unconditional loads of a clamped index, both halves of the step issued together (a load under a lane mask is followed by a full
+    // wait of its own; lanes past the cloud's end are excluded by `inb` below)
     int sidx = 0;
     for (int step = 0; step < nsteps; ++step) {
         const int base = sidx * kStepPts;
         sidx += sstride;
-        if (sidx >= nsteps) sidx %= nsteps;
+        if (sidx >= nsteps) { sidx -= nsteps; if (sidx >= nsteps) sidx %= nsteps; }
+        float hx[2], hy[2], hz[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int kk = min(base + h * 64 + lane, n - 1);
+            hx[h] = p[kk * 3 + 0]; hy[h] = p[kk * 3 + 1]; hz[h] = p[kk * 3 + 2];
+        }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int k = base + h * 64 + lane;
             const bool inb = k < n;
-            float x = 0.f, y = 0.f, z = 0.f;
-            if (inb) { x = p[k * 3 + 0]; y = p[k * 3 + 1]; z = p[k * 3 + 2]; }
+            const float x = hx[h], y = hy[h], z = hz[h];
             // two centres per arithmetic instruction (v_pk_add_f32 / v_pk_mul_f32 are IEEE per element: the same single roundings
             // in the same order as the scalar form, so the keys do not change): 8 packed operations per pair instead of 16
             float dist[kWaveCentres];
@@ -227,16 +241,30 @@ __global__ __launch_bounds__(kWaves * 64) void knn_wave_kernel(const float* __re
                     dist[c] = (dx * dx + dy * dy) + dz * dz;
                 }
             }
+            // one wave-uniform branch per 64 points for ALL the wave's centres: once the thresholds have settled almost no point passes
+            // any of them, and the per-centre key assembly + 64-bit compare + ballot + branch was most of the loop.  The filter in front
+            // compares the distance bits alone (d2 >= 0: its bit pattern orders as an unsigned) with the high word of the threshold, which
+            // is wave-uniform -- one 32-bit compare per centre, the lane masks united by scalar ORs; only a step that passes it builds
+            // the keys.  A centre's threshold only moves in its own prune, so the masks taken before the branch stay valid.
+            unsigned long long coarse = 0ull;
+#pragma unroll
+            for (int c = 0; c < kWaveCentres; ++c) coarse |= __ballot(__float_as_uint(dist[c]) <= tau_hi[c]);
+            if (!kKnnBranchPerCentre && (coarse & __ballot(inb)) == 0ull) continue;
+            unsigned long long key[kWaveCentres], m[kWaveCentres], any = 0ull;
 #pragma unroll
             for (int c = 0; c < kWaveCentres; ++c) {
-                const float d = dist[c];
-                const unsigned long long key = pack_key(d, (unsigned)k);
-                const bool pass = inb && key < tau[c];
-                const unsigned long long m = __ballot(pass);
-                if (m) {  // wave-uniform
-                    if (pass) s_cand[wave][c][cnt[c] + __popcll(m & ((1ull << lane) - 1ull))] = key;
-                    cnt[c] += __popcll(m);
-                    if (cnt[c] > 64) prune(c);
+                key[c] = pack_key(dist[c], (unsigned)k);
+                m[c] = __ballot(inb && key[c] < tau[c]);
+                any |= m[c];
+            }
+            if (kKnnBranchPerCentre || any) {  // wave-uniform
+#pragma unroll
+                for (int c = 0; c < kWaveCentres; ++c) {
+                    if (m[c]) {
+                        if ((m[c] >> lane) & 1ull) s_cand[wave][c][cnt[c] + __popcll(m[c] & ((1ull << lane) - 1ull))] = key[c];
+                        cnt[c] += __popcll(m[c]);
+                        if (cnt[c] > 64) prune(c);
+                    }
                 }
             }
         }

@@ -119,16 +119,16 @@ def test_bench_evaluate_mode_through_rccl_world_of_one():
     rank, all_gather_object of the metric dictionaries over the nccl backend -- and the coreset path (f_coreset 0.1)."""
     env = dict(os.environ, CMDIAD_FORCE_DIST="1")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--evaluate", "--classes", "cookie,peach,tire",
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--evaluate", "--classes", "cookie,peach",
                           "--class-scale", "0.02", "--class-test", "10"], capture_output=True, text=True, timeout=1200, env=env, cwd=REPO)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, lines
     d = json.loads(lines[0])
     leg = d["mtfi_classes"]
-    assert d["n_gpus"] == 1 and leg["world"] == 1 and leg["test_images"] == 30 and d["value"] == leg["predict_images_per_s"] > 0
-    assert leg["assignment"] == [["peach", "cookie", "tire"]]          # LPT order on one rank: by decreasing cost, ties by name
-    for cls, n_train in (("cookie", 4), ("peach", 7), ("tire", 4)):
+    assert d["n_gpus"] == 1 and leg["world"] == 1 and leg["test_images"] == 20 and d["value"] == leg["predict_images_per_s"] > 0
+    assert leg["assignment"] == [["peach", "cookie"]]          # LPT order on one rank: by decreasing cost
+    for cls, n_train in (("cookie", 4), ("peach", 7)):
         pc = leg["per_class"][cls]
         assert pc["n_train"] == n_train and pc["n_test"] == 10 and pc["rank"] == 0
         assert pc["library_rows"]["xyz"] == int(0.1 * n_train * 3136) and pc["library_rows"]["fusion"] == int(0.1 * n_train * 3136)

@@ -7,6 +7,8 @@ from tools.microbench import timeit
 pcs = torch.cat([synth_cloud_fixed_n(1000 + i, 24576) for i in range(32)]).cuda()
 xyz, nz, pix2pt, nv = ops.unorganize(pcs, 24576)
 idx, cen = ops.fps(xyz, 1024, nv)
+ms = timeit(lambda: ops.fps(xyz, 1024, nv), iters=10, warm=3)
+print(os.environ.get("CMDIAD_HIP_LIB", "default").split("/")[-1], f"fps B=32 N=24576 G=1024: {ms:.3f} ms", flush=True)
 for rep in range(3):
     ms = timeit(lambda: ops.knn_group(xyz, cen, 128, nv), iters=10, warm=3)
     print(os.environ.get("CMDIAD_HIP_LIB", "default").split("/")[-1], f"knn B=32 N=24576: {ms:.3f} ms", flush=True)
