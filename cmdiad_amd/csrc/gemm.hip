@@ -988,6 +988,8 @@ dim3 grid_for(long M, long N, int y = 1, int panel = 1)
 
 }  // namespace
 
+int gemm_residual_tiles_launch(const cmdiad_gemm_args* a, hipStream_t stream);   // gemm_sk.hip
+
 extern "C" int cmdiad_gemm_bf16(const cmdiad_gemm_args* a, cmdiad_stream_t stream)
 {
     CMDIAD_REQUIRE(a && a->A && a->W, CMDIAD_ERR_ARG, "cmdiad_gemm_bf16: null operand");
@@ -1033,6 +1035,13 @@ extern "C" int cmdiad_gemm_bf16(const cmdiad_gemm_args* a, cmdiad_stream_t strea
         return CMDIAD_OK;
     }
 #endif
+    {
+        // residual products (out_f32 = A.W^T + bias + residual) on the two-group 256 x 256 kernel, one tile per block (gemm_sk.hip)
+        const char* er = getenv("CMDIAD_GEMM_RES_WIDE");
+        const bool legal = a->residual && a->out_f32 && !a->out_bf16 && a->bias && !extras && !ln_out && !a->group_bias && split == 1 &&
+                           a->act == CMDIAD_ACT_NONE && !a->m_count && !a->row_scale && a->N % 256 == 0 && a->K >= 192;
+        if (legal && er && er[0] == '1') return gemm_residual_tiles_launch(a, s);
+    }
     {
         // two-group persistent kernel: whole 256-column tiles, bias, bf16-only output; chosen when every CU gets >= 2 tiles of
         // a wide product.  CMDIAD_GEMM_PP3=1 / 0 forces it on / off wherever it is legal (A/B runs, parity tests; read per call)

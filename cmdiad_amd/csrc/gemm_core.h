@@ -72,6 +72,34 @@ struct GlobalTile {
                                              16, 0, 0);
         }
     }
+    // The K loop's form of the same pieces.  stage() above computes every piece's 64-bit source address and its LDS base with vector
+    // arithmetic (~9 VALU instructions + a v_readfirstlane per piece, 75 per K-step of a 128 x 128 block), in the very phase that
+    // issues the LDS-DMA -- and that issue path, not the L2, is what bounds the 128 x 128 kernel (profiles/r4_notes.md section 12:
+    // no DMA at all 1 110 TFLOP/s, sources L1-hot 860, production 735-760 on the K = 3 072 product).  Here a lane's byte offset
+    // from the tile's first row is computed ONCE per tile (offsets()); the row base, the K offset and the LDS destination stay
+    // scalar, so a piece is an s_mov m0 and one global_load_lds with an SGPR base.
+    template <int ROWS, int WAVES>
+    __device__ __forceinline__ void offsets(unsigned (&voff)[ROWS / WAVES / 8], int row0, int lane, int wave) const
+    {
+        constexpr int PER_WAVE = ROWS / WAVES;
+        const int chunk = (lane & 7) ^ (lane >> 3);   // (r & 7) of stage(): the piece's first row is a multiple of 8
+#pragma unroll
+        for (int j = 0; j < PER_WAVE / 8; ++j) {
+            const int row = min(row0 + wave * PER_WAVE + j * 8 + (lane >> 3), rows - 1);
+            voff[j] = (unsigned)(row - row0) * (unsigned)(ld * 2) + (unsigned)(chunk * 16);   // row0 < rows: never negative
+        }
+    }
+    template <int ROWS, int WAVES>
+    __device__ __forceinline__ void stage_lean(const unsigned (&voff)[ROWS / WAVES / 8], char* tile, int row0, int k0, int wave) const
+    {
+        constexpr int PER_WAVE = ROWS / WAVES;
+        const char* sb = reinterpret_cast<const char*>(base) + ((size_t)row0 * ld + k0) * 2;   // block-uniform
+#pragma unroll
+        for (int j = 0; j < PER_WAVE / 8; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sb + voff[j]),
+                                             (__attribute__((address_space(3))) void*)(tile + (wave * PER_WAVE + j * 8) * (BK * 2)),
+                                             16, 0, 0);
+    }
 };
 
 // One output of the Point-MAE first conv (3 -> 128, BatchNorm folded, ReLU), models/models.py:188-190.  The FMA chain is
@@ -198,7 +226,8 @@ __device__ __forceinline__ void run(const ALoader& A, const WLoader& W, int m0, 
                                     char* lds, Epi&& epi, int kt_begin = 0)
 {
     constexpr int BM = S::BM, ST = S::STAGES, AHEAD = ST - 1;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr bool LEAN = std::is_same<ALoader, GlobalTile>::value && std::is_same<WLoader, GlobalTile>::value;
     // (tried and measured slower on MI355X, profiles/r1_notes.md: spreading the LDS-DMA pieces between MFMA
     //  groups -- 735 -> 650 TFLOP/s on the ViT qkv shape -- and a 3-stage counted-vmcnt pipeline at 256x128)
     constexpr int BN = S::BN;
@@ -211,10 +240,25 @@ __device__ __forceinline__ void run(const ALoader& A, const WLoader& W, int m0, 
 
     const int total = n_tiles * KT;
     int kt_s = 0, nt_s = nt0;  // coordinates of the next K-step to STAGE
+    unsigned va[LEAN ? BM / S::WAVES / 8 : 1], vw[LEAN ? BN / S::WAVES / 8 : 1];   // GlobalTile::offsets of this wave's pieces
+    int vw_tile = nt0;
+    if constexpr (LEAN) {
+        A.template offsets<BM, S::WAVES>(va, m0, lane, wave);
+        W.template offsets<BN, S::WAVES>(vw, nt0 * BN, lane, wave);
+    }
     auto stage_next = [&](int slot) {
         char* buf = lds + slot * S::STAGE_BYTES;
-        A.template stage<BM, S::WAVES>(buf, m0, (kt_begin + kt_s) * BK, tid);
-        W.template stage<BN, S::WAVES>(buf + BM * BK * 2, nt_s * BN, (kt_begin + kt_s) * BK, tid);
+        if constexpr (LEAN) {
+            if (nt_s != vw_tile) {  // block-uniform: the next N tile's rows (clamped at the ragged edge)
+                vw_tile = nt_s;
+                W.template offsets<BN, S::WAVES>(vw, nt_s * BN, lane, wave);
+            }
+            A.template stage_lean<BM, S::WAVES>(va, buf, m0, (kt_begin + kt_s) * BK, wave);
+            W.template stage_lean<BN, S::WAVES>(vw, buf + BM * BK * 2, nt_s * BN, (kt_begin + kt_s) * BK, wave);
+        } else {
+            A.template stage<BM, S::WAVES>(buf, m0, (kt_begin + kt_s) * BK, tid);
+            W.template stage<BN, S::WAVES>(buf + BM * BK * 2, nt_s * BN, (kt_begin + kt_s) * BK, tid);
+        }
         if (++kt_s == KT) { kt_s = 0; ++nt_s; }
     };
     stage_next(0);

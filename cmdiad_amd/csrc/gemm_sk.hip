@@ -354,6 +354,34 @@ constexpr int kSkBlocks = 256;   // one block per CU (MI355X)
 
 }  // namespace
 
+// The same kernel with ONE WHOLE TILE per block (grid = tiles: every block's unit range is exactly one tile, so nothing is parked
+// or taken over and the workspace is never touched).  Stand-alone this loses to the 128 x 128 kernel (294 tiles = a full round of
+// 256 CUs and a round of 38), but per CU-second a 256 x 256 tile is cheaper (half the LDS-DMA pieces per FLOP, the bound of the
+// 128 x 128 kernel: profiles/r4_notes.md section 12) -- and inside the pipeline the CUs its second round leaves idle are not idle:
+// the other streams' kernels take them.  Selected by cmdiad_gemm_bf16 (gemm.hip) for the residual products it is legal for.
+int gemm_residual_tiles_launch(const cmdiad_gemm_args* a, hipStream_t stream)
+{
+    constexpr int kLds = SPP3::LDS_BYTES + 8 * kRowStoreScratch;
+    static std::mutex mu;
+    static bool attr = false;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        if (!attr) {
+            if (hipFuncSetAttribute((const void*)gemm_sk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLds) != hipSuccess) {
+                cmdiad_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d) failed", kLds);
+                return CMDIAD_ERR_LAUNCH;
+            }
+            attr = true;
+        }
+    }
+    GlobalTile A{(const bf16_t*)a->A, a->lda, a->M}, W{(const bf16_t*)a->W, a->ldw, a->N};
+    SkParams p{a->M, a->N, a->K, a->bias, a->residual, a->ldr, a->out_f32, a->ldo32, nullptr, nullptr};
+    const long tiles = ((long)(a->M + 255) / 256) * (a->N / 256);
+    hipLaunchKernelGGL(gemm_sk_kernel, dim3((unsigned)tiles), dim3(512), kLds, stream, A, W, p);
+    CMDIAD_CHECK_LAUNCH();
+    return CMDIAD_OK;
+}
+
 extern "C" size_t cmdiad_gemm_streamk_workspace_bytes(void)
 {
     return (size_t)kSkBlocks * kSkSlotFloats * sizeof(float) + (size_t)kSkBlocks * 2 * sizeof(unsigned);

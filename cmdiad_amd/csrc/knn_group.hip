@@ -245,26 +245,20 @@ __global__ __launch_bounds__(kWaves * 64) void knn_wave_kernel(const float* __re
             // any of them, and the per-centre key assembly + 64-bit compare + ballot + branch was most of the loop.  The filter in front
             // compares the distance bits alone (d2 >= 0: its bit pattern orders as an unsigned) with the high word of the threshold, which
             // is wave-uniform -- one 32-bit compare per centre, the lane masks united by scalar ORs; only a step that passes it builds
-            // the keys.  A centre's threshold only moves in its own prune, so the masks taken before the branch stay valid.
+            // the keys and takes the centres one by one.
             unsigned long long coarse = 0ull;
 #pragma unroll
             for (int c = 0; c < kWaveCentres; ++c) coarse |= __ballot(__float_as_uint(dist[c]) <= tau_hi[c]);
             if (!kKnnBranchPerCentre && (coarse & __ballot(inb)) == 0ull) continue;
-            unsigned long long key[kWaveCentres], m[kWaveCentres], any = 0ull;
 #pragma unroll
             for (int c = 0; c < kWaveCentres; ++c) {
-                key[c] = pack_key(dist[c], (unsigned)k);
-                m[c] = __ballot(inb && key[c] < tau[c]);
-                any |= m[c];
-            }
-            if (kKnnBranchPerCentre || any) {  // wave-uniform
-#pragma unroll
-                for (int c = 0; c < kWaveCentres; ++c) {
-                    if (m[c]) {
-                        if ((m[c] >> lane) & 1ull) s_cand[wave][c][cnt[c] + __popcll(m[c] & ((1ull << lane) - 1ull))] = key[c];
-                        cnt[c] += __popcll(m[c]);
-                        if (cnt[c] > 64) prune(c);
-                    }
+                const unsigned long long key = pack_key(dist[c], (unsigned)k);
+                const bool pass = inb && key < tau[c];
+                const unsigned long long m = __ballot(pass);
+                if (m) {  // wave-uniform
+                    if (pass) s_cand[wave][c][cnt[c] + __popcll(m & ((1ull << lane) - 1ull))] = key;
+                    cnt[c] += __popcll(m);
+                    if (cnt[c] > 64) prune(c);
                 }
             }
         }

@@ -151,6 +151,32 @@ def test_knn_group_bit_exact(frac, G, K, knn_variant):
     np.testing.assert_array_equal(nb.cpu().numpy(), nb_ref)
 
 
+def test_knn_group_production_instantiation_ragged():
+    """The grid the pipeline runs (knn_wave_kernel<4, 4>: four waves per block, four centres per wave, chosen when
+    B * ceil(G / 16) >= 512) on eight ragged clouds, bit for bit against the oracle and identical over repeated launches.  The
+    smaller cases above all select the one-centre-per-wave instantiation: a round-4 form of the per-centre loop (lane masks of
+    all four centres taken before the first centre's work) returned wrong neighbours for the SECOND centre of every wave, on this
+    instantiation only, and no test saw it -- bench.py's step-to-step comparison did."""
+    B, G, K = 8, 1024, 128
+    clouds = [_cloud(20 + i, 0.05 + 0.01 * i)[0] for i in range(B)]
+    N = max(len(c) for c in clouds)
+    xyz = np.zeros((B, N, 3), np.float32)
+    for i, c in enumerate(clouds):
+        xyz[i, :len(c)] = c
+    nv = torch.tensor([len(c) for c in clouds], dtype=torch.int32, device=DEV)
+    cen = np.stack([ok.fps(c[None], G)[1][0] for c in clouds])
+    ref = [ok.knn_group(c[None], cen[i:i + 1], K) for i, c in enumerate(clouds)]
+    x, c = torch.from_numpy(xyz).to(DEV), torch.from_numpy(cen).to(DEV)
+    first = None
+    for rep in range(3):
+        idx, nb = ops.knn_group(x, c, K, n_valid=nv)
+        for i in range(B):
+            np.testing.assert_array_equal(idx[i].cpu().numpy(), ref[i][0][0], err_msg=f"cloud {i}, launch {rep}")
+            np.testing.assert_array_equal(nb[i].cpu().numpy(), ref[i][1][0], err_msg=f"cloud {i}, launch {rep}")
+        first = idx if first is None else first
+        assert torch.equal(idx, first)
+
+
 def test_knn_group_ties_and_ragged(knn_variant):
     a, _ = _cloud(8, 0.08)
     a = np.concatenate([a, a[:300]], 0)  # duplicates: ties at equal d2 resolved by index
