@@ -96,14 +96,20 @@ __global__ __launch_bounds__(256) void interp3nn_kernel(const float* __restrict_
                                                         const float* __restrict__ center, int N, int S,
                                                         int32_t* __restrict__ idx3, float* __restrict__ w3)
 {
+    // centres in LDS as PAIRS, {x0, x1, y0, y1} {z0, z1, |c0|^2, |c1|^2}: the distance arithmetic of two centres per v_pk_*_f32
+    // instruction (IEEE per element: the same single roundings in the same order as the scalar form, so d -- and with it idx3 /
+    // w3 -- does not change), 8 packed operations per pair instead of 16; an odd S is padded with a centre at +inf distance.
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4* s_c = reinterpret_cast<float4*>(smem);
     const int b = blockIdx.y;
     const int n = n_valid ? n_valid[b] : N;
     const float* cb = center + (size_t)b * S * 3;
-    for (int s = threadIdx.x; s < S; s += 256) {
-        const float x = cb[s * 3], y = cb[s * 3 + 1], z = cb[s * 3 + 2];
-        s_c[s] = make_float4(x, y, z, (x * x + y * y) + z * z);
+    const int SP = (S + 1) / 2;
+    for (int s = threadIdx.x; s < 2 * SP; s += 256) {
+        float x = 0.f, y = 0.f, z = 0.f, w = __builtin_inff();
+        if (s < S) { x = cb[s * 3]; y = cb[s * 3 + 1]; z = cb[s * 3 + 2]; w = (x * x + y * y) + z * z; }
+        float* q = reinterpret_cast<float*>(s_c + 2 * (s >> 1)) + (s & 1);
+        q[0] = x; q[2] = y; q[4] = z; q[6] = w;
     }
     __syncthreads();
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -113,20 +119,29 @@ __global__ __launch_bounds__(256) void interp3nn_kernel(const float* __restrict_
     const float n1 = (x * x + y * y) + z * z;
     float d0 = __builtin_inff(), d1 = __builtin_inff(), d2 = __builtin_inff();
     int i0 = 0, i1 = 0, i2 = 0;
-    for (int s = 0; s < S; ++s) {
-        const float4 c = s_c[s];
-        const float dot = (x * c.x + y * c.y) + z * c.z;
-        float d = -2.0f * dot;
-        d = d + n1;
-        d = d + c.w;
-        if (d < d2) {  // s increases, so strict '<' keeps the lowest index among equal distances
-            if (d < d1) {
-                d2 = d1; i2 = i1;
-                if (d < d0) { d1 = d0; i1 = i0; d0 = d; i0 = s; }
-                else { d1 = d; i1 = s; }
-            } else { d2 = d; i2 = s; }
+    // s increases, so strict '<' keeps the lowest index among equal distances; written as selects (the nested-if form of it,
+    // inlined twice per pair, sent i0..i2 to scratch)
+#define CMDIAD_TOP3_INSERT(d, s)                                               \
+    {                                                                          \
+        const bool l0 = (d) < d0, l1 = (d) < d1, l2 = (d) < d2;                \
+        d2 = l1 ? d1 : (l2 ? (d) : d2); i2 = l1 ? i1 : (l2 ? (s) : i2);        \
+        d1 = l0 ? d0 : (l1 ? (d) : d1); i1 = l0 ? i0 : (l1 ? (s) : i1);        \
+        d0 = l0 ? (d) : d0;             i0 = l0 ? (s) : i0;                    \
+    }
+    const f32x2 X = {x, x}, Y = {y, y}, Z = {z, z}, N1 = {n1, n1}, M2 = {-2.0f, -2.0f};
+    for (int sp = 0; sp < SP; ++sp) {
+        const float4 a = s_c[2 * sp], c = s_c[2 * sp + 1];
+        const f32x2 cx = {a.x, a.y}, cy = {a.z, a.w}, cz = {c.x, c.y}, cw = {c.z, c.w};
+        const f32x2 dot = (X * cx + Y * cy) + Z * cz;
+        f32x2 d = M2 * dot;
+        d = d + N1;
+        d = d + cw;
+        if (fminf(d[0], d[1]) < d2) {   // (a padded centre is +inf: never inserted)
+            CMDIAD_TOP3_INSERT(d[0], 2 * sp)
+            CMDIAD_TOP3_INSERT(d[1], 2 * sp + 1)
         }
     }
+#undef CMDIAD_TOP3_INSERT
     const float r0 = 1.0f / (d0 + 1e-8f);
     const float r1 = S > 1 ? 1.0f / (d1 + 1e-8f) : 0.0f;
     const float r2 = S > 2 ? 1.0f / (d2 + 1e-8f) : 0.0f;
@@ -308,8 +323,8 @@ extern "C" int cmdiad_interp3nn(const float* xyz, const int32_t* n_valid, const 
     CMDIAD_REQUIRE(B > 0 && N > 0 && S > 0 && S <= kMaxCentres, CMDIAD_ERR_ARG, "cmdiad_interp3nn: need 0<S<=%d (S=%d)",
                    kMaxCentres, S);
     dim3 grid((N + 255) / 256, B);
-    hipLaunchKernelGGL(interp3nn_kernel, grid, dim3(256), (size_t)S * sizeof(float4), (hipStream_t)stream, xyz, n_valid,
-                       center, N, S, idx3, w3);
+    hipLaunchKernelGGL(interp3nn_kernel, grid, dim3(256), (size_t)((S + 1) / 2) * 2 * sizeof(float4), (hipStream_t)stream, xyz,
+                       n_valid, center, N, S, idx3, w3);
     CMDIAD_CHECK_LAUNCH();
     return CMDIAD_OK;
 }

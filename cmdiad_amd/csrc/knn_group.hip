@@ -161,7 +161,16 @@ __global__ __launch_bounds__(kWaves * 64) void knn_wave_kernel(const float* __re
                                                               const float* __restrict__ center, int N, int G, int K,
                                                               int64_t* __restrict__ idx_out, float* __restrict__ neigh_out)
 {
-    __shared__ unsigned long long s_cand[kWaves][kWaveCentres][128];
+    // candidate list of a centre: a prune takes up to 128 of them (what its sorting network holds), so the list is let to grow to
+    // kTrig before one is run -- kTrig - 1 + the 64 of one more half step entries at most.  (With 128 slots a prune had to run above
+    // 64 entries: late in the stream, where a half step adds a few candidates, every prune then sorted ~65 keys in a 128-key
+    // network, 12 prunes per centre instead of 9; the prunes are two thirds of this kernel.)  Measured, 32 x 24 576 points, same
+    // box: 128 slots 0.795 ms; kTrig 80 / 96 / 112 / 128: 0.705 / 0.668 / 0.638 / 0.639 (the LDS of 128 costs a wave per SIMD).
+#ifndef CMDIAD_KNN_TRIG
+#define CMDIAD_KNN_TRIG 112
+#endif
+    constexpr int kTrig = CMDIAD_KNN_TRIG, kCandCap = kTrig + 64;
+    __shared__ unsigned long long s_cand[kWaves][kWaveCentres][kCandCap];
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g0 = (blockIdx.x * kWaves + wave) * kWaveCentres;
@@ -183,15 +192,24 @@ __global__ __launch_bounds__(kWaves * 64) void knn_wave_kernel(const float* __re
     }
     auto prune = [&](int c) {
         unsigned long long* buf = s_cand[wave][c];
-        unsigned long long ca = lane < cnt[c] ? buf[lane] : kInf;
-        unsigned long long cb = lane + 64 < cnt[c] ? buf[lane + 64] : kInf;
+        const int take = min(cnt[c], 128), rest = cnt[c] - take;   // rest <= 63
+        unsigned long long ca = lane < take ? buf[lane] : kInf;
+        unsigned long long cb = lane + 64 < take ? buf[lane + 64] : kInf;
         sort128(ca, cb, lane);
         merge128(ta[c], tb[c], ca, cb, lane);
         const unsigned long long kth = K <= 64 ? ta[c] : tb[c];   // element K-1 = (r, lane) = ((K-1) >> 6, (K-1) & 63)
         tau[c] = shfl_u64(kth, (K - 1) & 63);
         tau_hi[c] = __builtin_amdgcn_readfirstlane((unsigned)(tau[c] >> 32));
         tau[c] = ((unsigned long long)tau_hi[c] << 32) | __builtin_amdgcn_readfirstlane((unsigned)tau[c]);
+        // the entries beyond the 128 taken move to the front of the list -- those that still beat the new threshold
         cnt[c] = 0;
+        if (rest > 0) {  // wave-uniform
+            const unsigned long long k2 = lane < rest ? buf[128 + lane] : kInf;
+            const bool keep = lane < rest && k2 < tau[c];
+            const unsigned long long mk = __ballot(keep);
+            if (keep) buf[__popcll(mk & ((1ull << lane) - 1ull))] = k2;
+            cnt[c] = __popcll(mk);
+        }
     };
 
     // scattered (coprime-strided) visiting order of the 128-point steps: an organised cloud arrives in raster order, and a
@@ -258,14 +276,14 @@ __global__ __launch_bounds__(kWaves * 64) void knn_wave_kernel(const float* __re
                 if (m) {  // wave-uniform
                     if (pass) s_cand[wave][c][cnt[c] + __popcll(m & ((1ull << lane) - 1ull))] = key;
                     cnt[c] += __popcll(m);
-                    if (cnt[c] > 64) prune(c);
+                    if (cnt[c] >= kTrig) prune(c);
                 }
             }
         }
     }
 #pragma unroll
     for (int c = 0; c < kWaveCentres; ++c) {
-        if (cnt[c] > 0) prune(c);
+        if (cnt[c] > 0) prune(c);   // (fewer than 128 are left: one prune takes them all)
         const int g = g0 + c;
         if (g >= G) continue;
 #pragma unroll

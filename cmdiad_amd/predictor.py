@@ -113,7 +113,10 @@ class BatchPredictor:
         self.use_graph = use_graph
         dev = bank_xyz.f32.device
         self.dev = dev
-        self.side, self.post, self.copy = torch.cuda.Stream(dev), torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+        # CMDIAD_STREAM_PRIO="side,post" (A/B runs): stream priorities of the point-cloud branch and of the search / scoring stage
+        # (0 = default, -1 = high; the ViT branch runs on the caller's stream)
+        prio = [int(v) for v in os.environ.get("CMDIAD_STREAM_PRIO", "0,0").split(",")]
+        self.side, self.post, self.copy = torch.cuda.Stream(dev, priority=prio[0]), torch.cuda.Stream(dev, priority=prio[1]), torch.cuda.Stream(dev)
         # host ring: the step's FINAL outputs (image score, pixel map), f64 as sklearn's score_samples returns them
         self.ring = [(torch.empty((batch, 1), dtype=torch.float64, pin_memory=True),
                       torch.empty((batch, gt_size * gt_size), dtype=torch.float64, pin_memory=True)) for _ in range(ring)]
