@@ -326,6 +326,26 @@ def test_gemm_streamk_matches_128_tile_bit_for_bit():
         assert not ops.gemm_streamk_eligible(M, N, K)                       # too few tiles / N % 256 / two or more tiles per CU
 
 
+def test_gemm_residual_on_wide_tiles_matches_128_tile_bit_for_bit(monkeypatch):
+    """CMDIAD_GEMM_RES_WIDE=1 (a measurement switch, profiles/r4_notes.md section 12): the in-place residual products of
+    cmdiad_gemm_bf16 on the two-group 256 x 256 kernel with one whole tile per block -- identical bits to the 128 x 128 kernel,
+    ragged last M tile included; shapes it is not legal for (N % 256) fall through to the default kernel."""
+    g = torch.Generator().manual_seed(92)
+    for M, N, K in ((32 * 785, 768, 768), (9 * 256 + 17, 512, 1536), (300, 256, 192), (4000, 384, 384)):
+        dA = (torch.randn(M, K, generator=g)).to(DEV).bfloat16()
+        dW = (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV).bfloat16()
+        bias, res = torch.randn(N, generator=g).to(DEV), torch.randn(M, N, generator=g).to(DEV)
+        monkeypatch.setenv("CMDIAD_GEMM_RES_WIDE", "0")
+        want = res.clone()
+        ops.gemm(dA, dW, bias=bias, residual=want, out_f32=want, want_bf16=False)
+        monkeypatch.setenv("CMDIAD_GEMM_RES_WIDE", "1")
+        x = res.clone()
+        ops.gemm(dA, dW, bias=bias, residual=x, out_f32=x, want_bf16=False)
+        assert torch.equal(x, want), (M, N, K, float((x - want).abs().max()))
+        out, _ = ops.gemm(dA, dW, bias=bias, residual=res, want_f32=True, want_bf16=False)   # separate output buffer
+        assert torch.equal(out, want)
+
+
 def test_gemm_identity_asymmetric_layout():
     # A = I against an asymmetric W catches any row/column swap in the accumulator mapping
     K = 128
