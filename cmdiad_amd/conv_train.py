@@ -509,11 +509,44 @@ def hrnet_forward_backward(img, feature, P, batch, need_grad=True):
     return loss, G, stats
 
 
+# The trunk's step is ~500 launches; with its reductions parallelised (round 4) their device time at batch 8 is 9.7 ms, below the
+# ~13 ms the host needs to issue them one by one.  The whole forward + backward is therefore captured ONCE per (shapes, parameter
+# storages) as a HIP graph -- on the third step with that key, after two eager ones -- and replayed: inputs are copied into the
+# graph's static buffers, the loss / gradients / batch statistics are the graph's static outputs (consumed before the next replay:
+# autograd scales the gradients into new tensors, the running statistics are updated at once).  CMDIAD_HRNET_GRAPH=0: always eager.
+_HRNET_GRAPHS = {}
+
+
+def _hrnet_step(img, feature, P, batch, need_grad):
+    if os.environ.get("CMDIAD_HRNET_GRAPH", "1") == "0" or not need_grad:
+        return hrnet_forward_backward(img, feature, P, batch, need_grad)
+    key = (tuple(img.shape), tuple(feature.shape), img.device.index) + tuple(p.data_ptr() for p in P.values())
+    ent = _HRNET_GRAPHS.get(key)
+    if ent is None:
+        if len(_HRNET_GRAPHS) >= 4:      # parameters were re-allocated (a new module / optimizer state load): drop the old captures
+            _HRNET_GRAPHS.clear()
+        ent = _HRNET_GRAPHS[key] = {"seen": 0}
+    if "graph" not in ent:
+        ent["seen"] += 1
+        if ent["seen"] < 3:
+            return hrnet_forward_backward(img, feature, P, batch, need_grad)
+        ent["img"], ent["feature"] = img.clone(), feature.clone()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            ent["out"] = hrnet_forward_backward(ent["img"], ent["feature"], P, batch, need_grad)
+        ent["graph"] = graph
+    ent["img"].copy_(img)
+    ent["feature"].copy_(feature)
+    ent["graph"].replay()
+    loss, G, stats = ent["out"]
+    return loss.clone(), G, stats     # (the loss outlives the step in most training loops; the gradients do not)
+
+
 class _HRNetLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, img, feature, batch, need_grad, module, names, *params):
         P = {n: p.detach() for n, p in zip(names, params)}
-        loss, G, stats = hrnet_forward_backward(img, feature, P, batch, need_grad)
+        loss, G, stats = _hrnet_step(img, feature, P, batch, need_grad)
         M1, M2 = img.shape[0] * ((img.shape[-1] + 1) // 2) ** 2, feature.shape[0] * feature.shape[1]
         mods = dict(module.named_modules())
         with torch.no_grad():   # nn.BatchNorm2d in train(): momentum, UNBIASED variance into the running buffer

@@ -74,15 +74,16 @@ class HRNet(_PackedHead):
 
     def forward(self, img, feature):
         """hrnet.py:290-299."""
-        # hand-written forward + backward (cmdiad_amd/conv_train.py) from batch 16 up: 27.4 ms against 38.6 ms on the torch layers at
-        # batch 32, but 14.4 against 11.9 at batch 8, where its ~500 launches per step are not yet hidden (profiles/r3_notes.md).
-        # CMDIAD_HRNET_TRAIN = auto (default) | hip | torch.
+        # hand-written forward + backward (cmdiad_amd/conv_train.py), replayed as one HIP graph from the third step on: 9.1 / 12.9 /
+        # 21.3 ms at batch 8 / 16 / 32 against 11.9 / 21.0 / 39.9 ms on the module's torch layers (MIOpen / rocBLAS), 7.2 against
+        # 7.5 at batch 4 (profiles/r4_notes.md section 17).  CMDIAD_HRNET_TRAIN = auto (default: the hand-written path from a
+        # first batch of 4 images up) | hip | torch.
         mode = os.environ.get("CMDIAD_HRNET_TRAIN", "auto")
         if mode == "auto" and self._autograd():
             # decided ONCE per module, from the first training batch: a short last batch of an epoch must not switch a run between
             # the bf16 hand-written path and the fp32 torch layers (different numerics inside one training run)
             if getattr(self, "_train_path", None) is None:
-                self._train_path = "hip" if img.shape[0] >= 16 else "torch"
+                self._train_path = "hip" if img.shape[0] >= 4 else "torch"
             mode = self._train_path
         if self._autograd() and mode == "hip":
             from .. import conv_train

@@ -360,8 +360,8 @@ def bn_relu_bwd(dy, z, scale, shift, mean, rstd, chunks=None, masked=True):
     (cmdiad_bn_relu_bwd_reduce -> cmdiad_bn_partials_sum -> cmdiad_bn_relu_bwd_apply)."""
     _chk(dy, torch.float32, "bn_bwd.dy"); _chk(z, torch.float32, "bn_bwd.z")
     M, C = z.shape
-    if chunks is None:   # ~256 rows per workgroup (64 columns x 4 row lanes each), at most 256 row ranges
-        chunks = max(16, min(256, (M + 255) // 256))
+    if chunks is None:   # ~128 rows per workgroup (64 columns x 4 row lanes each), at most 256 row ranges
+        chunks = max(16, min(256, (M + 127) // 128))
     mk = 1 if masked else 0
     p1 = torch.empty((chunks, C), dtype=torch.float32, device=z.device)
     p2 = torch.empty((chunks, C), dtype=torch.float32, device=z.device)
