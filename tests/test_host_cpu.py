@@ -31,6 +31,28 @@ def test_cabi_library_loads_and_exports_every_declared_symbol():
     assert L.cmdiad_fps_workspace_bytes(2, 24576) == 0 and L.cmdiad_fps_workspace_bytes(2, 50176) == 2 * 50176 * 4
 
 
+def test_production_kernels_do_not_spill():
+    """tools/scratch_report.py on the built library (the AMDGPU metadata of every code object in it; nothing is compiled): no kernel
+    of the production library uses scratch, except the two known ones with a dozen bytes outside their loops.  A spill that creeps
+    into a hot kernel -- a lambda that keeps an index array addressable, an epilogue that outgrows the register file -- costs
+    silently: this makes it a test failure (round 4: both happened on the way, profiles/r4_notes.md sections 11 and 13)."""
+    import importlib.util
+    from cmdiad_amd import _native as nat
+    nat.lib()
+    spec = importlib.util.spec_from_file_location("scratch_report", os.path.join(REPO, "tools", "scratch_report.py"))
+    sr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sr)
+    ks = sr.kernels(os.path.join(REPO, "cmdiad_amd", "libcmdiad_hip.so"))
+    assert len(ks) > 150, len(ks)
+    allowed = {"fps_ragged_kernel": 16, "encoder_tail_persist_kernelILb0E": 12}
+    bad = {}
+    for name, v in ks.items():
+        sc = v.get("private_segment_fixed_size", 0)
+        if sc and not any(tag in name and sc <= lim for tag, lim in allowed.items()):
+            bad[name] = sc
+    assert not bad, bad
+
+
 def test_product_has_no_cpu_fallback_and_no_oracle_import():
     from cmdiad_amd import ops
     with pytest.raises(Exception, match="GPU|cuda|CUDA"):
