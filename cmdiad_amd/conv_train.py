@@ -519,7 +519,7 @@ _HRNET_GRAPHS = {}
 
 def _hrnet_step(img, feature, P, batch, need_grad):
     if os.environ.get("CMDIAD_HRNET_GRAPH", "1") == "0" or not need_grad:
-        return hrnet_forward_backward(img, feature, P, batch, need_grad)
+        return hrnet_forward_backward(img, feature, P, batch, need_grad) + (None,)
     key = (tuple(img.shape), tuple(feature.shape), img.device.index) + tuple(p.data_ptr() for p in P.values())
     ent = _HRNET_GRAPHS.get(key)
     if ent is None:
@@ -529,7 +529,7 @@ def _hrnet_step(img, feature, P, batch, need_grad):
     if "graph" not in ent:
         ent["seen"] += 1
         if ent["seen"] < 3:
-            return hrnet_forward_backward(img, feature, P, batch, need_grad)
+            return hrnet_forward_backward(img, feature, P, batch, need_grad) + (None,)
         ent["img"], ent["feature"] = img.clone(), feature.clone()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
@@ -538,15 +538,16 @@ def _hrnet_step(img, feature, P, batch, need_grad):
     ent["img"].copy_(img)
     ent["feature"].copy_(feature)
     ent["graph"].replay()
+    ent["gen"] = ent.get("gen", 0) + 1
     loss, G, stats = ent["out"]
-    return loss.clone(), G, stats     # (the loss outlives the step in most training loops; the gradients do not)
+    return loss.clone(), G, stats, (ent, ent["gen"])     # (the loss outlives the step in most training loops; the gradients do not)
 
 
 class _HRNetLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, img, feature, batch, need_grad, module, names, *params):
         P = {n: p.detach() for n, p in zip(names, params)}
-        loss, G, stats = _hrnet_step(img, feature, P, batch, need_grad)
+        loss, G, stats, ctx.replay = _hrnet_step(img, feature, P, batch, need_grad)
         M1, M2 = img.shape[0] * ((img.shape[-1] + 1) // 2) ** 2, feature.shape[0] * feature.shape[1]
         mods = dict(module.named_modules())
         with torch.no_grad():   # nn.BatchNorm2d in train(): momentum, UNBIASED variance into the running buffer
@@ -566,6 +567,10 @@ class _HRNetLoss(torch.autograd.Function):
     def backward(ctx, g):
         if ctx.grads is None:
             return (None,) * (6 + ctx.n_params)
+        if ctx.replay is not None and ctx.replay[0].get("gen") != ctx.replay[1]:
+            raise RuntimeError("HRNet training step: backward() of a forward whose gradients have been overwritten -- the hand-written "
+                               "step keeps them in its HIP graph's buffers until the NEXT forward of the same shapes; call backward() "
+                               "first, or set CMDIAD_HRNET_GRAPH=0")
         return (None,) * 6 + tuple(None if gr is None else gr * g for gr in ctx.grads)
 
 

@@ -270,3 +270,49 @@ def test_hrnet_trunk_trains_on_the_hip_path(monkeypatch):
     for k, v in res["torch"][2].items():
         if v.dtype.is_floating_point and not k.startswith("layer4."):
             np.testing.assert_allclose(res["hip"][2][k].cpu().numpy(), v.cpu().numpy(), rtol=1e-2, atol=2e-3, err_msg=k)
+
+
+def test_hrnet_step_replayed_as_a_graph_equals_the_eager_step(monkeypatch):
+    """conv_train._hrnet_step: from the third step with the same shapes and parameter storages the trunk's forward + backward is ONE
+    HIP-graph replay.  Five SGD steps on two copies of the module -- graph replay on / off -- give the same losses, parameters and
+    running statistics bit for bit (the graph holds the very launches of the eager step); the loss tensor of an earlier step keeps its
+    value; and a backward() whose gradients a later forward has overwritten raises instead of using them."""
+    from cmdiad_amd.models.hrnet import HRNet
+    from oracle import heads
+    gen = torch.Generator().manual_seed(22)
+    batches = [(torch.randn(2, 3, 224, 224, generator=gen).to(DEV), torch.randn(2, 3136, 768, generator=gen).to(DEV)) for _ in range(5)]
+    monkeypatch.setenv("CMDIAD_HRNET_TRAIN", "hip")
+    out = {}
+    for graph in ("1", "0"):
+        monkeypatch.setenv("CMDIAD_HRNET_GRAPH", graph)
+        conv_train._HRNET_GRAPHS.clear()
+        m = HRNet(512, 768, 0.1)
+        m.load_state_dict(heads.synth_head_state_dict("hrnet", 41))
+        m.to(DEV).train()
+        opt = torch.optim.SGD(m.parameters(), lr=1e-3)
+        losses = []
+        for img, feat in batches:
+            opt.zero_grad()
+            loss = m(img, feat)
+            loss.backward()
+            opt.step()
+            losses.append(loss)                      # kept as tensors: a replay must not change an earlier step's loss
+        if graph == "1":
+            assert any("graph" in e for e in conv_train._HRNET_GRAPHS.values())        # steps 3-5 were replays
+        out[graph] = ([float(l.detach()) for l in losses], {k: v.detach().clone() for k, v in m.state_dict().items()})
+    assert out["1"][0] == out["0"][0], (out["1"][0], out["0"][0])
+    assert len(set(out["1"][0])) == 5
+    for k, v in out["0"][1].items():
+        assert torch.equal(out["1"][1][k], v), k
+    # two forwards, then the first one's backward: its gradients are gone
+    monkeypatch.setenv("CMDIAD_HRNET_GRAPH", "1")
+    conv_train._HRNET_GRAPHS.clear()
+    m = HRNet(512, 768, 0.1)
+    m.load_state_dict(heads.synth_head_state_dict("hrnet", 41))
+    m.to(DEV).train()
+    for img, feat in batches[:3]:
+        m(img, feat).backward()
+    first = m(*batches[3])
+    m(*batches[4])
+    with pytest.raises(RuntimeError, match="overwritten"):
+        first.backward()
