@@ -74,22 +74,18 @@ class HRNet(_PackedHead):
 
     def forward(self, img, feature):
         """hrnet.py:290-299."""
-        # hand-written forward + backward (cmdiad_amd/conv_train.py), replayed as one HIP graph from the third step on: 9.1 / 12.9 /
-        # 21.3 ms at batch 8 / 16 / 32 against 11.9 / 21.0 / 39.9 ms on the module's torch layers (MIOpen / rocBLAS), 7.2 against
-        # 7.5 at batch 4 (profiles/r4_notes.md section 17).  CMDIAD_HRNET_TRAIN = auto (default: the hand-written path from a
-        # first batch of 4 images up) | hip | torch.
+        # hand-written forward + backward (cmdiad_amd/conv_train.py), replayed as one HIP graph from the third step on: 5.6 / 6.2 /
+        # 7.2 / 9.1 / 12.9 / 21.3 ms at batch 1 / 2 / 4 / 8 / 16 / 32 against 7.7 / 7.9 / 7.5 / 11.9 / 21.0 / 39.9 ms on the module's
+        # torch layers (MIOpen / rocBLAS; profiles/r4_notes.md section 17).  CMDIAD_HRNET_TRAIN = auto (default: the hand-written
+        # path) | hip | torch (the module's own layers, kept for A/B runs).
         mode = os.environ.get("CMDIAD_HRNET_TRAIN", "auto")
-        if mode == "auto" and self._autograd():
-            # decided ONCE per module, from the first training batch: a short last batch of an epoch must not switch a run between
-            # the bf16 hand-written path and the fp32 torch layers (different numerics inside one training run)
-            if getattr(self, "_train_path", None) is None:
-                self._train_path = "hip" if img.shape[0] >= 4 else "torch"
-            mode = self._train_path
+        if mode == "auto":
+            mode = "hip"
         if self._autograd() and mode == "hip":
             from .. import conv_train
             assert tuple(img.shape[1:]) == (3, 224, 224) and tuple(feature.shape[1:]) == (3136, self.final_layer.out_channels)
             return conv_train.hrnet_loss(self, img, feature)
-        if self._autograd():   # small batches (or CMDIAD_HRNET_TRAIN=torch): the module's own torch layers (MIOpen / rocBLAS, autograd)
+        if self._autograd():   # CMDIAD_HRNET_TRAIN=torch: the module's own torch layers (MIOpen / rocBLAS, autograd)
             dev = self._device()
             x = torch.relu(self.bn1(self.conv1(img.to(dev).float())))
             x = torch.relu(self.bn2(self.conv2(x)))

@@ -247,7 +247,7 @@ def test_hrnet_trunk_trains_on_the_hip_path(monkeypatch):
     img, feat = torch.randn(2, 3, 224, 224, generator=gen), torch.randn(2, 3136, 768, generator=gen)
     res = {}
     for mode in ("hip", "torch"):
-        monkeypatch.setenv("CMDIAD_HRNET_TRAIN", mode)      # (auto would pick the torch layers at this batch size, see hrnet.py)
+        monkeypatch.setenv("CMDIAD_HRNET_TRAIN", mode)      # (auto = hip, see hrnet.py)
         m = HRNet(512, 768, 0.1)
         m.load_state_dict(heads.synth_head_state_dict("hrnet", 41))
         m.to(DEV).train()

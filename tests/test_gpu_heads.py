@@ -131,7 +131,7 @@ def test_head_training_follows_the_reference_loss_curve(kind, golden, monkeypatc
     feature-to-input heads run their hand-written forward + backward (cmdiad_amd/conv_train.py: bf16 GEMM operands, fp32
     accumulation); the HRNet trunk runs the module's torch layers at this batch size and the hand-written path as "hrnet_hip"."""
     from cmdiad_amd.models.hrnet import HRNet
-    if kind == "hrnet_hip":   # the same golden through the hand-written path of the HRNet trunk (its default from batch 4 up; the third step is the HIP-graph capture + replay)
+    if kind == "hrnet_hip":   # the same golden through the hand-written path of the HRNet trunk (its default; the third step is the HIP-graph capture + replay)
         monkeypatch.setenv("CMDIAD_HRNET_TRAIN", "hip")
         kind = "hrnet"
     g12 = golden("g12_heads_train.npz")
