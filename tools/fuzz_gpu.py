@@ -253,11 +253,37 @@ def case_dedup(rs):
         assert n == 1 if not second else n <= 4
 
 
+def case_knn_production_grid(rs):
+    """kNN grouping on a grid that selects the four-centres-per-wave instantiation (B * ceil(G / 16) >= 512), ragged clouds, and the
+    3-nearest-centre interpolation weights on the same clouds."""
+    B = int(rs.randint(4, 9))
+    G = int(-(-512 // B) * 16 + rs.randint(0, 40))
+    ns = [int(rs.randint(G + 200, 3500)) for _ in range(B)]
+    N = max(ns)
+    xyz = np.zeros((B, N, 3), np.float32)
+    for b, n in enumerate(ns):
+        xyz[b, :n] = cloud(rs, n)
+    K = int(rs.choice([16, 64, 100, 128]))
+    nv = torch.tensor(ns, dtype=torch.int32, device=DEV)
+    x = torch.from_numpy(xyz).to(DEV)
+    idx, cen = ops.fps(x, G, n_valid=nv)
+    gi, nb = ops.knn_group(x, cen, K, n_valid=nv)
+    i3, w3 = ops.interp3nn(x, cen, nv)
+    for b in rs.choice(B, 2, replace=False):
+        n = ns[b]
+        c = cen[b:b + 1].cpu().numpy()
+        ir, nr = ok.knn_group(xyz[b:b + 1, :n], c, K)
+        assert np.array_equal(gi[b].cpu().numpy(), ir[0]), ("knn production grid", ns, G, K)
+        assert np.array_equal(nb[b].cpu().numpy(), nr[0]), ("knn production grid neighbourhoods", ns, G, K)
+        _, i3r, w3r = ok.interp3nn(xyz[b, :n], c[0], np.zeros((G, 4), np.float32), want_out=False)
+        assert np.array_equal(i3[b, :n].cpu().numpy(), i3r) and np.array_equal(w3[b, :n].cpu().numpy(), w3r), ("interp3nn", ns, G)
+
+
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     rs = np.random.RandomState(seed)
-    cases = [case_fps_knn, case_gemm, case_l2, case_attention, case_blur, case_fps_big, case_l2_big, case_encoder, case_ocsvm, case_dedup, case_unorganize]
+    cases = [case_fps_knn, case_gemm, case_l2, case_attention, case_blur, case_fps_big, case_l2_big, case_encoder, case_ocsvm, case_dedup, case_unorganize, case_knn_production_grid]
     counts = {c.__name__: 0 for c in cases}
     t0 = time.time()
     while time.time() - t0 < budget:
