@@ -91,34 +91,155 @@ def launch(n, argv):
     return res.returncode if res.returncode else (0 if js else 1)
 
 
+class LegRunner:
+    """Secondary legs of the JSON line, fault-isolated: whatever happens in one of them -- an exception on this rank, an exception
+    on ANOTHER rank that leaves this one inside a collective, a collective that never completes -- the headline fields the timed
+    loop has already earned are printed, the leg carries {"error": ...} and the job ends with exit code 0.
+
+    * An exception is caught, recorded in the leg and announced to the other ranks through the process group's key-value store (no
+      collective: the ranks are no longer in step); collective legs that have not started yet are skipped everywhere.
+    * A wall-clock budget per leg, kept by a watchdog thread on every rank: when it runs out, rank 0 prints the line as it stands
+      (the running leg marked as timed out) and every rank leaves with os._exit(0) -- a process that has touched the GPU exits, it
+      never re-executes anything.  (torch's own NCCL watchdog would abort the whole process group with SIGABRT instead: its
+      timeout is set beyond the budgets here, init_process_group(timeout=...).)"""
+
+    def __init__(self, out, rank, store=None, emit=None):
+        import threading
+        self.out, self.rank, self.store, self.emit = out, rank, store, emit
+        self.lock = threading.Lock()
+        self.current = None          # (name, deadline, budget)
+        self.failed_here = False
+        self._thread = threading.Thread(target=self._watch, daemon=True)
+        self._thread.start()
+
+    def _watch(self):
+        while True:
+            time.sleep(0.25)
+            with self.lock:
+                cur = self.current
+                if cur is None or time.monotonic() < cur[1]:
+                    continue
+                if self.rank == 0 and self.out is not None:
+                    self.out[cur[0]] = {"error": f"leg exceeded its wall-clock budget of {cur[2]:.0f} s (a rank failed or a collective hung); "
+                                                 "the legs after it were not run"}
+                    self.emit(self.out)
+            self._announce()
+            os._exit(0)
+
+    def _announce(self):
+        try:
+            if self.store is not None:
+                self.store.add("cmdiad_bench_leg_failed", 1)
+        except Exception:
+            pass
+
+    def others_failed(self):
+        try:
+            return self.store is not None and self.store.add("cmdiad_bench_leg_failed", 0) > 0
+        except Exception:
+            return True
+
+    @property
+    def in_step(self):
+        """False once any rank has failed a leg: the ranks may be at different points, no further collective is safe."""
+        return not self.failed_here and not self.others_failed()
+
+    def run(self, name, fn, budget_s, collective=False):
+        if collective and not self.in_step:
+            res = {"skipped": "an earlier leg failed on some rank: the ranks are no longer in step, collective legs are skipped"}
+        else:
+            with self.lock:
+                self.current = (name, time.monotonic() + budget_s, budget_s)
+            try:
+                res = fn()
+            except Exception as e:          # noqa: BLE001 -- a secondary leg must never cost the headline
+                import traceback
+                traceback.print_exc(file=sys.stderr)
+                res = {"error": f"{type(e).__name__}: {e}"[:600]}
+                self.failed_here = True
+                self._announce()
+            finally:
+                with self.lock:
+                    self.current = None
+        if self.out is not None and res is not None:
+            with self.lock:
+                self.out[name] = res
+        return res
+
+
+def emit_line(out):
+    """THE one JSON line.  RCCL writes its version banner to C stdout, which is flushed at exit -- i.e. AFTER a Python print: push it
+    out first so that the JSON line is the last line of stdout."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    print(json.dumps(out), flush=True)
+
+
 def selftest_launch():
     """CPU self-test of the launch path (tests/test_host_cpu.py): every rank joins a gloo group and runs the row-sharded merge
-    (engine.gather_queries + engine.merge_shard_keys) on host tensors; no GPU call anywhere."""
+    (engine.gather_queries + engine.merge_shard_keys) on host tensors; no GPU call anywhere.  The merge and two more collective
+    steps run as LegRunner legs, with CMDIAD_BENCH_INJECT="<leg>:<rank>:<raise|hang>" injecting a failure: rank 0 must still print
+    one JSON line with the headline fields intact."""
+    import datetime
     import torch
     import torch.distributed as td
     from cmdiad_amd import engine as eng
-    td.init_process_group("gloo")
+    td.init_process_group("gloo", timeout=datetime.timedelta(seconds=120))
     rank, world = td.get_rank(), td.get_world_size()
-    g = torch.Generator().manual_seed(5)
-    Q, Nb = 64, 1000
-    d2 = torch.rand(Q, Nb, generator=g)                        # the same on every rank
-    lo, hi = eng.shard_range(Nb, rank, world)
-    keys = torch.full((Q,), eng.KEY_EMPTY, dtype=torch.int64)
-    if hi > lo:
-        v, i = d2[:, lo:hi].min(1)
-        keys = (v.view(torch.int32).to(torch.int64) << 32) | (i + lo)
-    q16 = torch.full((4, 8), float(rank), dtype=torch.float16)
-    q_all, s_all = eng.gather_queries(q16, torch.full((4,), float(rank)), td.group.WORLD)
-    keys = eng.merge_shard_keys(keys, td.group.WORLD)
-    ok = bool(torch.equal(keys & 0xFFFFFFFF, d2.argmin(1))) and q_all.shape[0] == 4 * world \
-        and bool(torch.equal(s_all, torch.arange(world, dtype=torch.float32).repeat_interleave(4)))
-    flag = torch.tensor([1 if ok else 0])
-    td.all_reduce(flag, op=td.ReduceOp.MIN)
-    td.barrier()
-    td.destroy_process_group()
+    inject = (os.environ.get("CMDIAD_BENCH_INJECT") or "::").split(":")
+    budget = float(os.environ.get("CMDIAD_BENCH_LEG_BUDGET", "20"))
+    out = {"selftest_launch": True, "ranks": world, "metric": "selftest", "value": 1.0} if rank == 0 else None
+    legs = LegRunner(out, rank, td.distributed_c10d._get_default_store(), emit_line)
+
+    def maybe_fail(name):
+        if inject[0] == name and int(inject[1]) == rank:
+            if inject[2] == "raise":
+                raise RuntimeError(f"injected failure in {name} on rank {rank}")
+            time.sleep(3600)
+
+    def merge():
+        maybe_fail("merge")
+        g = torch.Generator().manual_seed(5)
+        Q, Nb = 64, 1000
+        d2 = torch.rand(Q, Nb, generator=g)                        # the same on every rank
+        lo, hi = eng.shard_range(Nb, rank, world)
+        keys = torch.full((Q,), eng.KEY_EMPTY, dtype=torch.int64)
+        if hi > lo:
+            v, i = d2[:, lo:hi].min(1)
+            keys = (v.view(torch.int32).to(torch.int64) << 32) | (i + lo)
+        q16 = torch.full((4, 8), float(rank), dtype=torch.float16)
+        q_all, s_all = eng.gather_queries(q16, torch.full((4,), float(rank)), td.group.WORLD)
+        keys = eng.merge_shard_keys(keys, td.group.WORLD)
+        ok = bool(torch.equal(keys & 0xFFFFFFFF, d2.argmin(1))) and q_all.shape[0] == 4 * world \
+            and bool(torch.equal(s_all, torch.arange(world, dtype=torch.float32).repeat_interleave(4)))
+        flag = torch.tensor([1 if ok else 0])
+        td.all_reduce(flag, op=td.ReduceOp.MIN)
+        return {"merge_ok": bool(flag.item())}
+
+    def count(name):
+        def fn():
+            maybe_fail(name)
+            t = torch.ones(1)
+            td.all_reduce(t)
+            return {"ranks_counted": int(t.item())}
+        return fn
+
+    res = legs.run("merge", merge, budget, collective=True)
+    legs.run("second", count("second"), budget, collective=True)
+    legs.run("third", count("third"), budget, collective=True)
+    if legs.in_step:
+        td.barrier()
+        td.destroy_process_group()
     if rank == 0:
-        print(json.dumps({"selftest_launch": True, "ranks": world, "merge_ok": bool(flag.item())}), flush=True)
-    return 0 if flag.item() else 1
+        out["merge_ok"] = bool(res.get("merge_ok", False))
+        emit_line(out)
+        sys.stdout.flush()
+    if not legs.in_step:
+        os._exit(0)          # the other ranks may sit in a collective that will never complete: no orderly teardown
+    return 0 if res.get("merge_ok") else 1
 
 
 # --------------------------------------------------------------------------------------------------------- state
@@ -665,6 +786,63 @@ def var_n_leg(st, dev, steps=16, warm=8):
                 xyz_search_ms=round(l2_ms, 3), xyz_search_TFLOPs=round(2.0 * live * rows * 768 / (l2_ms * 1e-3) / 1e12, 1))
 
 
+def mtfi_step_leg(st, dev, steps=12, warm=4):
+    """The metric's "distill" term, driver-timed: the per-GPU step of configs[4] -- MTFI feature-to-feature predict with main
+    modality xyz (RGBorXYZWithOneHallucination.predict, multiple_features.py:474-573) at batch 32 in steady state: Point-MAE
+    extraction -> xyz patches -> hallucinated rgb features (the distillation network's xyz -> rgb direction,
+    hallucination_network.py:34-45) -> two library searches (xyz and hallucinated-feature library, 76 518 x 768 each) -> scoring
+    tail.  Same engine, xyz library and inputs as the headline (`python bench.py --workload mtfi` times this step as `value`);
+    outputs compared step to step.  The hallucination MLP is then timed alone on the live rows of the last step."""
+    import torch
+    from cmdiad_amd import engine as eng
+    from cmdiad_amd import runtime
+    from cmdiad_amd.models.hallucination_network import HallucinationCrossModalityNetwork
+    from cmdiad_amd.predictor import BatchPredictor, EventTimer
+    from cmdiad_amd.synth import synth_bank
+    torch.manual_seed(0)
+    bank_second = eng.Bank(synth_bank(XYZ_ROWS, 768, 4323).to(dev))
+    halluc = runtime.PackedHallucination(HallucinationCrossModalityNetwork(None, 768, 768).state_dict(), device=dev)
+    timers = {"xyz": EventTimer(), "rgb": EventTimer()}
+    pred = BatchPredictor(st["engine"], st["bank_xyz"], bank_second, st["stats"], st["det"], st["seg"], batch=BATCH, n_max=N_POINTS,
+                          workload="mtfi", halluc=halluc, group=None, use_graph=os.environ.get("CMDIAD_GRAPH", "1") != "0", timers=timers)
+    batches = [(None, p.to(dev)) for _, p in make_batches(0, "mtfi")]
+    first = run_steps(pred, batches, warm)
+    for t in timers.values():
+        t.pairs.clear()
+    torch.cuda.synchronize()
+    pred.live_rows.zero_()
+    pred.xyz_searches = 0
+    t0 = time.perf_counter()
+    run_steps(pred, batches, steps, first)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    live = float(pred.live_rows.item()) / max(pred.xyz_searches, 1)
+    assert len({first[j][0].tobytes() for j in first}) == len(first), "the rotated batches must give distinct outputs"
+    # the hallucination MLP alone: LN + 768 -> 1920 -> 1920 -> 768 (GELU after each) on the rows the step ran it on
+    rows = int(round(live))
+    x = torch.randn(rows, 768, device=dev)
+    ev = EventTimer()
+    for _ in range(6):
+        with ev:
+            halluc.generate(x, "xyz")
+    torch.cuda.synchronize()
+    h_ms = ev.mean_ms(skip=1)
+    h_flops = 2.0 * rows * (768 * 1920 + 1920 * 1920 + 1920 * 768)
+    lib = st["bank_xyz"].shard_rows
+    return dict(what="configs[4] per-GPU step: MTFI FtoF predict, main modality xyz (Point-MAE extraction + hallucinated rgb features + "
+                     "kNN score against the xyz and the hallucinated-feature libraries, 76518 x 768 each), batch 32, steady state, "
+                     "inputs resident in HBM, outputs compared step to step",
+                value=round(BATCH / dt, 2), unit="images/s per GPU", ms_per_step=round(dt * 1e3, 3), steps=steps, warmup=warm,
+                query_rows=dict(per_step_per_library=BATCH * 3136, searched_per_step_per_library=round(live, 1), libraries=2,
+                                note="both searches share the xyz patches' row plan: a patch without a foreground pixel is one repeated "
+                                     "row in the xyz features AND in the features hallucinated from them"),
+                search_ms_in_pipeline=dict(xyz=round(timers["xyz"].mean_ms(), 3), hallucinated=round(timers["rgb"].mean_ms(), 3)),
+                search_TFLOPs_in_pipeline=round(2.0 * 2.0 * live * lib * 768 / ((timers["xyz"].mean_ms() + timers["rgb"].mean_ms()) * 1e-3) / 1e12, 1),
+                hallucination_mlp=dict(rows=rows, ms_alone=round(h_ms, 3), GFLOP=round(h_flops / 1e9, 1),
+                                       TFLOPs=round(h_flops / (h_ms * 1e-3) / 1e12, 1),
+                                       frac_of_mfma_peak=round(h_flops / (h_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)))
+
+
 def mtfi_classes(dev, group, rank, world, classes="all", scale=0.05, n_test=20, f_coreset=0.1):
     """configs[4] as a config: the reference's class loop (main.py:22-37 -> cmdiad_runner.CMDIAD.fit / evaluate) for the MTFI
     feature-to-feature method (RGBorXYZWithOneHallucination, main modality xyz) over synthetic stand-ins of the ten MVTec
@@ -772,11 +950,18 @@ def main():
         saved_fd = os.dup(1)
         os.dup2(2, 1)
         try:
-            td.init_process_group("nccl", device_id=dev)
+            import datetime
+            # beyond every leg budget of LegRunner: its watchdog ends a hung leg with the line printed; torch's would SIGABRT the job
+            td.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(minutes=45))
             group = td.group.WORLD
-            warm = torch.zeros(1, device=dev)
+            warm = torch.ones(1, device=dev)
             td.all_reduce(warm, group=group)
             torch.cuda.synchronize()
+            rccl_ranks_seen = int(warm.item())             # what RCCL itself summed over: one per rank that joined
+            census = [None] * td.get_world_size()
+            td.all_gather_object(census, dict(rank=rank, local_rank=local, device=torch.cuda.get_device_name(local),
+                                              pci_bus_id=getattr(torch.cuda.get_device_properties(local), "pci_bus_id", None),
+                                              host=socket.gethostname(), pid=os.getpid()))
         finally:
             sys.stdout.flush()
             import ctypes
@@ -799,12 +984,7 @@ def main():
                                "value_is": "test images / slowest rank's predict seconds; job_images_per_s divides by the whole "
                                            "fit + predict + metrics wall time", "class_scale": args.class_scale},
                     "mtfi_classes": leg}
-            try:
-                import ctypes
-                ctypes.CDLL(None).fflush(None)
-            except Exception:
-                pass
-            print(json.dumps(line), flush=True)
+            emit_line(line)
         return
 
     st = build_state(dev, args.workload)
@@ -842,49 +1022,7 @@ def main():
     distinct = len({first[j][0].tobytes() for j in first})
     assert distinct == len(first), "the rotated batches must give distinct outputs"
 
-    extras = {}
-    if not args.no_extras:
-        # PCIe-inclusive rate: the same batches from pinned host memory, H2D on the predictor's copy stream inside the loop
-        n_h2d = max(8, min(args.steps, 12))
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        run_steps(pred, host_batches, n_h2d, first)   # also checks H2D-fed outputs == resident-fed outputs
-        torch.cuda.synchronize()
-        h2d_dt = time.perf_counter() - t1
-        mb = sum(t.numel() * 4 for t in host_batches[0] if t is not None) / 1e6
-        extras["h2d_inclusive"] = dict(value=round(BATCH * n_h2d / h2d_dt, 2), unit="images/s per GPU", steps=n_h2d,
-                                       h2d_MB_per_step=round(mb, 1), note="inputs in pinned host memory, copied inside the loop; "
-                                       "outputs identical to the resident run")
-        if group is None and pred.dedup:
-            # the same steps with EVERY row of the patch grid searched, as the reference's cdist does (no row de-duplication):
-            # outputs are checked bit for bit against the de-duplicated run's (run_steps compares with `first`)
-            os.environ["CMDIAD_DEDUP"] = "0"
-            pred_all = BatchPredictor(st["engine"], st["bank_xyz"], st["bank_second"], st["stats"], st["det"], st["seg"], batch=BATCH,
-                                      n_max=N_POINTS, workload=args.workload, halluc=st["halluc"], group=None,
-                                      use_graph=pred.use_graph)
-            del os.environ["CMDIAD_DEDUP"]
-            run_steps(pred_all, batches, 3, first)
-            torch.cuda.synchronize()
-            t2 = time.perf_counter()
-            run_steps(pred_all, batches, n_h2d, first)
-            torch.cuda.synchronize()
-            all_dt = time.perf_counter() - t2
-            extras["every_row_searched"] = dict(value=round(BATCH * n_h2d / all_dt, 2), unit="images/s per GPU", steps=n_h2d,
-                                                ms_per_step=round(all_dt / n_h2d * 1e3, 3),
-                                                note="CMDIAD_DEDUP=0: all 100352 query rows per step go through the distance GEMM; "
-                                                     "outputs bit-identical to the default run")
-            del pred_all
-        if group is not None:
-            names = list(CLASS_TRAIN) if args.classes == "all" else [c for c in args.classes.split(",") if c]
-            extras["sharded_search"] = sharded_search(dev, group, rank, world, [(c, class_rows(c)) for c in names])
-        if group is None:
-            extras["fake_world"] = fake_world_leg(dev)
-            extras["var_n"] = var_n_leg(st, dev)
-            extras["train_step"] = train_step_leg(dev)
-            extras["conv_head_train_step"] = conv_head_train_leg(dev)
-        # configs[4] as a config (bounded): the class loop with the classes dealt to the ranks, metrics gathered at the end
-        extras["mtfi_classes"] = mtfi_classes(dev, group, rank, world, "all", args.class_scale, args.class_test)
-
+    # ---- the headline is complete here: everything below is a secondary leg and runs under LegRunner (fault-isolated, budgeted)
     out = None
     if rank == 0:
         images = BATCH * world * args.steps
@@ -896,13 +1034,15 @@ def main():
         # searched once, csrc/dedup.hip; CMDIAD_DEDUP=0 searches all q_total rows as the reference's cdist does)
         flops = 2.0 * q_live * rows * 768
         achieved = flops / (l2_ms * 1e-3) / 1e12
+        achieved_pipe = flops / (l2_pipe_ms * 1e-3) / 1e12 if l2_pipe_ms else None
         bytes_alg = (rows + q_live) * 768 * 2 + 12 * q_live
         out = {
             "metric": "images/sec end-to-end (extract+distill+kNN score)", "value": round(images / dt, 2), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": ("configs[1]: DINO ViT-B/8 + Point-MAE predict (DoubleRGBPointFeatures: both modalities are "
-                                    "extracted, this method has no distillation step at test time), 224x224 RGB + "
+                                    "extracted, this method has no distillation step at test time; the `mtfi_step` leg times the "
+                                    "method that has one), 224x224 RGB + "
                                     "24576-point clouds (1024 groups x 128), batch 32/GPU, bagel-sized banks "
                                     "(xyz 76518x768, rgb 19129x768)") if args.workload == "dino_pointmae" else
                                    ("configs[4] per-GPU work: MTFI FtoF predict (RGBorXYZWithOneHallucination, main modality "
@@ -919,9 +1059,12 @@ def main():
                        "weights": "seeded random init (no checkpoints offline)"},
             "roofline": {"kernel": "l2_min_pp3_kernel (xyz library distance GEMM + running min/argmin)", "bound": "mfma",
                          "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), **profiled_traffic(),
+                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
+                         "frac_in_pipeline": round(achieved_pipe / PEAK_BF16_TFLOPS, 4) if achieved_pipe else None,
+                         **profiled_traffic(),
                          "launch_ms": round(l2_ms, 3), "launch_ms_in_pipeline": round(l2_pipe_ms, 3),
-                         "launch_ms_note": "launch_ms: the step's launch repeated alone after the timed loop (HIP events, idle chip); "
+                         "launch_ms_note": "launch_ms / frac: the step's launch repeated alone after the timed loop (HIP events, idle chip) "
+                                           "-- the regime of the stand-alone rocprofv3 row in profiles/r5_standalone.md; "
                                            "in_pipeline: the same launch inside the timed steps, on the second stream beside the next "
                                            "step's extraction (shares the CUs)",
                          "flops_per_launch": flops,
@@ -929,25 +1072,86 @@ def main():
                                            "achieved_GBs": round(bytes_alg / (l2_ms * 1e-3) / 1e9, 1),
                                            "frac_of_8TBs": round(bytes_alg / (l2_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}},
         }
-        out.update(extras)
+        if group is not None:
+            out["rccl_ranks"] = rccl_ranks_seen          # the sum RCCL's all_reduce returned over a tensor of ones
+            out["world"] = world
+            out["ranks"] = census
+    store = None
     if group is not None:
-        td.barrier()
-        td.destroy_process_group()
+        store = td.distributed_c10d._get_default_store()
+    legs = LegRunner(out, rank, store, emit_line)
+    budget = float(os.environ.get("CMDIAD_BENCH_LEG_BUDGET", "0")) or None   # one budget for every leg (tests); default: per leg
+
+    def leg(name, fn, seconds, collective=False):
+        return legs.run(name, fn, budget or seconds, collective=collective)
+
+    if not args.no_extras:
+        n_h2d = max(8, min(args.steps, 12))
+
+        def h2d_leg():
+            # PCIe-inclusive rate: the same batches from pinned host memory, H2D on the predictor's copy stream inside the loop
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            run_steps(pred, host_batches, n_h2d, first)   # also checks H2D-fed outputs == resident-fed outputs
+            torch.cuda.synchronize()
+            h2d_dt = time.perf_counter() - t1
+            mb = sum(t.numel() * 4 for t in host_batches[0] if t is not None) / 1e6
+            return dict(value=round(BATCH * n_h2d / h2d_dt, 2), unit="images/s per GPU", steps=n_h2d, h2d_MB_per_step=round(mb, 1),
+                        note="inputs in pinned host memory, copied inside the loop; outputs identical to the resident run")
+
+        def every_row_leg():
+            # the same steps with EVERY row of the patch grid searched, as the reference's cdist does (no row de-duplication):
+            # outputs are checked bit for bit against the de-duplicated run's (run_steps compares with `first`)
+            os.environ["CMDIAD_DEDUP"] = "0"
+            try:
+                pred_all = BatchPredictor(st["engine"], st["bank_xyz"], st["bank_second"], st["stats"], st["det"], st["seg"], batch=BATCH,
+                                          n_max=N_POINTS, workload=args.workload, halluc=st["halluc"], group=None,
+                                          use_graph=pred.use_graph)
+            finally:
+                del os.environ["CMDIAD_DEDUP"]
+            run_steps(pred_all, batches, 3, first)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            run_steps(pred_all, batches, n_h2d, first)
+            torch.cuda.synchronize()
+            all_dt = time.perf_counter() - t2
+            return dict(value=round(BATCH * n_h2d / all_dt, 2), unit="images/s per GPU", steps=n_h2d,
+                        ms_per_step=round(all_dt / n_h2d * 1e3, 3),
+                        note="CMDIAD_DEDUP=0: all 100352 query rows per step go through the distance GEMM; "
+                             "outputs bit-identical to the default run")
+
+        # (with the row-sharded pipeline -- --bank sharded -- the H2D-fed steps are collective steps too)
+        leg("h2d_inclusive", h2d_leg, 120, collective=sharded)
+        if group is None and pred.dedup:
+            leg("every_row_searched", every_row_leg, 180)
+        if group is not None:
+            names = list(CLASS_TRAIN) if args.classes == "all" else [c for c in args.classes.split(",") if c]
+            leg("sharded_search", lambda: sharded_search(dev, group, rank, world, [(c, class_rows(c)) for c in names]), 300, collective=True)
+        if group is None:
+            leg("fake_world", lambda: fake_world_leg(dev), 240)
+            leg("var_n", lambda: var_n_leg(st, dev), 120)
+            if args.workload == "dino_pointmae":
+                leg("mtfi_step", lambda: mtfi_step_leg(st, dev), 180)
+            leg("train_step", lambda: train_step_leg(dev), 120)
+            leg("conv_head_train_step", lambda: conv_head_train_leg(dev), 120)
+        # configs[4] as a config (bounded): the class loop with the classes dealt to the ranks, metrics gathered at the end
+        leg("mtfi_classes", lambda: mtfi_classes(dev, group, rank, world, "all", args.class_scale, args.class_test), 600,
+            collective=group is not None)
+
+    if group is not None and legs.in_step:
+        leg("teardown", lambda: (td.barrier(), td.destroy_process_group(), None)[2], 60, collective=True)
     if rank == 0:
         if world == 1 and not args.no_extras and args.workload == "dino_pointmae":
             del pred, batches
             torch.cuda.empty_cache()
-            out["dropin_b1"] = dropin_b1()
+            leg("dropin_b1", dropin_b1, 300)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_images)
-        # RCCL writes its version banner to C stdout, which is flushed at exit -- i.e. AFTER a Python print: push it out
-        # first so that the JSON line is the last line of stdout
-        try:
-            import ctypes
-            ctypes.CDLL(None).fflush(None)
-        except Exception:
-            pass
-        print(json.dumps(out), flush=True)
+            leg("cpu_baseline", lambda: cpu_baseline(args.cpu_images), 600)
+        out.pop("teardown", None)
+        emit_line(out)
+    if group is not None and not legs.in_step:
+        sys.stdout.flush()
+        os._exit(0)      # some rank failed a leg: the others may sit in a collective that never completes -- no orderly teardown
 
 
 if __name__ == "__main__":

@@ -531,10 +531,19 @@ def _hrnet_step(img, feature, P, batch, need_grad):
         if ent["seen"] < 3:
             return hrnet_forward_backward(img, feature, P, batch, need_grad) + (None,)
         ent["img"], ent["feature"] = img.clone(), feature.clone()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            ent["out"] = hrnet_forward_backward(ent["img"], ent["feature"], P, batch, need_grad)
-        ent["graph"] = graph
+        try:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                ent["out"] = hrnet_forward_backward(ent["img"], ent["feature"], P, batch, need_grad)
+            ent["graph"] = graph
+        except Exception as e:      # noqa: BLE001 -- capture is an optimisation: this key stays eager, the step itself must not fail
+            import warnings
+            warnings.warn(f"HRNet trunk step: HIP-graph capture failed ({type(e).__name__}: {e}); this shape runs eagerly from now on")
+            ent["graph"] = None
+            ent.pop("out", None), ent.pop("img", None), ent.pop("feature", None)
+            torch.cuda.synchronize()
+    if ent["graph"] is None:
+        return hrnet_forward_backward(img, feature, P, batch, need_grad) + (None,)
     ent["img"].copy_(img)
     ent["feature"].copy_(feature)
     ent["graph"].replay()

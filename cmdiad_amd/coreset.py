@@ -55,7 +55,10 @@ class _HipRounds:
 def shard_rows(n, rank, world):
     """4-row aligned contiguous row range of `rank` (the scan kernel owns groups of four rows)."""
     per = ((n + world - 1) // world + 3) // 4 * 4
-    return min(rank * per, n), min((rank + 1) * per, n)
+    lo, hi = min(rank * per, n), min((rank + 1) * per, n)
+    if lo >= hi:          # a rank beyond the last row: an EMPTY range at an aligned row (n itself need not be a multiple of 4)
+        lo = hi = n // 4 * 4
+    return lo, hi
 
 
 def greedy_coreset_sharded(z, n_select, group, impl=_HipRounds):
@@ -73,7 +76,8 @@ def greedy_coreset_sharded(z, n_select, group, impl=_HipRounds):
     lo, hi = shard_rows(rounds.n, rank, world)
     keys = torch.zeros((max(n_select - 1, 1),), dtype=torch.int64, device=z.device)
     for r in range(n_select - 1):
-        rounds.round(lo, hi, keys[r - 1:r] if r else None, keys[r:r + 1])
+        if hi > lo:       # (a rank with no rows proposes nothing: its key stays 0 and loses the MAX)
+            rounds.round(lo, hi, keys[r - 1:r] if r else None, keys[r:r + 1])
         td.all_reduce(keys[r:r + 1], op=td.ReduceOp.MAX, group=group)      # keys are non-negative as int64: signed MAX == unsigned MAX
     return rounds.decode(keys, n_select)
 

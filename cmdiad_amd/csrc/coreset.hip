@@ -297,9 +297,10 @@ extern "C" int cmdiad_coreset_prepare(const float* z32, int n, int d, int first_
 extern "C" int cmdiad_coreset_round(void* workspace, int n, int d, int row_lo, int row_hi, const unsigned long long* pivot_key,
                                     int first_idx, unsigned long long* best_out, cmdiad_stream_t stream)
 {
-    CMDIAD_REQUIRE(workspace && best_out && n > 0 && d > 0 && d % 2 == 0 && d <= 1024 && row_lo >= 0 && row_lo <= row_hi && row_hi <= n &&
-                       row_lo % 4 == 0, CMDIAD_ERR_ARG, "cmdiad_coreset_round: bad args (row_lo %% 4 == 0, 0 <= row_lo <= row_hi <= n)");
-    if (row_lo == row_hi) return CMDIAD_OK;     // an empty shard proposes nothing: its key stays 0 and loses the MAX
+    CMDIAD_REQUIRE(workspace && best_out && n > 0 && d > 0 && d % 2 == 0 && d <= 1024 && row_lo >= 0 && row_lo <= row_hi && row_hi <= n,
+                   CMDIAD_ERR_ARG, "cmdiad_coreset_round: bad args (0 <= row_lo <= row_hi <= n)");
+    if (row_lo == row_hi) return CMDIAD_OK;     // an empty shard proposes nothing: its key stays 0 and loses the MAX (any row_lo)
+    CMDIAD_REQUIRE(row_lo % 4 == 0, CMDIAD_ERR_ARG, "cmdiad_coreset_round: row_lo %% 4 == 0 (the scan owns groups of four rows)");
     char* ws = (char*)workspace;
     const int n4 = (n + 3) / 4;
     __half* z16 = (__half*)ws;

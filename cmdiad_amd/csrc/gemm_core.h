@@ -78,6 +78,8 @@ struct GlobalTile {
     // no DMA at all 1 110 TFLOP/s, sources L1-hot 860, production 735-760 on the K = 3 072 product).  Here a lane's byte offset
     // from the tile's first row is computed ONCE per tile (offsets()); the row base, the K offset and the LDS destination stay
     // scalar, so a piece is an s_mov m0 and one global_load_lds with an SGPR base.
+    // PRECONDITION (both functions): row0 < rows -- a tile starts on an existing row; only rows INSIDE the tile are clamped.  Every
+    // caller derives row0 from a grid sized by ceil(rows / tile), so this holds; with row0 >= rows the unsigned offset would wrap.
     template <int ROWS, int WAVES>
     __device__ __forceinline__ void offsets(unsigned (&voff)[ROWS / WAVES / 8], int row0, int lane, int wave) const
     {
@@ -219,11 +221,24 @@ __device__ __forceinline__ void block_barrier()
     __builtin_amdgcn_s_barrier();
 }
 
+// What an N tile's accumulators start from: zeros (every network product; the distance GEMM has its own, l2min.hip)
+struct ZeroInit {
+    template <class Acc>
+    __device__ __forceinline__ void operator()(Acc& acc, int) const
+    {
+#pragma unroll
+        for (auto& row : acc)
+#pragma unroll
+            for (auto& v : row) v = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+};
+
 // Runs n_tiles consecutive BN-wide N tiles (starting at tile index nt0) against the block's M tile, over
-// K-steps [kt_begin, kt_begin + KT).  epi(acc, nt, scratch) is called once per finished N tile.
-template <class S, bool SWAP, bool F16 = false, class ALoader, class WLoader, class Epi>
+// K-steps [kt_begin, kt_begin + KT).  epi(acc, nt, scratch) is called once per finished N tile; init(acc, nt) sets the
+// accumulators an N tile starts from.
+template <class S, bool SWAP, bool F16 = false, class ALoader, class WLoader, class Epi, class Init = ZeroInit>
 __device__ __forceinline__ void run(const ALoader& A, const WLoader& W, int m0, int nt0, int n_tiles, int KT,
-                                    char* lds, Epi&& epi, int kt_begin = 0)
+                                    char* lds, Epi&& epi, int kt_begin = 0, Init&& init = Init())
 {
     constexpr int BM = S::BM, ST = S::STAGES, AHEAD = ST - 1;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -233,10 +248,7 @@ __device__ __forceinline__ void run(const ALoader& A, const WLoader& W, int m0, 
     constexpr int BN = S::BN;
     const int wr = wave / S::WN, wc = wave % S::WN;
     f32x4 acc[S::MI][4];
-#pragma unroll
-    for (int i = 0; i < S::MI; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    init(acc, nt0);
 
     const int total = n_tiles * KT;
     int kt_s = 0, nt_s = nt0;  // coordinates of the next K-step to STAGE
@@ -278,10 +290,7 @@ __device__ __forceinline__ void run(const ALoader& A, const WLoader& W, int m0, 
             epi(acc, nt, n_tiles == 1 ? lds + slot_s * S::STAGE_BYTES : nullptr);  // scratch: a stage nobody reads or fills (single-tile runs only)
             // (an LDS-staged 16-byte coalesced bf16 store through that scratch measured SLOWER than the direct
             //  8-byte stores: 3.32 vs 3.06 ms on the 4.2M x 512 x 256 product, profiles/r1_notes.md)
-#pragma unroll
-            for (int i = 0; i < S::MI; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (it + 1 < total) init(acc, nt + 1);   // block-uniform
         }
         // step it+1 must be in LDS before anyone reads it; with 3 stages the loads issued in THIS step
         // (step it+2) may stay in flight across the barrier

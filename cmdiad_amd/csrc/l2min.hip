@@ -3,22 +3,20 @@
 //
 // cmdiad_l2_min_keys: the Q x Nb x D distance contraction never leaves the chip.  Each block owns one query tile
 // (256 queries on the production shape) and a contiguous range of bank tiles; per bank tile the 16-bit MFMA mainloop
-// (fp16 or bf16 operands, fp32 accumulate; swapped orientation: a lane holds 4 bank rows for ONE query) produces q.b,
-// the epilogue forms d2 = |q|^2 + |b|^2 - 2 q.b and keeps a per-lane running (min, first index).  After the last tile
+// (fp16 or bf16 operands, fp32 accumulate; swapped orientation: a lane holds 4 bank rows for ONE query) starts from
+// -(|q|^2 + |b|^2) / 2, so a finished accumulator IS -d2 / 2 and the epilogue has no arithmetic left: it tags every value
+// with its place in the lane (RowMin below) and keeps a per-lane running (min, first index).  After the last tile
 // the four 16-lane groups are merged by shuffles and every query gets ONE 64-bit atomicMin per block on its packed key
 // (value bits << 32 | global row: integer order = (distance, row) order).  Blocks are dealt to the XCDs in groups of
 // `qgroup` query tiles x `splits` bank ranges, so a streamed bank tile is shared through that XCD's L2.
 // Shapes: l2_min_pp3_kernel (256 x 256, 8 waves in two groups, per-stream issuer waves) from Q >= 512; l2_min_kernel<S128>
-// below that and for the last Nb % 256 bank rows.  The superseded formulations -- l2_min_wide_kernel (gemm_wide.h: 4 waves of
-// 128 x 128), l2_min_pp_kernel, l2_min_kernel<S2x2> -- are compiled into the test-only build alone (make ab,
-// -DCMDIAD_AB_VARIANTS; selected with CMDIAD_L2_TILE); every variant returns the same keys.
+// below that and for the last Nb % 256 bank rows.  A third formulation, the lock-step l2_min_kernel<S2x2>, is compiled into the
+// test-only build alone (make ab, -DCMDIAD_AB_VARIANTS; CMDIAD_L2_TILE=2); all three return the same keys.  (Rounds 1-4 also kept
+// a 4-wave 128 x 128-per-wave kernel, a two-buffer two-group kernel and a 32-MFMA-per-phase kernel there: measured in
+// profiles/r1_notes.md .. r4_notes.md, removed in round 5 when the running minimum changed its definition.)
 #include <stdlib.h>
 
-#ifdef CMDIAD_AB_VARIANTS
-#include "gemm_wide.h"
-#else
 #include "gemm_core.h"
-#endif
 
 namespace {
 
@@ -85,6 +83,74 @@ __device__ __forceinline__ int tile_first_row(GlobalTile& A, L2Params& p, int qt
     return w * p.seg_stride + (qt - before) * BM;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// The running minimum of EVERY formulation (they must return identical keys: a row is searched by the 256 x 256 kernel in one
+// launch and by the 128 x 128 kernel in another -- the ragged last rows of a shard, tests/test_gpu_fakeworld.py).
+//   * A library tile's accumulators start at qh + bh, qh = -|q|^2 / 2, bh = -|b|^2 / 2 (one add per element where the zeroing
+//     move stood), so the finished accumulator is a = q.b - (|q|^2 + |b|^2) / 2 = -d2 / 2: no arithmetic per element is left
+//     (round 4: d2 = (|q|^2 + |b|^2) - 2 acc, compare, two selects = 5 operations per element, 8.5 % of the kernel).
+//   * The low four mantissa bits of a are replaced by the element's place e = 4 j + r among the lane's 16 columns of the tile
+//     (ascending library rows): one v_and_or_b32.  Tagged values compare as UNSIGNED integers: negative floats order by
+//     magnitude (smaller |a| = smaller d2 first) and a positive a (d2 < 0: rounding at an exact match) is below every
+//     negative one; the minimum of a row is a tree of v_min3_u32 (half an operation per element) and equal values resolve to
+//     the lowest e.  What the truncation gives up is 2^-19 of the value, three orders below the operand rounding.
+//   * Across tiles the candidates compare on the truncated value alone, strictly: of equal values the earlier tile stays.
+// So the result is, per query, the row with the smallest TRUNCATED -d2 / 2 in unsigned order, lowest row first -- a
+// definition that does not depend on the tile shape, the launch geometry or the shard a row lives in.
+// ------------------------------------------------------------------------------------------------
+constexpr unsigned kRowMinNone = 0xFFFFFFF0u;   // above every tagged value of a finite or infinite accumulator
+constexpr unsigned kRowMinDead = 0xFF800000u;   // -inf (masked columns start there and stay): from here on "no candidate"
+
+struct RowMin {
+    unsigned u;    // truncated bits of the best accumulator so far
+    unsigned at;   // (library tile << 4) | e of that element
+};
+
+__device__ __forceinline__ unsigned rowmin_tag(float a, unsigned e) { return (__float_as_uint(a) & ~15u) | e; }
+__device__ __forceinline__ unsigned umin3(unsigned a, unsigned b, unsigned c) { return min(min(a, b), c); }
+
+// one finished row (16 columns of one query in this lane) against the running minimum
+__device__ __forceinline__ void rowmin_update(RowMin& best, const f32x4 (&row)[4], unsigned tile)
+{
+    unsigned t[16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[j * 4 + r] = rowmin_tag(row[j][r], (unsigned)(j * 4 + r));
+    const unsigned m0 = umin3(t[0], t[1], t[2]), m1 = umin3(t[3], t[4], t[5]), m2 = umin3(t[6], t[7], t[8]);
+    const unsigned m3 = umin3(t[9], t[10], t[11]), m4 = umin3(t[12], t[13], t[14]);
+    const unsigned m = umin3(umin3(m0, m1, m2), umin3(m3, m4, t[15]), kRowMinNone);
+    const bool better = m < best.u;   // best.u is a multiple of 16: m < best.u  <=>  (m & ~15) < best.u
+    best.u = better ? (m & ~15u) : best.u;
+    best.at = better ? ((m & 15u) | (tile << 4)) : best.at;
+}
+
+// column of the element inside the launch's library (the lane's columns of tile t start at t * BN + col0)
+template <int BN>
+__device__ __forceinline__ unsigned rowmin_col(const RowMin& b, unsigned col0)
+{
+    const unsigned e = b.at & 15u;
+    return (b.at >> 4) * BN + col0 + (e >> 2) * 16 + (e & 3u);
+}
+
+__device__ __forceinline__ unsigned long long rowmin_key(const RowMin& b, unsigned row)
+{
+    if (b.u >= kRowMinDead) return ~0ull;
+    const float d2 = -2.0f * __uint_as_float(b.u);
+    return pack_key(d2 > 0.0f ? d2 : 0.0f, row);
+}
+
+// merge the four 16-lane groups of a wave and publish one key per query row
+__device__ __forceinline__ void rowmin_publish(unsigned long long key, int lane, bool live, unsigned long long* dst)
+{
+    unsigned long long o = shfl_xor_u64(key, 16);
+    key = o < key ? o : key;
+    o = shfl_xor_u64(key, 32);
+    key = o < key ? o : key;
+    if (lane < 16 && live) atomicMin(dst, key);
+}
+
 template <class S, bool F16>
 __global__ __launch_bounds__(S::THREADS, S::WAVES_PER_SIMD) void l2_min_kernel(GlobalTile A, GlobalTile W, L2Params p)
 {
@@ -110,51 +176,41 @@ __global__ __launch_bounds__(S::THREADS, S::WAVES_PER_SIMD) void l2_min_kernel(G
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave / S::WN, wc = wave % S::WN;
 
-    float best[MI], qn[MI];
-    int besti[MI];
+    RowMin best[MI];
+    float qh[MI];
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
-        best[i] = __builtin_inff();
-        besti[i] = 0;
+        best[i] = RowMin{kRowMinNone, 0u};
         const int m = m0 + wr * (MI * 16) + i * 16 + (lane & 15);
-        qn[i] = m < p.Q ? p.q_sqnorm[m] : 0.0f;
+        qh[i] = m < p.Q ? -0.5f * p.q_sqnorm[m] : 0.0f;
     }
 
     run<S, true, F16>(A, W, m0, nt0, ntc, p.D / BK, lds, [&](auto& acc, int ntile, char*) {
 #pragma unroll
+        for (int i = 0; i < MI; ++i) rowmin_update(best[i], acc[i], (unsigned)ntile);
+    }, 0, [&](auto& acc, int ntile) {   // a tile's accumulators start at -(|q|^2 + |b|^2) / 2; columns past Nb at -inf
+#pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int n = ntile * S::BN + wc * 64 + j * 16 + (lane >> 4) * 4;
-            float bn[4];
+            float bh[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) bn[r] = n + r < p.Nb ? p.b_sqnorm[n + r] : __builtin_inff();
+            for (int r = 0; r < 4; ++r) bh[r] = n + r < p.Nb ? -0.5f * p.b_sqnorm[n + r] : -__builtin_inff();
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float d2 = (qn[i] + bn[r]) - 2.0f * acc[i][j][r];
-                    if (d2 < best[i]) { best[i] = d2; besti[i] = n + r; }  // n increases: first occurrence wins
-                }
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = qh[i] + bh[r];
         }
     });
 
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
-        unsigned long long key = pack_key(fmaxf(best[i], 0.0f), p.row_offset + (unsigned)besti[i]);
-        if (!(best[i] < __builtin_inff())) key = ~0ull;
-        unsigned long long o = shfl_xor_u64(key, 16);
-        key = o < key ? o : key;
-        o = shfl_xor_u64(key, 32);
-        key = o < key ? o : key;
         const int m = m0 + wr * (MI * 16) + i * 16 + (lane & 15);
-        if (lane < 16 && m < p.Q) atomicMin(p.keys + m, key);
+        const unsigned n = rowmin_col<S::BN>(best[i], (unsigned)(wc * 64 + (lane >> 4) * 4));
+        rowmin_publish(rowmin_key(best[i], p.row_offset + n), lane, m < p.Q, p.keys + m);
     }
 }
 
 __device__ __forceinline__ void pp_barrier() { asm volatile("s_barrier" ::: "memory"); }
-
-#ifdef CMDIAD_AB_VARIANTS  // superseded formulations of the 256 x 256 distance GEMM: test-only build (make ab), A/B references
-#include "ab/l2min_wide_pp.inc"
-#endif  // CMDIAD_AB_VARIANTS
 
 // ------------------------------------------------------------------------------------------------
 // The two-group pipeline with MORE BANK BYTES IN FLIGHT (the ablations above put the remaining time in the latency of the
@@ -227,20 +283,42 @@ __global__ __launch_bounds__(512, 1) void l2_min_pp3_kernel(GlobalTile A, Global
     // LDS byte address of the [2][256] bank-norm area (the inline-asm accesses take raw LDS addresses)
     const unsigned bn_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(lds + S::BN_OFF);
 
-    float best[8], qn[8];
-    int besti[8];
+    RowMin best[8];
+    float qh[8];   // -|q|^2 / 2 of the lane's eight query rows
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        best[i] = __builtin_inff();
-        besti[i] = 0;
+        best[i] = RowMin{kRowMinNone, 0u};
         const int m = m0 + wr * 128 + i * 16 + (lane & 15);
-        qn[i] = m < p.Q ? p.q_sqnorm[m] : 0.0f;
+        qh[i] = m < p.Q ? -0.5f * p.q_sqnorm[m] : 0.0f;
     }
     f32x4 acc[8][4];
+    // The -|b|^2 / 2 of library tile t wait in LDS slot t & 1 ([2][256] floats): wave 0 fetches tile t + 1's norms in phase 0 of
+    // tile t's first K-tile and parks them in phase 3; every wave takes its 16 columns' values when tile t is finished and
+    // starts tile t + 1's accumulators from qh + bh (the first tile's are fetched in front of the prologue's DMA pieces).
+    auto bh_fetch = [&](f32x4& bnv, int tile) {
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(bnv) : "v"(p.b_sqnorm + (size_t)tile * S::BN + lane * 4) : "memory");
+    };
+    auto bh_park = [&](f32x4& bnv, int tile, auto VM) {   // VM: vector-memory operations issued after the fetch that may stay in flight
+        constexpr int vm = decltype(VM)::value;
+        asm volatile("s_waitcnt vmcnt(%1)" : "+v"(bnv) : "n"(vm) : "memory");   // (in-out: the scaling below cannot move above the wait)
+        const f32x4 h = bnv * -0.5f;
+        const unsigned wa = bn_lds + (unsigned)((tile & 1) * 1024 + lane * 16);
+        asm volatile("ds_write_b128 %0, %1" : : "v"(wa), "v"(h) : "memory");
+    };
+    auto acc_start = [&](int tile) {
+        f32x4 b4[4];
+        const unsigned ra = bn_lds + (unsigned)((tile & 1) * 1024 + (wc * 64 + (lane >> 4) * 4) * 4);
+        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:64\n\tds_read_b128 %2, %4 offset:128\n\t"
+                     "ds_read_b128 %3, %4 offset:192\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(b4[0]), "=&v"(b4[1]), "=&v"(b4[2]), "=&v"(b4[3]) : "v"(ra) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = qh[i] + b4[j][r];
+    };
 
     // Everything below is instantiated twice, once per stream: a wave only ever executes its own (lean) issue path.
     auto body = [&](auto BANK) {
@@ -302,15 +380,22 @@ __global__ __launch_bounds__(512, 1) void l2_min_pp3_kernel(GlobalTile A, Global
         else if (bank_wave) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     };
-    // prologue: bank half-units 0..9 (tiles 0, 1 and the lo unit of tile 2), query half-units 0..4 (tile 0 and lo h0 of tile 1)
+    // prologue: bank half-units 0..9 (tiles 0, 1 and the lo unit of tile 2), query half-units 0..4 (tile 0 and lo h0 of tile 1);
+    // wave 0's fetch of the first library tile's norms is older than its pieces and lands with them
+    f32x4 bnv0;
+    if (bank_wave && wave == 0) bh_fetch(bnv0, nt0);
     {
         using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
         using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
         issue_part(I0{}); issue_part(I1{}); issue_part(I2{}); issue_part(I3{}); issue_part(I0{});  // half-units 0..4
         if (bank_wave) { issue_part(I1{}); issue_part(I2{}); issue_part(I3{}); issue_part(I0{}); issue_part(I1{}); }  // 5..9
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (bank_wave && wave == 0) {
+        bh_park(bnv0, nt0, std::integral_constant<int, 0>{});
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     pp_barrier();
+    acc_start(nt0);
     if (wr == 1) pp_barrier();  // the second group runs one barrier (half a phase) behind the first
 
     // ---- fragment addresses: row*128 + ((chunk ^ (row & 7)) << 4), chunk = kk*4 + (lane >> 4); kk = 1 flips bit 6.
@@ -327,7 +412,6 @@ __global__ __launch_bounds__(512, 1) void l2_min_pp3_kernel(GlobalTile A, Global
         a_lo = S::A_OFF + ((2 * T) % 3) * S::HALF + a_off;
         a_hi = S::A_OFF + ((2 * T + 1) % 3) * S::HALF + a_off;
         b_base = (T % 3) * S::BUF + b_off;
-        f32x4 bnv;  // wave 0: this bank tile's squared norms on their way to LDS
         // ================= phase 0: B lo + A lo
         stamp();
 #pragma unroll
@@ -339,8 +423,9 @@ __global__ __launch_bounds__(512, 1) void l2_min_pp3_kernel(GlobalTile A, Global
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) af[i][kk] = lda(i, kk);
-        const bool bn_fetch = wave == 0 && kt_c == 0;  // wave-uniform
-        if (bn_fetch) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bnv) : "v"(p.b_sqnorm + (size_t)nt_c * S::BN + lane * 4) : "memory");
+        f32x4 bnv;  // wave 0: the next library tile's squared norms on their way to LDS
+        const bool bn_fetch = bank_wave && wave == 0 && kt_c == 0 && nt_c + 1 < nt0 + ntc;  // wave-uniform
+        if (bn_fetch) bh_fetch(bnv, nt_c + 1);
         { const bool is = issue_phase(std::integral_constant<int, 0>{}); stamp(); phase_wait(is); }
         stamp();
         pp_barrier();
@@ -397,8 +482,7 @@ __global__ __launch_bounds__(512, 1) void l2_min_pp3_kernel(GlobalTile A, Global
         pp_barrier();
         // ================= phase 3: no reads (B lo is still in registers)
         stamp();
-        if (bn_fetch)  // 6 DMA pieces were issued after the fetch (phases 0-2): a counted wait, then park the norms in LDS
-            asm volatile("s_waitcnt vmcnt(6)\n\tds_write_b128 %0, %1" ::"v"(bn_lds + (unsigned)((nt_c & 1) * 1024 + lane * 16)), "v"(bnv) : "memory");
+        if (bn_fetch) bh_park(bnv, nt_c + 1, std::integral_constant<int, 6>{});  // 6 DMA pieces were issued after the fetch (phases 0-2)
         { const bool is = issue_phase(std::integral_constant<int, 3>{}); stamp(); phase_wait(is); }
         stamp();
         pp_barrier();
@@ -412,30 +496,10 @@ __global__ __launch_bounds__(512, 1) void l2_min_pp3_kernel(GlobalTile A, Global
                 for (int j = 0; j < 2; ++j) acc[4 + i][j] = mfma16(wlo[j][kk], af[i][kk], acc[4 + i][j]);
         __builtin_amdgcn_s_setprio(0);
         stamp();
-        if (kt_c == KT - 1) {  // bank tile finished: d2 = |q|^2 + |b|^2 - 2 q.b, running (min, first index) per lane
-            const int nbase = nt_c * S::BN + wc * 64 + (lane >> 4) * 4;
-            f32x4 b4[4];
-            {
-                const unsigned ra = bn_lds + (unsigned)((nt_c & 1) * 1024 + (wc * 64 + (lane >> 4) * 4) * 4);
-                asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:64\n\tds_read_b128 %2, %4 offset:128\n\t"
-                             "ds_read_b128 %3, %4 offset:192\n\ts_waitcnt lgkmcnt(0)"
-                             : "=&v"(b4[0]), "=&v"(b4[1]), "=&v"(b4[2]), "=&v"(b4[3]) : "v"(ra) : "memory");
-                __builtin_amdgcn_sched_barrier(0);
-            }
+        if (kt_c == KT - 1) {  // library tile finished: the accumulators are -d2 / 2 (RowMin); then the next tile's start values
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float d2 = (qn[i] + b4[j][r]) - 2.0f * acc[i][j][r];
-                        if (d2 < best[i]) { best[i] = d2; besti[i] = nbase + j * 16 + r; }
-                    }
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < 8; ++i) rowmin_update(best[i], acc[i], (unsigned)nt_c);
+            if (T + 1 < T_total) acc_start(nt_c + 1);
         }
         pp_barrier();
         if (++kt_c == KT) { kt_c = 0; ++nt_c; }
@@ -444,14 +508,9 @@ __global__ __launch_bounds__(512, 1) void l2_min_pp3_kernel(GlobalTile A, Global
 
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        unsigned long long key = pack_key(fmaxf(best[i], 0.0f), p.row_offset + (unsigned)besti[i]);
-        if (!(best[i] < __builtin_inff())) key = ~0ull;
-        unsigned long long o = shfl_xor_u64(key, 16);
-        key = o < key ? o : key;
-        o = shfl_xor_u64(key, 32);
-        key = o < key ? o : key;
         const int m = m0 + wr * 128 + i * 16 + (lane & 15);
-        if (lane < 16 && m < p.Q) atomicMin(p.keys + m, key);
+        const unsigned n = rowmin_col<S::BN>(best[i], (unsigned)(wc * 64 + (lane >> 4) * 4));
+        rowmin_publish(rowmin_key(best[i], p.row_offset + n), lane, m < p.Q, p.keys + m);
     }
     if constexpr (DIAG) {
         if (diag_on) {
@@ -462,10 +521,6 @@ __global__ __launch_bounds__(512, 1) void l2_min_pp3_kernel(GlobalTile A, Global
     if (wave < 4) body(std::true_type{});
     else body(std::false_type{});
 }
-
-#ifdef CMDIAD_AB_VARIANTS  // measured formulation, test-only build: 0-3 % faster than the production kernel (profiles/r2_notes.md)
-#include "ab/l2min_pp4.inc"
-#endif  // CMDIAD_AB_VARIANTS
 
 // Exact fp32 distance to the winning row: one wave per query.
 __global__ __launch_bounds__(256) void l2_rescore_kernel(const float* __restrict__ q, const float* __restrict__ bank,
@@ -609,14 +664,7 @@ bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 }  // namespace
 
 template <class S, bool F16> struct L2Kernel { static constexpr auto fn = l2_min_kernel<S, F16>; };
-#ifdef CMDIAD_AB_VARIANTS
-template <bool F16> struct L2Kernel<SWide, F16> { static constexpr auto fn = l2_min_wide_kernel<F16>; };
-template <bool F16> struct L2Kernel<SPingPong, F16> { static constexpr auto fn = l2_min_pp_kernel<F16>; };
-#endif
 template <bool F16> struct L2Kernel<SPingPong3, F16> { static constexpr auto fn = l2_min_pp3_kernel<F16>; };
-#ifdef CMDIAD_AB_VARIANTS
-template <bool F16> struct L2Kernel<SPingPong4, F16> { static constexpr auto fn = l2_min_pp4_kernel<F16>; };
-#endif
 
 // Optional device-side row counts of a launch: one live count for the whole query set (counted) or one per segment.
 struct L2Live {
@@ -681,47 +729,41 @@ static int l2_min_keys_impl(const uint16_t* q, const float* q_sqnorm, const L2Li
                            const float* bank_sqnorm, int Q, int Nb, int D, uint32_t row_offset,
                            unsigned long long* keys, int dtype, cmdiad_stream_t stream)
 {
-    CMDIAD_REQUIRE(q && q_sqnorm && bank && bank_sqnorm && keys, CMDIAD_ERR_ARG, "cmdiad_l2_min_keys: null pointer");
     CMDIAD_REQUIRE(Q >= 0 && Nb >= 0 && D > 0 && D % 64 == 0, CMDIAD_ERR_ARG, "cmdiad_l2_min_keys: need D%%64==0 (D=%d)", D);
-    CMDIAD_REQUIRE(aligned16(q) && aligned16(bank), CMDIAD_ERR_ARG, "cmdiad_l2_min_keys: 16-byte alignment");
     CMDIAD_REQUIRE(dtype == CMDIAD_DT_BF16 || dtype == CMDIAD_DT_F16, CMDIAD_ERR_ARG, "cmdiad_l2_min_keys: dtype");
+    // nothing to search (an empty row shard: engine.Bank on a rank beyond the library's last row; a 0-row tensor has no address):
+    // the keys stay what the caller put there
     if (Q == 0 || Nb == 0) return CMDIAD_OK;
+    CMDIAD_REQUIRE(q && q_sqnorm && bank && bank_sqnorm && keys, CMDIAD_ERR_ARG, "cmdiad_l2_min_keys: null pointer");
+    CMDIAD_REQUIRE(aligned16(q) && aligned16(bank), CMDIAD_ERR_ARG, "cmdiad_l2_min_keys: 16-byte alignment");
     // production: the two-group 256 x 256 pipeline (l2_min_pp3_kernel) from Q >= 512, the 128 x 128 kernel below that, for the
     // last Nb % 256 library rows and for D < 192 (the two-group schedule assumes >= 3 K-tiles per library tile).
     // CMDIAD_L2_TILE (read per call: the parity tests force each shape on small inputs) = 0 / 5 for those two; the test-only
-    // build (make ab) also knows 2 = 256 x 256 lock-step, 3 = 4 waves of 128 x 128, 4 = two groups with two buffers, 6 = two groups
-    // with K-tiles of 32 columns (32 MFMAs per phase).
+    // build (make ab) also knows 2 = the lock-step 256 x 256 shape of gemm::run.
     const char* env_tile = getenv("CMDIAD_L2_TILE");
     const int force = env_tile ? atoi(env_tile) : -1;
     int tile = force >= 0 ? force : (Q >= 512 ? 5 : 0);
     if (q_count.seg_counts && tile != 0) tile = 5;    // segments exist for the production shapes only
 #ifndef CMDIAD_AB_VARIANTS
-    if (tile != 0 && tile != 5) {
-        cmdiad_set_error("cmdiad_l2_min_keys: CMDIAD_L2_TILE=%d names an A/B variant that only the test build (make ab) contains", tile);
+    if (tile == 2) {
+        cmdiad_set_error("cmdiad_l2_min_keys: CMDIAD_L2_TILE=2 names an A/B variant that only the test build (make ab) contains");
+        return CMDIAD_ERR_ARG;
+    }
+#endif
+    if (tile != 0 && tile != 2 && tile != 5) {
+        cmdiad_set_error("cmdiad_l2_min_keys: CMDIAD_L2_TILE=%d is not a distance-GEMM shape (0, 5; test build: 2)", tile);
         return CMDIAD_ERR_ARG;
     }
     if (tile == 5 && D < 192) tile = 0;
-#else
-    if ((tile == 4 || tile == 5 || tile == 6) && D < 192) tile = 3;
-#endif
     hipStream_t s = (hipStream_t)stream;
     const bool h = dtype == CMDIAD_DT_F16;
     int rc;
 #define L2_ARGS q, q_sqnorm, bank, bank_sqnorm, Q, Nb, D, row_offset, keys, s, q_count
-    if (tile == 4 || tile == 5 || tile == 6) {
+    if (tile == 5) {
         const int full = Nb / 256 * 256, rest = Nb - full;
         rc = CMDIAD_OK;
-#ifdef CMDIAD_AB_VARIANTS
-        if (full > 0 && tile == 6) rc = h ? launch_l2<SPingPong4, true>(q, q_sqnorm, bank, bank_sqnorm, Q, full, D, row_offset, keys, s, q_count)
-                                          : launch_l2<SPingPong4, false>(q, q_sqnorm, bank, bank_sqnorm, Q, full, D, row_offset, keys, s, q_count);
-        else
-#endif
-        if (full > 0 && tile == 5) rc = h ? launch_l2<SPingPong3, true>(q, q_sqnorm, bank, bank_sqnorm, Q, full, D, row_offset, keys, s, q_count)
-                                          : launch_l2<SPingPong3, false>(q, q_sqnorm, bank, bank_sqnorm, Q, full, D, row_offset, keys, s, q_count);
-#ifdef CMDIAD_AB_VARIANTS
-        else if (full > 0) rc = h ? launch_l2<SPingPong, true>(q, q_sqnorm, bank, bank_sqnorm, Q, full, D, row_offset, keys, s, q_count)
-                             : launch_l2<SPingPong, false>(q, q_sqnorm, bank, bank_sqnorm, Q, full, D, row_offset, keys, s, q_count);
-#endif
+        if (full > 0) rc = h ? launch_l2<SPingPong3, true>(q, q_sqnorm, bank, bank_sqnorm, Q, full, D, row_offset, keys, s, q_count)
+                             : launch_l2<SPingPong3, false>(q, q_sqnorm, bank, bank_sqnorm, Q, full, D, row_offset, keys, s, q_count);
         if (rc == CMDIAD_OK && rest > 0) {
             const uint16_t* b2 = bank + (size_t)full * D;
             rc = h ? launch_l2<S128, true>(q, q_sqnorm, b2, bank_sqnorm + full, Q, rest, D, row_offset + full, keys, s, q_count)
@@ -729,17 +771,6 @@ static int l2_min_keys_impl(const uint16_t* q, const float* q_sqnorm, const L2Li
         }
     }
 #ifdef CMDIAD_AB_VARIANTS
-    else if (tile == 3) {
-        const int full = Nb / 256 * 256, rest = Nb - full;
-        rc = CMDIAD_OK;
-        if (full > 0) rc = h ? launch_l2<SWide, true>(q, q_sqnorm, bank, bank_sqnorm, Q, full, D, row_offset, keys, s, q_count)
-                             : launch_l2<SWide, false>(q, q_sqnorm, bank, bank_sqnorm, Q, full, D, row_offset, keys, s, q_count);
-        if (rc == CMDIAD_OK && rest > 0) {
-            const uint16_t* b2 = bank + (size_t)full * D;
-            rc = h ? launch_l2<S128, true>(q, q_sqnorm, b2, bank_sqnorm + full, Q, rest, D, row_offset + full, keys, s, q_count)
-                   : launch_l2<S128, false>(q, q_sqnorm, b2, bank_sqnorm + full, Q, rest, D, row_offset + full, keys, s, q_count);
-        }
-    }
     else if (tile == 2) rc = h ? launch_l2<S2x2, true>(L2_ARGS) : launch_l2<S2x2, false>(L2_ARGS);
 #endif
     else rc = h ? launch_l2<S128, true>(L2_ARGS) : launch_l2<S128, false>(L2_ARGS);

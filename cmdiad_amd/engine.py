@@ -174,9 +174,12 @@ class ShardedSearch:
         self.counts = None           # live rows per rank at the last host read
         self.host_reads = 0
         self.overflow = None
+        self.floor = 0               # "auto": the largest cap this search has ever used (regrow)
 
     def regrow(self):
-        """Forget the sticky cap: the next gather() reads the live counts on the host again."""
+        """Let the next gather() read the live counts on the host again.  The sticky cap only ever GROWS ("auto"): a sparse batch
+        right after an overflow must not lower it below what a dense batch has already been seen to need."""
+        self.floor = max(self.floor, self.cap or 0)
         self.cap = None
 
     def overflowed(self):
@@ -197,6 +200,8 @@ class ShardedSearch:
             self.host_reads += 1
             grow = 1.0 if self.cap_rows == "exact" else 1.0 + self.slack
             cap = min(Q, (int(math.ceil(max(self.counts) * grow)) + 255) // 256 * 256)
+            if self.cap_rows == "auto":
+                cap = min(Q, max(cap, self.floor))
         else:
             cap = self.cap
         self.cap = cap

@@ -176,20 +176,31 @@ def gemm_streamk_eligible(M, N, K):
 def gemm_streamk(A, W, bias, residual, out_f32=None):
     """out_f32 = A[M,K] . W[N,K]^T + bias + residual (in place when out_f32 is residual) on the stream-K kernel
     (cmdiad_gemm_streamk_bf16; bit-identical to gemm()).  The workspace (64 MiB of hand-over slots + counters, zeroed once) is kept
-    per device and stream."""
+    per device; launches are serialised per device (see below)."""
     _chk(A, torch.bfloat16, "gemm_streamk.A"); _chk(W, torch.bfloat16, "gemm_streamk.W")
     _chk(bias, torch.float32, "gemm_streamk.bias"); _chk(residual, torch.float32, "gemm_streamk.residual")
     M, K = A.shape
     N = W.shape[0]
     if out_f32 is None:
         out_f32 = torch.empty((M, N), dtype=torch.float32, device=A.device)
-    key = (A.device.index, int(_stream() or 0))
-    ws = _streamk_ws.get(key)
-    if ws is None:
-        ws = _streamk_ws[key] = torch.zeros((nat.lib().cmdiad_gemm_streamk_workspace_bytes(),), dtype=torch.uint8, device=A.device)
+    # ONE workspace and ONE launch in flight per device: block b of the kernel spins on block b - 1's counter, so two launches
+    # that overlap (different streams) could fill every CU with waiting blocks whose predecessors are not resident yet -- a launch on
+    # another stream first waits for the previous one's event
+    key = A.device.index
+    ent = _streamk_ws.get(key)
+    if ent is None:
+        ent = _streamk_ws[key] = {"ws": torch.zeros((nat.lib().cmdiad_gemm_streamk_workspace_bytes(),), dtype=torch.uint8, device=A.device),
+                                  "done": None, "stream": None}
+    ws = ent["ws"]
+    cur = torch.cuda.current_stream(A.device)
+    if ent["done"] is not None and ent["stream"] != cur.cuda_stream:
+        cur.wait_event(ent["done"])
     a = nat.GemmArgs(_p(A), K, _p(W), K, M, N, K, _p(bias), None, 1, ACT_NONE, _p(residual), N, _p(out_f32), N, None, 0, None, None, 1,
                      None, None, None, 0, None, None, 0)
     _call("cmdiad_gemm_streamk_bf16", ctypes.byref(a), _p(ws), ws.numel(), _stream())
+    ent["done"] = torch.cuda.Event()
+    ent["done"].record(cur)
+    ent["stream"] = cur.cuda_stream
     return out_f32
 
 

@@ -131,6 +131,8 @@ class BatchPredictor:
         self.dedup = os.environ.get("CMDIAD_DEDUP", "1") != "0"
         # row-sharded search: rows of every rank that travel per step -- "auto" (sticky cap, no host read in steady state) | "exact"
         self.shard_cap = os.environ.get("CMDIAD_SHARD_CAP", "auto")
+        if self.shard_cap.strip().isdigit():
+            self.shard_cap = int(self.shard_cap)      # a fixed row count: ShardedSearch takes it as an int
         self.stage2_eager = bool(getattr(bank_xyz, "f32_sharded", False) or getattr(bank_second, "f32_sharded", False))
         if self.stage2_eager and group is None:
             raise ValueError("BatchPredictor: a library with sharded fp32 rows (Bank(replicate_f32=False)) needs the process group")
@@ -437,7 +439,7 @@ class BatchPredictor:
         torch.cuda.synchronize()
         self.redone += 1
         for k, v in self.static.items():
-            if k.startswith("ss_"):
+            if k.startswith("ss_") and (v.overflow is None or v.overflowed()):   # only the searches whose rows did not fit
                 v.regrow()
         inp = self.inputs[0]
         self._load_inputs(inp, rgb, pcs)

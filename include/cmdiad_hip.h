@@ -143,8 +143,11 @@ int cmdiad_gemm_bf16(const cmdiad_gemm_args* args, cmdiad_stream_t stream);
  * CU; a tile shared by two blocks is finished IN ORDER (the second block starts from the first one's parked accumulators), so the
  * result is bit-identical to cmdiad_gemm_bf16's.  Takes the cmdiad_gemm_args of the residual form only (A, W, bias, residual,
  * out_f32; everything else unset).  workspace: cmdiad_gemm_streamk_workspace_bytes() bytes, ZERO-INITIALISED once by the caller
- * and then left to the library (slots + hand-over counters; the kernel leaves the counters at zero again); one launch at a time
- * per workspace.  cmdiad_gemm_streamk_eligible(M, N, K) -> 1 when the shape qualifies. */
+ * and then left to the library (slots + hand-over counters; the kernel leaves the counters at zero again).  ONE stream-K launch in
+ * flight PER DEVICE, not only per workspace: block b spins on block b - 1's counter, which assumes its predecessor is resident or
+ * will be dispatched -- two overlapping launches (two streams) can fill every CU with waiting blocks of both.  The caller orders
+ * them (cmdiad_amd.ops.gemm_streamk: an event between consecutive launches on different streams).
+ * cmdiad_gemm_streamk_eligible(M, N, K) -> 1 when the shape qualifies. */
 size_t cmdiad_gemm_streamk_workspace_bytes(void);
 int cmdiad_gemm_streamk_eligible(int M, int N, int K);
 int cmdiad_gemm_streamk_bf16(const cmdiad_gemm_args* a, void* workspace, size_t workspace_bytes, cmdiad_stream_t stream);

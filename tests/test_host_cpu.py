@@ -293,7 +293,34 @@ def test_bench_gpus_2_spawns_two_ranks():
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
     rec = json.loads(line)
-    assert rec == {"selftest_launch": True, "ranks": 2, "merge_ok": True}
+    assert rec["selftest_launch"] is True and rec["ranks"] == 2 and rec["merge_ok"] is True
+    assert rec["merge"] == {"merge_ok": True} and rec["second"] == {"ranks_counted": 2} and rec["third"] == {"ranks_counted": 2}
+
+
+@pytest.mark.parametrize("inject", ["second:1:raise", "second:0:raise", "second:1:hang", "merge:1:raise"])
+def test_bench_line_survives_a_failing_leg(inject):
+    """bench.py's secondary legs are fault-isolated (bench.LegRunner).  A gloo world of two runs the
+    launcher's self-test with a failure injected into one leg on one rank -- an exception on the rank that prints, an exception on
+    the OTHER rank (rank 0 then waits in a collective nobody completes), a rank that hangs: every time rank 0 prints ONE JSON line
+    whose headline fields are intact, the failed leg carries an "error", later collective legs are skipped or carry the time-out,
+    and the job ends with exit code 0."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(CMDIAD_BENCH_INJECT=inject, CMDIAD_BENCH_LEG_BUDGET="6")
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--selftest-launch"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:] + out.stderr[-3000:]
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads(lines[0])
+    assert rec["metric"] == "selftest" and rec["value"] == 1.0 and rec["ranks"] == 2          # the headline survived
+    leg = inject.split(":")[0]
+    assert "error" in rec[leg], rec
+    if leg == "second":
+        assert rec["merge"] == {"merge_ok": True}                                                # the leg before it is intact
+    later = {"merge": ["second", "third"], "second": ["third"]}[leg]
+    for name in later:
+        assert name not in rec or "skipped" in rec[name] or "error" in rec[name], rec
 
 
 def test_empty_shard_cannot_win_the_min_reduce():

@@ -12,7 +12,7 @@ Q, Nb = int(os.environ.get("L2_Q", 100352)), int(os.environ.get("L2_NB", 76518))
 bank = torch.randn(Nb, 768, generator=g).cuda(); qq = torch.randn(Q, 768, generator=g).cuda()
 b16, b32, bsq = ops.normalize_cast(bank, want_f32=True); q16, q32, qsq = ops.normalize_cast(qq, want_f32=True)
 res, keys = {}, {}
-variants = os.environ.get("L2_VARIANTS", "3,4").split(",")
+variants = os.environ.get("L2_VARIANTS", "2,5").split(",")
 for rnd in range(5):
     for v in variants:
         os.environ["CMDIAD_L2_TILE"] = v

@@ -7,8 +7,13 @@
     rocprofv3 --pmc WRITE_SIZE  --output-format csv -d gpurun_out/prof_r4/standalone_pmc/write -- python3 tools/standalone_kernels.py hbm
     python tools/standalone_summary.py gpurun_out/prof_r4/standalone gpurun_out/prof_r4/standalone_pmc > profiles/r4_standalone.md
 
-`hbm`: only the two HBM-bound kernels whose bytes are the claim (re-weighting scan, coreset round).  The algorithmic work of
-every launch is written to standalone_work.json next to the trace (kernel-name prefix -> bytes / flops per launch)."""
+    rocprofv3 --pmc FETCH_SIZE  --output-format csv -d gpurun_out/prof_r5/standalone_pmc/l2fetch -- python3 tools/standalone_kernels.py l2
+    rocprofv3 --pmc WRITE_SIZE  --output-format csv -d gpurun_out/prof_r5/standalone_pmc/l2write -- python3 tools/standalone_kernels.py l2
+
+`hbm`: only the two HBM-bound kernels whose bytes are the claim (re-weighting scan, coreset round).  `l2`: only the distance GEMM
+(the dominant kernel of bench.py's `roofline`) at its four shapes.  The algorithmic work of every launch is written to
+standalone_work.json next to the trace (kernel-name prefix -> bytes / flops per launch; `seq` = (first, count) in the kernel's
+launch order where one kernel name runs several shapes on the same grid)."""
 import json
 import os
 import sys
@@ -22,6 +27,7 @@ from cmdiad_amd.synth import synth_cloud, synth_cloud_fixed_n  # noqa: E402
 
 DEV = "cuda"
 only_hbm = len(sys.argv) > 1 and sys.argv[1] == "hbm"
+only_l2 = len(sys.argv) > 1 and sys.argv[1] == "l2"
 B, G, K, D = 32, 1024, 128, 768
 g = torch.Generator().manual_seed(0)
 work = {}
@@ -31,8 +37,44 @@ def sync():
     torch.cuda.synchronize()
 
 
+# ---- distance GEMM + running minimum (features.py:186-190,227): l2_min_pp3_kernel alone, at the shapes it runs at
+def l2_rows():
+    from cmdiad_amd import engine as eng
+    n_launch, seq = 7, 0
+    Qmax, live = B * 3136, 54401              # bench.py: 100 352 rows per step, 54 401 of them distinct at its clouds
+    q16, _, qsq = ops.normalize_cast(torch.randn(Qmax, D, generator=g).to(DEV), want_f32=False)
+    xyz = eng.Bank(torch.randn(76518, D, generator=g).to(DEV))
+    rgb = eng.Bank(torch.randn(19129, D, generator=g).to(DEV))
+    shard = eng.Bank(xyz.f32, 0, 8)           # rank 0's row shard of an 8-rank node (9 600 rows)
+    cnt = torch.tensor([live], dtype=torch.int32, device=DEV)
+    cap = (live + 255) // 256 * 256
+    seg_cnt = torch.full((8,), live, dtype=torch.int32, device=DEV)
+    q_seg, s_seg = q16[:cap].repeat(8, 1), qsq[:cap].repeat(8)
+    k_all, k_seg = ops.new_keys(Qmax, DEV), ops.new_keys(8 * cap, DEV)
+    shapes = (
+        ("bench", live, xyz, lambda: ops.l2_min_keys_counted(q16, qsq, cnt, xyz.bf16, xyz.sqnorm, k_all, 0),
+         "the bench's launch: 54 401 live rows (device-resident count, grid sized for 100 352) x xyz library 76 518 (+26 pad) x 768, fp16"),
+        ("all", Qmax, xyz, lambda: ops.l2_min_keys(q16, qsq, xyz.bf16, xyz.sqnorm, k_all, 0),
+         "every row searched (CMDIAD_DEDUP=0, the reference's cdist): 100 352 x 76 518 x 768"),
+        ("w8", 8 * live, shard, lambda: ops.l2_min_keys_segments(q_seg, s_seg, seg_cnt, cap, shard.bf16, shard.sqnorm, k_seg, 0),
+         "one rank of an 8-rank node (configs[3]): 8 segments x 54 401 live rows x its 9 600-row shard, one segments launch"),
+        ("rgb", B * 784, rgb, lambda: ops.l2_min_keys(q16[:B * 784], qsq[:B * 784], rgb.bf16, rgb.sqnorm, k_all[:B * 784], 0),
+         "rgb library: 25 088 x 19 129 (+71 pad) x 768"),
+    )
+    for tag, rows_q, bank, fn, what in shapes:
+        for _ in range(n_launch):
+            fn()
+            sync()
+        nb = bank.bf16.shape[0]
+        work[f"l2_min_pp3_kernel/{tag}"] = dict(flops=2.0 * rows_q * nb * D, bytes=(nb + rows_q) * D * 2 + 12 * rows_q, what=what,
+                                               seq=[seq, n_launch])
+        seq += n_launch
+
+
+if not only_hbm:
+    l2_rows()
 # ---- re-weighting scan (features.py:235-254): 32 probes, the fp32 library streamed once
-for name, rows in (("xyz", 76518), ("rgb", 19129)):
+for name, rows in (() if only_l2 else (("xyz", 76518), ("rgb", 19129))):
     bank = torch.randn(rows, D, generator=g).to(DEV)
     blk = ops.bank_block16(bank)
     probes = bank[:32].contiguous()
@@ -42,15 +84,16 @@ for name, rows in (("xyz", 76518), ("rgb", 19129)):
     work[f"reweight_scan_mfma_kernel/{rows}"] = dict(bytes=rows * D * 4, what=f"re-weighting scan, {name} library {rows} x 768 fp32, 32 probes", match_rows=rows)
     del bank, blk
 # ---- greedy coreset round (features.py:401-420): 765 184 x 334 fp16 rows per round
-n, d = 765184, 334
-z = torch.randn(n, d, device=DEV)
-coreset.greedy_coreset(z, 5)
-sync()
-coreset.greedy_coreset(z, 201)
-sync()
-work["coreset_round_kernel"] = dict(bytes=n * d * 2, what="greedy coreset round, 765 184 x 334 fp16 (bagel xyz)")
-del z
-if not only_hbm:
+if not only_l2:
+    n, d = 765184, 334
+    z = torch.randn(n, d, device=DEV)
+    coreset.greedy_coreset(z, 5)
+    sync()
+    coreset.greedy_coreset(z, 201)
+    sync()
+    work["coreset_round_kernel"] = dict(bytes=n * d * 2, what="greedy coreset round, 765 184 x 334 fp16 (bagel xyz)")
+    del z
+if not only_hbm and not only_l2:
     # ---- farthest point sampling + kNN grouping (models/models.py:70-113)
     pcs = torch.cat([synth_cloud_fixed_n(1000 + i, 24576) for i in range(B)]).to(DEV)
     xyz, nz, pix2pt, nv = ops.unorganize(pcs, 24576)
@@ -103,6 +146,8 @@ if not only_hbm:
     work["gemm_tn_kernel"] = dict(flops=2.0 * M * 1920 * 1920, what="dW = sum_m P[m,:]^T Q[m,:], 1920 x 1920 x 100 352, split-K 8")
 out_dir = os.environ.get("STANDALONE_WORK_DIR", "gpurun_out")
 os.makedirs(out_dir, exist_ok=True)
-if not only_hbm:      # (the counter passes repeat a subset: they must not overwrite the full table)
+if not only_hbm and not only_l2:      # (the counter passes repeat a subset: they must not overwrite the full table)
     json.dump(work, open(os.path.join(out_dir, "standalone_work.json"), "w"), indent=1)
+elif only_l2:
+    json.dump(work, open(os.path.join(out_dir, "standalone_work_l2.json"), "w"), indent=1)
 print("done", sorted(work))

@@ -28,24 +28,42 @@ def short(name):
 
 
 dur = collections.defaultdict(list)
+by_name = collections.defaultdict(list)        # kernel name -> [(start, grid, us)] in launch order: `seq` rows (one name, several shapes)
 for f in glob.glob(os.path.join(trace_dir, "**", "*kernel_trace.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        dur[(short(r["Kernel_Name"]), int(r["Grid_Size_X"]) * max(int(r.get("Grid_Size_Y", 1) or 1), 1))].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+        grid = int(r["Grid_Size_X"]) * max(int(r.get("Grid_Size_Y", 1) or 1), 1)
+        us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        dur[(short(r["Kernel_Name"]), grid)].append(us)
+        by_name[short(r["Kernel_Name"])].append((int(r["Start_Timestamp"]), grid, us))
+for v in by_name.values():
+    v.sort()
 pmc = collections.defaultdict(lambda: collections.defaultdict(list))
+pmc_seq = collections.defaultdict(lambda: collections.defaultdict(list))   # kernel name -> counter -> [(dispatch id, value)]
 if pmc_dir:
     for f in glob.glob(os.path.join(pmc_dir, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             pmc[(short(r["Kernel_Name"]), int(r["Grid_Size"]))][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            pmc_seq[short(r["Kernel_Name"])][r["Counter_Name"]].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
+    for c in pmc_seq.values():
+        for v in c.values():
+            v.sort()
 
 print("| kernel | grid (threads) | launches | mean us | algorithmic work per launch | achieved | fraction of peak | fabric bytes per launch (PMC) | what |")
 print("|---|---|---|---|---|---|---|---|---|")
 for key, spec in work.items():
     kname = key.split("/")[0]
     cands = sorted(((k, v) for k, v in dur.items() if kname in k[0]), key=lambda kv: -kv[0][1])
+    seq_pmc = None
+    if "seq" in spec and cands:             # launches [first, first + count) of this kernel name, in launch order
+        first, count = spec["seq"]
+        full = next(n for n in by_name if kname in n)
+        rows = by_name[full][first:first + count]
+        cands = [((full, rows[0][1]), [us for _, _, us in rows])] if rows else []
+        seq_pmc = {cn: [val for _, val in vals[first:first + count]] for cn, vals in pmc_seq.get(full, {}).items()}
     if not cands:
         print(f"| `{kname}` | - | 0 | - | - | - | - | - | {spec['what']} (not in the trace) |")
         continue
-    if "/" in key:                          # the same kernel at two sizes: xyz / rgb library, fixed / ragged batch
+    if "/" in key and "seq" not in spec:    # the same kernel at two sizes: xyz / rgb library, fixed / ragged batch
         tag = key.split("/")[1]
         cands = [cands[0]] if tag in ("76518", "fixed") else [cands[-1]]
         if tag in ("fixed", "var"):         # same grid (32 blocks): split by launch order (the fixed-N batch runs first)
@@ -65,7 +83,7 @@ for key, spec in work.items():
         ach, frac, unit = spec["bytes"] / us / 1e3, spec["bytes"] / us / 1e3 / 8000.0, "GB/s"
         algo = f"{spec['bytes'] / 1e6:.1f} MB"
     fab = "-"
-    c = pmc.get(k)
+    c = seq_pmc if seq_pmc is not None else pmc.get(k)
     if c:
         parts = []
         if "FETCH_SIZE" in c:
