@@ -979,6 +979,11 @@ int launch_wide(Kern kernel, long M, long N, long K, P& p, const GlobalTile& A, 
 }
 #endif  // CMDIAD_AB_VARIANTS
 
+// (Round 5 tried 160-row tiles -- Shape<160,128,4,2>, 5 x 4 MFMA tiles per wave, still two blocks per CU -- for the in-place residual
+// products, whose 128-row tile count is a bad fit for 512 block slots at the ViT's batch-32 shape: 1 182 tiles = 2.31 rounds against
+// 942 = 1.84.  Bit-identical, and measured on one box, interleaved: proj 54.9 -> 56.5 us, fc2 139.1 -> 143.9 us, the whole step
+// 22.46 -> 22.72 ms: a partly filled last round is NOT a whole round -- its blocks have their CU to themselves and run ~1.5x faster,
+// and in the pipeline the other streams' kernels take the idle CUs.  Removed; profiles/r5_notes.md section 2.)
 template <class S>
 dim3 grid_for(long M, long N, int y = 1, int panel = 1)
 {

@@ -165,13 +165,13 @@ __device__ __forceinline__ void compute_stage(AccT& acc, const char* ta, const c
     if constexpr (S::MI == 4) {
         // all fragment reads of the K-step are issued up front (both 32-deep halves, 64 VGPRs): the second
         // half's LDS latency hides behind the first half's MFMAs instead of being exposed a second time
-        frag af[2][4], wf[2][4];
+        frag af[2][S::MI], wf[2][4];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int chunk = kk * 4 + (lane >> 4);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                af[kk][i] = *reinterpret_cast<const frag*>(ta + lds_off(wr * 64 + i * 16 + (lane & 15), chunk));
+            for (int i = 0; i < S::MI; ++i)
+                af[kk][i] = *reinterpret_cast<const frag*>(ta + lds_off(wr * (S::MI * 16) + i * 16 + (lane & 15), chunk));
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 wf[kk][j] = *reinterpret_cast<const frag*>(tw + lds_off(wc * 64 + j * 16 + (lane & 15), chunk));
@@ -180,7 +180,7 @@ __device__ __forceinline__ void compute_stage(AccT& acc, const char* ta, const c
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < S::MI; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = SWAP ? mfma16(wf[kk][j], af[kk][i], acc[i][j]) : mfma16(af[kk][i], wf[kk][j], acc[i][j]);
@@ -274,9 +274,11 @@ __device__ __forceinline__ void run(const ALoader& A, const WLoader& W, int m0, 
         if (++kt_s == KT) { kt_s = 0; ++nt_s; }
     };
     stage_next(0);
-    if (AHEAD == 2 && total >= 2) {
-        stage_next(1);
-        wait_vmcnt<S::GL>();  // step 0 landed, step 1 may still be in flight
+    if constexpr (AHEAD == 2) {
+        if (total >= 2) {
+            stage_next(1);
+            wait_vmcnt<S::GL>();  // step 0 landed, step 1 may still be in flight
+        } else wait_vmcnt<0>();
     } else wait_vmcnt<0>();
     block_barrier();
 
@@ -294,7 +296,9 @@ __device__ __forceinline__ void run(const ALoader& A, const WLoader& W, int m0, 
         }
         // step it+1 must be in LDS before anyone reads it; with 3 stages the loads issued in THIS step
         // (step it+2) may stay in flight across the barrier
-        if (AHEAD == 2 && more) wait_vmcnt<S::GL>(); else wait_vmcnt<0>();
+        if constexpr (AHEAD == 2) {
+            if (more) wait_vmcnt<S::GL>(); else wait_vmcnt<0>();
+        } else wait_vmcnt<0>();
         block_barrier();
         if (++kt == KT) { kt = 0; ++nt; }
         slot = slot + 1 == ST ? 0 : slot + 1;

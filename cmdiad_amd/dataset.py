@@ -1,4 +1,5 @@
-"""Trainer input path for the FtoF distillation.
+"""Trainer input paths: the feature-to-feature trainer's files + the pair files of the
+feature-to-input / input-to-feature heads (FeatureToInputPreTrainTensorDataset, InputToFeaturePreTrainTensorDataset, PairRing below).
 
 On-disk format (written by DoubleRGBPointFeatures with --save_feature_for_fusion, reference
 multiple_features.py:815-825 / 942-945; this package's drop-in writes the same): one ``torch.save``d float32 tensor
@@ -42,6 +43,151 @@ class PreTrainTensorDataset(Dataset):
     def __getitem__(self, idx):
         tensor = torch.load(Path(self.root_path, self.tensor_paths[idx]), map_location="cuda")
         return tensor, 0
+
+
+class FeatureToInputPreTrainTensorDataset(Dataset):
+    """The feature-to-INPUT heads' training pairs (reference dataset.py:268-314; selected at
+    hallucination_network_pretrain.py:180-201 for RGBFeatureToXYZInput{MLP,Conv} / XYZFeatureToRGBInput{MLP,Conv}).
+    Files as DoubleRGBPointFeatures writes them with --save_frgb_xyz / --save_rgb_fxyz (multiple_features.py:827-867, 947-962;
+    this package's drop-in writes the same names):
+      data_type 'xyz_frgb': <root>/frgb/<class><i>_frgb.pt [3136, 768]  +  <root>/xyz/<class><i>_xyz.pt [3, 224, 224]  -> (frgb, xyz)
+      data_type 'rgb_fxyz': <root>/rgb/<class><i>_rgb.pt [3, 224, 224]  +  <root>/fxyz/<class><i>_hfxyz.pt [3136, 768]  -> (fxyz, rgb)
+    (the [784, 768] `_lfxyz.pt` files beside them are not read), both loaded straight onto the GPU, paired by SORTED path -- a
+    plain string sort, so bagel10 comes before bagel2 in both lists alike.  Any other data_type leaves the object without a
+    length, as the reference does."""
+
+    def __init__(self, root_path, data_type):
+        super().__init__()
+        self.root_path = root_path
+        self.data_type = data_type
+        if data_type == 'rgb_fxyz':
+            self.rgb_root_path = Path(root_path, 'rgb')
+            self.fxyz_root_path = Path(root_path, 'fxyz')
+            self.rgb_paths = sorted(self.rgb_root_path.glob('*.pt'))
+            self.fxyz_paths = sorted(self.fxyz_root_path.glob('*hfxyz.pt'))
+            assert len(self.rgb_paths) == len(self.fxyz_paths)
+            self.len = len(self.rgb_paths)
+        elif data_type == 'xyz_frgb':
+            self.frgb_root_path = Path(root_path, 'frgb')
+            self.xyz_root_path = Path(root_path, 'xyz')
+            self.frgb_paths = sorted(self.frgb_root_path.glob('*.pt'))
+            self.xyz_paths = sorted(self.xyz_root_path.glob('*.pt'))
+            assert len(self.frgb_paths) == len(self.xyz_paths)
+            self.len = len(self.frgb_paths)
+
+    device = 'cuda'      # torch.load(map_location=...) of __getitem__ (the reference hard-codes 'cuda'; CPU tests override it)
+
+    def __len__(self):
+        return self.len
+
+    def pair_paths(self, idx):
+        """(first, second) file of sample idx, in the order __getitem__ returns them."""
+        if self.data_type == 'rgb_fxyz':
+            return self.fxyz_paths[idx], self.rgb_paths[idx]
+        if self.data_type == 'xyz_frgb':
+            return self.frgb_paths[idx], self.xyz_paths[idx]
+        return None
+
+    def __getitem__(self, idx):
+        pair = self.pair_paths(idx)
+        if pair is None:
+            return None          # (the reference's __getitem__ falls through both branches)
+        return torch.load(pair[0], map_location=self.device), torch.load(pair[1], map_location=self.device)
+
+
+class InputToFeaturePreTrainTensorDataset(Dataset):
+    """The input-to-FEATURE (HRNet) heads' training pairs (reference dataset.py:317-362; selected at
+    hallucination_network_pretrain.py:203-214 for RGBInputToXYZFeatureHRNET / XYZInputToRGBFeatureHRNET): the same files as
+    FeatureToInputPreTrainTensorDataset in the OTHER order -- 'rgb_fxyz' -> (rgb [3,224,224], fxyz [3136,768]),
+    'xyz_frgb' -> (xyz, frgb) -- loaded to the HOST (the reference's DataLoader pins and moves them); any other data_type
+    raises NotImplementedError."""
+
+    def __init__(self, root_path, data_type):
+        super().__init__()
+        self.data_type = data_type
+        self.root_path = root_path
+        if data_type == 'rgb_fxyz':
+            self.rgb_root_path = Path(root_path, 'rgb')
+            self.fxyz_root_path = Path(root_path, 'fxyz')
+            self.rgb_paths = sorted(self.rgb_root_path.glob('*.pt'))
+            self.fxyz_paths = sorted(self.fxyz_root_path.glob('*hfxyz.pt'))
+            assert len(self.rgb_paths) == len(self.fxyz_paths)
+            self.len = len(self.rgb_paths)
+        elif data_type == 'xyz_frgb':
+            self.frgb_root_path = Path(root_path, 'frgb')
+            self.xyz_root_path = Path(root_path, 'xyz')
+            self.frgb_paths = sorted(self.frgb_root_path.glob('*.pt'))
+            self.xyz_paths = sorted(self.xyz_root_path.glob('*.pt'))
+            assert len(self.frgb_paths) == len(self.xyz_paths)
+            self.len = len(self.frgb_paths)
+        else:
+            raise NotImplementedError
+
+    def __len__(self):
+        return self.len
+
+    def pair_paths(self, idx):
+        if self.data_type == 'rgb_fxyz':
+            return self.rgb_paths[idx], self.fxyz_paths[idx]
+        return self.xyz_paths[idx], self.frgb_paths[idx]
+
+    def __getitem__(self, idx):
+        a, b = self.pair_paths(idx)
+        return torch.load(a), torch.load(b)
+
+
+class PairRing:
+    """What FeatureRing is for the feature-to-feature trainer, for the PAIR datasets above: one epoch of batches
+    ``(first [b, ...], second [b, ...])`` already resident in HBM, in the order and composition the reference's
+    ``DataLoader(dataset, shuffle=..., batch_size=..., drop_last=...)`` produces under the same global torch seed
+    (`epoch_permutation`).  A pair is 9.6 MB + 0.6 MB, the ten MVTec 3D-AD classes 2 650 pairs = 27 GB: every pair is read from disk
+    ONCE (the first epoch, `readers` host threads), kept in two device-resident caches, and every later batch is an on-device
+    gather -- no DataLoader workers, no per-step H2D.  Works on the host too (device='cpu': tests)."""
+
+    def __init__(self, dataset, batch_size, shuffle=True, drop_last=True, device="cuda", readers=4):
+        self.ds, self.batch_size, self.shuffle, self.drop_last = dataset, batch_size, shuffle, drop_last
+        self.device, self.readers = torch.device(device), readers
+        a, b = (torch.load(p, map_location="cpu") for p in dataset.pair_paths(0))
+        n = len(dataset)
+        self._cache = (torch.empty((n, *a.shape), dtype=a.dtype, device=self.device), torch.empty((n, *b.shape), dtype=b.dtype, device=self.device))
+        self._have = torch.zeros(n, dtype=torch.bool)
+
+    def __len__(self):
+        n = len(self.ds)
+        return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
+
+    def batches(self):
+        order = epoch_permutation(len(self.ds), self.shuffle)
+        out = [order[i:i + self.batch_size] for i in range(0, len(order), self.batch_size)]
+        if self.drop_last and out and len(out[-1]) < self.batch_size:
+            out.pop()
+        return out
+
+    def _fill(self, idxs):
+        todo = [i for i in idxs if not bool(self._have[i])]
+        if not todo:
+            return
+
+        def one(i):
+            pa, pb = self.ds.pair_paths(i)
+            return i, torch.load(pa, map_location="cpu"), torch.load(pb, map_location="cpu")
+
+        if self.readers > 1 and len(todo) > 1:
+            import concurrent.futures as cf
+            with cf.ThreadPoolExecutor(max_workers=self.readers) as ex:
+                got = list(ex.map(one, todo))
+        else:
+            got = [one(i) for i in todo]
+        for i, a, b in got:
+            self._cache[0][i].copy_(a, non_blocking=True)
+            self._cache[1][i].copy_(b, non_blocking=True)
+            self._have[i] = True
+
+    def __iter__(self):
+        for idxs in self.batches():
+            self._fill(idxs)
+            sel = torch.tensor(idxs, dtype=torch.int64, device=self.device)
+            yield self._cache[0].index_select(0, sel), self._cache[1].index_select(0, sel)
 
 
 def epoch_permutation(n, shuffle):

@@ -340,6 +340,10 @@ class Features(torch.nn.Module):
         self.image_labels = np.stack(self.image_labels)
         self.pixel_preds = np.array(self.pixel_preds)
         self.img_name = np.stack(self.img_name)
+        if getattr(self.args, "save_raw_results", False):       # features.py:316-318 (the directory is created here)
+            txt_to_save = np.concatenate((self.image_preds, self.image_labels, self.img_name), axis=1)
+            os.makedirs(f'./visualization/{self.args.experiment_note}', exist_ok=True)
+            np.savetxt(f'./visualization/{self.args.experiment_note}/{self.class_name}_raw_results.csv', txt_to_save, delimiter=',', fmt="%s")
         self.image_rocauc = roc_auc_score(self.image_labels, self.image_preds)
         self.pixel_rocauc = roc_auc_score(self.pixel_labels, self.pixel_preds)
         self.au_pro, _ = calculate_au_pro(self.gts, self.predictions)

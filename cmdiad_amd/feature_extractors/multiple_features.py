@@ -348,17 +348,55 @@ class DoubleRGBPointFeatures(_MethodBase):
             torch.save(torch.cat([x, r], dim=1).cpu(), os.path.join(self.args.save_path, split, self.class_name + str(self.ins_id) + '.pt'))
             self.ins_id += 1
 
-    def _patches(self, samples):
-        if getattr(self.args, "use_depth", False):
+    def _save_pairs(self, samples, ex, xyz_patch, rgb_patch2, split):
+        """--save_frgb_xyz / --save_rgb_fxyz (multiple_features.py:827-867 while the memory bank is built, :947-962 in predict):
+        the training pairs of the feature-to-input and input-to-feature heads, per sample
+          <save_path_frgb_xyz>/<split>/frgb/<class><i>_frgb.pt  [3136, 768] f32 (ViT features on the 56 x 56 grid)
+          <save_path_frgb_xyz>/<split>/xyz/<class><i>_xyz.pt    [3, 224, 224]     (the organised point map as given)
+          <save_path_rgb_fxyz>/<split>/fxyz/<class><i>_hfxyz.pt [3136, 768] f32, _lfxyz.pt [784, 768] f32 (Point-MAE patch features
+                                                                 pooled to 56 x 56 / 28 x 28), <split>/rgb/<class><i>_rgb.pt [3, 224, 224]
+        read back by cmdiad_amd.dataset.{FeatureToInput,InputToFeature}PreTrainTensorDataset.  Tensors are saved from the host,
+        where the reference's patches live (features.py:139-140)."""
+        a = self.args
+        if getattr(a, "save_frgb_xyz", False):
+            for sub in ("frgb", "xyz"):
+                for sp in ("train", "test"):
+                    os.makedirs(os.path.join(a.save_path_frgb_xyz, sp, sub), exist_ok=True)
+            for smp, r in zip(samples, rgb_patch2):
+                pc = smp[1].squeeze()
+                assert tuple(pc.shape) == (3, 224, 224)
+                stem = self.class_name + str(self.ins_id2)
+                torch.save(r.cpu(), os.path.join(a.save_path_frgb_xyz, split, 'frgb', stem + '_frgb.pt'))
+                torch.save(pc.cpu(), os.path.join(a.save_path_frgb_xyz, split, 'xyz', stem + '_xyz.pt'))
+                self.ins_id2 += 1
+        if getattr(a, "save_rgb_fxyz", False):
+            for sub in ("rgb", "fxyz"):
+                for sp in ("train", "test"):
+                    os.makedirs(os.path.join(a.save_path_rgb_fxyz, sp, sub), exist_ok=True)
+            low = self._engine.xyz_patch(ex, P=28)          # get_xyz_patch(..., get_2828=True), features.py:169-184
+            for smp, hi, lo in zip(samples, xyz_patch, low):
+                img = smp[0].squeeze()
+                assert tuple(lo.shape) == (784, 768) and tuple(hi.shape) == (3136, 768) and tuple(img.shape) == (3, 224, 224)
+                stem = self.class_name + str(self.ins_id3)
+                torch.save(hi.cpu(), os.path.join(a.save_path_rgb_fxyz, split, 'fxyz', stem + '_hfxyz.pt'))
+                torch.save(lo.cpu(), os.path.join(a.save_path_rgb_fxyz, split, 'fxyz', stem + '_lfxyz.pt'))
+                torch.save(img.cpu(), os.path.join(a.save_path_rgb_fxyz, split, 'rgb', stem + '_rgb.pt'))
+                self.ins_id3 += 1
+
+    def _patches(self, samples, split=None):
+        if getattr(self.args, "use_depth", False) and split != 'train':
             samples = [(s[1], s[1], *s[2:]) for s in samples]   # multiple_features.py:931-932: the point map stands in for the image
         ex = self._extract_batch(samples)
-        return self._engine.xyz_patch(ex, P=56), eng.Engine.rgb_patch(ex), eng.Engine.rgb_patch56(ex)
+        xyz_patch, rgb_patch, rgb_patch2 = self._engine.xyz_patch(ex, P=56), eng.Engine.rgb_patch(ex), eng.Engine.rgb_patch56(ex)
+        if split is not None:
+            if getattr(self.args, "save_feature_for_fusion", False):
+                self._save_features(xyz_patch, rgb_patch2, split)
+            if getattr(self.args, "save_frgb_xyz", False) or getattr(self.args, "save_rgb_fxyz", False):
+                self._save_pairs(samples, ex, xyz_patch, rgb_patch2, split)
+        return xyz_patch, rgb_patch, rgb_patch2
 
     def _fit_batch(self, samples):
-        ex = self._extract_batch(samples)
-        xyz_patch, rgb_patch, rgb_patch2 = self._engine.xyz_patch(ex, P=56), eng.Engine.rgb_patch(ex), eng.Engine.rgb_patch56(ex)
-        if getattr(self.args, "save_feature_for_fusion", False):
-            self._save_features(xyz_patch, rgb_patch2, 'train')
+        xyz_patch, rgb_patch, _ = self._patches(samples, 'train')
         self.patch_xyz_lib.extend(xyz_patch.unbind(0))
         self.patch_rgb_lib.extend(rgb_patch.unbind(0))
 
@@ -375,9 +413,7 @@ class DoubleRGBPointFeatures(_MethodBase):
         self.patch_rgb_lib = self._coreset(eng.normalize(self.patch_rgb_lib, self.rgb_mean, self.rgb_std), 'patch_rgb_lib')
 
     def _score_batch(self, samples, test=False):
-        xyz_patch, rgb_patch, rgb_patch2 = self._patches(samples)
-        if test and getattr(self.args, "save_feature_for_fusion", False):
-            self._save_features(xyz_patch, rgb_patch2, 'test')
+        xyz_patch, rgb_patch, rgb_patch2 = self._patches(samples, 'test' if test else None)
         a = self.args
         return self._score_columns([(xyz_patch, self.xyz_mean, self.xyz_std, 'xyz', a.xyz_s_lambda, a.xyz_smap_lambda),
                                     (rgb_patch, self.rgb_mean, self.rgb_std, 'rgb', a.rgb_s_lambda, a.rgb_smap_lambda)])

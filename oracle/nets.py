@@ -229,3 +229,31 @@ def sharpen_pointmae(sd, conv_gain=400.0, qk_gain=36.0):
     logits): the generator lives beside the other synthetic inputs, cmdiad_amd/synth.py, shared by tests, goldens and bench."""
     from cmdiad_amd.synth import sharpen_pointmae as _sharpen
     return _sharpen(sd, conv_gain, qk_gain)
+
+
+# ----------------------------------------------------------------------------- heavy-tailed synthetic weights
+def outlier_vit(seed, channels=(7, 300, 555), gain=250.0, token=400, token_gain=400.0, from_block=2):
+    """synth_state_dict("vit", seed) with the dynamic range of a real DINO checkpoint (models/models.py:35-53 loads
+    `vit_base_patch8_224_dino`): from block `from_block` on a few residual CHANNELS carry values ~100x the typical one on every
+    token ("massive activations": the block's fc2 bias feeds them, as in trained ViTs), and ONE token enters with ~8x the norm of
+    the others (its positional embedding).  Downstream LayerNorms then see rows whose variance is three channels, attention sees one
+    key far from the others, and the bf16 operand casts see 100x outliers beside O(1) values."""
+    sd = synth_state_dict("vit", seed)
+    b = sd[f"blocks.{from_block}.mlp.fc2.bias"].clone()
+    for i, c in enumerate(channels):
+        b[c] += gain * (1.0 if i % 2 == 0 else -0.8)
+    sd[f"blocks.{from_block}.mlp.fc2.bias"] = b
+    pe = sd["pos_embed"].clone()
+    pe[0, token] *= token_gain
+    sd["pos_embed"] = pe
+    return sd
+
+
+def outlier_pointmae(seed, channel=37, gain=50.0):
+    """synth_state_dict("pointmae", seed) with ONE BatchNorm channel of the encoder's first point-MLP at 50x scale
+    (models/models.py:188-190: first_conv.1): the second convolution's input then has one column 50x the others."""
+    sd = synth_state_dict("pointmae", seed)
+    w = sd["encoder.first_conv.1.weight"].clone()
+    w[channel] *= gain
+    sd["encoder.first_conv.1.weight"] = w
+    return sd

@@ -363,9 +363,52 @@ def golden_coreset_tf32():
                         idx=sel.numpy().astype(np.int64))
 
 
+def write_pair_files(root, n=12, class_name="bagel"):
+    """The --save_frgb_xyz / --save_rgb_fxyz files of n train samples as THIS package's drop-in writes them
+    (DoubleRGBPointFeatures._save_pairs, driven without an extractor: sample i's tensors are filled with i, 100 + i, ...)."""
+    from cmdiad_amd.feature_extractors.multiple_features import DoubleRGBPointFeatures
+    me = types.SimpleNamespace(args=_ns(save_frgb_xyz=True, save_rgb_fxyz=True, save_path_frgb_xyz=os.path.join(root, "frgb_xyz"),
+                                        save_path_rgb_fxyz=os.path.join(root, "rgb_fxyz")),
+                               class_name=class_name, ins_id2=0, ins_id3=0,
+                               _engine=types.SimpleNamespace(xyz_patch=lambda ex, P: ex))
+    for i in range(n):
+        sample = (torch.full((1, 3, 224, 224), float(i)), torch.full((1, 3, 224, 224), 100.0 + i))
+        DoubleRGBPointFeatures._save_pairs(me, [sample], torch.full((1, 784, 768), 300.0 + i), torch.full((1, 3136, 768), 200.0 + i),
+                                           torch.full((1, 3136, 768), 400.0 + i), "train")
+    return me
+
+
+def golden_datasets():
+    """G13: the reference's OWN pair datasets (dataset.py:268-362) over files this package's drop-in wrote: per class and data_type the
+    length and, per index, which sample's tensors come back in which order (every tensor is filled with a value that names its
+    sample and kind).  map_location='cuda' of the feature-to-input class is served from the host here (no GPU in this container)."""
+    import tempfile
+    import dataset as rds      # the reference's dataset.py
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        write_pair_files(td)
+        orig = torch.load
+        torch.load = lambda f, map_location=None, **kw: orig(f, map_location="cpu", **kw)
+        try:
+            for cls in ("FeatureToInputPreTrainTensorDataset", "InputToFeaturePreTrainTensorDataset"):
+                for dt in ("xyz_frgb", "rgb_fxyz"):
+                    ds = getattr(rds, cls)(os.path.join(td, dt.split("_")[1] + "_" + dt.split("_")[0] if dt == "xyz_frgb" else dt, "train"), dt)
+                    rows = []
+                    for i in range(len(ds)):
+                        a, b = ds[i]
+                        rows.append([float(a.flatten()[0]), a.dim(), a.shape[0], float(b.flatten()[0]), b.dim(), b.shape[0]])
+                    out[f"{cls}.{dt}"] = np.array(rows)
+        finally:
+            torch.load = orig
+    np.savez_compressed(os.path.join(HERE, "g13_datasets.npz"), n=12, **out)
+    print({k: v.shape for k, v in out.items()})
+
+
 def main():
     _install_stubs()
     sys.path.insert(0, REF)
+    if len(sys.argv) > 1 and sys.argv[1] == "g13":  # only the pair-dataset fixture
+        return golden_datasets()
     if len(sys.argv) > 1 and sys.argv[1] == "g5b":  # only the mlp_depth = 2 hallucination fixture
         return golden_halluc_depth2()
     if len(sys.argv) > 1 and sys.argv[1] == "g10":  # only the distillation-head fixture

@@ -222,3 +222,69 @@ def test_method_classes_run_the_protocol_with_each_head(flags, cls_name, head_ki
     m.calculate_metrics()
     assert np.isfinite([m.image_rocauc, m.pixel_rocauc, m.au_pro]).all()
     assert m.predictions[0].shape == (224, 224) and np.isfinite(m.predictions[0]).all()
+
+
+def test_dumped_pairs_round_trip_into_the_head_trainers(tmp_path):
+    """the input side of the feature-to-input / input-to-feature trainers, end to end on the device.
+    DoubleRGBPointFeatures with --save_frgb_xyz --save_rgb_fxyz dumps its samples while the memory bank is built and in predict
+    (multiple_features.py:827-867, 947-962); the pair datasets (dataset.py:268-362) read them back; a batch of them drives one
+    training step of the FtoI conv head (hand-written forward + backward, conv_train.ftoi_conv_loss) and of the HRNet trunk
+    (conv_train.hrnet_loss): finite loss, gradients on every parameter.  The dumped features are what the extractor returns."""
+    import os
+    import warnings
+    from cmdiad_amd import dataset as ds
+    from cmdiad_amd import engine as eng
+    from oracle import nets
+    from cmdiad_amd.feature_extractors.multiple_features import DoubleRGBPointFeatures
+    from cmdiad_amd.models.hallucination_network import HallucinationFeatureToInputConv
+    from cmdiad_amd.synth import synth_cloud, synth_rgb
+    a = dict(rgb_backbone_name='vit_base_patch8_224_dino', xyz_backbone_name='Point_MAE', group_size=128, num_group=1024,
+             rgb_size=224, xyz_size=224, gt_size=224, f_coreset=1.0, coreset_eps=0.9, coreset_dtype='FP16',
+             random_state=None, dist_method_s='l2', dist_method_coreset='l2', main_modality='', use_hn=False,
+             fusion_module_path='', ocsvm_nu=0.5, ocsvm_maxiter=1000, xyz_s_lambda=1.0, xyz_smap_lambda=1.0,
+             rgb_s_lambda=0.1, rgb_smap_lambda=0.1, fusion_s_lambda=1.0, fusion_smap_lambda=1.0,
+             save_feature_for_fusion=False, save_seg_results=False, use_depth=False,
+             save_frgb_xyz=True, save_rgb_fxyz=True, save_path_frgb_xyz=str(tmp_path / "frgb_xyz"), save_path_rgb_fxyz=str(tmp_path / "rgb_fxyz"))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = DoubleRGBPointFeatures(types.SimpleNamespace(**a))
+    m.deep_feature_extractor.rgb_backbone.load_state_dict(nets.synth_state_dict("vit", 31))
+    m.deep_feature_extractor.xyz_backbone.load_state_dict(nets.synth_state_dict("pointmae", 21))
+    train = [(synth_rgb(i), synth_cloud(200 + i, 0.30, texture=0.004)) for i in range(3)]
+    for rgb, pc in train:
+        m.add_sample_to_mem_bank((rgb, pc, pc), class_name="synth")
+    m.run_coreset()
+    for sub, names in (("frgb_xyz/train/frgb", ["synth0_frgb.pt", "synth1_frgb.pt", "synth2_frgb.pt"]),
+                       ("frgb_xyz/train/xyz", ["synth0_xyz.pt", "synth1_xyz.pt", "synth2_xyz.pt"]),
+                       ("rgb_fxyz/train/rgb", ["synth0_rgb.pt", "synth1_rgb.pt", "synth2_rgb.pt"])):
+        assert sorted(os.listdir(tmp_path / sub)) == names
+    assert len(os.listdir(tmp_path / "rgb_fxyz" / "train" / "fxyz")) == 6          # _hfxyz + _lfxyz per sample
+    # what was dumped IS the extractor's output for that sample
+    ex = m._extract_batch([(train[1][0], train[1][1], train[1][1])])
+    d1 = ds.FeatureToInputPreTrainTensorDataset(str(tmp_path / "frgb_xyz" / "train"), "xyz_frgb")
+    frgb, xyz = d1[1]
+    assert frgb.is_cuda and tuple(frgb.shape) == (3136, 768) and tuple(xyz.shape) == (3, 224, 224)
+    assert torch.equal(frgb, eng.Engine.rgb_patch56(ex)[0]) and torch.equal(xyz.cpu(), train[1][1][0])
+    d2 = ds.InputToFeaturePreTrainTensorDataset(str(tmp_path / "rgb_fxyz" / "train"), "rgb_fxyz")
+    rgb, fxyz = d2[1]
+    assert not rgb.is_cuda and torch.equal(rgb, train[1][0][0]) and torch.equal(fxyz.to(DEV), m._engine.xyz_patch(ex, P=56)[0])
+    lo = torch.load(tmp_path / "rgb_fxyz" / "train" / "fxyz" / "synth1_lfxyz.pt")
+    assert torch.equal(lo.to(DEV), m._engine.xyz_patch(ex, P=28)[0])
+    # one training step of each head from a batch of the dumped pairs
+    torch.manual_seed(0)
+    ring = ds.PairRing(d1, 2, shuffle=True, drop_last=True, device=DEV)
+    feat, img = next(iter(ring))
+    head = HallucinationFeatureToInputConv(None, 768).to(DEV).train()
+    loss = head(feat, img)
+    loss.backward()
+    assert torch.isfinite(loss) and all(p.grad is not None and torch.isfinite(p.grad).all() for n, p in head.named_parameters() if not n.startswith("norm"))
+    ring2 = ds.PairRing(d2, 2, shuffle=False, drop_last=True, device=DEV)
+    img2, feat2 = next(iter(ring2))
+    trunk = HRNet(48, 768, 0.1).to(DEV).train()
+    loss2 = trunk(img2, feat2)
+    loss2.backward()
+    assert torch.isfinite(loss2) and all(p.grad is not None for p in trunk.parameters())
+    # predict dumps under test/
+    m.predict((train[0][0], train[0][1], train[0][1]), torch.zeros(1, 224, 224), 0, ["x.png"])
+    _ = m.image_preds            # (reading a result attribute runs the deferred micro-batch)
+    assert sorted(os.listdir(tmp_path / "frgb_xyz" / "test" / "frgb")) == ["synth3_frgb.pt"]
