@@ -86,6 +86,7 @@ SIGNATURES = {
     "cmdiad_rows_expand_f32": [P, P, I, I, P, P],
     "cmdiad_l2_rescore": [P, P, P, I, I, I, U32, P, P, P],
     "cmdiad_reweight_scan": [P, P, P, I, I, I, U32, P, P, SZ, P],
+    "cmdiad_reweight_scan_pair": [P, P, P, I, I, U32, P, P, P, P, I, I, U32, P, I, P, SZ, P],
     "cmdiad_bank_block16": [P, I, I, P, P],
     "cmdiad_col_moments": [P, SZ, I, I, P, P, P],
     "cmdiad_moments3": [P, SZ, P, P],
@@ -117,6 +118,7 @@ SIZE_QUERIES = {
     "cmdiad_gemm_streamk_workspace_bytes": [],
     "cmdiad_fps_workspace_bytes": [I, I],
     "cmdiad_reweight_workspace_bytes": [I, I],
+    "cmdiad_reweight_pair_workspace_bytes": [I, I],
     "cmdiad_bank_block16_floats": [I, I],
     "cmdiad_coreset_workspace_bytes": [I, I, I],
     "cmdiad_coreset_f32_workspace_bytes": [I, I, I],

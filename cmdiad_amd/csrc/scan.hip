@@ -82,14 +82,35 @@ __global__ __launch_bounds__(256) void bank_block16_kernel(const float* __restri
     }
 }
 
+// One scan problem: R probes against one library.  A launch carries one or TWO of them (cmdiad_reweight_scan_pair: the two
+// libraries of a scored batch -- features.py:235-254 runs once per library and sample); the grid's first `blocks` workgroups
+// belong to problem 0, the rest to problem 1.
+struct ScanProblem {
+    const float* probes;
+    const float* blocked;      // cmdiad_bank_block16 copy
+    const float* bank;         // row-major fp32 library (the exact re-evaluation of the merge kernel)
+    int R, Nb;
+    unsigned row_offset;
+    unsigned long long* partial;
+    unsigned long long* top3;
+    int blocks;                // workgroups of the scan kernel that stream this library
+};
+struct ScanPair { ScanProblem p[2]; };
+
 // One wave = 16 library rows x 32 probes at a time.  Groups are dealt to SIMD slots first (slot = CU-major, 4 per CU) and
 // alternate between the slot's two waves, so every SIMD gets the same MFMA work to within one group.
-__global__ __launch_bounds__(kWaves * 64) void reweight_scan_mfma_kernel(const float* __restrict__ probes,
-                                                                         const float* __restrict__ blocked, int R, int Nb,
-                                                                         int D, unsigned row_offset,
-                                                                         unsigned long long* __restrict__ partial)
+__global__ __launch_bounds__(kWaves * 64) void reweight_scan_mfma_kernel(ScanPair pair, int D)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // block-uniform: which library this workgroup streams, and its place among that library's workgroups
+    const bool second = (int)blockIdx.x >= pair.p[0].blocks;
+    const ScanProblem& pb = pair.p[second ? 1 : 0];
+    const float* __restrict__ probes = pb.probes;
+    const float* __restrict__ blocked = pb.blocked;
+    unsigned long long* __restrict__ partial = pb.partial;
+    const int R = pb.R, Nb = pb.Nb;
+    const unsigned row_offset = pb.row_offset;
+    const int bid = (int)blockIdx.x - (second ? pair.p[0].blocks : 0), nblk = pb.blocks;
     const int T = D >> 4;                                       // 16-float k-steps
     float4* s_probe = reinterpret_cast<float4*>(smem);          // [2][T][64] float4, A-operand layout
     float* s_pn = reinterpret_cast<float*>(smem + (size_t)2 * T * 64 * 16);                  // [32] probe norms
@@ -133,8 +154,8 @@ __global__ __launch_bounds__(kWaves * 64) void reweight_scan_mfma_kernel(const f
             for (int k = 0; k < kLane; ++k) top[pg][v][k] = ~0ull;
 
     const int groups = (Nb + 15) >> 4;
-    const int slots = gridDim.x * 4;
-    const int slot = blockIdx.x * 4 + (wave & 3);
+    const int slots = nblk * 4;
+    const int slot = bid * 4 + (wave & 3);
     // the slot's groups are slot, slot + slots, ...; its two waves take them alternately
     const int first = slot + (wave >> 2) * slots;
     const int stride = 2 * slots;
@@ -241,7 +262,7 @@ __global__ __launch_bounds__(kWaves * 64) void reweight_scan_mfma_kernel(const f
                 const unsigned long long key = s_cand[((size_t)w * kProbes + p) * kCand + k];
                 if (key < m[kCand - 1]) list_insert<kCand>(m, key);
             }
-        unsigned long long* o = partial + ((size_t)p * gridDim.x + blockIdx.x) * kCand;
+        unsigned long long* o = partial + ((size_t)p * nblk + bid) * kCand;
 #pragma unroll
         for (int k = 0; k < kCand; ++k) o[k] = m[k];
     }
@@ -249,15 +270,19 @@ __global__ __launch_bounds__(kWaves * 64) void reweight_scan_mfma_kernel(const f
 
 // One block per probe: the kCand smallest approximate keys over all blocks, their EXACT fp32 squared distances, and the
 // three smallest exact keys merged into top3 (which may already hold another shard's / an earlier call's keys).
-__global__ __launch_bounds__(kCand * 64) void reweight_exact_merge_kernel(const unsigned long long* __restrict__ partial,
-                                                                          int nblocks, const float* __restrict__ probes,
-                                                                          const float* __restrict__ bank, int Nb, int D,
-                                                                          unsigned row_offset,
-                                                                          unsigned long long* __restrict__ top3)
+__global__ __launch_bounds__(kCand * 64) void reweight_exact_merge_kernel(ScanPair pair, int D)
 {
     __shared__ unsigned long long s_c[kCand];
     __shared__ unsigned long long s_exact[kCand];
-    const int pr = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool second = (int)blockIdx.x >= pair.p[0].R;       // block-uniform: probes of problem 0 first
+    const ScanProblem& pb = pair.p[second ? 1 : 0];
+    const unsigned long long* __restrict__ partial = pb.partial;
+    const float* __restrict__ probes = pb.probes;
+    const float* __restrict__ bank = pb.bank;
+    unsigned long long* __restrict__ top3 = pb.top3;
+    const int nblocks = pb.blocks;
+    const unsigned row_offset = pb.row_offset;
+    const int pr = (int)blockIdx.x - (second ? pair.p[0].R : 0), wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (wave == 0) {
         unsigned long long m[kCand];
 #pragma unroll
@@ -378,6 +403,25 @@ extern "C" size_t cmdiad_reweight_workspace_bytes(int R, int Nb)
     return (size_t)kProbes * scan_blocks(Nb) * kCand * sizeof(unsigned long long);
 }
 
+static int scan_launch(ScanPair& pair, int D, hipStream_t s, const char* who)
+{
+    const size_t lds = (size_t)2 * (D / 16) * 64 * 16 + kProbes * 4 + (size_t)kWaves * kProbes * kCand * 8;
+    static size_t attr = 0;
+    if (lds > attr) {
+        if (hipFuncSetAttribute((const void*)reweight_scan_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+            hipSuccess) {
+            cmdiad_set_error("%s: %zu bytes of LDS exceed the device limit", who, lds);
+            return CMDIAD_ERR_ARG;
+        }
+        attr = lds;
+    }
+    hipLaunchKernelGGL(reweight_scan_mfma_kernel, dim3(pair.p[0].blocks + pair.p[1].blocks), dim3(kWaves * 64), lds, s, pair, D);
+    CMDIAD_CHECK_LAUNCH();
+    hipLaunchKernelGGL(reweight_exact_merge_kernel, dim3(pair.p[0].R + pair.p[1].R), dim3(kCand * 64), 0, s, pair, D);
+    CMDIAD_CHECK_LAUNCH();
+    return CMDIAD_OK;
+}
+
 extern "C" int cmdiad_reweight_scan(const float* probes, const float* bank, const float* bank_block16, int R, int Nb, int D,
                                     uint32_t row_offset, unsigned long long* top3, void* workspace, size_t workspace_bytes,
                                     cmdiad_stream_t stream)
@@ -389,26 +433,48 @@ extern "C" int cmdiad_reweight_scan(const float* probes, const float* bank, cons
     if (Nb == 0) return CMDIAD_OK;
     CMDIAD_REQUIRE(workspace && workspace_bytes >= cmdiad_reweight_workspace_bytes(R, Nb), CMDIAD_ERR_WORKSPACE,
                    "cmdiad_reweight_scan: workspace too small");
-    const int nblocks = scan_blocks(Nb);
-    const size_t lds = (size_t)2 * (D / 16) * 64 * 16 + kProbes * 4 + (size_t)kWaves * kProbes * kCand * 8;
-    static size_t attr = 0;
-    if (lds > attr) {
-        if (hipFuncSetAttribute((const void*)reweight_scan_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-            hipSuccess) {
-            cmdiad_set_error("cmdiad_reweight_scan: %zu bytes of LDS exceed the device limit", lds);
-            return CMDIAD_ERR_ARG;
-        }
-        attr = lds;
-    }
-    hipStream_t s = (hipStream_t)stream;
+    ScanPair pair{};
+    pair.p[0] = ScanProblem{probes, bank_block16, bank, R, Nb, row_offset, (unsigned long long*)workspace, top3, scan_blocks(Nb)};
+    return scan_launch(pair, D, (hipStream_t)stream, "cmdiad_reweight_scan");
+}
+
+// The two libraries of a scored batch in ONE launch pair (features.py:235-254 runs per library and sample): the scan kernel's
+// workgroups are divided between the libraries in proportion to their rows (one workgroup per CU in all), the merge kernel takes
+// the probes of both.  A call of cmdiad_reweight_scan costs ~45 us of prologue (probes into LDS), candidate merges and the second
+// launch on top of its stream time -- 42 us for the 59 MB rgb library of the bench (0.17 of the HBM rate) behind 68 us for the
+// 235 MB xyz library; as one pair the small library's fixed cost runs beside the large library's stream.  Results are those of two
+// separate calls, bit for bit (a workgroup's candidates do not depend on how many workgroups share the library: every row is
+// seen once, and the eight approximate candidates per probe are re-evaluated exactly either way).
+extern "C" size_t cmdiad_reweight_pair_workspace_bytes(int Nb0, int Nb1)
+{
+    return cmdiad_reweight_workspace_bytes(kProbes, Nb0) + cmdiad_reweight_workspace_bytes(kProbes, Nb1);   // (upper bound: <= 256 workgroups each)
+}
+
+extern "C" int cmdiad_reweight_scan_pair(const float* probes0, const float* bank0, const float* bank0_block16, int R0, int Nb0,
+                                         uint32_t row_offset0, unsigned long long* top3_0, const float* probes1, const float* bank1,
+                                         const float* bank1_block16, int R1, int Nb1, uint32_t row_offset1, unsigned long long* top3_1,
+                                         int D, void* workspace, size_t workspace_bytes, cmdiad_stream_t stream)
+{
+    CMDIAD_REQUIRE(probes0 && bank0 && bank0_block16 && top3_0 && probes1 && bank1 && bank1_block16 && top3_1, CMDIAD_ERR_ARG,
+                   "cmdiad_reweight_scan_pair: null pointer");
+    CMDIAD_REQUIRE(R0 > 0 && R0 <= kProbes && R1 > 0 && R1 <= kProbes && Nb0 > 0 && Nb1 > 0 && D % (16 * kChunk) == 0 && D <= 1024 &&
+                       aligned16h(probes0) && aligned16h(bank0) && aligned16h(bank0_block16) && aligned16h(probes1) && aligned16h(bank1) &&
+                       aligned16h(bank1_block16),
+                   CMDIAD_ERR_ARG, "cmdiad_reweight_scan_pair: 0<R<=32, Nb>0, D%%128==0, D<=1024, 16-byte alignment (R=%d,%d D=%d)", R0, R1, D);
+    CMDIAD_REQUIRE(workspace && workspace_bytes >= cmdiad_reweight_pair_workspace_bytes(Nb0, Nb1), CMDIAD_ERR_WORKSPACE,
+                   "cmdiad_reweight_scan_pair: workspace too small");
+    // one workgroup per CU in all, shared in proportion to the rows; never more than a library alone would get, never fewer than one
+    const int cap0 = scan_blocks(Nb0), cap1 = scan_blocks(Nb1);
+    int b0 = (int)((256.0 * Nb0) / ((double)Nb0 + Nb1) + 0.5);
+    b0 = b0 < 1 ? 1 : (b0 > 255 ? 255 : b0);
+    int b1 = 256 - b0;
+    b0 = b0 > cap0 ? cap0 : b0;
+    b1 = b1 > cap1 ? cap1 : b1;
+    ScanPair pair{};
     unsigned long long* ws = (unsigned long long*)workspace;
-    hipLaunchKernelGGL(reweight_scan_mfma_kernel, dim3(nblocks), dim3(kWaves * 64), lds, s, probes, bank_block16, R, Nb, D,
-                       row_offset, ws);
-    CMDIAD_CHECK_LAUNCH();
-    hipLaunchKernelGGL(reweight_exact_merge_kernel, dim3(R), dim3(kCand * 64), 0, s, (const unsigned long long*)ws, nblocks,
-                       probes, bank, Nb, D, row_offset, top3);
-    CMDIAD_CHECK_LAUNCH();
-    return CMDIAD_OK;
+    pair.p[0] = ScanProblem{probes0, bank0_block16, bank0, R0, Nb0, row_offset0, ws, top3_0, b0};
+    pair.p[1] = ScanProblem{probes1, bank1_block16, bank1, R1, Nb1, row_offset1, ws + (size_t)kProbes * cap0 * kCand, top3_1, b1};
+    return scan_launch(pair, D, (hipStream_t)stream, "cmdiad_reweight_scan_pair");
 }
 
 extern "C" int cmdiad_l2_dist_matrix(const float* q, const float* bank, int Q, int Nb, int D, float* out,

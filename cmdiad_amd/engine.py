@@ -376,6 +376,46 @@ def score_patches_from_keys(patch32, keys, bank, dims, gt_size=224, group=None):
                 s_map_pre=s_map, top3=top3, knn_d=knn_d)
 
 
+def score_patches_from_keys_pair(patch_a, keys_a, bank_a, dims_a, patch_b, keys_b, bank_b, dims_b, gt_size=224, group=None):
+    """score_patches_from_keys for the TWO libraries of a scored batch (multiple_features.py:976-1003: xyz and rgb / fusion) with
+    their re-weighting scans as ONE launch pair (ops.reweight_scan_pair: the small library's fixed cost runs beside the large
+    library's stream); every output is what the two separate calls return, bit for bit.  Falls back to them when a library's fp32
+    rows are sharded, a batch exceeds 32 samples, or the feature widths differ."""
+    B, Qa, D = patch_a.shape
+    if (getattr(bank_a, "f32_sharded", False) or getattr(bank_b, "f32_sharded", False) or B > 32 or patch_b.shape[0] != B
+            or patch_b.shape[2] != D or bank_a.rows == 0 or bank_b.rows == 0 or os.environ.get("CMDIAD_SCAN_PAIR", "1") == "0"):
+        return (score_patches_from_keys(patch_a, keys_a, bank_a, dims_a, gt_size, group),
+                score_patches_from_keys(patch_b, keys_b, bank_b, dims_b, gt_size, group))
+    dev = patch_a.device
+    st = ops._stream()
+    heads = []
+    for patch32, keys, bank in ((patch_a, keys_a, bank_a), (patch_b, keys_b, bank_b)):
+        Q = patch32.shape[1]
+        flat = patch32.reshape(B * Q, D)
+        min_val = torch.zeros((B * Q,), dtype=torch.float32, device=dev)
+        min_idx = torch.full((B * Q,), -1, dtype=torch.int64, device=dev)
+        ops.l2_rescore(flat, bank.f32, keys, min_val, min_idx, 0)
+        s_star = torch.empty((B,), dtype=torch.float32, device=dev)
+        s_idx = torch.empty((B,), dtype=torch.int32, device=dev)
+        m_test = torch.empty((B, D), dtype=torch.float32, device=dev)
+        m_star = torch.empty((B, D), dtype=torch.float32, device=dev)
+        _call("cmdiad_score_head", ops._p(min_val), ops._p(min_idx), ops._p(flat), ops._p(bank.f32), B, Q, D, bank.rows,
+              0, ops._p(s_star), ops._p(s_idx), ops._p(m_test), ops._p(m_star), st)
+        heads.append((min_val, min_idx, s_star, s_idx, m_test, m_star, Q))
+    tops = ops.reweight_scan_pair(heads[0][5], bank_a.f32, bank_a.blk16, heads[1][5], bank_b.f32, bank_b.blk16)
+    out = []
+    for (min_val, min_idx, s_star, s_idx, m_test, m_star, Q), top3, bank, dims in zip(heads, tops, (bank_a, bank_b), (dims_a, dims_b)):
+        knn_d = torch.empty((B, 2), dtype=torch.float32, device=dev)
+        _call("cmdiad_score_tail", ops._p(s_star), ops._p(m_test), ops._p(top3), ops._p(bank.f32), B, D, bank.rows, 0,
+              ops._p(knn_d), st)
+        s = torch.empty((B,), dtype=torch.float32, device=dev)
+        _call("cmdiad_score_final", ops._p(s_star), ops._p(knn_d), B, D, ops._p(s), st)
+        s_map = ops.bilinear_up(min_val.view(B, dims[0], dims[1]), gt_size)
+        out.append(dict(min_val=min_val.view(B, Q), min_idx=min_idx.view(B, Q), s_idx=s_idx, s_star=s_star, s=s,
+                        s_map_pre=s_map, top3=top3, knn_d=knn_d))
+    return out[0], out[1]
+
+
 class Extraction:
     """Device-resident outputs of one extract() call (everything Features.__call__ returns, plus the
     interpolation indices/weights that replace the reference's 154 MB interpolated tensor)."""

@@ -586,6 +586,25 @@ def reweight_scan(probes, bank32, blk16=None, top3=None, row_offset=0):
     return top3
 
 
+def reweight_scan_pair(probes0, bank0, blk0, probes1, bank1, blk1, row_offset0=0, row_offset1=0):
+    """reweight_scan for the TWO libraries of a scored batch in one launch pair (cmdiad_reweight_scan_pair): -> (top3_0, top3_1),
+    each [R,3] packed keys, identical to two separate reweight_scan calls.  R <= 32 per library (a batch of 32 images)."""
+    for t, n in ((probes0, "probes0"), (bank0, "bank0"), (probes1, "probes1"), (bank1, "bank1")):
+        _chk(t, torch.float32, "reweight_pair." + n)
+    (R0, D), R1 = probes0.shape, probes1.shape[0]
+    Nb0, Nb1 = bank0.shape[0], bank1.shape[0]
+    if R0 > 32 or R1 > 32 or Nb0 == 0 or Nb1 == 0 or probes1.shape[1] != D:
+        raise ValueError("reweight_scan_pair: R <= 32 per library, both libraries non-empty, equal D")
+    dev = probes0.device
+    top0 = torch.full((R0, 3), KEY_EMPTY, dtype=torch.int64, device=dev)
+    top1 = torch.full((R1, 3), KEY_EMPTY, dtype=torch.int64, device=dev)
+    wsb = nat.lib().cmdiad_reweight_pair_workspace_bytes(Nb0, Nb1)
+    ws = torch.empty(max(wsb // 8, 1), dtype=torch.int64, device=dev)
+    _call("cmdiad_reweight_scan_pair", _p(probes0), _p(bank0), _p(blk0), R0, Nb0, row_offset0, _p(top0),
+          _p(probes1), _p(bank1), _p(blk1), R1, Nb1, row_offset1, _p(top1), D, _p(ws), wsb, _stream())
+    return top0, top1
+
+
 def l2_dist_matrix(q32, bank32):
     """Exact fp32 [Q,Nb] matrix of L2 distances (features.py:186-190 materialised; API compatibility only)."""
     _chk(q32, torch.float32, "dist_matrix.q"); _chk(bank32, torch.float32, "dist_matrix.bank")

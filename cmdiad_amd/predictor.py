@@ -281,9 +281,9 @@ class BatchPredictor:
     def stage2(self, qs, keys):
         lam = self.lambdas
         gt = self.gt
-        rx = eng.score_patches_from_keys(qs["xyz"][0], keys["xyz"].contiguous(), self.bank_xyz, (56, 56), gt, self.group)
         side = (56, 56) if self.workload == "mtfi" else (28, 28)
-        rr = eng.score_patches_from_keys(qs["rgb"][0], keys["rgb"].contiguous(), self.bank_second, side, gt, self.group)
+        rx, rr = eng.score_patches_from_keys_pair(qs["xyz"][0], keys["xyz"].contiguous(), self.bank_xyz, (56, 56),
+                                                  qs["rgb"][0], keys["rgb"].contiguous(), self.bank_second, side, gt, self.group)
         s = torch.stack([rx["s"], rr["s"]], 1)                                   # [B,2]
         maps = torch.stack([rx["s_map_pre"], rr["s_map_pre"]], 1).contiguous()   # [B,2,gt,gt]
         B = maps.shape[0]

@@ -37,7 +37,9 @@ int cmdiad_abi_version(void); /* 2: cmdiad_reweight_scan's limits and workspace 
                                  3: LayerNorm fold -- cmdiad_gemm_args gained row_scale / ln_xb / ln_part / add2, cmdiad_gemm_qkv gained
                                     row_scale, cmdiad_block_weights the folded weights, cmdiad_transformer_block_fwd its flags;
                                     cmdiad_ln_stats_finalize is new
-                                 4: cmdiad_l2_min_keys_segments, cmdiad_gemm_streamk_*, cmdiad_coreset_greedy_f32, cmdiad_coreset_prepare / _round / _decode, cmdiad_im2col3x3_bf16 are new */
+                                 4: cmdiad_l2_min_keys_segments, cmdiad_gemm_streamk_*, cmdiad_coreset_greedy_f32, cmdiad_coreset_prepare / _round / _decode, cmdiad_im2col3x3_bf16 are new
+                                 5: cmdiad_reweight_scan_pair is new; the value bits of cmdiad_l2_min_keys' keys are the squared distance with
+                                    its four low mantissa bits cleared (see there) */
 /* 1 when the library is the test-only build that also contains the superseded kernel formulations (A/B references). */
 int cmdiad_has_ab_variants(void);
 
@@ -280,10 +282,13 @@ int cmdiad_gemm_groupmax(const uint16_t* A, const uint16_t* W, const float* bias
  * ------------------------------------------------------------------------------------------- */
 
 /* Per-query nearest bank row under L2 (torch.cdist + torch.min(dim=1), features.py:190,227) without
- * materialising the QxNb matrix: bf16 MFMA distance GEMM with a running (min, argmin) epilogue,
- * d2 = |q|^2 + |b|^2 - 2 q.b.  keys[q] = min over rows of ((fp32 bits of max(d2,0)) << 32 | row_offset+row):
+ * materialising the QxNb matrix: 16-bit MFMA distance GEMM whose accumulators start at -(|q|^2 + |b|^2) / 2, so that a
+ * finished accumulator is -d2 / 2, with a running (min, argmin) epilogue.  keys[q] = min over rows of
+ * ((fp32 bits of max(d2', 0)) << 32 | row_offset+row), d2' = d2 with the four low mantissa bits of -d2 / 2 cleared (the
+ * epilogue carries the element's place there; 2^-19 of the value, three orders below the operand rounding):
  * integer order == (distance, index) order, so bank shards combine with an integer MIN (RCCL
- * all-reduce over xGMI) and ties resolve to the lowest global row, as torch.min does.
+ * all-reduce over xGMI) and ties resolve to the lowest global row, as torch.min does.  The key of a (query, row) pair does
+ * not depend on the launch geometry, the tile shape or the shard the row is in.
  * q [Q,D] bf16, q_sqnorm [Q] f32, bank [Nb,D] bf16, bank_sqnorm [Nb] f32 (squared norms of the
  * bf16-rounded rows, from cmdiad_normalize_cast), keys [Q] u64: the caller initialises keys to
  * UINT64_MAX; the kernel combines with atomic min.  D % 64 == 0. */
@@ -358,6 +363,16 @@ size_t cmdiad_reweight_workspace_bytes(int R, int Nb);
 int cmdiad_reweight_scan(const float* probes, const float* bank, const float* bank_block16, int R, int Nb, int D,
                          uint32_t row_offset, unsigned long long* top3, void* workspace, size_t workspace_bytes,
                          cmdiad_stream_t stream);
+/* The same for the TWO libraries of a scored batch in one launch pair (features.py:235-254 runs per library: xyz and rgb / fusion,
+ * multiple_features.py:976-1003): problem 0 and problem 1 each as in cmdiad_reweight_scan (own probes, library, row offset and
+ * top3); the scan kernel's workgroups are shared between the libraries in proportion to their rows, so the small library's fixed
+ * cost (probes into LDS, candidate merges, the exact re-evaluation launch) runs beside the large library's stream instead of after
+ * it.  Results identical to two separate calls.  Both Nb > 0 (an empty shard takes the single-library call for the other). */
+size_t cmdiad_reweight_pair_workspace_bytes(int Nb0, int Nb1);
+int cmdiad_reweight_scan_pair(const float* probes0, const float* bank0, const float* bank0_block16, int R0, int Nb0,
+                              uint32_t row_offset0, unsigned long long* top3_0, const float* probes1, const float* bank1,
+                              const float* bank1_block16, int R1, int Nb1, uint32_t row_offset1, unsigned long long* top3_1,
+                              int D, void* workspace, size_t workspace_bytes, cmdiad_stream_t stream);
 
 /* calculate_dist (features.py:186-190) as a MATERIALISED matrix, exact fp32 (sum of squared differences):
  * out[q][n] = || Q[q] - bank[n] ||_2, [Q, Nb] row-major.  API compatibility of DistHandle.materialize() only: the

@@ -598,6 +598,27 @@ def test_reweight_scan_shapes_and_block16_layout(Nb, D, R):
         assert (top3[:, k:] == ops.KEY_EMPTY).all()
 
 
+@pytest.mark.parametrize("Nb0,Nb1,R0,R1", [(76518, 19129, 32, 32), (4001, 37, 32, 5), (16, 20000, 1, 32), (300, 300, 7, 7)])
+def test_reweight_scan_pair_equals_two_calls(Nb0, Nb1, R0, R1):
+    """cmdiad_reweight_scan_pair (the two libraries of a scored batch in ONE launch pair, the scan kernel's workgroups shared in
+    proportion to the rows) returns what two cmdiad_reweight_scan calls return, bit for bit -- the bench's library sizes, a
+    tiny second library, a tiny first one, equal ones -- and the exact float64 top-3."""
+    D = 768
+    g = torch.Generator().manual_seed(Nb0 + Nb1)
+    banks = [torch.randn(n, D, generator=g) for n in (Nb0, Nb1)]
+    probes = [torch.cat([b[torch.randint(0, b.shape[0], (r - r // 2,), generator=g)], torch.randn(r // 2, D, generator=g)])
+              for b, r in zip(banks, (R0, R1))]
+    db = [b.to(DEV) for b in banks]
+    blk = [ops.bank_block16(b) for b in db]
+    dp = [p.to(DEV) for p in probes]
+    t0, t1 = ops.reweight_scan_pair(dp[0], db[0], blk[0], dp[1], db[1], blk[1])
+    for t, p, b, k16 in ((t0, dp[0], db[0], blk[0]), (t1, dp[1], db[1], blk[1])):
+        assert torch.equal(t, ops.reweight_scan(p, b, k16))
+    for t, p, b in ((t0, probes[0], banks[0]), (t1, probes[1], banks[1])):
+        rv, ri = _exact_top3(p, b)
+        np.testing.assert_array_equal(ops.unpack_keys(t)[1][:, :ri.shape[1]].cpu().numpy(), ri.numpy())
+
+
 def test_reweight_scan_duplicates_near_ties_and_shards():
     """Exact duplicates of the probe row (all-zero background patches are exact duplicates in real libraries) resolve to
     the LOWEST rows like torch.topk on the exact matrix; rows closer together than the scan's approximation error are

@@ -180,6 +180,40 @@ def test_predict_batch_b32_vs_oracle(weights, cpu_ex, gpu_engine, monkeypatch):
         assert np.abs(m1[0] - pix[b]).max() <= 2.5 * np.ptp(pix[b]) / 255.0 + 1e-9   # at most one 8-bit blur level per column
 
 
+def test_predict_batch_heavy_tailed_weights_vs_oracle():
+    """test_predict_batch_b32_vs_oracle's protocol (fit, late-fusion models, batched predict against the
+    oracle sample by sample) on heavy-tailed weights -- oracle.nets.outlier_vit (three residual channels at ~100x from block 2 on,
+    one high-norm token) and outlier_pointmae (one 50x BatchNorm channel) on top of the sharpened Point-MAE -- at B = 8: the same
+    score / map bounds as on the O(1) weights."""
+    w_vit, w_pm = nets.outlier_vit(31), nets.sharpen_pointmae(nets.outlier_pointmae(21))
+    cpu_ex = pipeline.CpuExtractor(w_vit, w_pm)
+    gpu_engine = eng.Engine(runtime.PackedViT(w_vit, device=DEV), runtime.PackedPointMAE(w_pm, device=DEV))
+    cpu = pipeline.CpuDoubleRGBPoint(cpu_ex)
+    cpu.fit(pmap(lambda i: synth_sample(100 + i)[:2], range(4), 1))
+    rows = pmap(lambda i: cpu.predict(*synth_sample(200 + i)[:2])[:2], range(3), 3)
+    det, seg = _fit_svms([r[0] for r in rows], [r[1] for r in rows])
+    B = 8
+    samples = [synth_sample(i, anomalous=(i % 3 == 0)) for i in range(B)]
+    ref = pmap(lambda smp: cpu.predict(smp[0], smp[1])[:2], samples, 8)
+    ref_img = np.array([float(det.score_samples(s.numpy())[0]) for s, _ in ref])
+    ref_pix = np.stack([seg.score_samples(s_map.numpy()).reshape(224, 224) for _, s_map in ref])
+    bank_xyz, bank_rgb = eng.Bank(cpu.xyz_lib.to(DEV)), eng.Bank(cpu.rgb_lib.to(DEV))
+    stats = dict(xyz_mean=float(cpu.xyz_mean), xyz_std=float(cpu.xyz_std), rgb_mean=float(cpu.rgb_mean), rgb_std=float(cpu.rgb_std))
+    rgb = torch.cat([s[0] for s in samples]).to(DEV)
+    pcs = torch.cat([s[1] for s in samples]).to(DEV)
+    p = BatchPredictor(gpu_engine, bank_xyz, bank_rgb, stats, det, seg, lambdas=(1.0, 1.0, 0.1, 0.1), batch=B, use_graph=False)
+    img, pix = p.predict_batch(rgb, pcs)
+    spread = float(ref_img.max() - ref_img.min())
+    d_img = np.abs(img - ref_img)
+    d_pix = np.abs(pix - ref_pix).reshape(B, -1)
+    print(f"heavy-tailed weights: image score max |d| {d_img.max():.4f} of spread {spread:.4f} ({(d_img / np.abs(ref_img)).max():.4f} relative); "
+          f"pixel map max |d| {d_pix.max():.5f}, mean {d_pix.mean():.6f}, map range {np.ptp(ref_pix):.4f}")
+    assert (d_img / np.abs(ref_img)).max() <= 0.03, (d_img / np.abs(ref_img)).max()
+    assert d_pix.mean() <= 0.003 * np.ptp(ref_pix) and d_pix.max() <= 0.03 * np.ptp(ref_pix), (d_pix.mean(), d_pix.max(), np.ptp(ref_pix))
+    for b in range(B):
+        assert np.corrcoef(pix[b].ravel(), ref_pix[b].ravel())[0, 1] > 0.995, b
+
+
 def test_mtfi_batch_vs_oracle(weights, cpu_ex, gpu_engine, monkeypatch):
     """`--workload mtfi` (configs[4] per-GPU work): BatchPredictor with the hallucination network against
     oracle.pipeline.CpuOneHallucination(main xyz).predict -- [xyz, hallucinated-rgb] columns, cross-wired statistics -- at

@@ -17,7 +17,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_cabi_library_loads_and_exports_every_declared_symbol():
     from cmdiad_amd import _native as nat
     L = nat.lib()
-    assert L.cmdiad_abi_version() == 4
+    assert L.cmdiad_abi_version() == 5
     hdr = open(os.path.join(REPO, "include", "cmdiad_hip.h")).read()
     declared = set(re.findall(r"\b(cmdiad_[a-z0-9_]+)\s*\(", hdr))
     bound = set(nat.SIGNATURES) | set(nat.SIZE_QUERIES) | {"cmdiad_last_error", "cmdiad_abi_version", "cmdiad_has_ab_variants"}

@@ -81,8 +81,19 @@ for name, rows in (() if only_l2 else (("xyz", 76518), ("rgb", 19129))):
     for _ in range(30):
         ops.reweight_scan(probes, bank, blk)
     sync()
-    work[f"reweight_scan_mfma_kernel/{rows}"] = dict(bytes=rows * D * 4, what=f"re-weighting scan, {name} library {rows} x 768 fp32, 32 probes", match_rows=rows)
+    work[f"reweight_scan_mfma_kernel/{rows}"] = dict(bytes=rows * D * 4, what=f"re-weighting scan, {name} library {rows} x 768 fp32, 32 probes",
+                                                    seq=[0 if name == "xyz" else 30, 30])
     del bank, blk
+# ---- the same two scans as ONE launch pair (cmdiad_reweight_scan_pair: what a scored batch runs)
+if not only_l2:
+    ba, bb = torch.randn(76518, D, generator=g).to(DEV), torch.randn(19129, D, generator=g).to(DEV)
+    ka, kb = ops.bank_block16(ba), ops.bank_block16(bb)
+    pa, pb_ = ba[:32].contiguous(), bb[:32].contiguous()
+    for _ in range(30):
+        ops.reweight_scan_pair(pa, ba, ka, pb_, bb, kb)
+    sync()
+    work["reweight_scan_mfma_kernel/pair"] = dict(bytes=(76518 + 19129) * D * 4, what="re-weighting scans of BOTH libraries as one launch pair (xyz 76518 + rgb 19129 rows x 768 fp32, 32 probes each)", seq=[60, 30])
+    del ba, bb, ka, kb
 # ---- greedy coreset round (features.py:401-420): 765 184 x 334 fp16 rows per round
 if not only_l2:
     n, d = 765184, 334
