@@ -373,11 +373,18 @@ def profiled_traffic():
             if h.hexdigest() != meta["sha256"]:
                 note = f"the distance GEMM's source changed since profiles/{tag}_pmc.json was taken: re-profile"
                 continue
-            rows = [r for r in json.load(open(os.path.join(here, "profiles", f"{tag}_pmc.json"))) if r["kernel"].startswith("l2_min_pp3")]
-            row = max(rows, key=lambda r: r["grid_threads"])
-            return {"traffic": round(row["fetch_bytes"] + row["write_bytes"]),
-                    "traffic_note": f"bytes per launch from the committed PMC pass (profiles/{tag}_pmc.md, commit {meta['commit']}; kernel source "
-                                    f"unchanged since: sha256 {meta['sha256'][:12]}); L2 hit {row['l2_hit']:.3f}"}
+            if meta.get("standalone"):      # the launch ALONE on the chip: the regime `frac` / `launch_ms` are quoted in
+                row = next(r for r in json.load(open(os.path.join(here, meta["standalone"]))) if r["shape"] == "bench")
+                regime = "stand-alone launch of the bench's shape (tools/standalone_kernels.py l2), as `frac` / `launch_ms`"
+                where = meta["standalone"]
+            else:                           # the pipelined bench run (overlapped and isolated launches averaged)
+                rows = [r for r in json.load(open(os.path.join(here, "profiles", f"{tag}_pmc.json"))) if r["kernel"].startswith("l2_min_pp3")]
+                row = max(rows, key=lambda r: r["grid_threads"])
+                regime = "inside the pipelined bench run"
+                where = f"profiles/{tag}_pmc.md"
+            return {"traffic": round(row["fetch_bytes"] + row["write_bytes"]), "traffic_regime": regime,
+                    "traffic_note": f"fabric-side bytes per launch (2 x FETCH_SIZE + WRITE_SIZE) from the committed PMC passes ({where}, profiles/{tag}_pmc.md, "
+                                    f"commit {meta['commit']}; kernel source unchanged since: sha256 {meta['sha256'][:12]}); L2 hit {row['l2_hit']:.3f}"}
         except (OSError, KeyError, ValueError) as e:
             note = f"no usable committed PMC pass ({type(e).__name__})"
     return {"traffic": None, "traffic_note": note}

@@ -61,7 +61,7 @@ def class_cost(n_train, n_test, f_coreset=0.1, libraries=2, rows_per_image=3136,
     late-fusion bank) and one over the test images at ``t_image`` each; per library the sparse random projection on the host
     (``t_proj_row`` per library row) and a greedy coreset of f*rows rounds each scanning all rows (csrc/coreset.hip: 90 us per
     round at 765 184 rows, profiles/r2_notes.md -> 1.18e-10 s per row and round); the host fit of the pixel-level one-class SVM over
-    n_train * 224^2 rows, ~9 epochs (11.4 s at 12.2 M rows).  Calibrated on `bench.py --evaluate` (profiles/r3_notes.md:
+    n_train * 224^2 rows, ~9 epochs (docs/history.md 7: 11.4 s at 12.2 M rows).  Calibrated on `bench.py --evaluate` (profiles/r3_notes.md:
     61 / 90 train images -> 4.7 / 8.4 s bank + coreset, 3.4 / 5.8 s late fusion); only the ORDER of the costs matters to the
     assignment."""
     rows = n_train * rows_per_image

@@ -172,7 +172,7 @@ class Features(torch.nn.Module):
 
         # features.py:127-128.  CMDIAD_OCSVM_DEVICE=1 fits them on the GPU (cmdiad_ocsvm_fit: scikit-learn's float32 SGD in the same
         # update order, identical coef_ / offset_ / n_iter_, tests/test_gpu_ocsvm.py); the default stays scikit-learn on the host,
-        # which is faster at this strictly sequential recurrence
+        # which is faster at this strictly sequential recurrence (docs/history.md section 7)
         if os.environ.get("CMDIAD_OCSVM_DEVICE", "0") == "1":
             from ..ocsvm import DeviceSGDOneClassSVM as _OCSVM
         else:

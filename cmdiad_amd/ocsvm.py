@@ -5,7 +5,7 @@
 ``n_iter_``, ``t_``; ``score_samples`` / ``decision_function``) and runs scikit-learn's float32 SGD with the same update order
 in ``cmdiad_ocsvm_fit`` (cmdiad_amd/csrc/ocsvm.hip): coefficients, offset and epoch count equal scikit-learn's bit for bit
 (tests/test_gpu_ocsvm.py).  The recurrence is strictly sequential, so the device is SLOWER than one host core at it
-(DESIGN.md section 7 has the numbers); the drop-in classes keep scikit-learn's host fit unless ``CMDIAD_OCSVM_DEVICE=1``.
+(docs/history.md section 7 has the numbers); the drop-in classes keep scikit-learn's host fit unless ``CMDIAD_OCSVM_DEVICE=1``.
 The per-image side (``score_samples`` over 50 176 x k rows) is ``ops.ocsvm_score_maps`` either way.
 """
 import ctypes

@@ -18,6 +18,7 @@ if os.environ.get("CMDIAD_TEST_AB") == "1" and os.path.exists(_AB):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: a GPU test of a minute or more (a whole bench.py run); selected by -m gpu like the rest")
 
 
 @pytest.fixture(scope="session")

@@ -8,15 +8,20 @@ import sys
 
 import pytest
 
+import time
+
 pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+slow = pytest.mark.slow      # still selected by `-m gpu`; each prints its duration (the GPU suite has a 20-minute budget on the driver)
 
 
 def _run(extra_env, *args):
     env = dict(os.environ, **extra_env)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    t0 = time.perf_counter()
     out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", *args],
                          capture_output=True, text=True, timeout=900, env=env, cwd=REPO)
+    print(f"[bench.py {' '.join(args) or '(default legs)'} {extra_env or ''}: {time.perf_counter() - t0:.0f} s]")
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, lines          # exactly ONE line on stdout (RCCL's banner included: it goes to stderr)
@@ -29,14 +34,19 @@ def test_bench_single_gpu_line():
     assert d["value"] > 100 and abs(d["value"] - 32 / (d["ms_per_step"] * 1e-3)) < 0.01 * d["value"]
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
-    assert 0.2 < r["frac"] < 1.0 and "traffic" in r
+    assert 0.2 < r["frac"] < 1.0 and "traffic" in r and 0.1 < r["frac_in_pipeline"] <= r["frac"] * 1.05
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
 
 
+@slow
 def test_bench_default_line_carries_the_secondary_legs():
     """The driver's command (no flags beyond steps): besides the headline, configs[2] (distillation training step), the conv head's
-    training step (row f4), the variable-N leg and the class loop ride in the same JSON line."""
+    training step (row f4), the variable-N leg, the MTFI step (the metric's "distill" term) and the class loop
+    ride in the same JSON line; no leg carries an error."""
     d = _run({})
+    assert not [k for k, v in d.items() if isinstance(v, dict) and ("error" in v or "skipped" in v)], d
+    ms = d["mtfi_step"]
+    assert ms["value"] > 100 and ms["ms_per_step"] > 0 and ms["query_rows"]["libraries"] == 2 and ms["hallucination_mlp"]["TFLOPs"] > 100
     t, ct = d["train_step"], d["conv_head_train_step"]
     assert t["ms_per_step"] > 0 and t["loss_last_timed"] < t["loss_first_timed"]
     assert ct["batch"] == 8 and ct["achieved_TFLOPs"] > 100 and ct["loss_last"] < ct["loss_first"]
@@ -45,8 +55,11 @@ def test_bench_default_line_carries_the_secondary_legs():
     assert len(d["mtfi_classes"]["per_class"]) == 10
 
 
+@slow
 def test_bench_distributed_path_on_one_gpu():
     d = _run({"CMDIAD_FORCE_DIST": "1"})
+    assert d["rccl_ranks"] == 1 and d["world"] == 1 and d["ranks"][0]["rank"] == 0 and "device" in d["ranks"][0]
+    assert not [k for k, v in d.items() if isinstance(v, dict) and ("error" in v or "skipped" in v)], d
     s = d["sharded_search"]
     assert s["rccl_ranks"] == 1 and s["backend"] == "nccl"
     assert d["value"] > 100

@@ -61,10 +61,11 @@ def test_vit_b8_forward_heavy_tailed_weights_vs_oracle():
         # the premise: the residual stream in front of the last LayerNorm really has the outliers
         x = torch.nn.functional.conv2d(rgb, sd["patch_embed.proj.weight"], sd["patch_embed.proj.bias"], stride=8).flatten(2).transpose(1, 2)
         x = torch.cat([sd["cls_token"].expand(2, -1, -1), x], 1) + sd["pos_embed"]
+        assert float(x[:, 400].norm()) > 5 * float(x[:, 100].norm())          # one token enters with ~8x the norm of the others
         for i in range(12):
             x = nets._block(x, sd, f"blocks.{i}", 12, 1e-6)
     typical = float(x.abs().median())
-    assert float(x[:, :, 7].abs().mean()) > 60 * typical and float(x[:, 400].norm()) > 1.5 * float(x[:, 100].norm())
+    assert float(x[:, :, 7].abs().mean()) > 60 * typical                      # ... and three channels carry ~100x the typical value
     for fold in ("0", "1"):
         os.environ["CMDIAD_LN_FOLD"] = fold
         try:

@@ -453,7 +453,7 @@ def test_bench_traffic_is_tied_to_the_profiled_kernel_source(tmp_path, monkeypat
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     t = bench.profiled_traffic()
-    assert isinstance(t["traffic"], int) and 1e9 < t["traffic"] < 1e11 and "commit" in t["traffic_note"], t
+    assert isinstance(t["traffic"], int) and 1e9 < t["traffic"] < 1e11 and "commit" in t["traffic_note"] and "traffic_regime" in t, t
     newest = max(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_meta.json")), key=lambda f: int(re.search(r"r(\d+)_pmc_meta", f).group(1)))
     tag = re.search(r"(r\d+)_pmc_meta", newest).group(1)
     assert f"profiles/{tag}_pmc.md" in t["traffic_note"]
@@ -462,7 +462,7 @@ def test_bench_traffic_is_tied_to_the_profiled_kernel_source(tmp_path, monkeypat
     (root / "profiles").mkdir(parents=True)
     (root / "cmdiad_amd" / "csrc").mkdir(parents=True)
     meta = json.load(open(newest))
-    for f in meta["sources"] + [f"profiles/{tag}_pmc.json", f"profiles/{tag}_pmc_meta.json"]:
+    for f in meta["sources"] + [f"profiles/{tag}_pmc.json", f"profiles/{tag}_pmc_meta.json"] + ([meta["standalone"]] if meta.get("standalone") else []):
         shutil.copy(os.path.join(REPO, f), root / f)
     with open(root / meta["sources"][0], "ab") as fh:
         fh.write(b"\n")

@@ -388,7 +388,7 @@ def test_g11_method_classes_through_reference_glue(golden):
             d = np.abs(s_map_lib[::53, col].numpy() - ref_maps[:, col])
             # (lsb from the SUB-SAMPLED maximum of three separately normalised maps: a lower bound of one level)
             # never more than ONE level, and only where value / max * 255 sits on an integer boundary: the sharpened Point-MAE
-            # weights amplify the last-ulp differences of the 3-NN weights (numerical note on a7) to ~1e-4 of the
+            # weights amplify the last-ulp differences of the 3-NN weights (docs/history.md section 2, numerical note on a7) to ~1e-4 of the
             # map maximum, which moves a pixel of level L across a boundary with probability ~ L * 1e-4 * 255 / 255
             assert d.max() <= 2.0 * lsb + 1e-6 and (d > 1e-4 * max(1.0, lsb * 255)).mean() < 0.10, (tag, col, d.max(), lsb)
         det = linear_model.SGDOneClassSVM(random_state=42, nu=0.5, max_iter=1000).fit(s_lib)

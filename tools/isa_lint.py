@@ -22,7 +22,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def compile_to_asm(src):
     out = tempfile.NamedTemporaryFile(suffix=".s", delete=False).name
     # -DCMDIAD_AB_VARIANTS: the test-only formulations are linted too (they are the A/B references of the production loops)
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-DCMDIAD_AB_VARIANTS", "-I", os.path.join(ROOT, "include"),
+    # per-file flags as csrc/Makefile has them (NOSLP := l2min.o)
+    extra = ["-fno-slp-vectorize"] if os.path.basename(src) == "l2min.hip" else []
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-DCMDIAD_AB_VARIANTS", *extra, "-I", os.path.join(ROOT, "include"),
            "-S", "--cuda-device-only", "-o", out, src]
     subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     return out
