@@ -316,7 +316,7 @@ def run_steps(pred, batches, n, first=None):
     return first
 
 
-def isolated_xyz_search_ms(pred, iters=6):
+def isolated_xyz_search_ms(pred, iters=12):
     """The xyz-library distance GEMM of the LAST step once more, alone on an idle chip (same operands: the step's compacted query
     rows and live count, the same library operand, the same launch), HIP events around each launch: the kernel's own duration.
     Inside the pipelined step the searches run on the second stream beside the next step's extraction, where the measured
@@ -346,7 +346,8 @@ def isolated_xyz_search_ms(pred, iters=6):
         else:
             return None
         torch.cuda.synchronize()
-    return t.mean_ms(skip=1)
+    v = sorted(a.elapsed_time(b) for a, b in t.pairs[2:])      # the first two launches follow the pipeline's last steps: skipped
+    return v[len(v) // 2]                                        # median of ten: one launch beside a late D2H copy must not move it
 
 
 # --------------------------------------------------------------------------------------------------------- secondary legs
@@ -793,7 +794,7 @@ def var_n_leg(st, dev, steps=16, warm=8):
                 xyz_search_ms=round(l2_ms, 3), xyz_search_TFLOPs=round(2.0 * live * rows * 768 / (l2_ms * 1e-3) / 1e12, 1))
 
 
-def mtfi_step_leg(st, dev, steps=12, warm=4):
+def mtfi_step_leg(st, dev, steps=12, warm=8):
     """The metric's "distill" term, driver-timed: the per-GPU step of configs[4] -- MTFI feature-to-feature predict with main
     modality xyz (RGBorXYZWithOneHallucination.predict, multiple_features.py:474-573) at batch 32 in steady state: Point-MAE
     extraction -> xyz patches -> hallucinated rgb features (the distillation network's xyz -> rgb direction,
@@ -1070,7 +1071,7 @@ def main():
                          "frac_in_pipeline": round(achieved_pipe / PEAK_BF16_TFLOPS, 4) if achieved_pipe else None,
                          **profiled_traffic(),
                          "launch_ms": round(l2_ms, 3), "launch_ms_in_pipeline": round(l2_pipe_ms, 3),
-                         "launch_ms_note": "launch_ms / frac: the step's launch repeated alone after the timed loop (HIP events, idle chip) "
+                         "launch_ms_note": "launch_ms / frac: the step's launch repeated alone after the timed loop (HIP events, idle chip; median of ten) "
                                            "-- the regime of the stand-alone rocprofv3 row in profiles/r5_standalone.md; "
                                            "in_pipeline: the same launch inside the timed steps, on the second stream beside the next "
                                            "step's extraction (shares the CUs)",

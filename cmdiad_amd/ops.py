@@ -3,6 +3,7 @@ libcmdiad_hip.so kernels underneath.  Every op raises if the tensors are not on 
 native library is missing -- there is no eager / CPU fallback here by design.
 """
 import ctypes
+import os
 
 import torch
 
@@ -449,7 +450,9 @@ def gemm_groupmax(A, W, bias, groups, Mg, want_bf16=False):
 
 
 # ------------------------------------------------------------------------------------ scoring
-SEARCH_DTYPE = torch.float16  # 16-bit operand type of the patch-library distance GEMM (fp16: 3 more mantissa bits)
+# 16-bit operand type of the patch-library distance GEMM: fp16 (3 more mantissa bits than bf16; the features are normalised, O(1)).
+# CMDIAD_SEARCH_DTYPE=bf16 selects bfloat16 operands (A/B runs: the chip holds a higher clock on bf16 operands, profiles/r5_notes.md).
+SEARCH_DTYPE = torch.bfloat16 if os.environ.get("CMDIAD_SEARCH_DTYPE", "fp16").lower() in ("bf16", "bfloat16") else torch.float16
 
 
 def normalize_cast(x, mean=0.0, inv_std=1.0, want_f32=False, want_sq=True, dtype=None):

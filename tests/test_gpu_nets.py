@@ -91,8 +91,15 @@ def test_pointmae_heavy_tailed_weights_vs_oracle():
     np.testing.assert_array_equal(ori_idx.cpu().numpy(), idx)
     with torch.no_grad():
         ref = nets.pointmae_forward(sd, torch.from_numpy(nb), torch.from_numpy(cen))
-    mean_rel, max_rel = _rel_by_channel(feats.transpose(1, 2).cpu(), ref, 1)
-    print(f"heavy-tailed Point-MAE: mean {mean_rel:.4f}, max (per channel scale) {max_rel:.4f}")
+    got = feats.transpose(1, 2).cpu()
+    mean_rel, max_rel = _rel_by_channel(got, ref, 1)
+    g_mean, g_max = _rel(got, ref)
+    err = (got - ref).abs()
+    flat = int(err.argmax())
+    c, t = (flat // ref.shape[2]) % ref.shape[1], flat % ref.shape[2]
+    print(f"heavy-tailed Point-MAE: mean {mean_rel:.4f}, max (per channel scale) {max_rel:.4f}; global-scale max {g_max:.4f}; largest |err| {float(err.max()):.4f} at "
+          f"channel {c}, token {t}: ref {float(ref[0, c, t]):.4f} got {float(got[0, c, t]):.4f}; channel mean |ref| {float(ref[0, c].abs().mean()):.4f}, "
+          f"global mean |ref| {float(ref.abs().mean()):.4f}; token error norm / token norm {float(err[0, :, t].norm() / ref[0, :, t].norm()):.4f}")
     assert mean_rel < 0.015 and max_rel < 0.12, (mean_rel, max_rel)
 
 
@@ -318,7 +325,9 @@ def test_transformer_block_stage_by_stage_vs_fp64(kind):
     ops.gemm(a, blk["proj_w"], bias=blk["proj_b"], residual=x, out_f32=x, want_bf16=False)
     x_ref = x_ref.float().double() + (a.cpu().double() @ Wb("attn.proj.weight").T + W("attn.proj.bias"))
     scale_x = float(x_ref.abs().mean())
-    assert float((x.cpu().double() - x_ref).abs().max()) <= 2e-5 * scale_x
+    # fp32 outputs: 2e-5 of the feature scale -- plus, for the heavy-tailed stream, fp32's own relative step on the 100x elements
+    # (a value of 4 000 carries 2.4e-4 of absolute rounding per fp32 operation: 1e-6 of ITS size)
+    assert bool(((x.cpu().double() - x_ref).abs() <= 2e-5 * scale_x + 1e-6 * x_ref.abs()).all())
     # ---- LayerNorm 2, fc1 + GELU, fc2 + residual
     h2 = ops.layernorm(x, blk["ln2_w"], blk["ln2_b"], eps)
     off.append(_ulp_check(h2, ln(x.cpu().double(), "norm2"), "LayerNorm 2"))
@@ -330,7 +339,7 @@ def test_transformer_block_stage_by_stage_vs_fp64(kind):
     x_before = x.cpu().double()
     ops.gemm(mid, blk["fc2_w"], bias=blk["fc2_b"], residual=x, out_f32=x, want_bf16=False)
     x_ref2 = x_before + (mid.cpu().double() @ Wb("mlp.fc2.weight").T + W("mlp.fc2.bias"))
-    assert float((x.cpu().double() - x_ref2).abs().max()) <= 2e-5 * float(x_ref2.abs().mean())
+    assert bool(((x.cpu().double() - x_ref2).abs() <= 2e-5 * float(x_ref2.abs().mean()) + 1e-6 * x_ref2.abs()).all())
     print(f"{kind}: fraction of bf16 outputs that are not the nearest bf16 of the float64 value, per stage: {['%.1e' % v for v in off]}")
     # the chained production entry point gives the same block output as these separate calls (bit for bit: same kernels)
     from cmdiad_amd.runtime import transformer_block_unfused
