@@ -573,7 +573,7 @@ def sharded_search(dev, group, rank, world, rows_list, iters=10, warm=3):
                         gather_MB_received_without_compaction=round(stats["gather_bytes_received_without_compaction"] / 1e6, 2),
                         reduce_MB=round(stats["reduce_bytes"] / 1e6, 3)))
         del b16, bsq, searches
-    return dict(what="row-sharded library search: local de-duplication of the repeated background row -> all-gather of the live fp16 "
+    return dict(what="row-sharded library search: local de-duplication of the repeated background row -> all-gather of the live 16-bit "
                      "query rows only -> per-shard distance GEMM -> one all_reduce(MIN) of packed int64 keys -> expansion; the next "
                      "iteration's exchange runs under the current GEMM; weak scaling, 32 images (100 352 query rows) per rank",
                 rccl_ranks=td.get_world_size(group), backend=td.get_backend(group), classes=out)
@@ -1063,7 +1063,8 @@ def main():
                                           "note": "the 56x56 patch grid keeps a row for every patch; patches with no foreground pixel "
                                                   "(24576 of 50176 pixels are foreground, as in the reference's clouds) are one "
                                                   "repeated row, searched once with the key copied -- results identical to searching all"},
-                       "hip_graphs": bool(pred.use_graph), "search_operands": "fp16 (fp32 accumulate, exact fp32 re-score)",
+                       "hip_graphs": bool(pred.use_graph),
+                       "search_operands": ("bf16" if st["bank_xyz"].bf16.dtype == torch.bfloat16 else "fp16") + " (fp32 accumulate, exact fp32 re-score of the winner)",
                        "weights": "seeded random init (no checkpoints offline)"},
             "roofline": {"kernel": "l2_min_pp3_kernel (xyz library distance GEMM + running min/argmin)", "bound": "mfma",
                          "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",

@@ -450,9 +450,13 @@ def gemm_groupmax(A, W, bias, groups, Mg, want_bf16=False):
 
 
 # ------------------------------------------------------------------------------------ scoring
-# 16-bit operand type of the patch-library distance GEMM: fp16 (3 more mantissa bits than bf16; the features are normalised, O(1)).
-# CMDIAD_SEARCH_DTYPE=bf16 selects bfloat16 operands (A/B runs: the chip holds a higher clock on bf16 operands, profiles/r5_notes.md).
-SEARCH_DTYPE = torch.bfloat16 if os.environ.get("CMDIAD_SEARCH_DTYPE", "fp16").lower() in ("bf16", "bfloat16") else torch.float16
+# 16-bit operand type of the patch-library distance GEMM.  bfloat16 since round 5: the same kernel runs 6.5 % faster on bf16 operands
+# than on fp16 ones (5.05-5.16 against 5.38-5.57 ms, same box: fewer mantissa bits toggle, the chip holds a higher clock --
+# profiles/r5_notes.md section 6), and what the three mantissa bits buy is invisible behind the extractor's own 16-bit noise: the
+# operand rounding moves a distance of 4-35 by ~0.03, the bf16 feature chain by ~0.5 (tests/test_gpu_predictor.py: image scores,
+# pixel maps and AUROCs identical to the last printed digit on both types); the winner is re-scored in fp32 either way.
+# CMDIAD_SEARCH_DTYPE=fp16 restores IEEE half operands.
+SEARCH_DTYPE = torch.float16 if os.environ.get("CMDIAD_SEARCH_DTYPE", "bf16").lower() in ("fp16", "float16", "half") else torch.bfloat16
 
 
 def normalize_cast(x, mean=0.0, inv_std=1.0, want_f32=False, want_sq=True, dtype=None):

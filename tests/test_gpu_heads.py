@@ -288,6 +288,9 @@ def test_dumped_pairs_round_trip_into_the_head_trainers(tmp_path):
                                          for n in ("conv1.weight", "layer2.1.conv2.weight", "final_layer.weight"))
     # (layer4 exists in the state_dict but the reference's forward stops after layer3, hrnet.py:251-288: no gradient there)
     # predict dumps under test/
+    for rgb, pc in train:
+        m.add_sample_to_late_fusion_mem_bank((rgb, pc, pc))
+    m.run_late_fusion()
     m.predict((train[0][0], train[0][1], train[0][1]), torch.zeros(1, 224, 224), 0, ["x.png"])
     _ = m.image_preds            # (reading a result attribute runs the deferred micro-batch)
     assert sorted(os.listdir(tmp_path / "frgb_xyz" / "test" / "frgb")) == ["synth3_frgb.pt"]

