@@ -1147,8 +1147,13 @@ def main():
         leg("mtfi_classes", lambda: mtfi_classes(dev, group, rank, world, "all", args.class_scale, args.class_test), 600,
             collective=group is not None)
 
+    torn_down = False
     if group is not None and legs.in_step:
-        leg("teardown", lambda: (td.barrier(), td.destroy_process_group(), None)[2], 60, collective=True)
+        def teardown():
+            td.barrier()
+            td.destroy_process_group()
+            legs.store = None            # (gone with the process group; nothing collective follows)
+        torn_down = "error" not in (leg("teardown", lambda: teardown() or {"ok": True}, 60, collective=True) or {})
     if rank == 0:
         if world == 1 and not args.no_extras and args.workload == "dino_pointmae":
             del pred, batches
@@ -1158,7 +1163,7 @@ def main():
             leg("cpu_baseline", lambda: cpu_baseline(args.cpu_images), 600)
         out.pop("teardown", None)
         emit_line(out)
-    if group is not None and not legs.in_step:
+    if group is not None and not torn_down:
         sys.stdout.flush()
         os._exit(0)      # some rank failed a leg: the others may sit in a collective that never completes -- no orderly teardown
 

@@ -120,6 +120,57 @@ def case_l2(rs):
     os.environ.pop("CMDIAD_L2_TILE", None)
 
 
+def case_l2_identity(rs):
+    """The key of a (query, row) pair must not depend on the formulation, the launch geometry or the shard the row is in (RowMin,
+    csrc/l2min.hip): the 128 x 128 kernel, the lock-step 256 x 256 kernel (test build) and the two-group kernel on random shapes with
+    ragged query / library tiles, both operand types, duplicates planted in the library; the MIN over a random two- or three-way row
+    split; the counted launch on a random live count."""
+    Q, Nb, D = int(rs.randint(1, 2500)), int(rs.randint(1, 5000)), 64 * int(rs.randint(3, 13))
+    dt = torch.float16 if rs.rand() < 0.5 else torch.bfloat16
+    bank = torch.from_numpy(rs.randn(Nb, D).astype(np.float32))
+    if Nb > 20:      # repeated rows: ties must go to the lowest row in every formulation
+        src = torch.from_numpy(rs.randint(0, Nb, 10))
+        bank[torch.from_numpy(rs.randint(0, Nb, 10))] = bank[src]
+    q = bank[torch.from_numpy(rs.randint(0, Nb, Q))] + float(rs.choice([0.0, 0.3])) * torch.from_numpy(rs.randn(Q, D).astype(np.float32))
+    b16, _, bsq = ops.normalize_cast(bank.to(DEV), dtype=dt)
+    q16, _, qsq = ops.normalize_cast(q.to(DEV), dtype=dt)
+    keys = {}
+    for tile in ("0", "2", "5"):
+        os.environ["CMDIAD_L2_TILE"] = tile
+        keys[tile] = ops.l2_min_keys(q16, qsq, b16, bsq, ops.new_keys(Q, DEV)).clone()
+    os.environ.pop("CMDIAD_L2_TILE", None)
+    assert torch.equal(keys["0"], keys["2"]) and torch.equal(keys["0"], keys["5"]), ("l2 identity", Q, Nb, D, dt)
+    cuts = sorted(set([0, Nb] + [int(c) // 64 * 64 for c in rs.randint(0, Nb + 1, int(rs.randint(1, 3)))]))
+    merged = ops.new_keys(Q, DEV)
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        if hi > lo:
+            k = ops.l2_min_keys(q16, qsq, b16[lo:hi].contiguous(), bsq[lo:hi].contiguous(), ops.new_keys(Q, DEV), row_offset=lo)
+            merged = torch.minimum(merged, k)
+    assert torch.equal(merged, keys["0"]), ("l2 shards", Q, Nb, D, dt, cuts)
+    live = int(rs.randint(1, Q + 1))
+    cnt = torch.tensor([live], dtype=torch.int32, device=DEV)
+    kc = ops.l2_min_keys_counted(q16, qsq, cnt, b16, bsq, ops.new_keys(Q, DEV))
+    assert torch.equal(kc[:live], keys["0"][:live]) and bool((kc[live:] == ops.KEY_EMPTY).all()), ("l2 counted", Q, Nb, D, live)
+
+
+def case_reweight_pair(rs):
+    """cmdiad_reweight_scan_pair == two cmdiad_reweight_scan calls == the exact float64 top-3, random library sizes and probe counts."""
+    D = 128 * int(rs.randint(1, 7))
+    n0, n1 = int(rs.randint(1, 9000)), int(rs.randint(1, 9000))
+    r0, r1 = int(rs.randint(1, 33)), int(rs.randint(1, 33))
+    banks = [torch.from_numpy(rs.randn(n, D).astype(np.float32)) for n in (n0, n1)]
+    probes = [torch.cat([b[torch.from_numpy(rs.randint(0, b.shape[0], r - r // 2))], torch.from_numpy(rs.randn(r // 2, D).astype(np.float32))])
+              for b, r in zip(banks, (r0, r1))]
+    db, dp = [b.to(DEV) for b in banks], [p.to(DEV) for p in probes]
+    blk = [ops.bank_block16(b) for b in db]
+    t0, t1 = ops.reweight_scan_pair(dp[0], db[0], blk[0], dp[1], db[1], blk[1])
+    for t, p, b, k16, pc, bc in ((t0, dp[0], db[0], blk[0], probes[0], banks[0]), (t1, dp[1], db[1], blk[1], probes[1], banks[1])):
+        assert torch.equal(t, ops.reweight_scan(p, b, k16)), ("reweight pair", n0, n1, r0, r1, D)
+        d = torch.stack([(bc.double() - x.double()).pow(2).sum(1) for x in pc])
+        ri = torch.topk(d, min(3, bc.shape[0]), largest=False).indices
+        assert torch.equal(ops.unpack_keys(t)[1][:, :ri.shape[1]].cpu(), ri), ("reweight exact", n0, n1, r0, r1, D)
+
+
 def case_attention(rs):
     B, H, T = int(rs.randint(1, 4)), int(rs.randint(1, 7)), int(rs.randint(1, 1100))
     Tp = (T + 63) // 64 * 64
@@ -283,7 +334,11 @@ def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     rs = np.random.RandomState(seed)
-    cases = [case_fps_knn, case_gemm, case_l2, case_attention, case_blur, case_fps_big, case_l2_big, case_encoder, case_ocsvm, case_dedup, case_unorganize, case_knn_production_grid]
+    cases = [case_fps_knn, case_gemm, case_l2, case_attention, case_blur, case_fps_big, case_l2_big, case_encoder, case_ocsvm, case_dedup, case_unorganize, case_knn_production_grid,
+             case_l2_identity, case_reweight_pair]
+    only = [c for c in os.environ.get("FUZZ_ONLY", "").split(",") if c]        # e.g. FUZZ_ONLY=l2_identity,reweight_pair
+    if only:
+        cases = [c for c in cases if c.__name__[5:] in only]
     counts = {c.__name__: 0 for c in cases}
     t0 = time.time()
     while time.time() - t0 < budget:
