@@ -45,6 +45,31 @@ class PreTrainTensorDataset(Dataset):
         return tensor, 0
 
 
+# data_type -> ((attribute stem, sub-directory, glob), (…)): the files of a pair, in the reference's attribute names
+_PAIR_LAYOUT = {
+    "rgb_fxyz": (("rgb", "rgb", "*.pt"), ("fxyz", "fxyz", "*hfxyz.pt")),
+    "xyz_frgb": (("frgb", "frgb", "*.pt"), ("xyz", "xyz", "*.pt")),
+}
+
+
+def _discover_pairs(ds, root_path, data_type):
+    """Sets <stem>_root_path / <stem>_paths (sorted as plain strings: bagel10 before bagel2, in both lists alike) and `len` on ds,
+    the attributes the reference's classes carry; False for a data_type without a layout."""
+    layout = _PAIR_LAYOUT.get(data_type)
+    if layout is None:
+        return False
+    counts = []
+    for stem, sub, pattern in layout:
+        root = Path(root_path, sub)
+        paths = sorted(root.glob(pattern))
+        setattr(ds, stem + "_root_path", root)
+        setattr(ds, stem + "_paths", paths)
+        counts.append(len(paths))
+    assert counts[0] == counts[1], f"{root_path}: {counts[0]} / {counts[1]} files of the two kinds"
+    ds.len = counts[0]
+    return True
+
+
 class FeatureToInputPreTrainTensorDataset(Dataset):
     """The feature-to-INPUT heads' training pairs (reference dataset.py:268-314; selected at
     hallucination_network_pretrain.py:180-201 for RGBFeatureToXYZInput{MLP,Conv} / XYZFeatureToRGBInput{MLP,Conv}).
@@ -52,39 +77,24 @@ class FeatureToInputPreTrainTensorDataset(Dataset):
     this package's drop-in writes the same names):
       data_type 'xyz_frgb': <root>/frgb/<class><i>_frgb.pt [3136, 768]  +  <root>/xyz/<class><i>_xyz.pt [3, 224, 224]  -> (frgb, xyz)
       data_type 'rgb_fxyz': <root>/rgb/<class><i>_rgb.pt [3, 224, 224]  +  <root>/fxyz/<class><i>_hfxyz.pt [3136, 768]  -> (fxyz, rgb)
-    (the [784, 768] `_lfxyz.pt` files beside them are not read), both loaded straight onto the GPU, paired by SORTED path -- a
-    plain string sort, so bagel10 comes before bagel2 in both lists alike.  Any other data_type leaves the object without a
-    length, as the reference does."""
+    (the [784, 768] `_lfxyz.pt` files beside them are not read), both loaded straight onto the GPU, the FEATURE first.  Any other
+    data_type leaves the object without a length, as the reference does."""
+
+    device = "cuda"      # torch.load(map_location=...) of __getitem__ (the reference hard-codes 'cuda'; CPU tests override it)
 
     def __init__(self, root_path, data_type):
         super().__init__()
-        self.root_path = root_path
-        self.data_type = data_type
-        if data_type == 'rgb_fxyz':
-            self.rgb_root_path = Path(root_path, 'rgb')
-            self.fxyz_root_path = Path(root_path, 'fxyz')
-            self.rgb_paths = sorted(self.rgb_root_path.glob('*.pt'))
-            self.fxyz_paths = sorted(self.fxyz_root_path.glob('*hfxyz.pt'))
-            assert len(self.rgb_paths) == len(self.fxyz_paths)
-            self.len = len(self.rgb_paths)
-        elif data_type == 'xyz_frgb':
-            self.frgb_root_path = Path(root_path, 'frgb')
-            self.xyz_root_path = Path(root_path, 'xyz')
-            self.frgb_paths = sorted(self.frgb_root_path.glob('*.pt'))
-            self.xyz_paths = sorted(self.xyz_root_path.glob('*.pt'))
-            assert len(self.frgb_paths) == len(self.xyz_paths)
-            self.len = len(self.frgb_paths)
-
-    device = 'cuda'      # torch.load(map_location=...) of __getitem__ (the reference hard-codes 'cuda'; CPU tests override it)
+        self.root_path, self.data_type = root_path, data_type
+        _discover_pairs(self, root_path, data_type)
 
     def __len__(self):
         return self.len
 
     def pair_paths(self, idx):
-        """(first, second) file of sample idx, in the order __getitem__ returns them."""
-        if self.data_type == 'rgb_fxyz':
+        """(first, second) file of sample idx, in the order __getitem__ returns them: feature, then input."""
+        if self.data_type == "rgb_fxyz":
             return self.fxyz_paths[idx], self.rgb_paths[idx]
-        if self.data_type == 'xyz_frgb':
+        if self.data_type == "xyz_frgb":
             return self.frgb_paths[idx], self.xyz_paths[idx]
         return None
 
@@ -92,7 +102,7 @@ class FeatureToInputPreTrainTensorDataset(Dataset):
         pair = self.pair_paths(idx)
         if pair is None:
             return None          # (the reference's __getitem__ falls through both branches)
-        return torch.load(pair[0], map_location=self.device), torch.load(pair[1], map_location=self.device)
+        return tuple(torch.load(f, map_location=self.device) for f in pair)
 
 
 class InputToFeaturePreTrainTensorDataset(Dataset):
@@ -104,36 +114,21 @@ class InputToFeaturePreTrainTensorDataset(Dataset):
 
     def __init__(self, root_path, data_type):
         super().__init__()
-        self.data_type = data_type
-        self.root_path = root_path
-        if data_type == 'rgb_fxyz':
-            self.rgb_root_path = Path(root_path, 'rgb')
-            self.fxyz_root_path = Path(root_path, 'fxyz')
-            self.rgb_paths = sorted(self.rgb_root_path.glob('*.pt'))
-            self.fxyz_paths = sorted(self.fxyz_root_path.glob('*hfxyz.pt'))
-            assert len(self.rgb_paths) == len(self.fxyz_paths)
-            self.len = len(self.rgb_paths)
-        elif data_type == 'xyz_frgb':
-            self.frgb_root_path = Path(root_path, 'frgb')
-            self.xyz_root_path = Path(root_path, 'xyz')
-            self.frgb_paths = sorted(self.frgb_root_path.glob('*.pt'))
-            self.xyz_paths = sorted(self.xyz_root_path.glob('*.pt'))
-            assert len(self.frgb_paths) == len(self.xyz_paths)
-            self.len = len(self.frgb_paths)
-        else:
+        self.root_path, self.data_type = root_path, data_type
+        if not _discover_pairs(self, root_path, data_type):
             raise NotImplementedError
 
     def __len__(self):
         return self.len
 
     def pair_paths(self, idx):
-        if self.data_type == 'rgb_fxyz':
+        """(first, second) file of sample idx: input, then feature."""
+        if self.data_type == "rgb_fxyz":
             return self.rgb_paths[idx], self.fxyz_paths[idx]
         return self.xyz_paths[idx], self.frgb_paths[idx]
 
     def __getitem__(self, idx):
-        a, b = self.pair_paths(idx)
-        return torch.load(a), torch.load(b)
+        return tuple(torch.load(f) for f in self.pair_paths(idx))
 
 
 class PairRing:
