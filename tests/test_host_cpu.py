@@ -385,6 +385,30 @@ def test_pair_datasets_match_the_reference_over_files_the_dropin_wrote(tmp_path,
         ds.FeatureToInputPreTrainTensorDataset.device = "cuda"
 
 
+def test_save_raw_results_writes_the_reference_csv(tmp_path, monkeypatch):
+    """--save_raw_results (features.py:316-318): calculate_metrics writes ./visualization/<note>/<class>_raw_results.csv with one
+    row per test image -- score, label, image path -- before the metrics; the drop-in creates the directory."""
+    import types
+    from cmdiad_amd.feature_extractors.features import Features
+    monkeypatch.chdir(tmp_path)
+    rs = np.random.RandomState(0)
+    n = 6
+    labels = [np.array([i % 2]) for i in range(n)]
+    gts = [np.zeros((16, 16), dtype=np.float32) for _ in range(n)]
+    for i in range(1, n, 2):
+        gts[i][4:8, 4:8] = 1.0
+    preds = [rs.rand(16, 16).astype(np.float32) + g for g in gts]
+    me = types.SimpleNamespace(args=types.SimpleNamespace(save_raw_results=True, experiment_note="note7"), class_name="bagel",
+                               image_preds=[np.array([float(p.max())]) for p in preds], image_labels=labels,
+                               pixel_preds=list(np.concatenate([p.ravel() for p in preds])), pixel_labels=list(np.concatenate([g.ravel() for g in gts])),
+                               predictions=preds, gts=gts, img_name=[[f"/data/mvtec_3d/bagel/test/x/rgb/{i:03d}.png"] for i in range(n)])
+    Features.calculate_metrics(me)
+    rows = open(tmp_path / "visualization" / "note7" / "bagel_raw_results.csv").read().strip().splitlines()
+    assert len(rows) == n and rows[1].split(",")[1] == "1" and rows[1].split(",")[2].endswith("001.png")
+    assert abs(float(rows[3].split(",")[0]) - float(preds[3].max())) < 1e-5
+    assert 0.5 < me.image_rocauc <= 1.0 and 0.5 < me.pixel_rocauc <= 1.0 and me.au_pro > 0
+
+
 def test_empty_shard_cannot_win_the_min_reduce():
     """ADVICE (round 1): shard_range yields EMPTY shards when n <= 128 * (world - 1); such a rank contributes only the
     'no candidate' key, which must lose a signed MIN reduce against every real key (0xFFFF...F = -1 would have won)."""
