@@ -282,7 +282,8 @@ def score_patches(patch32, bank, dims, gt_size=224, group=None):
 
 def _sharded_score_steps(patch32, keys, bank, dims, gt_size):
     """score_patches_from_keys for a library whose fp32 rows are SHARDED too (Bank(replicate_f32=False)); SURVEY 8(e)'s re-weight
-    step, features.py:225-290 per shard.  A generator: every `yield (kind, tensor)` is one collective over the ranks and receives its
+    step, features.py:225-290 per shard.  PRECONDITION ("queries are replicated"): every rank passes the SAME patch32 and
+    keys -- a rank contributes the parts of the rows it owns to sums over the ranks.  A generator: every `yield (kind, tensor)` is one collective over the ranks and receives its
     result -- "sum": element-wise sum (exactly one rank, the owner of the row in question, contributes a non-zero value, so the sum
     is exact); "gather": [W, *shape] of every rank's tensor.  Driven by real collectives (`_drive_collectives`) or, on one device,
     by a lock-step loop over W generators (tests/test_gpu_fakeworld.py).

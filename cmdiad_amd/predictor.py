@@ -136,6 +136,10 @@ class BatchPredictor:
         self.stage2_eager = bool(getattr(bank_xyz, "f32_sharded", False) or getattr(bank_second, "f32_sharded", False))
         if self.stage2_eager and group is None:
             raise ValueError("BatchPredictor: a library with sharded fp32 rows (Bank(replicate_f32=False)) needs the process group")
+        # Sharded fp32 rows = SURVEY 8(e)'s partitioning to the letter, whose queries are REPLICATED: the owner of a winning row adds
+        # its part to a sum over the ranks, so every rank must be scoring the SAME batch (submit() checks a fingerprint of the
+        # inputs across the ranks).  Ranks that score DIFFERENT images use the default (replicated fp32 rows, no collective in the tail).
+        self._same_batch_check = self.stage2_eager and group is not None
         self.live_rows = torch.zeros((1,), dtype=torch.int64, device=dev)   # rows actually searched, summed over the xyz searches
         self.xyz_searches = 0
         self._raw_norm = None
@@ -349,6 +353,15 @@ class BatchPredictor:
         out: submitting into a slot whose ticket has not been waited for raises instead of overwriting that batch's results."""
         if pcs.shape[0] != self.B:
             raise ValueError(f"batch of {pcs.shape[0]} given to a predictor built for {self.B}")
+        if self._same_batch_check:
+            import torch.distributed as td
+            fp = torch.stack([pcs.double().sum(), (rgb.double().sum() if rgb is not None else pcs.double().abs().sum())]).to(self.dev)
+            lo, hi = fp.clone(), fp.clone()
+            td.all_reduce(lo, op=td.ReduceOp.MIN, group=self.group)
+            td.all_reduce(hi, op=td.ReduceOp.MAX, group=self.group)
+            if not torch.equal(lo, hi):
+                raise ValueError("BatchPredictor: libraries with sharded fp32 rows (Bank(replicate_f32=False)) score REPLICATED queries -- "
+                                 "every rank must submit the same batch; ranks that score different images use the default Bank")
         old = self.tickets[self.slot]
         if old is not None and not old.taken:
             raise RuntimeError(f"BatchPredictor.submit: {len(self.ring)} tickets are outstanding; wait() for the oldest one first "
@@ -438,16 +451,33 @@ class BatchPredictor:
         searches read the live counts again (a larger cap from now on), run the batch eagerly."""
         torch.cuda.synchronize()
         self.redone += 1
-        for k, v in self.static.items():
-            if k.startswith("ss_") and (v.overflow is None or v.overflowed()):   # only the searches whose rows did not fit
-                v.regrow()
+        # Grow only the LIBRARIES whose rows did not fit -- but every buffer set's search of such a library: the repeat runs on set 0
+        # whichever set the step used.  The flags the searches hold now may belong to LATER steps (two tickets are outstanding and
+        # an earlier repeat re-gathered set 0), so they only save a launch: the repeat itself checks its own flags and grows again.
+        searches = {k: v for k, v in self.static.items() if k.startswith("ss_")}
+
+        def grow(names):
+            for k, v in searches.items():
+                if k.split("_")[1] in names:
+                    v.regrow()
+
+        grow({k.split("_")[1] for k, v in searches.items() if v.overflow is None or v.overflowed()})
         inp = self.inputs[0]
         self._load_inputs(inp, rgb, pcs)
         qs = self.stage1(inp)
         inp["free"] = torch.cuda.Event()
         inp["free"].record()
-        s_dev, maps_dev = self.stage2(qs, self.search(qs, 0))
-        self.step_flags = []
+        for _ in range(3):
+            keys = self.search(qs, 0)
+            self.step_flags = []
+            over = {k.split("_")[1] for k, v in searches.items() if k.endswith("_0") and v.overflowed()}
+            if not over:
+                break
+            grow(over)
+        else:   # a fixed CMDIAD_SHARD_CAP below the live rows of this batch: nothing to re-read
+            raise RuntimeError("BatchPredictor: the repeated batch still overflows the gather cap (CMDIAD_SHARD_CAP too small?); "
+                               "its keys would be incomplete")
+        s_dev, maps_dev = self.stage2(qs, keys)
         B = s_dev.shape[0]
         return s_dev.cpu().numpy().reshape(B).copy(), maps_dev.cpu().numpy().reshape(B, self.gt, self.gt).copy()
 
