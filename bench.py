@@ -944,6 +944,11 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (cmdiad_amd has no CPU fallback)")
+    # Rehearsal of the N > 1 line on a ONE-GPU box (tests/test_gpu_world2.py): every rank uses device 0 and the collectives go
+    # over gloo, because RCCL refuses two ranks on one device.  The code path is the driver's N > 1 path; the numbers are not.
+    rehearsal = world > 1 and os.environ.get("CMDIAD_BENCH_ONE_DEVICE", "0") == "1"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     group = None
@@ -960,7 +965,10 @@ def main():
         try:
             import datetime
             # beyond every leg budget of LegRunner: its watchdog ends a hung leg with the line printed; torch's would SIGABRT the job
-            td.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(minutes=45))
+            if rehearsal:
+                td.init_process_group("gloo", timeout=datetime.timedelta(minutes=45))
+            else:
+                td.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(minutes=45))
             group = td.group.WORLD
             warm = torch.ones(1, device=dev)
             td.all_reduce(warm, group=group)
@@ -1085,6 +1093,9 @@ def main():
             out["rccl_ranks"] = rccl_ranks_seen          # the sum RCCL's all_reduce returned over a tensor of ones
             out["world"] = world
             out["ranks"] = census
+            out["backend"] = td.get_backend(group)
+            if rehearsal:
+                out["rehearsal"] = f"{world} ranks share device 0, collectives over gloo (CMDIAD_BENCH_ONE_DEVICE=1): a code-path check, not a measurement"
     store = None
     if group is not None:
         store = td.distributed_c10d._get_default_store()
