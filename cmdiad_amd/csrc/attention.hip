@@ -24,6 +24,10 @@ constexpr int kThreads = 256;
 constexpr int kKeys = 64;          // keys per tile
 constexpr int kKStride = 144;      // bytes per K row in LDS  (64 bf16 + 16 pad)
 constexpr int kVStride = 136;      // bytes per V^T row in LDS (64 bf16 + 8 pad)
+#ifndef CMDIAD_ATT_LAZY
+#define CMDIAD_ATT_LAZY 8.0f
+#endif
+constexpr float kLazy = CMDIAD_ATT_LAZY;   // log2 units a score may exceed the softmax reference before the accumulators are rescaled
 
 // q is pre-multiplied by head_dim^-0.5 * log2(e) (cmdiad_gemm_qkv), so softmax is exp2 of the raw dot product.
 template <int OCC>
@@ -145,7 +149,11 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(OCC, O
             asm("v_max_f32 %0, %1, %2" : "=v"(mloc) : "v"(mloc), "v"(t[3]));
         }
         mloc = half_max(mloc);   // the other 32 keys of this query sit on lane ^ 32
-        const float thr = kt == 0 ? -__builtin_inff() : 0.0f;   // first tile: always take the full path
+        // m_run is a REFERENCE, not the exact running maximum: it moves only when some query of the wave found a score more than
+        // kLazy above it (P <= 2^kLazy: nothing near the fp32 / bf16 range, and the normalisation O / l cancels the reference).
+        // With the exact maximum the branch was taken on nearly every tile -- among a wave's 32 queries one maximum almost always
+        // grows -- and its ~100 vector instructions were a third of the loop's issue slots (profiles/r5_notes.md section 10).
+        const float thr = kt == 0 ? -__builtin_inff() : kLazy;   // first tile: always take the full path
         if (!__all(mloc <= thr)) {
             // delta = growth of this query's maximum (0 where it did not grow); the tile becomes S - m_new
             const float m_new = kt == 0 ? mloc : m_run + fmaxf(mloc, 0.0f);
@@ -156,14 +164,18 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(OCC, O
 #pragma unroll
             for (int e = 0; e < 16; ++e) { o0[e] *= alpha; o1[e] *= alpha; s0[e] -= delta; s1[e] -= delta; }
         }
-        float psum = 0.0f;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             s0[e] = __builtin_amdgcn_exp2f(s0[e]);
             s1[e] = __builtin_amdgcn_exp2f(s1[e]);
-            psum += s0[e] + s1[e];
         }
-        l_run += psum;
+        f32x2 ps = {0.0f, 0.0f};   // two partial sums: v_pk_add_f32 takes a register pair per issue slot
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+            ps += f32x2{s0[e], s0[e + 1]};
+            ps += f32x2{s1[e], s1[e + 1]};
+        }
+        l_run += ps[0] + ps[1];
 
         // ---- O^T += V^T . P   (k-step = 16 keys; P fragment = 8 consecutive accumulator registers)
 #pragma unroll

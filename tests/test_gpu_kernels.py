@@ -401,6 +401,31 @@ def test_attention_peaked_rows_exercise_rescale():
     np.testing.assert_allclose(out.float().cpu().numpy(), ref.numpy(), rtol=2e-2, atol=2e-2)
 
 
+@pytest.mark.parametrize("step", [3.0, 6.0, 7.9, 8.1, 20.0, -6.0])
+def test_attention_reference_moves_lazily(step):
+    """The softmax reference of a wave moves only when a score exceeds it by more than 8 (log2 units): scores that climb by `step`
+    per 64-key tile stay below that for one tile or more (P up to 2^8 against the stale reference), cross it, or fall; one query of
+    every wave climbs while the other 31 do not (the decision is wave-uniform, the amount per query).  Against float64 softmax_2."""
+    B, H, T = 2, 3, 600
+    Tp = 640
+    g = torch.Generator().manual_seed(int(abs(step) * 10))
+    q = torch.zeros(B, H, Tp, 64)
+    k = torch.zeros(B, H, Tp, 64)
+    v = torch.zeros(B, H, Tp, 64)
+    q[:, :, :T] = 0.3 * torch.randn(B, H, T, 64, generator=g)
+    k[:, :, :T] = torch.randn(B, H, T, 64, generator=g)
+    v[:, :, :T] = torch.randn(B, H, T, 64, generator=g)
+    q[:, :, :T:32, :] = 0.0
+    q[:, :, :T:32, 5] = 1.0                                       # query 0 of every wave reads column 5 of the keys only ...
+    k[:, :, :T, 5] = step * (torch.arange(T) // 64).float()       # ... which climbs (or falls) by `step` per tile
+    q, k, v = _bf(q), _bf(k), _bf(v)
+    out = ops.attention(q.to(DEV).bfloat16(), k.to(DEV).bfloat16(), v.transpose(-1, -2).contiguous().to(DEV).bfloat16(), B, H, T)
+    sc = q[:, :, :T].double() @ k[:, :, :T].double().transpose(-1, -2)
+    ref = (torch.softmax(sc * np.log(2.0), -1) @ v[:, :, :T].double()).transpose(1, 2).reshape(B * T, H * 64)
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref.numpy(), rtol=2e-2, atol=2e-2)
+    assert float((out.float().cpu() - ref).abs().mean()) < 3e-3
+
+
 @pytest.mark.parametrize("M,C", [(785, 768), (1024, 384), (5, 128)])
 def test_layernorm(M, C):
     g = torch.Generator().manual_seed(M)

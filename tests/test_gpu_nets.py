@@ -295,21 +295,29 @@ def test_transformer_block_stage_by_stage_vs_fp64(kind):
     off.append(_ulp_check(k[:, :, :T], qkv[1], "k"))
     off.append(_ulp_check(vt[:, :, :, :T].transpose(-1, -2), qkv[2], "v"))
     assert not bool(q[:, :, T:].any()) and not bool(k[:, :, T:].any()) and not bool(vt[:, :, :, T:].any())   # padding stays zero
-    # ---- attention on the GPU's own q, k, v: keys in tiles of 64, P = bf16(exp2(S - running max)), row sum of the unrounded exp2
+    # ---- attention on the GPU's own q, k, v: keys in tiles of 64, P = bf16(exp2(S - reference)), row sum of the unrounded exp2.
+    # The reference is the first tile's maximum and moves up only when some query of the WAVE (32 consecutive queries) meets a
+    # score more than 8 (log2 units) above its own; then every query of that wave moves to its running maximum (csrc/attention.hip)
     a = ops.attention(q, k, vt, B, H, T)
     qd, kd, vd = q[:, :, :T].cpu().double(), k[:, :, :T].cpu().double(), vt[:, :, :, :T].transpose(-1, -2).cpu().double()
     sc = qd @ kd.transpose(-2, -1)
     m_run = torch.full((B, H, T), -float("inf"), dtype=torch.float64)
     l_run = torch.zeros((B, H, T), dtype=torch.float64)
     o = torch.zeros((B, H, T, hd), dtype=torch.float64)
+    moved, pad32 = 0, (-T) % 32
     for t0 in range(0, T, 64):
         st = sc[..., t0:t0 + 64]
-        m_new = torch.maximum(m_run, st.amax(-1))
+        grow = st.amax(-1) - m_run                                           # [B,H,T]; +inf in the first tile
+        over = torch.nn.functional.pad(grow > 8.0, (0, pad32)).reshape(B, H, -1, 32).any(-1)   # (queries past T are zero rows: never)
+        move = over.repeat_interleave(32, -1)[..., :T] | (t0 == 0)          # the wave-uniform decision, per query
+        moved += int(move.any(-1).sum()) if t0 else 0
+        m_new = torch.where(move, torch.maximum(m_run, st.amax(-1)), m_run)
         alpha = torch.exp2(m_run - m_new)
         p = torch.exp2(st - m_new[..., None])
         l_run = l_run * alpha + p.sum(-1)
         o = o * alpha[..., None] + r16(p) @ vd[:, :, t0:t0 + 64]
         m_run = m_new
+    print(f"  [attention model: the reference moved in {moved} of {(T // 64) * B * H} (head, later tile) pairs]")
     a_ref = (o / l_run[..., None]).transpose(1, 2).reshape(M, C)
     # A P element whose rounding falls the other way (1 in ~3 000: the fp32 scores carry ~1e-6 of absolute error) moves every output
     # of its query by one bf16 step of that weight times the value: <= 2^-8 (p_i / l) |v_i|.  Under uniform attention that is 4e-5
