@@ -182,9 +182,10 @@ __global__ __launch_bounds__(256) void interp_gather_kernel(const float* __restr
 }
 
 // ---------------------------------------------------------------------------------------------
-// a7 (gather) + a9 fused: one 256-thread block per output patch.
+// a7 (gather) + a9 fused: one NT-thread block per output patch.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void xyz_patch_fused_kernel(const float* __restrict__ feat, const int32_t* __restrict__ idx3,
+template <int NT>   // threads per patch: see cmdiad_xyz_patch_fused
+__global__ __launch_bounds__(NT) void xyz_patch_fused_kernel(const float* __restrict__ feat, const int32_t* __restrict__ idx3,
                                                               const float* __restrict__ w3,
                                                               const int32_t* __restrict__ pix2pt, int B, int N, int S, int D,
                                                               int size, int P, float mean, float inv_std,
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(256) void xyz_patch_fused_kernel(const float* __res
     if (tid == 0) s_cnt = 0;
 
     // entry e = (pixel, neighbour k): centre index and combined coefficient
-    for (int e = tid; e < ne; e += 256) {
+    for (int e = tid; e < ne; e += NT) {
         const int k = e % 3, pix = e / 3;
         const int fy = pix / fw, fx = pix % fw;
         const int Y = y0 + fy, X = x0 + fx;
@@ -230,12 +231,12 @@ __global__ __launch_bounds__(256) void xyz_patch_fused_kernel(const float* __res
         s_g[e] = g; s_w[e] = w;
     }
     const int ne4 = (ne + 3) & ~3;
-    for (int e = ne + tid; e < ne4; e += 256) { s_g[e] = -1; s_w[e] = 0.0f; }   // pad to a multiple of four
+    for (int e = ne + tid; e < ne4; e += NT) { s_g[e] = -1; s_w[e] = 0.0f; }   // pad to a multiple of four
     __syncthreads();
     // deterministic fold: the first entry of every distinct centre sums all its entries in index order.  Branch-free over the
     // whole list, four entries per LDS read: the earlier form (a data-dependent `break` loop per entry, then a second loop for
     // the sums) was a chain of up to 2 x 108 dependent LDS round trips per thread -- most of the kernel's time
-    for (int e = tid; e < ne; e += 256) {
+    for (int e = tid; e < ne; e += NT) {
         const int g = s_g[e];
         if (g < 0) continue;
         bool first = true;
@@ -262,9 +263,9 @@ __global__ __launch_bounds__(256) void xyz_patch_fused_kernel(const float* __res
     // order the short list by centre index so the channel sums are run-to-run reproducible: rank sort, one thread per
     // entry (centres are distinct after the fold), into the entry arrays that are no longer needed
     const int cnt4 = (cnt + 3) & ~3;
-    for (int e = cnt + tid; e < cnt4; e += 256) s_lg[e] = 0x7FFFFFFF;
+    for (int e = cnt + tid; e < cnt4; e += NT) s_lg[e] = 0x7FFFFFFF;
     __syncthreads();
-    for (int e = tid; e < cnt; e += 256) {
+    for (int e = tid; e < cnt; e += NT) {
         const int g = s_lg[e];
         int rank = 0;
         for (int j = 0; j < cnt4; j += 4) {
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(256) void xyz_patch_fused_kernel(const float* __res
     __syncthreads();
 
     const size_t orow = ((size_t)b * P * P + patch) * D;
-    for (int c = tid * 4; c < D; c += 1024) {
+    for (int c = tid * 4; c < D; c += NT * 4) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         // eight centre rows in flight per thread (same summation order; sixteen measured slower: 0.65 against 0.45 ms): one row per iteration made the block a chain of
         // ~30 dependent L2 round trips -- 15 us per patch, the whole kernel (100 352 patches, eight blocks per CU) 0.71 ms
@@ -355,7 +356,13 @@ extern "C" int cmdiad_xyz_patch_fused(const float* feat, const int32_t* idx3, co
     CMDIAD_REQUIRE((((uintptr_t)feat | (uintptr_t)patch_f32) & 15) == 0 && ((uintptr_t)patch_bf16 & 7) == 0, CMDIAD_ERR_ARG,
                    "cmdiad_xyz_patch_fused: alignment");
     dim3 grid((unsigned)((B + 7) / 8 * 8 * P * P));
-    hipLaunchKernelGGL(xyz_patch_fused_kernel, grid, dim3(256), 0, (hipStream_t)stream, feat, idx3, w3, pix2pt, B, N, S, D,
+    // One workgroup per patch is a chain of dependent phases (pixel -> point -> centres, fold, rank sort, row gather: ~7 us) that
+    // only other resident workgroups hide: the fewer waves a patch takes, the more patches a CU has in flight (32 wave slots).
+    // Batch 32, 224 x 224, 56 x 56 patches, D = 768 (tools/xyz_patch_time.py, identical bits): 256 threads per patch 0.386-0.403 ms,
+    // 128: 0.322-0.350, 64: 0.326-0.355.
+    static const int nt = getenv("CMDIAD_XYZ_PATCH_THREADS") ? atoi(getenv("CMDIAD_XYZ_PATCH_THREADS")) : 128;
+    auto kern = nt == 64 ? xyz_patch_fused_kernel<64> : nt == 128 ? xyz_patch_fused_kernel<128> : xyz_patch_fused_kernel<256>;
+    hipLaunchKernelGGL(kern, grid, dim3(nt == 64 ? 64 : nt == 128 ? 128 : 256), 0, (hipStream_t)stream, feat, idx3, w3, pix2pt, B, N, S, D,
                        size, P, mean, inv_std, patch_f32, (bf16_t*)patch_bf16);
     CMDIAD_CHECK_LAUNCH();
     return CMDIAD_OK;

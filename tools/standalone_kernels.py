@@ -53,7 +53,7 @@ def l2_rows():
     k_all, k_seg = ops.new_keys(Qmax, DEV), ops.new_keys(8 * cap, DEV)
     shapes = (
         ("bench", live, xyz, lambda: ops.l2_min_keys_counted(q16, qsq, cnt, xyz.bf16, xyz.sqnorm, k_all, 0),
-         "the bench's launch: 54 401 live rows (device-resident count, grid sized for 100 352) x xyz library 76 518 (+26 pad) x 768, fp16"),
+         "the bench's launch: 54 401 live rows (device-resident count, grid sized for 100 352) x xyz library 76 518 (+26 pad) x 768, " + ("bf16" if xyz.bf16.dtype == torch.bfloat16 else "fp16") + " operands"),
         ("all", Qmax, xyz, lambda: ops.l2_min_keys(q16, qsq, xyz.bf16, xyz.sqnorm, k_all, 0),
          "every row searched (CMDIAD_DEDUP=0, the reference's cdist): 100 352 x 76 518 x 768"),
         ("w8", 8 * live, shard, lambda: ops.l2_min_keys_segments(q_seg, s_seg, seg_cnt, cap, shard.bf16, shard.sqnorm, k_seg, 0),
@@ -143,6 +143,18 @@ if not only_hbm and not only_l2:
     work["encoder_stage1_persist_kernel"] = dict(flops=2.0 * pts * (3 * 128 + 128 * 256), bytes=pts * (12 + 512), what="encoder stage 1: conv1 + conv2 + group max, h2 written as bf16")
     work["encoder_tail_persist_kernel"] = dict(flops=2.0 * pts * (256 * 512 + 512 * 384), bytes=pts * 512, what="encoder tail: conv3 (per-point half) + ReLU + conv4 + group max")
     del nb, h2
+    # ---- attention at the two production shapes (models/models.py:148-160 and timm's blocks, models.py:48): q pre-scaled as gemm_qkv does
+    seq_a = 0
+    for tag, T, H, what in (("vit", 785, 12, "ViT-B/8: 785 tokens x 12 heads x 64"), ("pmae", 1024, 6, "Point-MAE: 1 024 tokens x 6 heads x 64")):
+        Tp = (T + 63) // 64 * 64
+        qa = (torch.randn(B, H, Tp, 64, generator=g) * 0.18).to(DEV).bfloat16()
+        ka_ = torch.randn(B, H, Tp, 64, generator=g).to(DEV).bfloat16()
+        va = torch.randn(B, H, 64, Tp, generator=g).to(DEV).bfloat16()
+        for _ in range(8):
+            ops.attention(qa, ka_, va, B, H, T)
+        sync()
+        work[f"attention_kernel/{tag}"] = dict(flops=4.0 * B * H * T * T * 64, what=f"fused softmax(q k^T) v, batch 32, {what} (useful FLOPs: padding not counted)", seq=[seq_a, 8])
+        seq_a += 8
     # ---- implicit-GEMM convolution of the distillation heads (hallucination_network.py:72-143)
     x = torch.randn(B, 56, 56, 768, generator=g).to(DEV).bfloat16()
     wc = (torch.randn(768, 9 * 768, generator=g) / (9 * 768) ** 0.5).to(DEV).bfloat16()
