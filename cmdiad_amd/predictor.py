@@ -356,10 +356,9 @@ class BatchPredictor:
         if self._same_batch_check:
             import torch.distributed as td
             fp = torch.stack([pcs.double().sum(), (rgb.double().sum() if rgb is not None else pcs.double().abs().sum())]).to(self.dev)
-            lo, hi = fp.clone(), fp.clone()
-            td.all_reduce(lo, op=td.ReduceOp.MIN, group=self.group)
-            td.all_reduce(hi, op=td.ReduceOp.MAX, group=self.group)
-            if not torch.equal(lo, hi):
+            both = torch.cat([fp, -fp])                      # one collective: max(x) and max(-x) = -min(x)
+            td.all_reduce(both, op=td.ReduceOp.MAX, group=self.group)
+            if not torch.equal(both[:2], -both[2:]):
                 raise ValueError("BatchPredictor: libraries with sharded fp32 rows (Bank(replicate_f32=False)) score REPLICATED queries -- "
                                  "every rank must submit the same batch; ranks that score different images use the default Bank")
         old = self.tickets[self.slot]

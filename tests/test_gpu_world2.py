@@ -28,7 +28,8 @@ def test_row_sharded_paths_with_two_real_ranks_on_one_gpu():
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
     rec = json.loads(line)
     assert rec["world2"] is True and rec["ranks"] == 2
-    assert [c.split("(")[0] for c in rec["checked"]] == ["sharded_search", "sharded_fp32_scoring", "sharded_coreset", "sharded_pipeline"]
+    assert [c.split("(")[0] for c in rec["checked"]] == ["sharded_search", "sharded_fp32_scoring", "sharded_coreset", "sharded_pipeline",
+                                                          "sharded_fp32_pipeline"]
 
 
 def _launch(nproc, script_args, extra_env, timeout=900):

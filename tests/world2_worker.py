@@ -118,6 +118,21 @@ def main():
     assert not bad, f"rank {rank}: the row-sharded pipeline's outputs differ: {bad}"
     done.append(f"sharded_pipeline(redone={sh_p.redone})")
 
+    # ---- 5. the same pipeline over libraries whose fp32 rows are sharded too: the ranks score the SAME batches (replicated queries);
+    # ranks that submit different batches are refused on every rank
+    fx, fr = (eng.Bank(st["bank_xyz"].f32, rank, world, replicate_f32=False), eng.Bank(st["bank_second"].f32, rank, world, replicate_f32=False))
+    f_p = mk(group, fx, fr)
+    same = [pbatch(10, 0.36), pbatch(50, 0.62), pbatch(30, 0.40)]
+    want_same = [ref_p.predict_batch(*b) for b in same]
+    for (gs, gm), (ws, wm) in zip([f_p.predict_batch(*b) for b in same], want_same):
+        assert np.array_equal(gs, ws) and np.array_equal(gm, wm), f"rank {rank}: sharded-fp32 pipeline differs from the unsharded one"
+    try:
+        f_p.predict_batch(*pbatch(10 + 100 * rank, 0.36))
+        raise AssertionError("different batches on the two ranks were accepted by a predictor over sharded fp32 rows")
+    except ValueError as exc:
+        assert "REPLICATED" in str(exc)
+    done.append(f"sharded_fp32_pipeline(redone={f_p.redone})")
+
     ok = torch.tensor([1])
     td.all_reduce(ok, op=td.ReduceOp.MIN)
     td.barrier()

@@ -4,7 +4,7 @@
 # then, back in the dev container:
 #   python tools/summarize_profile.py gpurun_out/prof_r1/trace/*/*kernel_trace.csv 12 > profiles/r1_summary.md
 #   python tools/pmc_summary.py gpurun_out/prof_r1/pmc profiles/r1_pmc.json > profiles/r1_pmc.md
-#   python tools/standalone_summary.py gpurun_out/prof_r1/standalone gpurun_out/prof_r1/standalone_pmc gpurun_out/prof_r1/standalone_work.json > profiles/r1_standalone.md
+#   python tools/standalone_summary.py gpurun_out/prof_r1/standalone gpurun_out/prof_r1/standalone_pmc,gpurun_out/prof_r1/standalone_l2_pmc/fetch,gpurun_out/prof_r1/standalone_l2_pmc/write gpurun_out/prof_r1/standalone_work.json > profiles/r1_standalone.md
 #   python tools/l2_standalone_pmc.py gpurun_out/prof_r1 profiles/r1   (-> profiles/r1_l2_standalone.json + the meta file bench.py reads)
 # Counter passes are separate runs (TCC has 4 slots: FETCH_SIZE takes 3, WRITE_SIZE 2) and never combined with
 # sys/hip/hsa tracing.  The program sits directly after `--` (no env/bash hop after the profiler preloads).

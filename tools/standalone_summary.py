@@ -13,7 +13,9 @@ import os
 import sys
 
 trace_dir = sys.argv[1]
-pmc_dir = sys.argv[2] if len(sys.argv) > 2 and os.path.isdir(sys.argv[2]) else None
+# counter directories, comma-separated (the HBM-bound kernels' passes and the distance GEMM's FETCH / WRITE passes live apart)
+pmc_dirs = [d for d in (sys.argv[2].split(",") if len(sys.argv) > 2 else []) if os.path.isdir(d)]
+pmc_dir = pmc_dirs or None
 work_file = next((a for a in sys.argv[2:] if a.endswith(".json")), os.path.join("gpurun_out", "standalone_work.json"))
 work = json.load(open(work_file))
 
@@ -40,7 +42,7 @@ for v in by_name.values():
 pmc = collections.defaultdict(lambda: collections.defaultdict(list))
 pmc_seq = collections.defaultdict(lambda: collections.defaultdict(list))   # kernel name -> counter -> [(dispatch id, value)]
 if pmc_dir:
-    for f in glob.glob(os.path.join(pmc_dir, "**", "*counter_collection.csv"), recursive=True):
+    for f in (f for d in pmc_dirs for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)):
         for r in csv.DictReader(open(f)):
             pmc[(short(r["Kernel_Name"]), int(r["Grid_Size"]))][r["Counter_Name"]].append(float(r["Counter_Value"]))
             pmc_seq[short(r["Kernel_Name"])][r["Counter_Name"]].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
