@@ -178,6 +178,10 @@ def case_attention(rs):
     q[:, :, :T] = torch.from_numpy(rs.randn(B, H, T, 64).astype(np.float32))
     k[:, :, :T] = torch.from_numpy(rs.randn(B, H, T, 64).astype(np.float32))
     v[:, :, :T] = torch.from_numpy(rs.randn(B, H, T, 64).astype(np.float32))
+    q *= float(rs.choice([0.05, 0.18, 0.5, 1.0, 2.0]))          # flat ... nearly one-hot softmax: the lazily moved reference never / often moves
+    if rs.rand() < 0.4:                                          # scores that climb (or fall) along the keys for some queries
+        k[:, :, :T, 7] = float(rs.uniform(-0.2, 0.2)) * torch.arange(T, dtype=torch.float32)
+        q[:, :, ::int(rs.randint(1, 40)), 7] = 1.0
     qb, kb, vb = q.bfloat16(), k.bfloat16(), v.bfloat16()
     out = ops.attention(qb.to(DEV), kb.to(DEV), vb.transpose(2, 3).contiguous().to(DEV), B, H, T).float().cpu()
     p = torch.softmax(qb[:, :, :T].double() @ kb[:, :, :T].double().transpose(2, 3) * np.log(2.0), -1)
