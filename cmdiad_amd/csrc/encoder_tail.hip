@@ -300,9 +300,9 @@ __global__ __launch_bounds__(TW * 64, 1) void encoder_tail_persist_kernel(Global
         if (!(ABL && (p.ablate & 64)))
 #pragma unroll
         for (int o = 0; o < 3; ++o) {
-            float red[32];
+            float red[16];   // the lane's 4 x 4 columns of this output chunk, maximum over its two 16-row blocks
 #pragma unroll
-            for (int q = 0; q < 32; ++q) red[q] = fmaxf(acco[o][0][q >> 2][q & 3], acco[o][1][q >> 2][q & 3]);
+            for (int q = 0; q < 16; ++q) red[q] = fmaxf(acco[o][0][q >> 2][q & 3], acco[o][1][q >> 2][q & 3]);
             row16_max_batch(red);
             if ((lane & 15) == 0) {
 #pragma unroll
