@@ -404,9 +404,53 @@ def golden_datasets():
     print({k: v.shape for k, v in out.items()})
 
 
+def golden_surface():
+    """G14: what the reference's scripts that the drop-in does NOT replace (dataset.py, main.py, cmdiad_runner.py,
+    hallucination_network_pretrain.py) take from the modules it DOES redirect -- names only, from their import statements (and, for
+    `from m import *`, the names of m they use) -- and the reference's own resize_organized_pc (utils/mvtec3d_util.py:14-22) on
+    small seeded scans, both output forms."""
+    import ast
+    import cmdiad_amd
+    need = set()
+    for f in ("dataset.py", "main.py", "cmdiad_runner.py", "hallucination_network_pretrain.py"):
+        tree = ast.parse(open(os.path.join(REF, f)).read())
+        used = {n.id for n in ast.walk(tree) if isinstance(n, ast.Name)} | {n.attr for n in ast.walk(tree) if isinstance(n, ast.Attribute)}
+        for n in ast.walk(tree):
+            mods = []
+            if isinstance(n, ast.ImportFrom) and n.module in cmdiad_amd._DROPIN:
+                for a in n.names:
+                    if a.name == "*":
+                        mods.append(n.module)
+                    else:
+                        need.add(f"{n.module}:{a.name}")
+            if isinstance(n, ast.ImportFrom) and n.module and any(f"{n.module}.{a.name}" in cmdiad_amd._DROPIN for a in n.names):
+                mods += [f"{n.module}.{a.name}" for a in n.names if f"{n.module}.{a.name}" in cmdiad_amd._DROPIN]
+            if isinstance(n, ast.Import):
+                mods += [a.name for a in n.names if a.name in cmdiad_amd._DROPIN]
+            for mod in mods:      # a module object or a star import: every top-level name of the reference's module that the script mentions
+                ref_mod = ast.parse(open(os.path.join(REF, mod.replace(".", "/") + ".py")).read())
+                defined = {d.name for d in ref_mod.body if isinstance(d, (ast.FunctionDef, ast.ClassDef))}
+                need |= {f"{mod}:{name}" for name in defined & used}
+    from utils import mvtec3d_util as rmv
+    out = {"names": np.array(sorted(need))}
+    rs = np.random.RandomState(14)
+    for i, (H, W, h, w) in enumerate([(37, 53, 16, 24), (40, 40, 56, 56), (61, 29, 7, 30), (48, 48, 48, 48)]):
+        scan = rs.randn(H, W, 3).astype(np.float32)
+        scan[rs.rand(H, W) < 0.3] = 0.0
+        out[f"scan_{i}"] = scan
+        out[f"size_{i}"] = np.array([h, w])
+        out[f"tensor_{i}"] = rmv.resize_organized_pc(scan, target_height=h, target_width=w).numpy()
+        out[f"array_{i}"] = rmv.resize_organized_pc(scan, target_height=h, target_width=w, tensor_out=False)
+        out[f"depth_{i}"] = np.ascontiguousarray(rmv.organized_pc_to_depth_map(scan))
+    np.savez_compressed(os.path.join(HERE, "g14_surface.npz"), **out)
+    print(list(out["names"]))
+
+
 def main():
     _install_stubs()
     sys.path.insert(0, REF)
+    if len(sys.argv) > 1 and sys.argv[1] == "g14":  # only the drop-in surface fixture
+        return golden_surface()
     if len(sys.argv) > 1 and sys.argv[1] == "g13":  # only the pair-dataset fixture
         return golden_datasets()
     if len(sys.argv) > 1 and sys.argv[1] == "g5b":  # only the mlp_depth = 2 hallucination fixture

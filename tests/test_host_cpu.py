@@ -1040,3 +1040,42 @@ def test_row_sharded_coreset_exchange_gloo(tmp_path, world):
     the reference's single loop (features.py:372-425), ties between duplicate rows in different shards included."""
     outs = _run_gloo(_GLOO_CORESET_WORKER.format(repo=REPO), tmp_path, world=world)
     assert all("ok" in o for o in outs), outs
+
+
+def test_dropin_serves_every_name_the_reference_scripts_take_from_redirected_modules(golden):
+    """The reference's dataset.py / main.py / cmdiad_runner.py / hallucination_network_pretrain.py are NOT replaced, and they import
+    from modules that install_dropin() redirects to this package (`from utils.mvtec3d_util import *`, dataset.py:9): every name
+    they take (tests/golden/make_golden.py G14, from the reference's import statements) must exist here.  Round 5 found three
+    missing: the redirected utils.mvtec3d_util had only organized_pc_to_unorganized_pc, so the reference's own dataset would have
+    raised NameError on its first sample."""
+    import importlib
+    import cmdiad_amd
+    g = golden("g14_surface.npz")
+    names = [str(n) for n in g["names"]]
+    assert len(names) >= 18
+    missing = [n for n in names if not hasattr(importlib.import_module(cmdiad_amd._DROPIN[n.split(":")[0]]), n.split(":")[1])]
+    assert not missing, missing
+
+
+def test_resize_organized_pc_equals_the_reference(golden):
+    """utils/mvtec3d_util.py:14-26 on seeded scans with invalid (all-zero) points: nearest-neighbour resize to smaller, larger and
+    equal grids, both output forms, and the depth channel -- bit for bit the reference's outputs (G14), and torch's mode='nearest'
+    on MVTec-sized scans (800 x 800 -> 224 x 224)."""
+    from cmdiad_amd.utils import mvtec3d_util as mv
+    g = golden("g14_surface.npz")
+    for i in range(4):
+        scan, (h, w) = g[f"scan_{i}"], g[f"size_{i}"]
+        t = mv.resize_organized_pc(scan, target_height=int(h), target_width=int(w))
+        assert t.is_contiguous() and t.dtype == torch.float32 and np.array_equal(t.numpy(), g[f"tensor_{i}"])
+        a = mv.resize_organized_pc(scan, target_height=int(h), target_width=int(w), tensor_out=False)
+        assert isinstance(a, np.ndarray) and np.array_equal(a, g[f"array_{i}"])
+        assert np.array_equal(mv.organized_pc_to_depth_map(scan), g[f"depth_{i}"])
+    rs = np.random.RandomState(3)
+    for H, W in ((800, 800), (400, 400), (777, 333)):
+        scan = rs.randn(H, W, 3).astype(np.float32)
+        ref = torch.nn.functional.interpolate(torch.tensor(scan).permute(2, 0, 1).unsqueeze(0).contiguous(), size=(224, 224), mode="nearest")[0]
+        assert torch.equal(mv.resize_organized_pc(scan), ref)
+    flat = mv.organized_pc_to_unorganized_pc(scan)
+    assert flat.shape == (H * W, 3) and np.array_equal(flat[W + 2], scan[1, 2])
+    with pytest.raises((ImportError, FileNotFoundError, OSError, ValueError)):
+        mv.read_tiff_organized_pc("/nonexistent/file.tiff")
