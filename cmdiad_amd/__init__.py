@@ -21,22 +21,36 @@ _DROPIN = {
 }
 
 
+class _ParentFallback:
+    """Last entry of sys.meta_path: serves `feature_extractors`, `models`, `utils` as EMPTY packages when nothing else provides
+    them (this package used without the reference's tree).  Being last, the reference's own directories -- namespace packages,
+    found by the regular path finder whenever its tree is on sys.path at import time -- always win, so its `utils.misc`,
+    `utils.heatmap`, ... stay importable whether install_dropin() ran before or after sys.path was set up."""
+
+    parents = frozenset(name.rpartition(".")[0] for name in _DROPIN)
+
+    def find_spec(self, name, path=None, target=None):
+        if name not in self.parents:
+            return None
+        import importlib.machinery
+        spec = importlib.machinery.ModuleSpec(name, None, is_package=True)
+        spec.submodule_search_locations = []
+        return spec
+
+
 def install_dropin():
     """Redirect the reference's module paths (``feature_extractors.features``, ``models.models``, ...) to this
     package, submodule by submodule, so ``cmdiad_runner.py`` / ``hallucination_network_pretrain.py`` import the
-    MI355X implementation without being edited.  Parent packages that the reference provides (e.g. its own
-    ``utils`` with ``utils.misc``) stay importable; missing parents are created as empty packages."""
+    MI355X implementation without being edited.  Only the listed submodules are registered (``sys.modules``); their parent
+    packages are NOT imported here: the import system resolves them when first needed -- to the reference's own directories if
+    its tree is on ``sys.path`` by then (so ``utils.misc``, ``dataset.py`` keep working), to empty packages otherwise."""
     import importlib
     import sys
-    import types
     for name, target in _DROPIN.items():
         mod = importlib.import_module(target)
         sys.modules[name] = mod
         parent, _, leaf = name.rpartition(".")
-        try:
-            pkg = importlib.import_module(parent)
-        except ImportError:
-            pkg = types.ModuleType(parent)
-            pkg.__path__ = []
-            sys.modules[parent] = pkg
-        setattr(pkg, leaf, mod)
+        if parent in sys.modules:
+            setattr(sys.modules[parent], leaf, mod)
+    if not any(isinstance(f, _ParentFallback) for f in sys.meta_path):
+        sys.meta_path.append(_ParentFallback())

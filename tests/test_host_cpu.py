@@ -1079,3 +1079,18 @@ def test_resize_organized_pc_equals_the_reference(golden):
     assert flat.shape == (H * W, 3) and np.array_equal(flat[W + 2], scan[1, 2])
     with pytest.raises((ImportError, FileNotFoundError, OSError, ValueError)):
         mv.read_tiff_organized_pc("/nonexistent/file.tiff")
+
+
+@pytest.mark.parametrize("order", ["path_first", "install_first", "no_reference"])
+def test_install_dropin_is_order_independent(order):
+    """install_dropin() before or after the reference's tree enters sys.path, or with no reference at all: the reference's own
+    unreplaced scripts import (dataset.py star-imports a redirected module; hallucination_network_pretrain.py needs the reference's
+    OWN utils.misc beside the redirected utils.lr_sched), redirected names resolve here.  Round 5: installed first, the old
+    install_dropin() registered an empty `utils` package and the reference's utils.misc was gone."""
+    ref = os.environ.get("CMDIAD_REFERENCE", "/root/reference")
+    if order != "no_reference" and not os.path.isdir(ref):
+        pytest.skip("the reference's tree is not on this machine")
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", CMDIAD_ALLOW_RANDOM_INIT="1")
+    out = subprocess.run([sys.executable, os.path.join(REPO, "tests", "dropin_order_check.py"), order, ref], capture_output=True, text=True,
+                         timeout=300, env=env, cwd="/tmp")
+    assert out.returncode == 0 and f"{order} ok" in out.stdout, out.stderr[-2500:]
