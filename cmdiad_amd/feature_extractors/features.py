@@ -324,6 +324,11 @@ class Features(torch.nn.Module):
     def predict(self, sample, mask, label, rgb_path):
         raise NotImplementedError
 
+    def interpolate_points(self, rgb, xyz):
+        """features.py:216-219: the point-cloud feature maps and group centres of one forward pass, and the cloud itself."""
+        rgb_feature_maps, xyz_feature_maps, center, ori_idx, center_idx, _ = self(rgb, xyz)
+        return xyz_feature_maps, center, xyz
+
     def add_sample_to_late_fusion_mem_bank(self, sample):
         raise NotImplementedError
 

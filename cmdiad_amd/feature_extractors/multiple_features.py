@@ -116,6 +116,8 @@ class _MethodBase(Features):
     sample's numbers do not depend on the batch it rode in (tests/test_gpu_engine.py::test_batch_invariance,
     test_gpu_predictor.py::test_dropin_micro_batching_is_invisible); at B = 1 the GPU is bound by a 2 ms single-CU FPS
     chain and ~200 tiny launches per image, in a micro-batch of 16 those run side by side."""
+    _image_slot = 0      # which element of a sample goes through the RGB backbone (DepthFeatures: 2)
+
 
     patch_xyz_lib = _lazy_result("patch_xyz_lib", "fit")
     patch_rgb_lib = _lazy_result("patch_rgb_lib", "fit")
@@ -241,7 +243,7 @@ class _MethodBase(Features):
                 host.copy_(torch.cat([t.cpu() for t in tensors]))
             return host, host.to(dev, non_blocking=True)
 
-        rgb = staged([s[0] for s in samples])[1] if want_rgb else None
+        rgb = staged([s[self._image_slot] for s in samples])[1] if want_rgb else None
         if not want_xyz:
             with torch.no_grad():
                 return self._engine.extract(rgb, want_xyz=False)
@@ -320,6 +322,12 @@ class RGBFeatures(_MethodBase):
         ex = self._extract_batch(samples, want_xyz=False)
         return self._score_columns([(eng.Engine.rgb_patch(ex), self.rgb_mean, self.rgb_std, 'rgb',
                                      self.args.rgb_s_lambda, self.args.rgb_smap_lambda)])
+
+
+class DepthFeatures(RGBFeatures):
+    """multiple_features.py:124-200: the RGB method fed with the three-channel depth image of the sample (sample[2]) instead of
+    the photograph -- same backbone, same library, same scoring.  (No caller in the reference constructs it: cmdiad_runner.py:16-31.)"""
+    _image_slot = 2
 
 
 class PointFeatures(_MethodBase):

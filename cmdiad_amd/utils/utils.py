@@ -90,3 +90,14 @@ def save_model(args, epoch, model, model_without_ddp, optimizer, loss_scaler, wi
     elif not without_opt:
         to_save.update(optimizer=optimizer.state_dict())
     torch.save(to_save, path)
+
+
+class Interpolate(torch.nn.Module):
+    """utils/utils.py:118-127: F.interpolate(size, mode, align_corners=False) as a layer (no caller in the reference)."""
+
+    def __init__(self, size, mode):
+        super().__init__()
+        self.size, self.mode = size, mode
+
+    def forward(self, x):
+        return torch.nn.functional.interpolate(x, size=self.size, mode=self.mode, align_corners=False)

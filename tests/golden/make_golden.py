@@ -431,8 +431,21 @@ def golden_surface():
                 ref_mod = ast.parse(open(os.path.join(REF, mod.replace(".", "/") + ".py")).read())
                 defined = {d.name for d in ref_mod.body if isinstance(d, (ast.FunctionDef, ast.ClassDef))}
                 need |= {f"{mod}:{name}" for name in defined & used}
+    # every top-level function, class and method of the redirected modules with its positional argument names
+    sigs = []
+    for mod in cmdiad_amd._DROPIN:
+        tree = ast.parse(open(os.path.join(REF, mod.replace(".", "/") + ".py")).read())
+        for node in tree.body:
+            if isinstance(node, ast.FunctionDef):
+                sigs.append(f"{mod}|{node.name}|{','.join(a.arg for a in node.args.posonlyargs + node.args.args)}")
+            elif isinstance(node, ast.ClassDef):
+                sigs.append(f"{mod}|{node.name}|")
+                for sub in node.body:
+                    if isinstance(sub, ast.FunctionDef):
+                        star = "*" if sub.args.vararg else ""
+                        sigs.append(f"{mod}|{node.name}.{sub.name}|{','.join(a.arg for a in sub.args.posonlyargs + sub.args.args)}{star}")
     from utils import mvtec3d_util as rmv
-    out = {"names": np.array(sorted(need))}
+    out = {"names": np.array(sorted(need)), "signatures": np.array(sorted(sigs))}
     rs = np.random.RandomState(14)
     for i, (H, W, h, w) in enumerate([(37, 53, 16, 24), (40, 40, 56, 56), (61, 29, 7, 30), (48, 48, 48, 48)]):
         scan = rs.randn(H, W, 3).astype(np.float32)

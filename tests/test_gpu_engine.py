@@ -381,6 +381,40 @@ def test_other_method_classes_run_the_protocol(weights):
         assert m.predictions[0].shape == (224, 224)
 
 
+def test_depth_features_is_the_rgb_method_on_the_third_sample_slot(weights):
+    """multiple_features.py:124-200: DepthFeatures runs the RGB backbone on sample[2] (the three-channel depth image).  Given the
+    photograph in slot 2 (and garbage in slot 0) it returns what RGBFeatures returns for the photograph in slot 0, bit for bit;
+    Features.interpolate_points (features.py:216-219) returns the point branch of one forward pass."""
+    import warnings
+    from cmdiad_amd.feature_extractors import multiple_features as mf
+    sd_vit, sd_pm = weights
+    train = [synth_sample(40 + i) for i in range(3)]
+    outs = []
+    for cls, slot in ((mf.RGBFeatures, 0), (mf.DepthFeatures, 2)):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m = cls(make_args())
+        m.deep_feature_extractor.rgb_backbone.load_state_dict(sd_vit)
+        m.deep_feature_extractor.xyz_backbone.load_state_dict(sd_pm)
+        place = lambda rgb, pc: (rgb, pc, torch.full_like(rgb, 7.0)) if slot == 0 else (torch.full_like(rgb, 7.0), pc, rgb)   # noqa: E731
+        for rgb, pc in train:
+            m.add_sample_to_mem_bank(place(rgb, pc), class_name="synth")
+        m.run_coreset()
+        for rgb, pc in train:
+            m.add_sample_to_late_fusion_mem_bank(place(rgb, pc))
+        m.run_late_fusion()
+        for i, anomalous in ((50, False), (51, True)):
+            rgb, pc = synth_sample(i, anomalous)
+            m.predict(place(rgb, pc), torch.zeros(1, 1, 224, 224), np.array([int(anomalous)]), [f"synth/{i}.png"])
+        outs.append((np.concatenate([np.ravel(x) for x in m.image_preds]), np.stack(m.predictions)))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    rgb, pc = train[0]
+    pts, _ = mf.organized_pc_to_unorganized_pc_no_zeros((rgb, pc, pc))
+    xyz_maps, center, xyz_back = m.interpolate_points(rgb, pts.contiguous())
+    full = m(rgb, pts.contiguous())
+    assert torch.equal(xyz_maps[0], full[1][0]) and torch.equal(center.cpu(), full[2].cpu()) and xyz_back is not None
+
+
 def test_public_features_contract(weights):
     """the PUBLIC surface the reference's callers use -- Features.__call__(rgb, xyz_unorganized) for all
     three out_types (features.py:123-158), get_xyz_patch with CALLER-supplied nonzero_indices (:169-184),

@@ -1094,3 +1094,51 @@ def test_install_dropin_is_order_independent(order):
     out = subprocess.run([sys.executable, os.path.join(REPO, "tests", "dropin_order_check.py"), order, ref], capture_output=True, text=True,
                          timeout=300, env=env, cwd="/tmp")
     assert out.returncode == 0 and f"{order} ok" in out.stdout, out.stderr[-2500:]
+
+
+# names of the redirected modules that this package deliberately does not carry (each with its reason); everything else of the
+# reference's 143 top-level functions, classes and methods must exist with the same positional argument names
+_SURFACE_OMISSIONS = {
+    "models.models|PointTransformer.load_model_from_pb_ckpt": "Point-BERT backbone (encoder_dims 256): out of scope, PointTransformer raises for it",
+    "models.hrnet|BasicBlock": "building block of the reference's HRNet composition; HRNet here keeps the state_dict keys, not the classes",
+    "models.hrnet|StageModule": "as BasicBlock",
+    "utils.au_pro_util|GroundTruthComponent": "internal of calculate_au_pro (vectorised here)",
+    "utils.au_pro_util|collect_anomaly_scores": "internal of calculate_au_pro",
+    "utils.au_pro_util|compute_pro": "internal of calculate_au_pro",
+}
+
+
+def test_dropin_modules_carry_the_reference_surface(golden):
+    """Every top-level function, class and method of the ten redirected reference modules (G14: names and positional argument
+    names, from the reference's source) exists in the module that replaces it with the same leading arguments -- except the six
+    listed omissions.  Round 5 found Features.interpolate_points, DepthFeatures and utils.utils.Interpolate missing."""
+    import importlib
+    import inspect
+    import cmdiad_amd
+    sigs = [str(x) for x in golden("g14_surface.npz")["signatures"]]
+    assert len(sigs) >= 140
+    problems = []
+    for line in sigs:
+        mod, qual, args = line.split("|")
+        if any(f"{mod}|{qual}" == k or f"{mod}|{qual}".startswith(k + ".") for k in _SURFACE_OMISSIONS):
+            continue
+        obj = importlib.import_module(cmdiad_amd._DROPIN[mod])
+        try:
+            for part in qual.split("."):
+                obj = getattr(obj, part)
+        except AttributeError:
+            problems.append(f"missing: {mod}.{qual}")
+            continue
+        if not args or args.endswith("*"):
+            continue
+        want = args.split(",")
+        try:
+            params = list(inspect.signature(obj).parameters.values())
+        except (TypeError, ValueError):
+            continue
+        if any(p.kind in (p.VAR_POSITIONAL, p.VAR_KEYWORD) for p in params):
+            continue          # (*a, **k) pass-throughs accept the reference's arguments whatever their names
+        have = [p.name for p in params]
+        if have[:len(want)] != want:
+            problems.append(f"arguments of {mod}.{qual}: reference {want}, here {have}")
+    assert not problems, problems
