@@ -505,7 +505,7 @@ def sharded_search(dev, group, rank, world, rows_list, iters=10, warm=3):
     q32[bg] = -0.3
     q16, _, qsq = ops.normalize_cast(q32)
     del q32
-    side = torch.cuda.Stream(dev)
+    side = ops.shared_stream(dev, "bench.exchange")
     out = []
     for name, rows in rows_list:
         lo, hi = eng.shard_range(rows, rank, world)

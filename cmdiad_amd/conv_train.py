@@ -533,7 +533,7 @@ def _hrnet_step(img, feature, P, batch, need_grad):
         ent["img"], ent["feature"] = img.clone(), feature.clone()
         try:
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 ent["out"] = hrnet_forward_backward(ent["img"], ent["feature"], P, batch, need_grad)
             ent["graph"] = graph
         except Exception as e:      # noqa: BLE001 -- capture is an optimisation: this key stays eager, the step itself must not fail

@@ -31,6 +31,11 @@ import torch
 from torch.utils.data import Dataset
 
 
+def _shared_stream(device, role):
+    from . import ops          # (lazy: this module is importable without the HIP library; the device ring is not usable without it)
+    return ops.shared_stream(device, role)
+
+
 class PreTrainTensorDataset(Dataset):
     def __init__(self, root_path):
         super().__init__()
@@ -216,7 +221,7 @@ class FeatureRing:
         pin = self.device.type == "cuda"
         self._staging = [torch.empty((batch_size, *self.sample_shape), dtype=self.dtype, pin_memory=pin) for _ in range(depth)]
         self._dev = [torch.empty((batch_size, *self.sample_shape), dtype=self.dtype, device=self.device) for _ in range(depth)]
-        self._copy_stream = torch.cuda.Stream(device=self.device) if pin else None
+        self._copy_stream = _shared_stream(self.device, "dataset.copy") if pin else None
         n_bytes = len(self.files) * probe.numel() * probe.element_size()
         self._cache = None
         self._cached = [False] * len(self.files)

@@ -238,7 +238,7 @@ class Features(torch.nn.Module):
                 # for the point count, so that wait costs nothing either.
                 side = self.__dict__.get("_vit_stream")
                 if side is None:
-                    side = self.__dict__["_vit_stream"] = torch.cuda.Stream()
+                    side = self.__dict__["_vit_stream"] = ops.shared_stream(dev, "features.vit")
                 cur = torch.cuda.current_stream()
                 rgb_dev = rgb.to(dev).float()
                 side.wait_stream(cur)

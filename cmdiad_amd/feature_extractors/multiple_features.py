@@ -18,6 +18,7 @@ import numpy as np
 import torch
 
 from .. import engine as eng
+from .. import ops
 from .features import Features
 
 
@@ -255,7 +256,7 @@ class _MethodBase(Features):
                              f"grouping (models/models.py:88-113) needs at least {self.args.group_size}")
         side = self.__dict__.get("_side_stream")
         if side is None:
-            side = self.__dict__["_side_stream"] = torch.cuda.Stream()
+            side = self.__dict__["_side_stream"] = ops.shared_stream(dev, "predictor.side")
         with torch.no_grad():
             return self._engine.extract(rgb, pcs_dev, want_rgb=want_rgb, n_max=int(counts.max()),
                                         side_stream=side if want_rgb else None)

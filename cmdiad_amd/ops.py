@@ -28,6 +28,25 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_SHARED_STREAMS = {}
+
+
+def shared_stream(device, role, priority=0):
+    """One HIP stream per (device, role, priority) for the whole process.  torch hands out streams from a pool of 32 per device
+    and priority, round robin: objects that each create their own (a predictor per class, a method object per run) walk
+    through the pool and end up on the SAME underlying stream as somebody else's -- RCCL's communicator stream, the graph-capture
+    stream -- and a capture that forks onto such a stream puts RCCL's events "in a capturing stream": its watchdog thread then
+    raises and takes the process down (tools/fuzz_pipeline.py, profiles/r5_notes.md section 15).  Roles are few and fixed."""
+    dev = torch.device(device)
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    key = (dev.index, role, int(priority))
+    st = _SHARED_STREAMS.get(key)
+    if st is None:
+        st = _SHARED_STREAMS[key] = torch.cuda.Stream(dev, priority=int(priority))
+    return st
+
+
 def _p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 

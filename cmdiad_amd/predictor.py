@@ -116,7 +116,8 @@ class BatchPredictor:
         # CMDIAD_STREAM_PRIO="side,post" (A/B runs): stream priorities of the point-cloud branch and of the search / scoring stage
         # (0 = default, -1 = high; the ViT branch runs on the caller's stream)
         prio = [int(v) for v in os.environ.get("CMDIAD_STREAM_PRIO", "0,0").split(",")]
-        self.side, self.post, self.copy = torch.cuda.Stream(dev, priority=prio[0]), torch.cuda.Stream(dev, priority=prio[1]), torch.cuda.Stream(dev)
+        self.side, self.post, self.copy = (ops.shared_stream(dev, "predictor.side", prio[0]), ops.shared_stream(dev, "predictor.post", prio[1]),
+                                           ops.shared_stream(dev, "predictor.copy"))
         # host ring: the step's FINAL outputs (image score, pixel map), f64 as sklearn's score_samples returns them
         self.ring = [(torch.empty((batch, 1), dtype=torch.float64, pin_memory=True),
                       torch.empty((batch, gt_size * gt_size), dtype=torch.float64, pin_memory=True)) for _ in range(ring)]
@@ -300,11 +301,16 @@ class BatchPredictor:
         qs = self.stage1(self.inputs[0])  # one eager pass first: module loading / attribute setting must not happen in capture
         self.stage2(qs, self.search(qs, 0))
         torch.cuda.synchronize()
+        # capture_error_mode="thread_local": with a process group alive, RCCL's watchdog THREAD polls the events of earlier
+        # collectives (hipEventQuery); under the default "global" mode that call from another thread invalidates this thread's
+        # capture (hipErrorStreamCaptureInvalidated -> eager fallback) and raises inside the watchdog, which aborts the process
+        # (tools/fuzz_pipeline.py met both within seconds; profiles/r5_notes.md section 15)
+        caller_stream = torch.cuda.current_stream()
         try:
             sets = []
             for s in range(2):  # two complete buffer sets: step i+1's extraction overlaps step i's scoring tail
                 g1 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g1):
+                with torch.cuda.graph(g1, capture_error_mode="thread_local"):
                     qs = self.stage1(self.inputs[s])
                 g1.replay()
                 keys = self.search(qs, s)
@@ -314,7 +320,7 @@ class BatchPredictor:
                     out = self.stage2(qs, k)
                 else:
                     g2 = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g2):
+                    with torch.cuda.graph(g2, capture_error_mode="thread_local"):
                         out = self.stage2(qs, k)
                 torch.cuda.synchronize()
                 sets.append(dict(g1=g1, g2=g2, qs=qs, k=k, out=out, done=None))
@@ -325,7 +331,13 @@ class BatchPredictor:
                   file=sys.stderr)
             self.sets = None
             self.use_graph = False
-            torch.cuda.synchronize()
+            # torch.cuda.graph.__exit__ ends the capture BEFORE it restores the stream context: when the end itself raises (an
+            # invalidated capture), the capture stream stays current and every later launch fails on it -- put the caller's back
+            torch.cuda.set_stream(caller_stream)
+            try:
+                torch.cuda.synchronize()
+            except Exception:
+                pass
 
     def _load_inputs(self, inp, rgb, pcs):
         """Copies one batch into a set's static input buffers on the copy stream (H2D when the source is pinned host memory,
