@@ -327,7 +327,7 @@ def test_row_sharded_coreset_through_rccl_world_of_one():
 
 
 def test_pipeline_invariants_hold_on_random_batches_with_a_live_process_group():
-    """tools/fuzz_pipeline.py for 30 s: random batches (1-6 clouds of a few hundred points ... no background at all, both workloads)
+    """tools/fuzz_pipeline.py for 12 s: random batches (1-6 clouds of a few hundred points ... no background at all, both workloads)
     through dozens of BatchPredictor instances beside a live RCCL process group -- graph == eager == second submit, the row
     de-duplication changes nothing, a sample's scores do not depend on its batch, the row-sharded search (world of one) equals the
     plain one, bit for bit.  Round 5: per-instance torch streams walked through torch's pool of 32 onto RCCL's own stream; a graph
@@ -337,8 +337,8 @@ def test_pipeline_invariants_hold_on_random_batches_with_a_live_process_group():
     import sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    out = subprocess.run([sys.executable, os.path.join(repo, "tools", "fuzz_pipeline.py"), "30", "17"], capture_output=True, text=True,
+    out = subprocess.run([sys.executable, os.path.join(repo, "tools", "fuzz_pipeline.py"), "12", "17"], capture_output=True, text=True,
                          timeout=600, env=env, cwd=repo)
     assert out.returncode == 0, out.stderr[-3000:]
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("pipeline fuzz ok")][-1]
-    assert int(line.split()[3]) >= 40, line
+    assert int(line.split()[3]) >= 15, line
