@@ -150,7 +150,7 @@ def test_scoring_exact_features_isolated(fitted, search_dtype, agree, monkeypatc
 
 
 def test_batch_invariance(weights):
-    """B = 3 (ragged clouds, padded) gives the per-sample B = 1 results."""
+    """B = 3 (ragged clouds, padded) gives the per-sample B = 1 results: indices and patch features bit for bit."""
     from cmdiad_amd import runtime
     sd_vit, sd_pm = weights
     e = eng.Engine(runtime.PackedViT(sd_vit, device=DEV), runtime.PackedPointMAE(sd_pm, device=DEV))
@@ -166,8 +166,7 @@ def test_batch_invariance(weights):
         assert int(ex.n_valid[i]) == n
         assert torch.equal(ex.center_idx[i], ex1.center_idx[0]) and torch.equal(ex.ori_idx[i], ex1.ori_idx[0])
         assert torch.equal(ex.idx3[i, :n], ex1.idx3[0, :n])
-        torch.testing.assert_close(e.xyz_patch(ex1)[0], xp[i], rtol=1e-5, atol=1e-5)
-        torch.testing.assert_close(e.rgb_patch(ex1)[0], rp[i], rtol=1e-5, atol=1e-5)
+        assert torch.equal(e.xyz_patch(ex1)[0], xp[i]) and torch.equal(e.rgb_patch(ex1)[0], rp[i])      # bit for bit
 
 
 def test_greedy_coreset_matches_fp16_restatement():
@@ -473,10 +472,10 @@ def test_public_features_contract(weights):
     assert _rel(xp28.cpu(), ref28)[0] < 0.03
     # the method classes' private device path gives the same patches
     ex = m._extract_device(rgb, pc)
-    torch.testing.assert_close(m._engine.xyz_patch(ex)[0], xp, rtol=1e-5, atol=1e-5)
+    assert torch.equal(m._engine.xyz_patch(ex)[0].cpu(), xp.cpu())
     rp, rp2 = m.get_rgb_patch(rgb_maps)
     assert tuple(rp.shape) == (784, 768) and tuple(rp2.shape) == (3136, 768)
-    torch.testing.assert_close(rp, m._engine.rgb_patch(ex)[0], rtol=1e-5, atol=1e-5)
+    assert torch.equal(rp.cpu(), m._engine.rgb_patch(ex)[0].cpu())
     # get_rgb_patch on a plain CPU tensor list (no device handle attached), as a caller that re-built the list would pass
     rp_plain, rp2_plain = m.get_rgb_patch([rgb_maps[0].clone()])
     torch.testing.assert_close(rp_plain, rp, rtol=0, atol=0)
