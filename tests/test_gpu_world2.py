@@ -32,6 +32,9 @@ def test_row_sharded_paths_with_two_real_ranks_on_one_gpu():
                                                           "sharded_fp32_pipeline"]
 
 
+_CLASS_METRICS = {}     # (world, bank) -> per-class metric tuples of the bench's class loop, compared across the parametrised runs
+
+
 def _launch(nproc, script_args, extra_env, timeout=900):
     import socket
     with socket.socket() as sk:
@@ -71,4 +74,11 @@ def test_bench_line_of_n_ranks_rehearsed_on_one_gpu(world, bank):
         assert len(c["live_rows_per_rank"]) == world and c["rows_this_rank"] < c["rows"] and c["gather_MB_received_per_rank"] > 0
     m = d["mtfi_classes"]
     assert m["world"] == world and len(m["per_class"]) == 10 and len(m["assignment"]) == world
+    # a class is evaluated start to finish on one rank: its metrics cannot depend on how many ranks there are, which rank got it,
+    # or whether its host SVM fits ran beside another class's device work (they do when a rank has more than one class)
+    metrics = {c: tuple(v[k] for k in ("image_rocauc", "pixel_rocauc", "au_pro", "au_pro_001") if k in v) for c, v in m["per_class"].items()}
+    assert all(len(t) >= 3 for t in metrics.values())
+    for other_world, other in _CLASS_METRICS.items():
+        assert other == metrics, f"per-class metrics differ between {other_world} and {world} ranks"
+    _CLASS_METRICS[(world, bank)] = metrics
     assert ("row-sharded" in d["config"]["bank"]) == (bank == "sharded")
