@@ -59,6 +59,60 @@ __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, c
     }
 }
 
+// The same for C % 256 == 0 (ViT-B: 768) with 16-byte accesses: a lane holds C/256 float4 at columns 4*(lane + 64 e) -- one
+// wave-instruction moves 1 KiB instead of 512 B, and the bf16 row goes out in 8-byte stores (24.5 -> see profiles/r5_notes.md
+// section 18).  Same two-pass statistics; the partial sums a lane forms differ from the float2 form, so the two agree to fp32
+// rounding, not bitwise (every caller of a given C always takes the same one).
+template <int QUADS>
+__global__ __launch_bounds__(256) void layernorm4_kernel(float* __restrict__ x, const float* __restrict__ add,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float eps, int M, bf16_t* __restrict__ out_bf16,
+                                                         float* __restrict__ out_f32, int ldo32,
+                                                         float* __restrict__ mean_out, float* __restrict__ rstd_out)
+{
+    constexpr int C = QUADS * 256;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= M) return;
+    float4 v[QUADS];
+    float s = 0.0f;
+#pragma unroll
+    for (int e = 0; e < QUADS; ++e) {
+        const int c = 4 * (lane + 64 * e);
+        v[e] = *reinterpret_cast<const float4*>(x + (size_t)row * C + c);
+        if (add) {
+            const float4 a = *reinterpret_cast<const float4*>(add + (size_t)row * C + c);
+            v[e].x += a.x; v[e].y += a.y; v[e].z += a.z; v[e].w += a.w;
+            *reinterpret_cast<float4*>(x + (size_t)row * C + c) = v[e];
+        }
+        s += (v[e].x + v[e].y) + (v[e].z + v[e].w);
+    }
+    s = wave_sum(s);
+    const float mean = s / C;
+    float q = 0.0f;
+#pragma unroll
+    for (int e = 0; e < QUADS; ++e) {
+        const float a = v[e].x - mean, b = v[e].y - mean, c2 = v[e].z - mean, d = v[e].w - mean;
+        q += (a * a + b * b) + (c2 * c2 + d * d);
+    }
+    q = wave_sum(q);
+    const float rstd = rsqrtf(q / C + eps);
+    if (mean_out && lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+#pragma unroll
+    for (int e = 0; e < QUADS; ++e) {
+        const int c = 4 * (lane + 64 * e);
+        const float4 g = *reinterpret_cast<const float4*>(gamma + c);
+        const float4 bb = *reinterpret_cast<const float4*>(beta + c);
+        const float y0 = (v[e].x - mean) * rstd * g.x + bb.x, y1 = (v[e].y - mean) * rstd * g.y + bb.y;
+        const float y2 = (v[e].z - mean) * rstd * g.z + bb.z, y3 = (v[e].w - mean) * rstd * g.w + bb.w;
+        if (out_bf16) {
+            bf16x4 o = {f2bf(y0), f2bf(y1), f2bf(y2), f2bf(y3)};
+            *reinterpret_cast<bf16x4*>(out_bf16 + (size_t)row * C + c) = o;
+        }
+        if (out_f32) *reinterpret_cast<float4*>(out_f32 + (size_t)row * ldo32 + c) = make_float4(y0, y1, y2, y3);
+    }
+}
+
 // rgb [B,3,S,S] f32 -> patches [B*(S/8)^2, 192] bf16, k = c*64 + dy*8 + dx (conv weight [768,3,8,8] flattened).
 // One thread per (patch, c, dy): reads 8 contiguous floats, writes 8 contiguous bf16 (16 B).
 __global__ __launch_bounds__(256) void im2col_patch8_kernel(const float* __restrict__ rgb, int B, int S,
@@ -273,6 +327,17 @@ extern "C" int cmdiad_layernorm(float* x, const float* add, const float* gamma, 
     if (M == 0) return CMDIAD_OK;
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((M + 3) / 4), block(256);
+    // 16-byte form: C % 256 == 0 and every pointer it touches 16-byte (bf16 row: 8-byte) aligned; CMDIAD_LN_WIDE=0: the float2 form (A/B)
+    static const bool wide_ok = !(getenv("CMDIAD_LN_WIDE") && getenv("CMDIAD_LN_WIDE")[0] == '0');
+    const bool wide = wide_ok && C % 256 == 0 && C <= 1024 && (((uintptr_t)x | (uintptr_t)add | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)out_f32) & 15) == 0 &&
+                      ((uintptr_t)out_bf16 & 7) == 0 && (!out_f32 || ldo32 % 4 == 0);
+    if (wide) {
+#define LN4_CASE(Q) case Q: hipLaunchKernelGGL(layernorm4_kernel<Q>, grid, block, 0, s, x, add, gamma, beta, eps, M, (bf16_t*)out_bf16, out_f32, ldo32, mean_out, rstd_out); break;
+        switch (C / 256) { LN4_CASE(1) LN4_CASE(2) LN4_CASE(3) LN4_CASE(4) }
+#undef LN4_CASE
+        CMDIAD_CHECK_LAUNCH();
+        return CMDIAD_OK;
+    }
 #define LN_CASE(P) case P: hipLaunchKernelGGL(layernorm_kernel<P>, grid, block, 0, s, x, add, gamma, beta, eps, M, (bf16_t*)out_bf16, out_f32, ldo32, mean_out, rstd_out); break;
     switch (C / 128) {
         LN_CASE(1) LN_CASE(2) LN_CASE(3) LN_CASE(4) LN_CASE(5) LN_CASE(6) LN_CASE(7) LN_CASE(8)
