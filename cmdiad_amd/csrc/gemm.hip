@@ -424,6 +424,7 @@ struct QkvParams {
     const float* bias;
     bf16_t *q, *k, *vt;
     const float* row_scale;   // LayerNorm fold (see gemm_std_kernel): qkv = row_scale[m] * (A . W^T) + bias, or null
+    int v_rows;               // V tiles leave through the wave's LDS scratch as 128-byte token rows (see the kernel)
 };
 
 template <class S, bool RSCALE = false>
@@ -480,12 +481,52 @@ __global__ __launch_bounds__(S::THREADS, S::WAVES_PER_SIMD) void gemm_qkv_kernel
         // token offset inside an image is arbitrary, so the stores are 2-byte aligned: fine on this device, tools/
         // unaligned_store_test.hip).  The scalar form (64 two-byte stores and 64 divisions by T per lane and tile) stays for the
         // four-token groups that straddle two images or the end of the matrix.
+        // A wave's 64 tokens x 64 channels (one head) lie in ONE image almost always (the tile straddles two images, or the end of the
+        // matrix, in 64 of every T rows): then each 16-channel block goes through the wave's LDS scratch -- the lane's four-token pieces
+        // of the four row blocks are the 8-byte slots 4 i + g of channel row (lane & 15), exactly RowStore16's layout with the row
+        // block in place of the column block -- and leaves as 8 channel rows x 128 contiguous bytes (64 tokens) per store instead
+        // of 16 rows x 32 bytes: a quarter of the line accesses (CMDIAD_QKV_VROWS=0: the direct form, A/B).
         run<S, false>(A, W, c.m0, c.nt, 1, p.C / BK, lds, [&](auto& acc, int ntile, char*) {
+            static_assert(S::MI == 4, "RowStore16 takes four 8-byte pieces per lane");
+            int m0w = c.m0 + c.wr * (S::MI * 16);
+            int ln = c.lane;
+            asm volatile("" : "+v"(m0w), "+v"(ln));   // everything below is computed HERE: hoisted above the K loop it spills
+            const int b0 = m0w / p.T, t0w = m0w - b0 * p.T;
+            if (!RSCALE && p.v_rows && m0w + 63 < p.M && t0w + 63 < p.T) {   // (the folded-LayerNorm variant has no registers to spare: direct form)
+                RowStore16 rsv;
+                rsv.init(lds + S::LDS_BYTES + (threadIdx.x >> 6) * kRowStoreScratch, ln);
+                const int hd = (ntile * S::BN + c.wc * 64 - 2 * p.C) >> 6;
+                bf16_t* base = p.vt + ((size_t)b0 * p.H + hd) * 64 * p.Tp + t0w + rsv.u * 8;
+                f32x4 rs4[S::MI];
+                if constexpr (RSCALE) {
+#pragma unroll
+                    for (int i = 0; i < S::MI; ++i) {
+                        rs4[i] = *reinterpret_cast<const f32x4*>(p.row_scale + m0w + i * 16 + (ln >> 4) * 4);      // (rows < M here; row_scale is 16-byte aligned)
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float bb = p.bias ? p.bias[ntile * S::BN + c.wc * 64 + j * 16 + (ln & 15)] : 0.0f;
+                    bf16x4 h[4];
+#pragma unroll
+                    for (int i = 0; i < S::MI; ++i) {
+                        const f32x4 v = RSCALE ? __builtin_elementwise_fma(acc[i][j], rs4[i], f32x4{bb, bb, bb, bb}) : acc[i][j] + bb;
+                        h[i] = bf16x4{f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+                    }
+                    rsv.park(h);
+                    uint4 t0, t1;
+                    rsv.fetch_issue(t0, t1);
+                    rsv.fetch_wait();
+                    __builtin_memcpy(base + (size_t)(j * 16 + rsv.R) * p.Tp, &t0, 16);       // 2-byte aligned (the token offset is arbitrary)
+                    __builtin_memcpy(base + (size_t)(j * 16 + rsv.R + 8) * p.Tp, &t1, 16);
+                }
+                return;
+            }
             int tb[S::MI], tt[S::MI];   // image and token of the lane's first token in row block i
             f32x4 rsc[S::MI];           // 1 / sigma of the lane's four tokens
 #pragma unroll
             for (int i = 0; i < S::MI; ++i) {
-                const int m = c.m0 + c.wr * (S::MI * 16) + i * 16 + (c.lane >> 4) * 4;
+                const int m = m0w + i * 16 + (ln >> 4) * 4;
                 tb[i] = m / p.T;
                 tt[i] = m - tb[i] * p.T;
                 rsc[i] = f32x4{1.f, 1.f, 1.f, 1.f};
@@ -498,13 +539,13 @@ __global__ __launch_bounds__(S::THREADS, S::WAVES_PER_SIMD) void gemm_qkv_kernel
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int n = ntile * S::BN + c.wc * 64 + j * 16 + (c.lane & 15);
+                const int n = ntile * S::BN + c.wc * 64 + j * 16 + (ln & 15);
                 const int cc = n - 2 * p.C;
                 const int h = cc >> 6, d = cc & 63;
                 const float bb = p.bias ? p.bias[n] : 0.0f;
 #pragma unroll
                 for (int i = 0; i < S::MI; ++i) {
-                    const int m = c.m0 + c.wr * (S::MI * 16) + i * 16 + (c.lane >> 4) * 4;
+                    const int m = m0w + i * 16 + (ln >> 4) * 4;
                     if (m + 3 < p.M && tt[i] + 3 < p.T) {
                         const f32x4 v = RSCALE ? __builtin_elementwise_fma(acc[i][j], rsc[i], f32x4{bb, bb, bb, bb}) : acc[i][j] + bb;
                         const bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
@@ -1126,7 +1167,8 @@ extern "C" int cmdiad_gemm_qkv(const uint16_t* A, const uint16_t* W, const float
                    CMDIAD_ERR_ARG, "cmdiad_gemm_qkv: 16-byte alignment");
     const int M = B * T;
     GlobalTile At{(const bf16_t*)A, C, M}, Wt{(const bf16_t*)W, C, 3 * C};
-    QkvParams p{M, T, (T + 63) / 64 * 64, C, C / 64, group_m_tiles(), bias, (bf16_t*)q_out, (bf16_t*)k_out, (bf16_t*)vt_out, row_scale};
+    static const int v_rows = !(getenv("CMDIAD_QKV_VROWS") && getenv("CMDIAD_QKV_VROWS")[0] == '0');
+    QkvParams p{M, T, (T + 63) / 64 * 64, C, C / 64, group_m_tiles(), bias, (bf16_t*)q_out, (bf16_t*)k_out, (bf16_t*)vt_out, row_scale, v_rows};
     hipStream_t s = (hipStream_t)stream;
     const int rc = row_scale ? launch<S128>(gemm_qkv_kernel<S128, true>, grid_for<S128>(M, 3 * C), S128::LDS_BYTES + S128::WAVES * kRowStoreScratch, s, At, Wt, p)
                              : launch<S128>(gemm_qkv_kernel<S128, false>, grid_for<S128>(M, 3 * C), S128::LDS_BYTES + S128::WAVES * kRowStoreScratch, s, At, Wt, p);
