@@ -1,0 +1,96 @@
+"""Constants and the three helpers every leg of bench.py shares: the resident state (networks, libraries, SVMs), the rotating
+synthetic batches and the pipelined step loop.  Nothing here is timed by itself."""
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+BATCH = 32
+N_POINTS = 24576          # fixed-N regime of the batch-32 config
+XYZ_ROWS, RGB_ROWS = 76518, 19129   # floor(0.1 * 244 * 3136), floor(0.1 * 244 * 784): 'bagel'
+# MVTec 3D-AD train-set sizes [external counts, SURVEY 8d]: bank rows = floor(0.1 * n_train * 3136)
+CLASS_TRAIN = {"bagel": 244, "cable_gland": 223, "carrot": 286, "cookie": 210, "dowel": 288, "foam": 236, "peach": 361,
+               "potato": 300, "rope": 298, "tire": 210}
+PEAK_BF16_TFLOPS = 2500.0           # dense bf16 / fp16 MFMA, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+ROTATE = 4                          # distinct input batches rotated through the timed region
+DEFECT_SEVERITY = float(os.environ.get("CMDIAD_DEFECT_SEVERITY", "0.22"))   # synthetic defects of the class loop: hard enough that I-AUROC is not saturated (synth.SyntheticClass)
+
+
+def class_rows(name):
+    return int(0.1 * CLASS_TRAIN[name] * 3136)
+
+
+def build_state(dev, workload="dino_pointmae"):
+    import numpy as np
+    import torch
+    from cmdiad_amd import engine as eng
+    from cmdiad_amd import runtime
+    from cmdiad_amd.models.hallucination_network import HallucinationCrossModalityNetwork
+    from cmdiad_amd.models.models import PointTransformer, VisionTransformer
+    from cmdiad_amd.synth import synth_bank
+    torch.manual_seed(0)  # random-init weights of the named architectures (no checkpoints offline)
+    vit = runtime.PackedViT(VisionTransformer().state_dict(), device=dev)
+    pm = runtime.PackedPointMAE(PointTransformer().state_dict(), device=dev)
+    e = eng.Engine(vit, pm)
+    bank_xyz = eng.Bank(synth_bank(XYZ_ROWS, 768, 4321).to(dev))
+    if workload == "mtfi":
+        # MTFI feature-to-feature, main modality xyz (multiple_features.py:312-573): the rgb sensor is absent at test time;
+        # its features are hallucinated from the xyz patches and scored against the library of hallucinated train features
+        # (one row per 56 x 56 patch -> as many rows as the xyz library)
+        bank_second = eng.Bank(synth_bank(XYZ_ROWS, 768, 4323).to(dev))
+        halluc = runtime.PackedHallucination(HallucinationCrossModalityNetwork(None, 768, 768).state_dict(), device=dev)
+    else:
+        bank_second = eng.Bank(synth_bank(RGB_ROWS, 768, 4322).to(dev))
+        halluc = None
+    # scalar library statistics (cross-wired as the reference): synthetic banks are N(0,1)
+    stats = dict(xyz_mean=0.0, xyz_std=1.0, rgb_mean=0.0, rgb_std=1.0)
+    # late-fusion linear one-class SVMs fitted on synthetic score rows (host sklearn)
+    from sklearn import linear_model
+    rs = np.random.RandomState(0)
+    det = linear_model.SGDOneClassSVM(random_state=42, nu=0.5, max_iter=1000).fit(rs.rand(64, 2))
+    seg = linear_model.SGDOneClassSVM(random_state=42, nu=0.5, max_iter=1000).fit(rs.rand(4096, 2))
+    return dict(engine=e, bank_xyz=bank_xyz, bank_second=bank_second, stats=stats, det=det, seg=seg, halluc=halluc,
+                workload=workload)
+
+
+def make_batches(rank, workload, pinned=False):
+    """ROTATE distinct batches of BATCH synthetic samples (host tensors; pinned for the H2D-inclusive measurement)."""
+    import torch
+    from cmdiad_amd.synth import synth_cloud_fixed_n, synth_rgb
+    out = []
+    for j in range(ROTATE):
+        base = (rank * ROTATE + j) * BATCH
+        rgb = torch.cat([synth_rgb(base + i) for i in range(BATCH)]) if workload == "dino_pointmae" else None
+        pcs = torch.cat([synth_cloud_fixed_n(1000 + base + i, N_POINTS) for i in range(BATCH)])
+        if pinned:
+            rgb, pcs = (rgb.pin_memory() if rgb is not None else None), pcs.pin_memory()
+        out.append((rgb, pcs))
+    return out
+
+
+def run_steps(pred, batches, n, first=None):
+    """n pipelined steps over the rotating batches; returns the outputs and checks each against the first output seen for
+    the same batch index (`first`, filled on the way)."""
+    import numpy as np
+    first = {} if first is None else first
+    pending = []
+
+    def take(j, ticket):
+        s, m = ticket.wait()
+        assert np.isfinite(s).all() and np.isfinite(m).all()
+        if j not in first:
+            first[j] = (s, m)
+        else:
+            assert np.array_equal(s, first[j][0]) and np.array_equal(m, first[j][1]), f"batch {j}: steps disagree"
+
+    for i in range(n):
+        if len(pending) >= 2:  # pinned output ring of 3: the slot reused next must have been consumed
+            take(*pending.pop(0))
+        j = i % len(batches)
+        pending.append((j, pred.submit(*batches[j])))
+    for p in pending:
+        take(*p)
+    return first
