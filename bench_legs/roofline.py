@@ -24,12 +24,12 @@ def isolated_xyz_search_ms(pred, iters=12):
             ss.gemm(t)
         elif qs is not None and qs.get("xyz_plan") is not None:
             plan = qs["xyz_plan"]
-            kc = ops.new_keys(plan.q16.shape[0], plan.q16.device)
+            kc = ops.new_keys(plan.q16.shape[0], plan.q16.device, runner=True)       # as the pipeline launches it: best + runner-up
             with t:
                 ops.l2_min_keys_counted(plan.q16, plan.q_sq, plan.count, bank.bf16, bank.sqnorm, kc, bank.row_offset)
         elif qs is not None:
             _, q16, qsq = qs["xyz"]
-            k = ops.new_keys(q16.shape[0], q16.device)
+            k = ops.new_keys(q16.shape[0], q16.device, runner=True)
             with t:
                 ops.l2_min_keys(q16, qsq, bank.bf16, bank.sqnorm, k, bank.row_offset)
         else:

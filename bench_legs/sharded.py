@@ -137,7 +137,7 @@ def fake_world_leg(dev, classes=("bagel", "peach"), worlds=(1, 2, 4, 8), iters=4
         gb = torch.Generator(device=dev).manual_seed(4321 + rows)
         full = torch.randn(rows, D, generator=gb, device=dev)
         whole = eng.Bank(full, 0, 1)             # the single-library answer for rank 0's live rows (the counted launch of the pipeline)
-        ref_keys = ops.l2_min_keys_counted(plans[0].q16, plans[0].q_sq, plans[0].count, whole.bf16, whole.sqnorm, ops.new_keys(Q, dev))
+        ref_keys = ops.l2_min_keys_counted(plans[0].q16, plans[0].q_sq, plans[0].count, whole.bf16, whole.sqnorm, ops.new_keys(Q, dev, runner=True))
         del whole
         for W in worlds:
             q_all = torch.cat([p.q16[:cap] for p in plans[:W]])
@@ -147,10 +147,10 @@ def fake_world_leg(dev, classes=("bagel", "peach"), worlds=(1, 2, 4, 8), iters=4
             ms = []
             for r in range(W):
                 bank = eng.Bank(full, r, W)
-                keys = ops.new_keys(W * cap, dev)
+                keys = ops.new_keys(W * cap, dev, runner=True)
                 ops.l2_min_keys_segments(q_all, s_all, cnt, cap, bank.bf16, bank.sqnorm, keys, bank.row_offset)   # warm + the checked result
-                merged = keys if merged is None else torch.minimum(merged, keys)
-                scratch = ops.new_keys(W * cap, dev)
+                merged = keys if merged is None else eng.merge_key_planes(merged, keys)
+                scratch = ops.new_keys(W * cap, dev, runner=True)
                 t = 0.0
                 for _ in range(iters):
                     scratch.fill_(eng.KEY_EMPTY)
@@ -162,13 +162,13 @@ def fake_world_leg(dev, classes=("bagel", "peach"), worlds=(1, 2, 4, 8), iters=4
                 ms.append(t / iters)
                 shard_rows, shard_tiles = bank.shard_rows, bank.bf16.shape[0] // 256
                 del bank, keys, scratch
-            same = bool(torch.equal(merged[:counts[0]], ref_keys[:counts[0]]))
+            same = bool(torch.equal(merged[:, :counts[0]], ref_keys[:, :counts[0]]))     # best AND runner-up planes
             live = sum(counts[:W])
             per = ((rows + W - 1) // W + 127) // 128 * 128
             flops = 2.0 * live * min(per, rows) * D      # the largest (= every but the last) shard
             gemm = max(ms)
             gather_b = (W - 1) * cap * row_bytes
-            reduce_b = W * cap * 8
+            reduce_b = W * cap * 8 * 2                   # two MIN all-reduces: best and runner-up planes
             t_gather = cap * row_bytes / (LINK_GBS * 1e9 * LINK_EFF) * 1e3 + COLL_LAT_US * 1e-3 if W > 1 else 0.0   # every peer's segment over its own link
             t_reduce = (2.0 * (W - 1) / W * reduce_b / (min(W - 1, 7) * LINK_GBS * 1e9 * LINK_EFF) * 1e3 + COLL_LAT_US * 1e-3) if W > 1 else 0.0
             t_search = dedup_ms + max(gemm, t_gather) + t_reduce

@@ -78,13 +78,15 @@ SIGNATURES = {
     "cmdiad_adam_step": [P, P, P, P, SZ, F, F, F, F, I, F, P, P],
     "cmdiad_encoder_stage1": [P, P, P, P, I, I, P, P, P, P],
     "cmdiad_gemm_groupmax": [P, P, P, I, I, I, I, P, P, P],
-    "cmdiad_l2_min_keys": [P, P, P, P, I, I, I, U32, P, I, P],
-    "cmdiad_l2_min_keys_counted": [P, P, P, I, P, P, I, I, U32, P, I, P],
-    "cmdiad_l2_min_keys_segments": [P, P, P, I, I, P, P, I, I, U32, P, I, P],
+    "cmdiad_l2_min_keys": [P, P, P, P, I, I, I, U32, P, P, I, P],
+    "cmdiad_l2_min_keys_counted": [P, P, P, I, P, P, I, I, U32, P, P, I, P],
+    "cmdiad_l2_min_keys_segments": [P, P, P, I, I, P, P, I, I, U32, P, P, I, P],
     "cmdiad_rows_dedup_plan": [P, P, I, I, P, P, P, P, P, P, P],
     "cmdiad_keys_expand": [P, P, I, P, P],
     "cmdiad_rows_expand_f32": [P, P, I, I, P, P],
     "cmdiad_l2_rescore": [P, P, P, I, I, I, U32, P, P, P],
+    "cmdiad_l2_rescore2": [P, P, P, P, I, I, I, U32, P, P, P, P],
+    "cmdiad_l2_choose": [P, P, P, I, P, P, P],
     "cmdiad_reweight_scan": [P, P, P, I, I, I, U32, P, P, SZ, P],
     "cmdiad_reweight_scan_pair": [P, P, P, I, I, U32, P, P, P, P, I, I, U32, P, I, P, SZ, P],
     "cmdiad_bank_block16": [P, I, I, P, P],
@@ -101,6 +103,7 @@ SIGNATURES = {
     "cmdiad_coreset_decode": [P, I, I, P, P],
     "cmdiad_sparse_project_f32": [P, SZ, I, P, P, P, I, P, P],
     "cmdiad_normalize_cast": [P, SZ, I, F, F, P, P, P, I, P],
+    "cmdiad_normalize_cast_rows": [P, SZ, I, I, I, F, F, P, P, P, I, P],
     "cmdiad_im2col_patch8": [P, I, I, P, P],
     "cmdiad_im2col3x3_bf16": [P, I, I, I, I, I, I, P, P],
     "cmdiad_vit_assemble": [P, P, P, I, I, I, P, P],

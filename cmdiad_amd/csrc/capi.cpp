@@ -15,7 +15,7 @@ void cmdiad_set_error(const char* fmt, ...)
 }
 
 extern "C" const char* cmdiad_last_error(void) { return g_err; }
-extern "C" int cmdiad_abi_version(void) { return 5; }
+extern "C" int cmdiad_abi_version(void) { return 6; }
 
 // 1 in the test-only build (make ab, -DCMDIAD_AB_VARIANTS) that also carries the superseded kernel formulations the A/B
 // tools and the variant parity tests select through CMDIAD_L2_TILE / CMDIAD_FPS_PK / CMDIAD_KNN_WAVE / CMDIAD_GEMM_WIDE /

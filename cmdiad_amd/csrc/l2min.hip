@@ -28,6 +28,7 @@ struct L2Params {
     const float* b_sqnorm;
     unsigned row_offset;
     unsigned long long* keys;
+    unsigned long long* keys2;   // runner-up per query (RowMin), or null
     int nq_tiles, n_bank_tiles, splits, qgroup;
     unsigned* diag;    // test-only build: in-kernel stamps of one workgroup (l2_min_pp3_kernel<F16, true>), else null
     int diag_wg;
@@ -104,13 +105,24 @@ constexpr unsigned kRowMinDead = 0xFF800000u;   // -inf (masked columns start th
 
 struct RowMin {
     unsigned u;    // truncated bits of the best accumulator so far
-    unsigned at;   // (library tile << 4) | e of that element
+    unsigned u2;   // the runner-up: the best of the OTHER 16-row groups (see below)
+    unsigned at;   // places of both: bits 15..0 = (library tile - the block's first tile) << 4 | e of the best, bits 31..16 the
+                   // runner-up's (packed: the two-group kernel has no eight registers to spare; a block walks <= 4096 tiles)
 };
 
+// The runner-up (ABI v6, keys2): a lane's 16 columns of one library tile are the 16 rows {64 a + 16 j + 4 g + r: j, r = 0..3} of
+// the library -- "group" (a, g) = (row >> 6, (row >> 2) & 3), the same rows in the 128-column and in the 256-column kernels --
+// and the running state keeps the two smallest GROUP MINIMA (same order: truncated value, then lowest row), each with its place.
+// So per query the search returns (1) the nearest row and (2) the nearest row outside the nearest row's group of 16: a definition
+// in terms of library rows alone, independent of tile shape, launch geometry and shard (row_offset is a multiple of 64 wherever
+// keys of different launches are merged).  The exact fp32 re-score of BOTH (cmdiad_l2_rescore2) then decides: a near-tie that the
+// 16-bit operands resolve the wrong way is repaired unless the true nearest row shares its group with the 16-bit winner (15 of
+// Nb - 1 rows) or a THIRD row lies inside the operand noise as well.  Cost: 5 selects per row and tile instead of 2.
 __device__ __forceinline__ unsigned rowmin_tag(float a, unsigned e) { return (__float_as_uint(a) & ~15u) | e; }
 __device__ __forceinline__ unsigned umin3(unsigned a, unsigned b, unsigned c) { return min(min(a, b), c); }
 
-// one finished row (16 columns of one query in this lane) against the running minimum
+// one finished row (16 columns of one query in this lane = one group) against the running two best; tile: relative to the block's
+// first library tile (< 4096)
 __device__ __forceinline__ void rowmin_update(RowMin& best, const f32x4 (&row)[4], unsigned tile)
 {
     unsigned t[16];
@@ -121,34 +133,56 @@ __device__ __forceinline__ void rowmin_update(RowMin& best, const f32x4 (&row)[4
     const unsigned m0 = umin3(t[0], t[1], t[2]), m1 = umin3(t[3], t[4], t[5]), m2 = umin3(t[6], t[7], t[8]);
     const unsigned m3 = umin3(t[9], t[10], t[11]), m4 = umin3(t[12], t[13], t[14]);
     const unsigned m = umin3(umin3(m0, m1, m2), umin3(m3, m4, t[15]), kRowMinNone);
-    const bool better = m < best.u;   // best.u is a multiple of 16: m < best.u  <=>  (m & ~15) < best.u
-    best.u = better ? (m & ~15u) : best.u;
-    best.at = better ? ((m & 15u) | (tile << 4)) : best.at;
+    const unsigned mt = m & ~15u, mat = (m & 15u) | (tile << 4);
+    const bool b1 = m < best.u;    // best.u / best.u2 are multiples of 16: m < u  <=>  (m & ~15) < u: of equal values the earlier
+    const bool b2 = m < best.u2;   // tile (= the lower row: a lane walks its groups in ascending row order) stays
+    best.u2 = b1 ? best.u : (b2 ? mt : best.u2);
+    best.u = b1 ? mt : best.u;
+    const unsigned shifted = (best.at << 16) | mat;             // new best: the old best becomes the runner-up
+    const unsigned second = (best.at & 0xFFFFu) | (mat << 16);  // new runner-up only
+    best.at = b1 ? shifted : (b2 ? second : best.at);
 }
 
 // column of the element inside the launch's library (the lane's columns of tile t start at t * BN + col0)
 template <int BN>
-__device__ __forceinline__ unsigned rowmin_col(const RowMin& b, unsigned col0)
+__device__ __forceinline__ unsigned rowmin_col(unsigned at16, unsigned tile0, unsigned col0)
 {
-    const unsigned e = b.at & 15u;
-    return (b.at >> 4) * BN + col0 + (e >> 2) * 16 + (e & 3u);
+    const unsigned e = at16 & 15u;
+    return (tile0 + ((at16 & 0xFFFFu) >> 4)) * BN + col0 + (e >> 2) * 16 + (e & 3u);
 }
 
-__device__ __forceinline__ unsigned long long rowmin_key(const RowMin& b, unsigned row)
+__device__ __forceinline__ unsigned long long rowmin_key(unsigned u, unsigned row)
 {
-    if (b.u >= kRowMinDead) return ~0ull;
-    const float d2 = -2.0f * __uint_as_float(b.u);
+    if (u >= kRowMinDead) return ~0ull;
+    const float d2 = -2.0f * __uint_as_float(u);
     return pack_key(d2 > 0.0f ? d2 : 0.0f, row);
 }
 
-// merge the four 16-lane groups of a wave and publish one key per query row
-__device__ __forceinline__ void rowmin_publish(unsigned long long key, int lane, bool live, unsigned long long* dst)
+__device__ __forceinline__ unsigned long long umin64(unsigned long long a, unsigned long long b) { return a < b ? a : b; }
+__device__ __forceinline__ unsigned long long umax64(unsigned long long a, unsigned long long b) { return a < b ? b : a; }
+
+// merge the four 16-lane groups of a wave and publish the query row's best key -- and, with keys2, its runner-up:
+//   old = atomicMin(best slot, k1) (returning); whichever of (old, k1) lost moves on to the runner-up slot together with k2.
+// Whatever the order in which the blocks and waves of a query arrive, slot 1 ends as the smallest and slot 2 as the second
+// smallest of everything published: a key enters slot 2 exactly when something smaller holds or takes slot 1, the second smallest
+// of all is displaced from (or kept out of) slot 1 by the smallest alone, and (query, row) pairs are unique, so no key is ever
+// compared with itself.  "No candidate" is ~0 here and ops.KEY_EMPTY (2^63 - 1) in the caller's arrays: both lose to every key.
+__device__ __forceinline__ void rowmin_publish(unsigned long long k1, unsigned long long k2, int lane, bool live,
+                                               unsigned long long* dst, unsigned long long* dst2)
 {
-    unsigned long long o = shfl_xor_u64(key, 16);
-    key = o < key ? o : key;
-    o = shfl_xor_u64(key, 32);
-    key = o < key ? o : key;
-    if (lane < 16 && live) atomicMin(dst, key);
+#pragma unroll
+    for (int m = 16; m <= 32; m <<= 1) {
+        const unsigned long long o1 = shfl_xor_u64(k1, m), o2 = shfl_xor_u64(k2, m);
+        k2 = umin64(umax64(k1, o1), umin64(k2, o2));
+        k1 = umin64(k1, o1);
+    }
+    if (lane < 16 && live) {
+        if (dst2) {
+            const unsigned long long old = atomicMin(dst, k1);
+            const unsigned long long c = umin64(umax64(old, k1), k2);
+            if (c != ~0ull) atomicMin(dst2, c);
+        } else atomicMin(dst, k1);
+    }
 }
 
 template <class S, bool F16>
@@ -180,14 +214,14 @@ __global__ __launch_bounds__(S::THREADS, S::WAVES_PER_SIMD) void l2_min_kernel(G
     float qh[MI];
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
-        best[i] = RowMin{kRowMinNone, 0u};
+        best[i] = RowMin{kRowMinNone, kRowMinNone, 0u};
         const int m = m0 + wr * (MI * 16) + i * 16 + (lane & 15);
         qh[i] = m < p.Q ? -0.5f * p.q_sqnorm[m] : 0.0f;
     }
 
     run<S, true, F16>(A, W, m0, nt0, ntc, p.D / BK, lds, [&](auto& acc, int ntile, char*) {
 #pragma unroll
-        for (int i = 0; i < MI; ++i) rowmin_update(best[i], acc[i], (unsigned)ntile);
+        for (int i = 0; i < MI; ++i) rowmin_update(best[i], acc[i], (unsigned)(ntile - nt0));
     }, 0, [&](auto& acc, int ntile) {   // a tile's accumulators start at -(|q|^2 + |b|^2) / 2; columns past Nb at -inf
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -205,8 +239,10 @@ __global__ __launch_bounds__(S::THREADS, S::WAVES_PER_SIMD) void l2_min_kernel(G
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int m = m0 + wr * (MI * 16) + i * 16 + (lane & 15);
-        const unsigned n = rowmin_col<S::BN>(best[i], (unsigned)(wc * 64 + (lane >> 4) * 4));
-        rowmin_publish(rowmin_key(best[i], p.row_offset + n), lane, m < p.Q, p.keys + m);
+        const unsigned col0 = (unsigned)(wc * 64 + (lane >> 4) * 4);
+        rowmin_publish(rowmin_key(best[i].u, p.row_offset + rowmin_col<S::BN>(best[i].at, (unsigned)nt0, col0)),
+                       rowmin_key(best[i].u2, p.row_offset + rowmin_col<S::BN>(best[i].at >> 16, (unsigned)nt0, col0)), lane, m < p.Q,
+                       p.keys + m, p.keys2 ? p.keys2 + m : nullptr);
     }
 }
 
@@ -287,7 +323,7 @@ __global__ __launch_bounds__(512, 1) void l2_min_pp3_kernel(GlobalTile A, Global
     float qh[8];   // -|q|^2 / 2 of the lane's eight query rows
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        best[i] = RowMin{kRowMinNone, 0u};
+        best[i] = RowMin{kRowMinNone, kRowMinNone, 0u};
         const int m = m0 + wr * 128 + i * 16 + (lane & 15);
         qh[i] = m < p.Q ? -0.5f * p.q_sqnorm[m] : 0.0f;
     }
@@ -498,7 +534,7 @@ __global__ __launch_bounds__(512, 1) void l2_min_pp3_kernel(GlobalTile A, Global
         stamp();
         if (kt_c == KT - 1) {  // library tile finished: the accumulators are -d2 / 2 (RowMin); then the next tile's start values
 #pragma unroll
-            for (int i = 0; i < 8; ++i) rowmin_update(best[i], acc[i], (unsigned)nt_c);
+            for (int i = 0; i < 8; ++i) rowmin_update(best[i], acc[i], (unsigned)(nt_c - nt0));
             if (T + 1 < T_total) acc_start(nt_c + 1);
         }
         pp_barrier();
@@ -509,8 +545,10 @@ __global__ __launch_bounds__(512, 1) void l2_min_pp3_kernel(GlobalTile A, Global
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int m = m0 + wr * 128 + i * 16 + (lane & 15);
-        const unsigned n = rowmin_col<S::BN>(best[i], (unsigned)(wc * 64 + (lane >> 4) * 4));
-        rowmin_publish(rowmin_key(best[i], p.row_offset + n), lane, m < p.Q, p.keys + m);
+        const unsigned col0 = (unsigned)(wc * 64 + (lane >> 4) * 4);
+        rowmin_publish(rowmin_key(best[i].u, p.row_offset + rowmin_col<S::BN>(best[i].at, (unsigned)nt0, col0)),
+                       rowmin_key(best[i].u2, p.row_offset + rowmin_col<S::BN>(best[i].at >> 16, (unsigned)nt0, col0)), lane, m < p.Q,
+                       p.keys + m, p.keys2 ? p.keys2 + m : nullptr);
     }
     if constexpr (DIAG) {
         if (diag_on) {
@@ -549,19 +587,87 @@ __global__ __launch_bounds__(256) void l2_rescore_kernel(const float* __restrict
     }
 }
 
-// (x - mean) * inv_std -> bf16 (+ optional f32 copy, + optional |row|^2 of the ROUNDED values).
+// The same for BOTH candidates of a query (best and runner-up of the 16-bit search, RowMin): the squared fp32 distances in the
+// SAME summation order, the smaller one wins, of equal ones the lower row.  d2_pair (optional, [2][Q]): the squared distances of
+// the candidates whose rows THIS shard owns (others untouched: the caller sums over the shards, then cmdiad_l2_choose).
+// min_val / min_idx (optional): the decision, for queries whose candidates are all local or absent.
+__device__ __forceinline__ float row_dist2(const float* __restrict__ a, const float* __restrict__ b, int D, int lane)
+{
+    float s = 0.0f;
+    for (int c = lane * 4; c < D; c += 256) {
+        const float4 x = *reinterpret_cast<const float4*>(a + c);
+        const float4 y = *reinterpret_cast<const float4*>(b + c);
+        const float d0 = x.x - y.x, d1 = x.y - y.y, d2 = x.z - y.z, d3 = x.w - y.w;
+        s += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+    }
+    return wave_sum(s);
+}
+
+__global__ __launch_bounds__(256) void l2_rescore2_kernel(const float* __restrict__ q, const float* __restrict__ bank,
+                                                          const unsigned long long* __restrict__ keys,
+                                                          const unsigned long long* __restrict__ keys2, int Q, int Nb, int D,
+                                                          unsigned row_offset, float* __restrict__ d2_pair,
+                                                          float* __restrict__ min_val, int64_t* __restrict__ min_idx)
+{
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= Q) return;
+    const unsigned long long k1 = keys[row], k2 = keys2[row];
+    const unsigned g1 = (unsigned)(k1 & 0xFFFFFFFFull), g2 = (unsigned)(k2 & 0xFFFFFFFFull);
+    // "no candidate": every value field of a real key is the bit pattern of a finite d2 >= 0 (< 0x7F800000)
+    const bool has1 = (unsigned)(k1 >> 32) < 0x7F800000u, has2 = (unsigned)(k2 >> 32) < 0x7F800000u;
+    const bool own1 = has1 && g1 >= row_offset && g1 < row_offset + (unsigned)Nb;
+    const bool own2 = has2 && g2 >= row_offset && g2 < row_offset + (unsigned)Nb;
+    const float* a = q + (size_t)row * D;
+    float s1 = 0.0f, s2 = 0.0f;
+    if (own1) s1 = row_dist2(a, bank + (size_t)(g1 - row_offset) * D, D, lane);
+    if (own2) s2 = row_dist2(a, bank + (size_t)(g2 - row_offset) * D, D, lane);
+    if (lane == 0) {
+        if (d2_pair) {
+            if (own1) d2_pair[row] = s1;
+            if (own2) d2_pair[(size_t)Q + row] = s2;
+        }
+        if (min_val && own1) {
+            const bool second = own2 && (s2 < s1 || (s2 == s1 && g2 < g1));
+            min_val[row] = sqrtf(second ? s2 : s1);
+            min_idx[row] = (int64_t)(second ? g2 : g1);
+        }
+    }
+}
+
+// the decision alone, from squared distances summed over the shards (every candidate row is owned by exactly one of them)
+__global__ void l2_choose_kernel(const unsigned long long* __restrict__ keys, const unsigned long long* __restrict__ keys2,
+                                 const float* __restrict__ d2_pair, int Q, float* __restrict__ min_val, int64_t* __restrict__ min_idx)
+{
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= Q) return;
+    const unsigned long long k1 = keys[row], k2 = keys2[row];
+    if ((unsigned)(k1 >> 32) >= 0x7F800000u) return;
+    const bool has2 = (unsigned)(k2 >> 32) < 0x7F800000u;
+    const unsigned g1 = (unsigned)(k1 & 0xFFFFFFFFull), g2 = (unsigned)(k2 & 0xFFFFFFFFull);
+    const float s1 = d2_pair[row], s2 = d2_pair[(size_t)Q + row];
+    const bool second = has2 && (s2 < s1 || (s2 == s1 && g2 < g1));
+    min_val[row] = sqrtf(second ? s2 : s1);
+    min_idx[row] = (int64_t)(second ? g2 : g1);
+}
+
+// (x - mean) * inv_std -> bf16 (+ optional f32 copy, + optional |row|^2 of the ROUNDED values; non-finite rows: see below).
 // One wave per row.
 template <bool F16>
 __global__ __launch_bounds__(256) void normalize_cast_kernel(const float* __restrict__ x, size_t rows, int D, float mean,
                                                              float inv_std, uint16_t* __restrict__ out16,
-                                                             float* __restrict__ out_f32, float* __restrict__ sq)
+                                                             float* __restrict__ out_f32, float* __restrict__ sq,
+                                                             int group_rows, int group_skip)
 {
     const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
+    // input rows in groups with rows to skip in front of each (the ViT's tokens [B, 1 + 784, C]: one cls row per image): output
+    // row r reads input row r + (r / group_rows + 1) * group_skip -- the patch rows leave compactly, no gather copy in between
+    const size_t in_row = group_rows > 0 ? row + (row / (size_t)group_rows + 1) * (size_t)group_skip : row;
     float s = 0.0f;
     for (int c = lane * 4; c < D; c += 256) {
-        float4 v = *reinterpret_cast<const float4*>(x + row * D + c);
+        float4 v = *reinterpret_cast<const float4*>(x + in_row * D + c);
         v.x = (v.x - mean) * inv_std; v.y = (v.y - mean) * inv_std;
         v.z = (v.z - mean) * inv_std; v.w = (v.w - mean) * inv_std;
         if (out_f32) *reinterpret_cast<float4*>(out_f32 + row * D + c) = v;
@@ -582,6 +688,15 @@ __global__ __launch_bounds__(256) void normalize_cast_kernel(const float* __rest
     }
     if (sq) {
         s = wave_sum(s);
+        // A row with a non-finite element (or whose squares overflow) must not reach the distance GEMM's unsigned running minimum
+        // as NaN / +inf accumulators (they would sort BELOW every finite candidate, RowMin in this file): its 16-bit copy becomes
+        // zeros and its squared norm +inf, so every accumulator that involves it starts at -inf and stays there -- as a library
+        // row it never wins, as a query row it finds nothing.  (The fp32 copy keeps what the caller passed.)
+        if (!(s < __builtin_inff())) {   // wave-uniform
+            s = __builtin_inff();
+            if (out16)
+                for (int c = lane * 4; c < D; c += 256) *reinterpret_cast<uint2*>(out16 + row * D + c) = uint2{0u, 0u};
+        }
         if (lane == 0) sq[row] = s;
     }
 }
@@ -688,7 +803,8 @@ static int segment_splits(int nbt)
 
 template <class S, bool F16>
 int launch_l2(const uint16_t* q, const float* q_sqnorm, const uint16_t* bank, const float* bank_sqnorm, int Q, int Nb,
-              int D, uint32_t row_offset, unsigned long long* keys, hipStream_t stream, const L2Live& live = L2Live())
+              int D, uint32_t row_offset, unsigned long long* keys, unsigned long long* keys2, hipStream_t stream,
+              const L2Live& live = L2Live())
 {
     static bool attr = false;
     if (!attr) {
@@ -715,10 +831,11 @@ int launch_l2(const uint16_t* q, const float* q_sqnorm, const uint16_t* bank, co
     if (env_splits <= 0 && S::BM == 256 && !std::is_same<S, S2x2>::value) splits = nbt / 4 < 1 ? 1 : (nbt / 4 > 20 ? 20 : nbt / 4);
     if (live.seg_counts && S::BM == 256) splits = env_seg_splits && atoi(env_seg_splits) > 0 ? atoi(env_seg_splits) : segment_splits(nbt);
     splits = splits > nbt ? nbt : splits;
+    if ((nbt + splits - 1) / splits > 4096) splits = (nbt + 4095) / 4096;   // RowMin keeps a tile's place in 12 bits
     int qgroup = env_qgroup > 0 ? env_qgroup : 4;
     qgroup = qgroup > nq ? nq : qgroup;
     GlobalTile A{(const bf16_t*)q, D, Q}, W{(const bf16_t*)bank, D, Nb};
-    L2Params p{Q, Nb, D, q_sqnorm, bank_sqnorm, row_offset, keys, nq, nbt, splits, qgroup, nullptr, -1, live.q_count,
+    L2Params p{Q, Nb, D, q_sqnorm, bank_sqnorm, row_offset, keys, keys2, nq, nbt, splits, qgroup, nullptr, -1, live.q_count,
                live.seg_counts, live.n_seg, live.seg_stride};
     const int ngroups = (nq + qgroup - 1) / qgroup;
     hipLaunchKernelGGL((L2Kernel<S, F16>::fn), dim3(ngroups * qgroup * splits), dim3(S::THREADS), S::LDS_BYTES, stream, A, W, p);
@@ -727,7 +844,7 @@ int launch_l2(const uint16_t* q, const float* q_sqnorm, const uint16_t* bank, co
 
 static int l2_min_keys_impl(const uint16_t* q, const float* q_sqnorm, const L2Live& q_count, const uint16_t* bank,
                            const float* bank_sqnorm, int Q, int Nb, int D, uint32_t row_offset,
-                           unsigned long long* keys, int dtype, cmdiad_stream_t stream)
+                           unsigned long long* keys, unsigned long long* keys2, int dtype, cmdiad_stream_t stream)
 {
     CMDIAD_REQUIRE(Q >= 0 && Nb >= 0 && D > 0 && D % 64 == 0, CMDIAD_ERR_ARG, "cmdiad_l2_min_keys: need D%%64==0 (D=%d)", D);
     CMDIAD_REQUIRE(dtype == CMDIAD_DT_BF16 || dtype == CMDIAD_DT_F16, CMDIAD_ERR_ARG, "cmdiad_l2_min_keys: dtype");
@@ -736,6 +853,8 @@ static int l2_min_keys_impl(const uint16_t* q, const float* q_sqnorm, const L2Li
     if (Q == 0 || Nb == 0) return CMDIAD_OK;
     CMDIAD_REQUIRE(q && q_sqnorm && bank && bank_sqnorm && keys, CMDIAD_ERR_ARG, "cmdiad_l2_min_keys: null pointer");
     CMDIAD_REQUIRE(aligned16(q) && aligned16(bank), CMDIAD_ERR_ARG, "cmdiad_l2_min_keys: 16-byte alignment");
+    // the runner-up is defined on groups of 16 library rows (row >> 6, (row >> 2) & 3): launches whose keys are merged must agree on them
+    CMDIAD_REQUIRE(!keys2 || row_offset % 64 == 0, CMDIAD_ERR_ARG, "cmdiad_l2_min_keys: keys2 needs row_offset %% 64 == 0 (row_offset=%u)", row_offset);
     // production: the two-group 256 x 256 pipeline (l2_min_pp3_kernel) from Q >= 512, the 128 x 128 kernel below that, for the
     // last Nb % 256 library rows and for D < 192 (the two-group schedule assumes >= 3 K-tiles per library tile).
     // CMDIAD_L2_TILE (read per call: the parity tests force each shape on small inputs) = 0 / 5 for those two; the test-only
@@ -758,16 +877,16 @@ static int l2_min_keys_impl(const uint16_t* q, const float* q_sqnorm, const L2Li
     hipStream_t s = (hipStream_t)stream;
     const bool h = dtype == CMDIAD_DT_F16;
     int rc;
-#define L2_ARGS q, q_sqnorm, bank, bank_sqnorm, Q, Nb, D, row_offset, keys, s, q_count
+#define L2_ARGS q, q_sqnorm, bank, bank_sqnorm, Q, Nb, D, row_offset, keys, keys2, s, q_count
     if (tile == 5) {
         const int full = Nb / 256 * 256, rest = Nb - full;
         rc = CMDIAD_OK;
-        if (full > 0) rc = h ? launch_l2<SPingPong3, true>(q, q_sqnorm, bank, bank_sqnorm, Q, full, D, row_offset, keys, s, q_count)
-                             : launch_l2<SPingPong3, false>(q, q_sqnorm, bank, bank_sqnorm, Q, full, D, row_offset, keys, s, q_count);
+        if (full > 0) rc = h ? launch_l2<SPingPong3, true>(q, q_sqnorm, bank, bank_sqnorm, Q, full, D, row_offset, keys, keys2, s, q_count)
+                             : launch_l2<SPingPong3, false>(q, q_sqnorm, bank, bank_sqnorm, Q, full, D, row_offset, keys, keys2, s, q_count);
         if (rc == CMDIAD_OK && rest > 0) {
             const uint16_t* b2 = bank + (size_t)full * D;
-            rc = h ? launch_l2<S128, true>(q, q_sqnorm, b2, bank_sqnorm + full, Q, rest, D, row_offset + full, keys, s, q_count)
-                   : launch_l2<S128, false>(q, q_sqnorm, b2, bank_sqnorm + full, Q, rest, D, row_offset + full, keys, s, q_count);
+            rc = h ? launch_l2<S128, true>(q, q_sqnorm, b2, bank_sqnorm + full, Q, rest, D, row_offset + full, keys, keys2, s, q_count)
+                   : launch_l2<S128, false>(q, q_sqnorm, b2, bank_sqnorm + full, Q, rest, D, row_offset + full, keys, keys2, s, q_count);
         }
     }
 #ifdef CMDIAD_AB_VARIANTS
@@ -782,24 +901,26 @@ static int l2_min_keys_impl(const uint16_t* q, const float* q_sqnorm, const L2Li
 
 extern "C" int cmdiad_l2_min_keys(const uint16_t* q, const float* q_sqnorm, const uint16_t* bank,
                                   const float* bank_sqnorm, int Q, int Nb, int D, uint32_t row_offset,
-                                  unsigned long long* keys, int dtype, cmdiad_stream_t stream)
+                                  unsigned long long* keys, unsigned long long* keys2, int dtype, cmdiad_stream_t stream)
 {
-    return l2_min_keys_impl(q, q_sqnorm, L2Live(), bank, bank_sqnorm, Q, Nb, D, row_offset, keys, dtype, stream);
+    return l2_min_keys_impl(q, q_sqnorm, L2Live(), bank, bank_sqnorm, Q, Nb, D, row_offset, keys, keys2, dtype, stream);
 }
 
 extern "C" int cmdiad_l2_min_keys_counted(const uint16_t* q, const float* q_sqnorm, const int* q_count, int Q_max,
                                           const uint16_t* bank, const float* bank_sqnorm, int Nb, int D,
-                                          uint32_t row_offset, unsigned long long* keys, int dtype, cmdiad_stream_t stream)
+                                          uint32_t row_offset, unsigned long long* keys, unsigned long long* keys2, int dtype,
+                                          cmdiad_stream_t stream)
 {
     CMDIAD_REQUIRE(q_count, CMDIAD_ERR_ARG, "cmdiad_l2_min_keys_counted: null count");
     L2Live live;
     live.q_count = q_count;
-    return l2_min_keys_impl(q, q_sqnorm, live, bank, bank_sqnorm, Q_max, Nb, D, row_offset, keys, dtype, stream);
+    return l2_min_keys_impl(q, q_sqnorm, live, bank, bank_sqnorm, Q_max, Nb, D, row_offset, keys, keys2, dtype, stream);
 }
 
 extern "C" int cmdiad_l2_min_keys_segments(const uint16_t* q, const float* q_sqnorm, const int* seg_counts, int n_seg,
                                            int seg_stride, const uint16_t* bank, const float* bank_sqnorm, int Nb, int D,
-                                           uint32_t row_offset, unsigned long long* keys, int dtype, cmdiad_stream_t stream)
+                                           uint32_t row_offset, unsigned long long* keys, unsigned long long* keys2, int dtype,
+                                           cmdiad_stream_t stream)
 {
     CMDIAD_REQUIRE(seg_counts, CMDIAD_ERR_ARG, "cmdiad_l2_min_keys_segments: null counts");
     CMDIAD_REQUIRE(n_seg >= 1 && n_seg <= 64 && seg_stride >= 0 && (long long)n_seg * seg_stride < (1ll << 31), CMDIAD_ERR_ARG,
@@ -808,7 +929,7 @@ extern "C" int cmdiad_l2_min_keys_segments(const uint16_t* q, const float* q_sqn
     live.seg_counts = seg_counts;
     live.n_seg = n_seg;
     live.seg_stride = seg_stride;
-    return l2_min_keys_impl(q, q_sqnorm, live, bank, bank_sqnorm, n_seg * seg_stride, Nb, D, row_offset, keys, dtype, stream);
+    return l2_min_keys_impl(q, q_sqnorm, live, bank, bank_sqnorm, n_seg * seg_stride, Nb, D, row_offset, keys, keys2, dtype, stream);
 }
 
 #ifdef CMDIAD_AB_VARIANTS
@@ -833,7 +954,7 @@ extern "C" int cmdiad_l2_diag(const uint16_t* q, const float* q_sqnorm, const ui
     int splits = nbt / 4 < 1 ? 1 : (nbt / 4 > 32 ? 32 : nbt / 4);
     int qgroup = 4 > nq ? nq : 4;
     GlobalTile A{(const bf16_t*)q, D, Q}, W{(const bf16_t*)bank, D, Nb};
-    L2Params p{Q, Nb, D, q_sqnorm, bank_sqnorm, 0u, keys, nq, nbt, splits, qgroup, stamps, wg, nullptr};
+    L2Params p{Q, Nb, D, q_sqnorm, bank_sqnorm, 0u, keys, nullptr, nq, nbt, splits, qgroup, stamps, wg, nullptr};
     const int ngroups = (nq + qgroup - 1) / qgroup;
     hipLaunchKernelGGL((l2_min_pp3_kernel<true, true>), dim3(ngroups * qgroup * splits), dim3(S::THREADS), lds_bytes, (hipStream_t)stream, A, W, p);
     CMDIAD_CHECK_LAUNCH();
@@ -853,20 +974,54 @@ extern "C" int cmdiad_l2_rescore(const float* q, const float* bank, const unsign
     return CMDIAD_OK;
 }
 
+extern "C" int cmdiad_l2_rescore2(const float* q, const float* bank, const unsigned long long* keys, const unsigned long long* keys2,
+                                  int Q, int Nb, int D, uint32_t row_offset, float* d2_pair, float* min_val, int64_t* min_idx,
+                                  cmdiad_stream_t stream)
+{
+    CMDIAD_REQUIRE(q && bank && keys && keys2 && (d2_pair || (min_val && min_idx)) && (!min_val == !min_idx), CMDIAD_ERR_ARG,
+                   "cmdiad_l2_rescore2: null pointer");
+    CMDIAD_REQUIRE(D % 4 == 0 && aligned16(q) && aligned16(bank), CMDIAD_ERR_ARG, "cmdiad_l2_rescore2: D%%4, alignment");
+    if (Q == 0) return CMDIAD_OK;
+    hipLaunchKernelGGL(l2_rescore2_kernel, dim3((Q + 3) / 4), dim3(256), 0, (hipStream_t)stream, q, bank, keys, keys2, Q, Nb, D,
+                       row_offset, d2_pair, min_val, min_idx);
+    CMDIAD_CHECK_LAUNCH();
+    return CMDIAD_OK;
+}
+
+extern "C" int cmdiad_l2_choose(const unsigned long long* keys, const unsigned long long* keys2, const float* d2_pair, int Q,
+                                float* min_val, int64_t* min_idx, cmdiad_stream_t stream)
+{
+    CMDIAD_REQUIRE(keys && keys2 && d2_pair && min_val && min_idx, CMDIAD_ERR_ARG, "cmdiad_l2_choose: null pointer");
+    if (Q == 0) return CMDIAD_OK;
+    hipLaunchKernelGGL(l2_choose_kernel, dim3((Q + 255) / 256), dim3(256), 0, (hipStream_t)stream, keys, keys2, d2_pair, Q, min_val,
+                       min_idx);
+    CMDIAD_CHECK_LAUNCH();
+    return CMDIAD_OK;
+}
+
 extern "C" int cmdiad_normalize_cast(const float* x, size_t rows, int D, float mean, float inv_std, uint16_t* out_bf16,
                                      float* out_f32, float* row_sqnorm, int out_dtype, cmdiad_stream_t stream)
 {
+    return cmdiad_normalize_cast_rows(x, rows, D, 0, 0, mean, inv_std, out_bf16, out_f32, row_sqnorm, out_dtype, stream);
+}
+
+extern "C" int cmdiad_normalize_cast_rows(const float* x, size_t rows, int D, int group_rows, int group_skip, float mean,
+                                          float inv_std, uint16_t* out_bf16, float* out_f32, float* row_sqnorm, int out_dtype,
+                                          cmdiad_stream_t stream)
+{
     CMDIAD_REQUIRE(x, CMDIAD_ERR_ARG, "cmdiad_normalize_cast: null input");
+    CMDIAD_REQUIRE(group_rows >= 0 && group_skip >= 0 && (group_rows > 0 || group_skip == 0), CMDIAD_ERR_ARG,
+                   "cmdiad_normalize_cast_rows: group_rows=%d group_skip=%d", group_rows, group_skip);
     CMDIAD_REQUIRE(D % 4 == 0 && aligned16(x) && (!out_f32 || aligned16(out_f32)) &&
                        (!out_bf16 || ((uintptr_t)out_bf16 & 7) == 0),
                    CMDIAD_ERR_ARG, "cmdiad_normalize_cast: D%%4==0 and aligned buffers");
     if (rows == 0) return CMDIAD_OK;
     if (out_dtype == CMDIAD_DT_F16)
         hipLaunchKernelGGL(normalize_cast_kernel<true>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x,
-                           rows, D, mean, inv_std, out_bf16, out_f32, row_sqnorm);
+                           rows, D, mean, inv_std, out_bf16, out_f32, row_sqnorm, group_rows, group_skip);
     else
         hipLaunchKernelGGL(normalize_cast_kernel<false>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x,
-                           rows, D, mean, inv_std, out_bf16, out_f32, row_sqnorm);
+                           rows, D, mean, inv_std, out_bf16, out_f32, row_sqnorm, group_rows, group_skip);
     CMDIAD_CHECK_LAUNCH();
     return CMDIAD_OK;
 }

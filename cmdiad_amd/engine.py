@@ -93,11 +93,30 @@ class _Null:
 def merge_shard_keys(keys, group=None):
     """Combine per-shard packed keys: key = (fp32 bits of d2 >= 0) << 32 | global row.  The keys -- and the "no
     candidate" sentinel ops.KEY_EMPTY a rank with an EMPTY shard leaves behind -- are non-negative as int64, so
-    signed MIN == unsigned MIN == (smallest distance, lowest global row)."""
+    signed MIN == unsigned MIN == (smallest distance, lowest global row).
+    keys [2, n] (best + runner-up per query, ops.new_keys(runner=True)): the best plane as above; the runner-up of the whole
+    library is the smallest key among every shard's best OTHER than the global best and every shard's runner-up -- a second
+    MIN all-reduce over (own best == global best ? own runner-up : own best).  Both planes then equal what one device searching
+    the whole library returns (the runner-up is defined on groups of 16 GLOBAL rows, and shards start on multiples of 128)."""
     if group is not None:
         import torch.distributed as td
-        td.all_reduce(keys, op=td.ReduceOp.MIN, group=group)
+        if keys.dim() == 2:
+            own_best = keys[0].clone()
+            td.all_reduce(keys[0], op=td.ReduceOp.MIN, group=group)
+            cand = torch.where(own_best == keys[0], keys[1], own_best)
+            td.all_reduce(cand, op=td.ReduceOp.MIN, group=group)
+            keys[1].copy_(cand)
+        else:
+            td.all_reduce(keys, op=td.ReduceOp.MIN, group=group)
     return keys
+
+
+def merge_key_planes(a, b):
+    """The merge of merge_shard_keys for two key sets that live on ONE device (replayed shards: tests, bench.py `fake_world`):
+    [n] keys -> element-wise minimum; [2, n] keys -> (smallest, second smallest) of the four candidates of every query."""
+    if a.dim() == 1:
+        return torch.minimum(a, b)
+    return torch.stack([torch.minimum(a[0], b[0]), torch.minimum(torch.maximum(a[0], b[0]), torch.minimum(a[1], b[1]))])
 
 
 def gather_queries(q16, qsq, group=None):
@@ -116,6 +135,7 @@ def gather_queries(q16, qsq, group=None):
 class _HipSearch:
     """The device-side pieces of the row-sharded search (HIP kernels); tests/test_host_cpu.py swaps in a torch stand-in to check
     the host-side composition -- who gathers what, which rows are searched, how the keys come back -- without a GPU."""
+    RUNNER = True     # the kernels also return every query's runner-up (keys [2, n]); a stand-in without it says False
 
     @staticmethod
     def plan(q16, q_sq, reuse=None):
@@ -166,6 +186,7 @@ class ShardedSearch:
         import torch.distributed as td
         self.bank, self.group, self.impl, self.stats = bank, group, impl, stats
         self.world, self.rank = td.get_world_size(group), td.get_rank(group)
+        self.runner = bool(getattr(impl, "RUNNER", False))   # keys [2, n]: best + runner-up (exact fp32 decision downstream)
         self.plan = None
         if not (cap_rows in ("auto", "exact") or (isinstance(cap_rows, int) and cap_rows > 0)):
             raise ValueError(f"cap_rows must be 'auto', 'exact' or a positive row count, not {cap_rows!r}")
@@ -216,12 +237,13 @@ class ShardedSearch:
                               host_reads=self.host_reads,
                               gather_bytes_received=(self.world - 1) * cap * row,
                               gather_bytes_received_without_compaction=(self.world - 1) * Q * row,
-                              reduce_bytes=self.world * cap * 8)
+                              reduce_bytes=self.world * cap * 8 * (2 if self.runner else 1))
         return self
 
     def gemm(self, timer=None):
         cap = self.cap
-        self.keys_all = torch.full((self.world * cap,), KEY_EMPTY, dtype=torch.int64, device=self.q_all.device)
+        shape = (2, self.world * cap) if self.runner else (self.world * cap,)
+        self.keys_all = torch.full(shape, KEY_EMPTY, dtype=torch.int64, device=self.q_all.device)
         with (timer if timer is not None else _Null()):
             self.impl.search_segments(self.q_all, self.s_all, self.counts_dev, cap, self.bank, self.keys_all)
         return self
@@ -229,14 +251,15 @@ class ShardedSearch:
     def reduce(self):
         cap = self.cap
         keys_all = merge_shard_keys(self.keys_all, self.group)
-        mine = keys_all[self.rank * cap:(self.rank + 1) * cap]
+        mine = keys_all[..., self.rank * cap:(self.rank + 1) * cap]
+        lead = keys_all.shape[:-1]
         if cap < self.Q:
             # slot[] names compacted rows up to count - 1, and count is known on the device only: in a step that overflowed the
             # cap the expansion must still read inside its buffer (such rows get "no candidate"; `overflow` tells the caller)
-            kc = torch.full((self.Q,), KEY_EMPTY, dtype=torch.int64, device=keys_all.device)
-            kc[:cap] = mine
+            kc = torch.full((*lead, self.Q), KEY_EMPTY, dtype=torch.int64, device=keys_all.device)
+            kc[..., :cap] = mine
             mine = kc
-        return self.impl.expand(mine.contiguous(), self.plan.slot, torch.empty((self.Q,), dtype=torch.int64, device=keys_all.device))
+        return self.impl.expand(mine.contiguous(), self.plan.slot, torch.empty((*lead, self.Q), dtype=torch.int64, device=keys_all.device))
 
 
 def sharded_min_keys(q16, q_sq, bank, group, plan=None, timer=None, stats=None, impl=_HipSearch):
@@ -266,7 +289,7 @@ def score_patches(patch32, bank, dims, gt_size=224, group=None):
         keys, _ = sharded_min_keys(q16, qsq, bank, group)      # compact locally, gather the live rows only
         return score_patches_from_keys(patch32, keys, bank, dims, gt_size, group)
     q_all, s_all = gather_queries(q16, qsq, group)
-    keys = ops.new_keys(q_all.shape[0], dev)
+    keys = ops.new_keys(q_all.shape[0], dev, runner=True)
     if os.environ.get("CMDIAD_DEDUP", "1") != "0":
         # the rows of the patches without a foreground pixel repeat one vector: searched once (csrc/dedup.hip), keys identical
         plan = ops.rows_dedup_plan(q_all, s_all)
@@ -276,7 +299,7 @@ def score_patches(patch32, bank, dims, gt_size=224, group=None):
         ops.l2_min_keys(q_all, s_all, bank.bf16, bank.sqnorm, keys, bank.row_offset)
     keys = merge_shard_keys(keys, group)
     if group is not None:
-        keys = keys[bank.rank * B * Q:(bank.rank + 1) * B * Q].contiguous()
+        keys = keys[..., bank.rank * B * Q:(bank.rank + 1) * B * Q].contiguous()
     return score_patches_from_keys(patch32, keys, bank, dims, gt_size, group)
 
 
@@ -287,7 +310,7 @@ def _sharded_score_steps(patch32, keys, bank, dims, gt_size):
     result -- "sum": element-wise sum (exactly one rank, the owner of the row in question, contributes a non-zero value, so the sum
     is exact); "gather": [W, *shape] of every rank's tensor.  Driven by real collectives (`_drive_collectives`) or, on one device,
     by a lock-step loop over W generators (tests/test_gpu_fakeworld.py).
-      1. exact fp32 distance to the winning row: computed by the rank that owns it                      -> sum   [B*Q] f32
+      1. exact fp32 distance to the winning row (keys [2, .]: to the best and the runner-up): by the rank that owns it -> sum [B*Q] / [2, B*Q] f32
       2. s* = max over a sample's patches; m_star = the winning row of that patch: sent by its owner       -> sum   [B, D] f32
       3. re-weighting scan of the LOCAL rows: three smallest (distance, global row) keys per probe         -> gather [W, B, 3] keys,
          merged by integer order (ties -> lowest global row, as the single-library scan)
@@ -296,11 +319,22 @@ def _sharded_score_steps(patch32, keys, bank, dims, gt_size):
     dev = patch32.device
     flat = patch32.reshape(B * Q, D)
     off, nloc = bank.f32_offset, bank.f32_rows
-    min_val = torch.zeros((B * Q,), dtype=torch.float32, device=dev)
-    scratch_idx = torch.full((B * Q,), -1, dtype=torch.int64, device=dev)
-    ops.l2_rescore(flat, bank.f32, keys, min_val, scratch_idx, off) if nloc else None
-    min_val = yield ("sum", min_val)
-    min_idx = torch.where(keys == KEY_EMPTY, torch.full_like(keys, -1), keys & 0xFFFFFFFF)       # global rows, known everywhere
+    if keys.dim() == 2:
+        # best + runner-up: every candidate's squared fp32 distance is computed by the rank that owns its row (one sum over the
+        # ranks, [2, B*Q]); the decision -- the nearer one, of equal ones the lower row -- is then the same everywhere
+        d2_pair = torch.zeros((2, B * Q), dtype=torch.float32, device=dev)
+        if nloc:
+            ops.l2_rescore_pair_d2(flat, bank.f32, keys, d2_pair, off)
+        d2_pair = yield ("sum", d2_pair)
+        min_val = torch.zeros((B * Q,), dtype=torch.float32, device=dev)
+        min_idx = torch.full((B * Q,), -1, dtype=torch.int64, device=dev)
+        ops.l2_choose(keys, d2_pair, min_val, min_idx)
+    else:
+        min_val = torch.zeros((B * Q,), dtype=torch.float32, device=dev)
+        scratch_idx = torch.full((B * Q,), -1, dtype=torch.int64, device=dev)
+        ops.l2_rescore(flat, bank.f32, keys, min_val, scratch_idx, off) if nloc else None
+        min_val = yield ("sum", min_val)
+        min_idx = torch.where(keys == KEY_EMPTY, torch.full_like(keys, -1), keys & 0xFFFFFFFF)       # global rows, known everywhere
     s_star = torch.empty((B,), dtype=torch.float32, device=dev)
     s_idx = torch.empty((B,), dtype=torch.int32, device=dev)
     m_test = torch.empty((B, D), dtype=torch.float32, device=dev)

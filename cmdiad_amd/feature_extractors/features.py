@@ -69,8 +69,8 @@ class DistHandle:
         bank = eng.Bank(self.lib.to(dev).float())
         q = self.patch.to(dev).float().contiguous()
         q16, _, qsq = ops.normalize_cast(q)
-        keys = ops.l2_min_keys(q16, qsq, bank.bf16, bank.sqnorm, ops.new_keys(q.shape[0], q.device))
-        return ops.l2_rescore(q, bank.f32, keys)
+        keys = ops.l2_min_keys(q16, qsq, bank.bf16, bank.sqnorm, ops.new_keys(q.shape[0], q.device, runner=True))
+        return ops.l2_rescore(q, bank.f32, keys)      # best and runner-up measured in fp32: torch.min's answer on near-ties too
 
 
 class PixelList:

@@ -478,30 +478,54 @@ def gemm_groupmax(A, W, bias, groups, Mg, want_bf16=False):
 SEARCH_DTYPE = torch.float16 if os.environ.get("CMDIAD_SEARCH_DTYPE", "bf16").lower() in ("fp16", "float16", "half") else torch.bfloat16
 
 
-def normalize_cast(x, mean=0.0, inv_std=1.0, want_f32=False, want_sq=True, dtype=None):
-    """x [rows,D] f32 -> (16-bit [rows,D] (fp16 by default, or bf16), f32 normalised | None,
-    row |.|^2 of the ROUNDED rows | None)."""
+def normalize_cast(x, mean=0.0, inv_std=1.0, want_f32=False, want_sq=True, dtype=None, skip_leading=0):
+    """x [rows,D] f32 -> (16-bit [rows,D] (the search operand type: bf16 by default, or fp16), f32 normalised | None,
+    row |.|^2 of the ROUNDED rows | None).
+    skip_leading = s > 0: x is [G, s + R, D] and the first s rows of every group are not taken (the cls token of the ViT's
+    [B, 785, C] tokens): outputs have G * R rows, read in place -- no gather copy of the patch rows in between."""
     _chk(x, torch.float32, "normalize_cast.x")
-    rows, D = x.shape
     dtype = dtype or SEARCH_DTYPE
+    if skip_leading:
+        G, T, D = x.shape
+        group = T - skip_leading
+        rows = G * group
+    else:
+        rows, D = x.shape
+        group = 0
     o16 = torch.empty((rows, D), dtype=dtype, device=x.device)
     o32 = torch.empty((rows, D), dtype=torch.float32, device=x.device) if want_f32 else None
     sq = torch.empty((rows,), dtype=torch.float32, device=x.device) if want_sq else None
-    _call("cmdiad_normalize_cast", _p(x), rows, D, float(mean), float(inv_std), _p(o16), _p(o32), _p(sq),
+    _call("cmdiad_normalize_cast_rows", _p(x), rows, D, group, int(skip_leading), float(mean), float(inv_std), _p(o16), _p(o32), _p(sq),
           1 if dtype == torch.float16 else 0, _stream())
     return o16, o32, sq
 
 
-def new_keys(Q, device):
-    return torch.full((Q,), KEY_EMPTY, dtype=torch.int64, device=device)
+def new_keys(Q, device, runner=False):
+    """Packed nearest-neighbour keys, "no candidate" everywhere.  runner=True: [2, Q] -- plane 0 the best row of every query,
+    plane 1 its runner-up (the nearest row outside the winner's group of 16 rows, include/cmdiad_hip.h) for the exact fp32
+    decision of l2_rescore; every function below that takes `keys` accepts either shape."""
+    return torch.full((2, Q) if runner else (Q,), KEY_EMPTY, dtype=torch.int64, device=device)
+
+
+def _key_planes(keys, n, name):
+    """-> (pointer of the best plane, pointer of the runner-up plane or None) of a [n] or [2, n] int64 key tensor."""
+    _chk(keys, torch.int64, name)
+    if keys.dim() == 2:
+        if keys.shape[0] != 2 or keys.shape[1] < n:
+            raise ValueError(f"{name}: expected [2, >={n}] keys, got {tuple(keys.shape)}")
+        return _p(keys[0]), _p(keys[1])
+    if keys.shape[0] < n:
+        raise ValueError(f"{name}: {keys.shape[0]} keys for {n} query rows")
+    return _p(keys), None
 
 
 def l2_min_keys(q16, q_sq, bank16, bank_sq, keys, row_offset=0):
     Q, D = q16.shape
     if q16.dtype != bank16.dtype:
         raise TypeError("l2_min_keys: queries and bank must share the 16-bit dtype")
+    k1, k2 = _key_planes(keys, Q, "l2_min_keys.keys")
     _call("cmdiad_l2_min_keys", _p(q16), _p(q_sq), _p(bank16), _p(bank_sq), Q, bank16.shape[0], D, row_offset,
-          _p(keys), 1 if q16.dtype == torch.float16 else 0, _stream())
+          k1, k2, 1 if q16.dtype == torch.float16 else 0, _stream())
     return keys
 
 
@@ -538,8 +562,9 @@ def l2_min_keys_counted(q16, q_sq, count, bank16, bank_sq, keys, row_offset=0):
     if q16.dtype != bank16.dtype:
         raise TypeError("l2_min_keys_counted: queries and bank must share the 16-bit dtype")
     _chk(count, torch.int32, "l2_min_keys_counted.count")
+    k1, k2 = _key_planes(keys, Q, "l2_min_keys_counted.keys")
     _call("cmdiad_l2_min_keys_counted", _p(q16), _p(q_sq), _p(count), Q, _p(bank16), _p(bank_sq), bank16.shape[0], D, row_offset,
-          _p(keys), 1 if q16.dtype == torch.float16 else 0, _stream())
+          k1, k2, 1 if q16.dtype == torch.float16 else 0, _stream())
     return keys
 
 
@@ -551,10 +576,11 @@ def l2_min_keys_segments(q16, q_sq, seg_counts, seg_stride, bank16, bank_sq, key
         raise TypeError("l2_min_keys_segments: queries and bank must share the 16-bit dtype")
     _chk(seg_counts, torch.int32, "l2_min_keys_segments.seg_counts")
     n_seg = seg_counts.shape[0]
-    if n_seg * seg_stride != Q or keys.shape[0] < Q:
-        raise ValueError(f"l2_min_keys_segments: {n_seg} segments of {seg_stride} rows != {Q} query rows (keys: {keys.shape[0]})")
+    if n_seg * seg_stride != Q or keys.shape[-1] < Q:
+        raise ValueError(f"l2_min_keys_segments: {n_seg} segments of {seg_stride} rows != {Q} query rows (keys: {keys.shape[-1]})")
+    k1, k2 = _key_planes(keys, Q, "l2_min_keys_segments.keys")
     _call("cmdiad_l2_min_keys_segments", _p(q16), _p(q_sq), _p(seg_counts), n_seg, seg_stride, _p(bank16), _p(bank_sq),
-          bank16.shape[0], D, row_offset, _p(keys), 1 if q16.dtype == torch.float16 else 0, _stream())
+          bank16.shape[0], D, row_offset, k1, k2, 1 if q16.dtype == torch.float16 else 0, _stream())
     return keys
 
 
@@ -569,18 +595,47 @@ def rows_expand_f32(rows_compact, slot, out=None):
 
 
 def keys_expand(keys_compact, slot, keys):
+    """keys[..., q] = keys_compact[..., slot[q]] ([n] or [2, n] key tensors: both planes)."""
     _chk(slot, torch.int32, "keys_expand.slot")
+    if keys_compact.dim() != keys.dim():
+        raise ValueError("keys_expand: compact and expanded keys must have the same number of planes")
+    if keys.dim() == 2:
+        for pl in range(2):
+            _call("cmdiad_keys_expand", _p(keys_compact[pl]), _p(slot), slot.shape[0], _p(keys[pl]), _stream())
+        return keys
     _call("cmdiad_keys_expand", _p(keys_compact), _p(slot), slot.shape[0], _p(keys), _stream())
     return keys
 
 
 def l2_rescore(q32, bank32, keys, min_val=None, min_idx=None, row_offset=0):
+    """Exact fp32 distance and row of every query's nearest library row.  keys [Q]: the search's winner is taken as it is;
+    keys [2, Q] (best + runner-up): both are measured in fp32 and the nearer one wins (ties: the lower row) -- torch.min on the
+    fp32 distance matrix (features.py:227)."""
     Q, D = q32.shape
     if min_val is None:
         min_val = torch.zeros((Q,), dtype=torch.float32, device=q32.device)
         min_idx = torch.zeros((Q,), dtype=torch.int64, device=q32.device)
+    if keys.dim() == 2:
+        _call("cmdiad_l2_rescore2", _p(q32), _p(bank32), _p(keys[0]), _p(keys[1]), Q, bank32.shape[0], D, row_offset, None,
+              _p(min_val), _p(min_idx), _stream())
+        return min_val, min_idx
     _call("cmdiad_l2_rescore", _p(q32), _p(bank32), _p(keys), Q, bank32.shape[0], D, row_offset, _p(min_val),
           _p(min_idx), _stream())
+    return min_val, min_idx
+
+
+def l2_rescore_pair_d2(q32, bank32, keys, d2_pair, row_offset=0):
+    """Squared fp32 distances [2, Q] of the candidates of keys [2, Q] whose rows lie in this shard's [row_offset, +rows); the other
+    entries are left as they are (zero-filled by the caller, summed over the shards, then l2_choose)."""
+    Q, D = q32.shape
+    _call("cmdiad_l2_rescore2", _p(q32), _p(bank32), _p(keys[0]), _p(keys[1]), Q, bank32.shape[0], D, row_offset, _p(d2_pair),
+          None, None, _stream())
+    return d2_pair
+
+
+def l2_choose(keys, d2_pair, min_val, min_idx):
+    """The decision of l2_rescore on [2, Q] keys from squared distances that were summed over the shards."""
+    _call("cmdiad_l2_choose", _p(keys[0]), _p(keys[1]), _p(d2_pair), keys.shape[1], _p(min_val), _p(min_idx), _stream())
     return min_val, min_idx
 
 

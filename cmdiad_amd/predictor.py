@@ -195,13 +195,16 @@ class BatchPredictor:
         def rgb_branch(ex):
             # everything the rgb library needs depends on the ViT only: normalise, cast and SEARCH it here, beside the
             # rest of the point-cloud branch (the Point-MAE transformer leaves half of the chip's issue slots idle)
-            rq = eng.normalize(e.rgb_patch(ex).contiguous(), s["rgb_mean"], s["rgb_std"])
-            B, Q, D = rq.shape
-            q16, _, qsq = ops.normalize_cast(rq.reshape(B * Q, D))
+            # the patch rows of the [B, 785, C] tokens are read in place (cls skipped): normalised fp32 rows, 16-bit rows and norms
+            # in ONE pass -- (x - mean) / std then the cast, the same two roundings as normalising first and casting after
+            tok = ex.rgb_tokens
+            B, Q, D = tok.shape[0], tok.shape[1] - 1, tok.shape[2]
+            q16, rq, qsq = ops.normalize_cast(tok, float(s["rgb_mean"]), 1.0 / float(s["rgb_std"]), want_f32=True, skip_leading=1)
+            rq = rq.view(B, Q, D)
             early["rgb"] = (rq, q16, qsq)
             if self.group is None:
                 bank = self.bank_second
-                k = ops.new_keys(B * Q, rq.device)
+                k = ops.new_keys(B * Q, rq.device, runner=True)
                 ops.l2_min_keys(q16, qsq, bank.bf16, bank.sqnorm, k, bank.row_offset)
                 early["rgb_keys"] = k
 
@@ -254,17 +257,17 @@ class BatchPredictor:
             plan = qs.get(f"{name}_plan") if self.dedup else None    # made in stage 1 already (unsharded library)
             q_all, s_all = (None, None) if plan is not None else eng.gather_queries(q16, qsq, self.group)
             n_rows = B * Q if q_all is None else q_all.shape[0]
-            k = self.static.get(f"keys_{name}_{buf}")
-            if k is None or k.shape[0] != n_rows:
-                k = self.static[f"keys_{name}_{buf}"] = torch.empty((n_rows,), dtype=torch.int64, device=q.device)
+            k = self.static.get(f"keys_{name}_{buf}")       # [2, rows]: best + runner-up (ops.new_keys(runner=True))
+            if k is None or k.shape[1] != n_rows:
+                k = self.static[f"keys_{name}_{buf}"] = torch.empty((2, n_rows), dtype=torch.int64, device=q.device)
             if self.dedup:
                 # patches without a foreground pixel are one and the same row (and so are their hallucinated features in the MTFI
                 # workload): searched once, the key copied to all
                 if plan is None:
                     plan = self.static[f"plan_{name}_{buf}"] = ops.rows_dedup_plan(q_all, s_all, self.static.get(f"plan_{name}_{buf}"))
                 kc = self.static.get(f"keysc_{name}_{buf}")
-                if kc is None or kc.shape[0] != n_rows:
-                    kc = self.static[f"keysc_{name}_{buf}"] = torch.empty((n_rows,), dtype=torch.int64, device=q.device)
+                if kc is None or kc.shape[1] != n_rows:
+                    kc = self.static[f"keysc_{name}_{buf}"] = torch.empty((2, n_rows), dtype=torch.int64, device=q.device)
                 kc.fill_(eng.KEY_EMPTY)
                 with self.timers.get(name, _NoTimer()):
                     ops.l2_min_keys_counted(plan.q16, plan.q_sq, plan.count, bank.bf16, bank.sqnorm, kc, bank.row_offset)
@@ -279,7 +282,7 @@ class BatchPredictor:
                 self.live_rows += live
                 self.xyz_searches += 1
             k = eng.merge_shard_keys(k, self.group)
-            keys[name] = k[bank.rank * B * Q:(bank.rank + 1) * B * Q] if self.group is not None else k
+            keys[name] = k[..., bank.rank * B * Q:(bank.rank + 1) * B * Q] if self.group is not None else k
         return keys
 
     # ---- stage 2: exact re-score, re-weighting, bilinear maps, 8-bit blur (a14), lambda weights + one-class SVMs (a19)

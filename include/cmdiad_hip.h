@@ -39,7 +39,10 @@ int cmdiad_abi_version(void); /* 2: cmdiad_reweight_scan's limits and workspace 
                                     cmdiad_ln_stats_finalize is new
                                  4: cmdiad_l2_min_keys_segments, cmdiad_gemm_streamk_*, cmdiad_coreset_greedy_f32, cmdiad_coreset_prepare / _round / _decode, cmdiad_im2col3x3_bf16 are new
                                  5: cmdiad_reweight_scan_pair is new; the value bits of cmdiad_l2_min_keys' keys are the squared distance with
-                                    its four low mantissa bits cleared (see there) */
+                                    its four low mantissa bits cleared (see there)
+                                 6: cmdiad_l2_min_keys / _counted / _segments gained keys2 (the runner-up per query, NULL = off);
+                                    cmdiad_l2_rescore2 and cmdiad_l2_choose are new; cmdiad_normalize_cast turns a non-finite row into a
+                                    row that cannot win */
 /* 1 when the library is the test-only build that also contains the superseded kernel formulations (A/B references). */
 int cmdiad_has_ab_variants(void);
 
@@ -291,17 +294,26 @@ int cmdiad_gemm_groupmax(const uint16_t* A, const uint16_t* W, const float* bias
  * not depend on the launch geometry, the tile shape or the shard the row is in.
  * q [Q,D] bf16, q_sqnorm [Q] f32, bank [Nb,D] bf16, bank_sqnorm [Nb] f32 (squared norms of the
  * bf16-rounded rows, from cmdiad_normalize_cast), keys [Q] u64: the caller initialises keys to
- * UINT64_MAX; the kernel combines with atomic min.  D % 64 == 0. */
+ * UINT64_MAX (or any value above every key, e.g. INT64_MAX); the kernel combines with atomic min.  D % 64 == 0.
+ * keys2 [Q] u64 or NULL (ABI 6), initialised like keys: the RUNNER-UP of every query, so that the exact fp32 re-score
+ * (cmdiad_l2_rescore2) can repair a near-tie that the 16-bit operands resolved the wrong way -- torch.min on the fp32 cdist
+ * (features.py:227) is index work, and with it min_idx equals the fp32 argmin except where a THIRD row lies inside the operand
+ * noise too.  Definition (library rows only -- no tile shape, launch geometry or shard in it): the library is cut into groups of
+ * 16 rows, group(row) = (row >> 6, (row >> 2) & 3) on GLOBAL rows (row_offset % 64 == 0 is required with keys2); keys2[q] is the
+ * smallest key among the group minima other than keys[q]'s own group, i.e. the nearest row outside the winner's group.  Shards
+ * combine as: K1 = MIN over shards of keys; K2 = MIN over shards of (keys == K1 ? keys2 : keys).
+ * Contract: operands and norms finite (cmdiad_normalize_cast guarantees it: a row with a non-finite element is stored as zeros
+ * with squared norm +inf -- as a library row it can never win, as a query it finds nothing and its keys stay untouched). */
 enum { CMDIAD_DT_BF16 = 0, CMDIAD_DT_F16 = 1 };   /* 16-bit operand type of the distance GEMM */
 int cmdiad_l2_min_keys(const uint16_t* q, const float* q_sqnorm, const uint16_t* bank, const float* bank_sqnorm,
-                       int Q, int Nb, int D, uint32_t row_offset, unsigned long long* keys, int dtype,
+                       int Q, int Nb, int D, uint32_t row_offset, unsigned long long* keys, unsigned long long* keys2, int dtype,
                        cmdiad_stream_t stream);
 
 /* The same search over a query set whose live row count is known only on the device (*q_count <= Q_max, e.g. the compacted set of
  * cmdiad_rows_dedup_plan): the launch is sized for Q_max, rows at and beyond *q_count are neither read nor written. */
 int cmdiad_l2_min_keys_counted(const uint16_t* q, const float* q_sqnorm, const int* q_count, int Q_max, const uint16_t* bank,
-                               const float* bank_sqnorm, int Nb, int D, uint32_t row_offset, unsigned long long* keys, int dtype,
-                               cmdiad_stream_t stream);
+                               const float* bank_sqnorm, int Nb, int D, uint32_t row_offset, unsigned long long* keys,
+                               unsigned long long* keys2, int dtype, cmdiad_stream_t stream);
 
 /* The same search over n_seg query SEGMENTS laid out at a fixed stride -- the row-sharded search of SURVEY 8(e): the gathered,
  * separately compacted query sets of the W ranks of a node against THIS rank's library shard (what features.py:186-190,227 do on
@@ -311,7 +323,7 @@ int cmdiad_l2_min_keys_counted(const uint16_t* q, const float* q_sqnorm, const i
  * segment.  1 <= n_seg <= 64. */
 int cmdiad_l2_min_keys_segments(const uint16_t* q, const float* q_sqnorm, const int* seg_counts, int n_seg, int seg_stride,
                                 const uint16_t* bank, const float* bank_sqnorm, int Nb, int D, uint32_t row_offset,
-                                unsigned long long* keys, int dtype, cmdiad_stream_t stream);
+                                unsigned long long* keys, unsigned long long* keys2, int dtype, cmdiad_stream_t stream);
 
 /* Exact removal of repeated query rows in front of the search.  Every patch of the 56 x 56 grid without a foreground pixel under
  * it is the same vector ((0 - mean) / std in every column; features.py:169-184, multiple_features.py:976-977) and the reference's
@@ -337,6 +349,17 @@ int cmdiad_rows_expand_f32(const float* rows_compact, const int* slot, int Q, in
  * left untouched (another shard owns them). */
 int cmdiad_l2_rescore(const float* q, const float* bank, const unsigned long long* keys, int Q, int Nb,
                       int D, uint32_t row_offset, float* min_val, int64_t* min_idx, cmdiad_stream_t stream);
+/* The same over BOTH candidates of every query (keys = best, keys2 = runner-up of cmdiad_l2_min_keys): squared fp32 distances in
+ * one summation order; the smaller one wins, of equal ones the lower row -- torch.min's answer on the fp32 distance matrix
+ * (features.py:227) wherever the true nearest row is one of the two.
+ *   min_val / min_idx (both or neither): the decision, written for queries whose best candidate lies in [row_offset, row_offset+Nb)
+ *     (a runner-up outside that range is ignored: use d2_pair + cmdiad_l2_choose when the fp32 rows are sharded);
+ *   d2_pair [2][Q] f32 or NULL: the squared distances of the candidates THIS shard owns, others untouched -- zero-filled by the
+ *     caller and summed over the shards, every entry has exactly one contributor; cmdiad_l2_choose then takes the decision. */
+int cmdiad_l2_rescore2(const float* q, const float* bank, const unsigned long long* keys, const unsigned long long* keys2, int Q,
+                       int Nb, int D, uint32_t row_offset, float* d2_pair, float* min_val, int64_t* min_idx, cmdiad_stream_t stream);
+int cmdiad_l2_choose(const unsigned long long* keys, const unsigned long long* keys2, const float* d2_pair, int Q, float* min_val,
+                     int64_t* min_idx, cmdiad_stream_t stream);
 
 /* Batch-statistics BatchNorm support (the reference runs Point-MAE's BatchNorm1d layers, models/models.py:189,195,
  * in training mode because the extractor is never put in .eval()).  Double-precision moment sums, ACCUMULATED into
@@ -433,6 +456,12 @@ int cmdiad_sparse_project_f32(const float* X, size_t n, int d, const int* indptr
  * optional per-row squared norm of the bf16-rounded row (a11 + the |b|^2 term of the distance GEMM). */
 int cmdiad_normalize_cast(const float* x, size_t rows, int D, float mean, float inv_std, uint16_t* out_bf16,
                           float* out_f32, float* row_sqnorm, int out_dtype, cmdiad_stream_t stream);
+/* The same with the input rows in groups of group_rows, each preceded by group_skip rows that are NOT taken (ABI 6): output row r
+ * reads input row r + (r / group_rows + 1) * group_skip.  The rgb patch features are rows 1..784 of every image's 785 ViT tokens
+ * (features.py:160-162 drops the cls token, multiple_features.py:976-977 normalises): group_rows 784, group_skip 1 reads the
+ * token tensor in place and writes the patch rows compactly.  A non-finite row: see cmdiad_l2_min_keys. */
+int cmdiad_normalize_cast_rows(const float* x, size_t rows, int D, int group_rows, int group_skip, float mean, float inv_std,
+                               uint16_t* out_bf16, float* out_f32, float* row_sqnorm, int out_dtype, cmdiad_stream_t stream);
 
 /* ViT patch embedding as a GEMM operand: rgb [B,3,S,S] f32 -> patches [B*(S/8)^2, 192] bf16 with
  * k = (c, dy, dx) matching conv weight [768,3,8,8] flattened (timm PatchEmbed, models/models.py:41). */

@@ -103,12 +103,13 @@ def test_predict_scores_match_oracle(fitted):
                 assert np.corrcoef(a, b)[0, 1] > 0.99
 
 
-@pytest.mark.parametrize("search_dtype,agree", [(torch.bfloat16, 0.99), (torch.float16, 0.995)], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("search_dtype,agree", [(torch.bfloat16, 0.9999), (torch.float16, 0.9999)], ids=["bf16", "fp16"])
 def test_scoring_exact_features_isolated(fitted, search_dtype, agree, monkeypatch):
     """Same (oracle) features fed to the GPU scorer: isolates a11-a13 from the network tolerance -- on both operand types of the
-    distance GEMM (bf16: the default since round 5; fp16: CMDIAD_SEARCH_DTYPE=fp16).  What the three mantissa bits change is how
-    many NEAR-TIES go the other way (4 of 784 queries against 1-3 here); a flipped row's exact distance agrees with the true minimum
-    to 2e-3 either way (asserted below), and everything behind the argmin is fp32.
+    distance GEMM (bf16: the default since round 5; fp16: CMDIAD_SEARCH_DTYPE=fp16).  Rounds 1-5 took the 16-bit search's winner
+    as it was: 4 of 784 near-ties went the other way with bf16 operands, 1-3 with fp16 (argmin agreement 99.5 %).  Since round 6
+    the search also returns every query's runner-up and the fp32 re-score decides between the two (include/cmdiad_hip.h,
+    cmdiad_l2_rescore2): min_idx is the float64 argmin on >= 99.99 % of the queries -- here: on all of them -- for both types.
     Uses the rgb modality: its patches are well separated (distances O(10)), whereas the xyz features of
     this smooth synthetic surface are near-duplicates whose distances sit below the 16-bit operand noise
     of ANY half-precision search (covered separately, with an absolute bound, in the predict test)."""
@@ -125,7 +126,7 @@ def test_scoring_exact_features_isolated(fitted, search_dtype, agree, monkeypatc
     ref32 = scoring.single_s_s_map(q, torch.cdist(q, cpu.rgb_lib), cpu.rgb_lib, (28, 28), blur=False)
     assert float(r["min_val"][0].max()) < 1e-3
     np.testing.assert_allclose(r["min_val"][0].cpu().numpy(), ref32["min_val"].numpy(), atol=5e-2)
-    assert (r["min_idx"][0].cpu() == ref32["min_idx"]).float().mean() > 0.99
+    assert (r["min_idx"][0].cpu() == ref32["min_idx"]).float().mean() > 0.995   # (ref32 = fp32 cdist at distance ~0: its own noise)
     # (2) an unseen query: every stage of compute_single_s_s_map against the same composition fed with a
     # float64 distance matrix (exact), and against the reference's fp32 cdist at its own error floor
     rgb, pc = synth_sample(12, True)

@@ -17,7 +17,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_cabi_library_loads_and_exports_every_declared_symbol():
     from cmdiad_amd import _native as nat
     L = nat.lib()
-    assert L.cmdiad_abi_version() == 5
+    assert L.cmdiad_abi_version() == 6
     hdr = open(os.path.join(REPO, "include", "cmdiad_hip.h")).read()
     declared = set(re.findall(r"\b(cmdiad_[a-z0-9_]+)\s*\(", hdr))
     bound = set(nat.SIGNATURES) | set(nat.SIZE_QUERIES) | {"cmdiad_last_error", "cmdiad_abi_version", "cmdiad_has_ab_variants"}
@@ -242,6 +242,25 @@ rv, ri = d2f.min(1)
 assert torch.equal(keys & 0xFFFFFFFF, ri), "merged argmin differs from the single-bank argmin"
 assert int(keys[0] & 0xFFFFFFFF) == 100          # the duplicate at row 700 must lose to row 100
 assert torch.equal((keys >> 32).to(torch.int32).view(torch.float32), rv)
+# best + runner-up planes (ops.new_keys(runner=True)): the runner-up is the nearest row OUTSIDE the winner's group of 16 rows,
+# group(row) = (row >> 6, (row >> 2) & 3) on global rows; two MIN all-reduces give what one device searching everything returns
+def top2(d2m, first_row):
+    rows = torch.arange(d2m.shape[1]) + first_row
+    k = (d2m.contiguous().view(torch.int32).to(torch.int64) << 32) | rows[None]
+    best = k.min(1).values
+    gid = (rows >> 6) * 4 + ((rows >> 2) & 3)
+    bg = gid[(best & 0xFFFFFFFF) - first_row]
+    runner = k.masked_fill(gid[None] == bg[:, None], eng.KEY_EMPTY).min(1).values
+    return torch.stack([best, runner])
+if hi > lo:
+    mine2 = top2(d2, lo)
+else:
+    mine2 = torch.full((2, qs.shape[0]), eng.KEY_EMPTY, dtype=torch.int64)
+merged2 = eng.merge_shard_keys(mine2.clone(), td.group.WORLD)
+want2 = top2(d2f, 0)
+assert torch.equal(merged2, want2), (merged2 != want2).nonzero()[:6]
+halves = [top2(d2f[:, a:b], a) for a, b in ((0, 512), (512, 1000))]
+assert torch.equal(eng.merge_key_planes(*halves), want2)          # the same merge for shards replayed on one device
 td.destroy_process_group()
 print("rank", rank, "ok")
 """

@@ -12,6 +12,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cmdiad_amd import engine as eng
 from cmdiad_amd import ops  # noqa: E402
 from oracle import kernels as ok  # noqa: E402
 
@@ -137,20 +138,26 @@ def case_l2_identity(rs):
     keys = {}
     for tile in ("0", "2", "5"):
         os.environ["CMDIAD_L2_TILE"] = tile
-        keys[tile] = ops.l2_min_keys(q16, qsq, b16, bsq, ops.new_keys(Q, DEV)).clone()
+        keys[tile] = ops.l2_min_keys(q16, qsq, b16, bsq, ops.new_keys(Q, DEV, runner=True)).clone()     # best + runner-up planes
     os.environ.pop("CMDIAD_L2_TILE", None)
     assert torch.equal(keys["0"], keys["2"]) and torch.equal(keys["0"], keys["5"]), ("l2 identity", Q, Nb, D, dt)
+    one = ops.l2_min_keys(q16, qsq, b16, bsq, ops.new_keys(Q, DEV))
+    assert torch.equal(one, keys["0"][0]), ("l2 best plane == single-plane launch", Q, Nb, D, dt)
+    _, idx = ops.unpack_keys(keys["0"])
+    has2 = keys["0"][1] != ops.KEY_EMPTY
+    assert bool(((idx[0] >> 6 != idx[1] >> 6) | ((idx[0] >> 2) & 3 != (idx[1] >> 2) & 3))[has2].all()), ("runner-up outside the winner's group", Q, Nb, D)
+    assert bool(has2.all()) or Nb <= 4, ("runner-up present (rows 0..3 are one group)", Q, Nb, D)
     cuts = sorted(set([0, Nb] + [int(c) // 64 * 64 for c in rs.randint(0, Nb + 1, int(rs.randint(1, 3)))]))
-    merged = ops.new_keys(Q, DEV)
+    merged = ops.new_keys(Q, DEV, runner=True)
     for lo, hi in zip(cuts[:-1], cuts[1:]):
         if hi > lo:
-            k = ops.l2_min_keys(q16, qsq, b16[lo:hi].contiguous(), bsq[lo:hi].contiguous(), ops.new_keys(Q, DEV), row_offset=lo)
-            merged = torch.minimum(merged, k)
+            k = ops.l2_min_keys(q16, qsq, b16[lo:hi].contiguous(), bsq[lo:hi].contiguous(), ops.new_keys(Q, DEV, runner=True), row_offset=lo)
+            merged = eng.merge_key_planes(merged, k)
     assert torch.equal(merged, keys["0"]), ("l2 shards", Q, Nb, D, dt, cuts)
     live = int(rs.randint(1, Q + 1))
     cnt = torch.tensor([live], dtype=torch.int32, device=DEV)
-    kc = ops.l2_min_keys_counted(q16, qsq, cnt, b16, bsq, ops.new_keys(Q, DEV))
-    assert torch.equal(kc[:live], keys["0"][:live]) and bool((kc[live:] == ops.KEY_EMPTY).all()), ("l2 counted", Q, Nb, D, live)
+    kc = ops.l2_min_keys_counted(q16, qsq, cnt, b16, bsq, ops.new_keys(Q, DEV, runner=True))
+    assert torch.equal(kc[:, :live], keys["0"][:, :live]) and bool((kc[:, live:] == ops.KEY_EMPTY).all()), ("l2 counted", Q, Nb, D, live)
 
 
 def case_reweight_pair(rs):

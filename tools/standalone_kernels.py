@@ -50,7 +50,7 @@ def l2_rows():
     cap = (live + 255) // 256 * 256
     seg_cnt = torch.full((8,), live, dtype=torch.int32, device=DEV)
     q_seg, s_seg = q16[:cap].repeat(8, 1), qsq[:cap].repeat(8)
-    k_all, k_seg = ops.new_keys(Qmax, DEV), ops.new_keys(8 * cap, DEV)
+    k_all, k_seg = ops.new_keys(Qmax, DEV, runner=True), ops.new_keys(8 * cap, DEV, runner=True)   # best + runner-up, as the pipeline launches it
     shapes = (
         ("bench", live, xyz, lambda: ops.l2_min_keys_counted(q16, qsq, cnt, xyz.bf16, xyz.sqnorm, k_all, 0),
          "the bench's launch: 54 401 live rows (device-resident count, grid sized for 100 352) x xyz library 76 518 (+26 pad) x 768, " + ("bf16" if xyz.bf16.dtype == torch.bfloat16 else "fp16") + " operands"),
@@ -58,7 +58,7 @@ def l2_rows():
          "every row searched (CMDIAD_DEDUP=0, the reference's cdist): 100 352 x 76 518 x 768"),
         ("w8", 8 * live, shard, lambda: ops.l2_min_keys_segments(q_seg, s_seg, seg_cnt, cap, shard.bf16, shard.sqnorm, k_seg, 0),
          "one rank of an 8-rank node (configs[3]): 8 segments x 54 401 live rows x its 9 600-row shard, one segments launch"),
-        ("rgb", B * 784, rgb, lambda: ops.l2_min_keys(q16[:B * 784], qsq[:B * 784], rgb.bf16, rgb.sqnorm, k_all[:B * 784], 0),
+        ("rgb", B * 784, rgb, lambda: ops.l2_min_keys(q16[:B * 784], qsq[:B * 784], rgb.bf16, rgb.sqnorm, k_all[:, :B * 784].contiguous(), 0),
          "rgb library: 25 088 x 19 129 (+71 pad) x 768"),
     )
     n_warm = 20     # ~0.2 s of back-to-back launches first: whatever a process measures first loses to the clocks settling (r4_notes 16)
