@@ -25,13 +25,20 @@ def _segments_case(counts, stride, Nb, D, dtype, seed):
     b16, _, bsq = ops.normalize_cast(bank, dtype=dtype)
     q16, _, qsq = ops.normalize_cast(q, dtype=dtype)
     cnt = torch.tensor(counts, dtype=torch.int32, device=DEV)
+    # single plane at an arbitrary row offset; best + runner-up planes at a multiple of 64 (the runner-up's groups of 16 rows)
     got = ops.l2_min_keys_segments(q16, qsq, cnt, stride, b16, bsq, ops.new_keys(W * stride, DEV), 7)
-    want = ops.new_keys(W * stride, DEV)
+    got2 = ops.l2_min_keys_segments(q16, qsq, cnt, stride, b16, bsq, ops.new_keys(W * stride, DEV, runner=True), 192)
+    want, want2 = ops.new_keys(W * stride, DEV), ops.new_keys(W * stride, DEV, runner=True)
     for w, n in enumerate(counts):
         n = max(0, min(n, stride))
         if n:
             lo = w * stride
             ops.l2_min_keys(q16[lo:lo + n].contiguous(), qsq[lo:lo + n].contiguous(), b16, bsq, want[lo:lo + n], 7)
+            part = ops.l2_min_keys(q16[lo:lo + n].contiguous(), qsq[lo:lo + n].contiguous(), b16, bsq, ops.new_keys(n, DEV, runner=True), 192)
+            want2[:, lo:lo + n] = part
+    assert torch.equal(got2, want2), "segments launch, best + runner-up planes"
+    live = got != eng.KEY_EMPTY
+    assert torch.equal(got2[0][live] - 185, got[live]) and bool((got2[:, ~live] == eng.KEY_EMPTY).all())   # same keys, rows shifted
     return got, want
 
 
@@ -83,28 +90,28 @@ def test_fake_world_full_size_sharded_search_equals_single_library(W, cls_rows):
     q_all = torch.cat([p.q16[:cap] for p in plans])
     s_all = torch.cat([p.q_sq[:cap] for p in plans])
     cnt = torch.tensor(counts, dtype=torch.int32, device=DEV)
-    merged = ops.new_keys(W * cap, DEV)
+    merged = ops.new_keys(W * cap, DEV, runner=True)             # best + runner-up planes (include/cmdiad_hip.h)
     covered = 0
     for r in range(W):
         bank = eng.Bank(full, r, W)
         assert bank.row_offset == covered and bank.bf16.shape[0] % 256 == 0
         covered += bank.shard_rows
-        keys = eng._HipSearch.search_segments(q_all, s_all, cnt, cap, bank, ops.new_keys(W * cap, DEV))
-        merged = torch.minimum(merged, keys)                                # the all_reduce(MIN) of the packed keys
+        keys = eng._HipSearch.search_segments(q_all, s_all, cnt, cap, bank, ops.new_keys(W * cap, DEV, runner=True))
+        merged = eng.merge_key_planes(merged, keys)                         # the two all_reduce(MIN) of engine.merge_shard_keys
         del bank, keys
     assert covered == cls_rows
     whole = eng.Bank(full, 0, 1)
     for w in range(W):
         p = plans[w]
-        ref_c = ops.l2_min_keys_counted(p.q16, p.q_sq, p.count, whole.bf16, whole.sqnorm, ops.new_keys(Q, DEV))
-        seg = merged[w * cap:w * cap + counts[w]]
-        assert torch.equal(seg, ref_c[:counts[w]]), f"rank {w}: sharded keys differ from the single-library keys"
-        assert bool((merged[w * cap + counts[w]:(w + 1) * cap] == eng.KEY_EMPTY).all())
-        out = ops.keys_expand(merged[w * cap:(w + 1) * cap].contiguous(), p.slot, torch.empty((Q,), dtype=torch.int64, device=DEV)) \
+        ref_c = ops.l2_min_keys_counted(p.q16, p.q_sq, p.count, whole.bf16, whole.sqnorm, ops.new_keys(Q, DEV, runner=True))
+        seg = merged[:, w * cap:w * cap + counts[w]]
+        assert torch.equal(seg, ref_c[:, :counts[w]]), f"rank {w}: sharded keys (best + runner-up) differ from the single-library keys"
+        assert bool((merged[:, w * cap + counts[w]:(w + 1) * cap] == eng.KEY_EMPTY).all())
+        out = ops.keys_expand(merged[:, w * cap:(w + 1) * cap].contiguous(), p.slot, torch.empty((2, Q), dtype=torch.int64, device=DEV)) \
             if cap == Q else None
         if out is not None:
             assert torch.equal(out, ops.keys_expand(ref_c, p.slot, torch.empty_like(out)))
-    idx = (merged[:counts[0]] & 0xFFFFFFFF)
+    idx = (merged[:, :counts[0]] & 0xFFFFFFFF)
     assert int(idx.max()) < cls_rows                                        # no key names a pad row
 
 
@@ -183,7 +190,7 @@ def test_sharded_search_object_world_of_one_rccl_sticky_cap_and_overflow():
             return ops.normalize_cast(q.to(DEV))
 
         def single(q16, qsq):
-            return ops.l2_min_keys(q16, qsq, bank.bf16, bank.sqnorm, ops.new_keys(Q, DEV))
+            return ops.l2_min_keys(q16, qsq, bank.bf16, bank.sqnorm, ops.new_keys(Q, DEV, runner=True))
 
         ss = eng.ShardedSearch(bank, td.group.WORLD, cap_rows="auto", slack=0.02)
         for i in range(3):
@@ -244,7 +251,7 @@ def test_fake_world_sharded_fp32_library_reweight_equals_single_library(W, rows)
     patch = patch.view(B, Q, D).to(DEV)
     whole = eng.Bank(lib.to(DEV))
     q16, _, qsq = ops.normalize_cast(patch.reshape(B * Q, D))
-    keys = ops.l2_min_keys(q16, qsq, whole.bf16, whole.sqnorm, ops.new_keys(B * Q, DEV))
+    keys = ops.l2_min_keys(q16, qsq, whole.bf16, whole.sqnorm, ops.new_keys(B * Q, DEV, runner=True))
     want = eng.score_patches_from_keys(patch, keys, whole, (28, 28))
     banks = [eng.Bank(lib.to(DEV), r, W, replicate_f32=False) for r in range(W)]
     assert sum(b.f32_rows for b in banks) == rows and all(b.f32_sharded for b in banks)

@@ -45,7 +45,7 @@ def main():
         return ops.normalize_cast(q.to(DEV))
 
     def single(q16, qsq):
-        return ops.l2_min_keys(q16, qsq, whole.bf16, whole.sqnorm, ops.new_keys(Q, DEV))
+        return ops.l2_min_keys(q16, qsq, whole.bf16, whole.sqnorm, ops.new_keys(Q, DEV, runner=True))     # best + runner-up planes
 
     ss = eng.ShardedSearch(shard, group, cap_rows="auto", slack=0.02)
     for i in range(3):
