@@ -614,7 +614,7 @@ def test_l2_runner_up_makes_the_argmin_exact(dt):
     one, two = (mi1 == ri).float().mean().item(), (mi == ri).float().mean().item()
     print(f"[argmin == fp32 brute force: winner only {one:.4f}, winner + runner-up {two:.5f}]")
     assert torch.equal(k2[0], k1), "the best plane is the single-plane search"
-    assert one < 0.97, "the planted near-ties must actually defeat the 16-bit search (else this test shows nothing)"
+    assert one < (0.97 if dt == torch.bfloat16 else 0.998), "the planted near-ties must actually defeat the 16-bit search (else this test shows nothing)"
     # >= 99.99 % identical rows; a different row is admissible only as a tie at fp32 resolution
     diff = mi != ri
     assert two >= 0.9995 and bool(((d[diff, mi[diff]] - rv[diff]) <= 2e-7 * rv[diff]).all()), (two, d[diff, mi[diff]] - rv[diff])
