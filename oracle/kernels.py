@@ -14,11 +14,17 @@ _SO = os.path.join(_HERE, "_build", "libcmdiad_oracle.so")
 _lib = None
 
 
+_SO_ASAN = os.path.join(_HERE, "_build", "libcmdiad_oracle_asan.so")
+
+
 def build(force=False):
+    """-> path of the shared object.  CMDIAD_ORACLE_SANITIZE=1: the AddressSanitizer + UBSan build (`make asan`); the python
+    process must then have been started with LD_PRELOAD=<gcc's libasan.so> (tests/test_sanitizers_cpu.py)."""
     src = os.path.join(_HERE, "cmdiad_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-s", "-C", _HERE], stdout=subprocess.DEVNULL)
-    return _SO
+    so, target = (_SO_ASAN, ["asan"]) if os.environ.get("CMDIAD_ORACLE_SANITIZE") == "1" else (_SO, [])
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE] + target, stdout=subprocess.DEVNULL)
+    return so
 
 
 def lib():
