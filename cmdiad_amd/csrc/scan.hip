@@ -443,8 +443,12 @@ extern "C" int cmdiad_reweight_scan(const float* probes, const float* bank, cons
 // the probes of both.  A call of cmdiad_reweight_scan costs ~45 us of prologue (probes into LDS), candidate merges and the second
 // launch on top of its stream time -- 42 us for the 59 MB rgb library of the bench (0.17 of the HBM rate) behind 68 us for the
 // 235 MB xyz library; as one pair the small library's fixed cost runs beside the large library's stream.  Results are those of two
-// separate calls, bit for bit (a workgroup's candidates do not depend on how many workgroups share the library: every row is
-// seen once, and the eight approximate candidates per probe are re-evaluated exactly either way).
+// separate calls -- every row is seen once and the eight approximate candidates per probe are re-evaluated exactly either way --
+// with ONE caveat: a lane keeps kLane = 4 approximate candidates per (probe, row residue) slot, and WHICH rows share a slot depends
+// on the number of workgroups a library gets (256 alone, its share of 256 in a pair).  If more than four of a probe's eight best
+// approximate rows fall into one slot (clusters of near-duplicate rows at a stride of 2 x slots), the candidate lists -- and in the
+// extreme the exact top-3 -- can differ between the pair and the single launch.  Both are valid answers of the same approximation;
+// the parity tests (bench-sized libraries, random and duplicated rows: tests/test_gpu_kernels.py, tools/fuzz_gpu.py) have not met a case.
 extern "C" size_t cmdiad_reweight_pair_workspace_bytes(int Nb0, int Nb1)
 {
     return cmdiad_reweight_workspace_bytes(kProbes, Nb0) + cmdiad_reweight_workspace_bytes(kProbes, Nb1);   // (upper bound: <= 256 workgroups each)

@@ -414,7 +414,8 @@ def score_patches_from_keys(patch32, keys, bank, dims, gt_size=224, group=None):
 def score_patches_from_keys_pair(patch_a, keys_a, bank_a, dims_a, patch_b, keys_b, bank_b, dims_b, gt_size=224, group=None):
     """score_patches_from_keys for the TWO libraries of a scored batch (multiple_features.py:976-1003: xyz and rgb / fusion) with
     their re-weighting scans as ONE launch pair (ops.reweight_scan_pair: the small library's fixed cost runs beside the large
-    library's stream); every output is what the two separate calls return, bit for bit.  Falls back to them when a library's fp32
+    library's stream); every output is what the two separate calls return (bit for bit, unless more than four of a probe's eight
+    best approximate rows share one lane slot of the scan: csrc/scan.hip, cmdiad_reweight_scan_pair).  Falls back to them when a library's fp32
     rows are sharded, a batch exceeds 32 samples, or the feature widths differ."""
     B, Qa, D = patch_a.shape
     if (getattr(bank_a, "f32_sharded", False) or getattr(bank_b, "f32_sharded", False) or B > 32 or patch_b.shape[0] != B

@@ -213,6 +213,11 @@ def gemm_streamk(A, W, bias, residual, out_f32=None):
                                   "done": None, "stream": None}
     ws = ent["ws"]
     cur = torch.cuda.current_stream(A.device)
+    # Not under stream capture: the cross-stream serialisation is an event recorded OUTSIDE the graph (waiting on it from inside a
+    # capture, or keeping one that was recorded inside, invalidates the capture or raises), and replays of a captured stream-K
+    # launch could overlap an eager one.  The plain tile kernel returns the same bits.
+    if torch.cuda.is_current_stream_capturing():
+        return gemm(A, W, bias=bias, residual=residual, out_f32=out_f32, want_f32=True, want_bf16=False)[0]
     if ent["done"] is not None and ent["stream"] != cur.cuda_stream:
         cur.wait_event(ent["done"])
     a = nat.GemmArgs(_p(A), K, _p(W), K, M, N, K, _p(bias), None, 1, ACT_NONE, _p(residual), N, _p(out_f32), N, None, 0, None, None, 1,
