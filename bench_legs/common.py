@@ -86,8 +86,14 @@ def run_steps(pred, batches, n, first=None):
         else:
             assert np.array_equal(s, first[j][0]) and np.array_equal(m, first[j][1]), f"batch {j}: steps disagree"
 
+    # Tickets outstanding on the host.  The predictor's pinned output ring has 3 slots, so the ticket of step i - 3 must have been
+    # consumed before step i is submitted -- not the one of step i - 2: with three outstanding the host queues step i while the
+    # tail of step i - 2 is still running (the predictor orders the reuse of its two buffer sets with events ON THE DEVICE), so
+    # neither the host's work on a finished batch (copy out of the ring, comparison with the first outputs: milliseconds) nor the
+    # H2D copy of the next batch ever sits between two steps.  CMDIAD_BENCH_DEPTH=2 is rounds 1-5's loop, for A/B runs.
+    depth = max(1, min(int(os.environ.get("CMDIAD_BENCH_DEPTH", "3")), len(pred.ring)))
     for i in range(n):
-        if len(pending) >= 2:  # pinned output ring of 3: the slot reused next must have been consumed
+        if len(pending) >= depth:
             take(*pending.pop(0))
         j = i % len(batches)
         pending.append((j, pred.submit(*batches[j])))

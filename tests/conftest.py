@@ -18,6 +18,10 @@ if os.environ.get("CMDIAD_TEST_AB") == "1" and os.path.exists(_AB):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "oracle_prefetch(*names): module-level zero-argument functions of the test's module that compute "
+                                       "its CPU-oracle reference; started on host threads as soon as the session's tests are collected")
+    config.addinivalue_line("markers", "rehearsal: a further whole-bench.py subprocess run beyond the two the default suite keeps; "
+                                       "runs only with CMDIAD_TEST_FULL=1")
     config.addinivalue_line("markers", "slow: a GPU test of a minute or more (a whole bench.py run); selected by -m gpu like the rest")
 
 
@@ -55,3 +59,60 @@ def pmap(fn, items, workers=4, total=None):
             return list(ex.map(fn, items))
     finally:
         torch.set_num_threads(before)
+
+
+# ---- CPU-oracle references in the background -----------------------------------------------------------------------------------
+# The GPU parity tests spend most of their wall-clock in the CPU oracle (oracle/pipeline.py: seconds per sample), one test after
+# the other, while the GPU box's 128 host threads idle during every other test.  A test marks the module-level functions that
+# compute its oracle side with @pytest.mark.oracle_prefetch("fn"); they start on a small host thread pool when collection ends
+# and the test picks the result up with prefetched(fn).  Nothing about the references changes: the same function, the same
+# arguments, computed once -- only earlier.  (Not selected / not started: prefetched() computes in line.)
+_PREFETCH = {}
+_PREFETCH_POOL = None
+
+
+def _prefetch_start(key, fn):
+    global _PREFETCH_POOL
+    if key in _PREFETCH:
+        return
+    if _PREFETCH_POOL is None:
+        import concurrent.futures as cf
+        _PREFETCH_POOL = cf.ThreadPoolExecutor(max_workers=int(os.environ.get("CMDIAD_TEST_PREFETCH_WORKERS", "2")))
+    _PREFETCH[key] = _PREFETCH_POOL.submit(fn)
+
+
+def prefetched(fn):
+    """Result of the zero-argument oracle function `fn` (computed in the background since collection, or now)."""
+    key = (fn.__module__, fn.__name__)
+    if key not in _PREFETCH:
+        import concurrent.futures as cf
+        fut = cf.Future()
+        _PREFETCH[key] = fut
+        try:
+            fut.set_result(fn())
+        except BaseException as e:      # noqa: BLE001 -- re-raised by result() in every test that asks
+            fut.set_exception(e)
+    return _PREFETCH[key].result()
+
+
+def pytest_collection_finish(session):
+    if os.environ.get("CMDIAD_TEST_PREFETCH", "1") == "0" or session.config.option.collectonly:
+        return
+    import torch
+    if torch.cuda.device_count() == 0:      # (counting devices does not initialise the GPU): the marked tests will not run here
+        return
+    for item in session.items:
+        m = item.get_closest_marker("oracle_prefetch")
+        if m is not None:
+            for name in m.args:
+                fn = getattr(item.module, name)
+                _prefetch_start((fn.__module__, fn.__name__), fn)
+
+
+def pytest_collection_modifyitems(config, items):
+    if os.environ.get("CMDIAD_TEST_FULL") == "1":
+        return
+    skip = pytest.mark.skip(reason="a further bench.py rehearsal: CMDIAD_TEST_FULL=1 runs it (the default suite keeps one default run and one --gpus 2 rehearsal)")
+    for item in items:
+        if item.get_closest_marker("rehearsal") is not None:
+            item.add_marker(skip)

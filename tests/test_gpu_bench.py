@@ -28,6 +28,7 @@ def _run(extra_env, *args):
     return json.loads(lines[0])
 
 
+@pytest.mark.rehearsal
 def test_bench_single_gpu_line():
     d = _run({}, "--no-extras")
     assert d["metric"].startswith("images/sec") and d["unit"] == "images/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
@@ -45,6 +46,13 @@ def test_bench_default_line_carries_the_secondary_legs():
     ride in the same JSON line; no leg carries an error."""
     d = _run({})
     assert not [k for k, v in d.items() if isinstance(v, dict) and ("error" in v or "skipped" in v)], d
+    # the headline contract (what test_bench_single_gpu_line checks on a --no-extras run)
+    assert d["metric"].startswith("images/sec") and d["unit"] == "images/s" and d["n_gpus"] == 1
+    assert d["value"] > 100 and abs(d["value"] - 32 / (d["ms_per_step"] * 1e-3)) < 0.01 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert 0.2 < r["frac"] < 1.0 and "traffic" in r and 0.1 < r["frac_in_pipeline"] <= r["frac"] * 1.05
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
     ms = d["mtfi_step"]
     assert ms["value"] > 100 and ms["ms_per_step"] > 0 and ms["query_rows"]["libraries"] == 2 and ms["hallucination_mlp"]["TFLOPs"] > 100
     t, ct = d["train_step"], d["conv_head_train_step"]
@@ -56,6 +64,7 @@ def test_bench_default_line_carries_the_secondary_legs():
 
 
 @slow
+@pytest.mark.rehearsal
 def test_bench_distributed_path_on_one_gpu():
     d = _run({"CMDIAD_FORCE_DIST": "1"})
     assert d["rccl_ranks"] == 1 and d["world"] == 1 and d["ranks"][0]["rank"] == 0 and "device" in d["ranks"][0]

@@ -37,9 +37,28 @@ def synth_sample(i, anomalous=False):
     return rgb, pc
 
 
+import functools  # noqa: E402
+
+from conftest import prefetched  # noqa: E402
+
+
+@functools.lru_cache(maxsize=None)
+def _weights():
+    return nets.synth_state_dict("vit", 31), nets.synth_state_dict("pointmae", 21)
+
+
 @pytest.fixture(scope="module")
 def weights():
-    return nets.synth_state_dict("vit", 31), nets.synth_state_dict("pointmae", 21)
+    return _weights()
+
+
+def oracle_fit():
+    """The CPU oracle's fit on the 4 train samples (no GPU call); started in the background at collection (conftest.prefetched)."""
+    sd_vit, sd_pm = _weights()
+    train = [synth_sample(i) for i in range(4)]
+    cpu = CpuDoubleRGBPoint(CpuExtractor(sd_vit, sd_pm))
+    cpu_feats = cpu.fit(train)
+    return cpu, cpu_feats, train
 
 
 @pytest.fixture(scope="module")
@@ -48,9 +67,7 @@ def fitted(weights):
     import warnings
     from cmdiad_amd.feature_extractors.multiple_features import DoubleRGBPointFeatures
     sd_vit, sd_pm = weights
-    train = [synth_sample(i) for i in range(4)]
-    cpu = CpuDoubleRGBPoint(CpuExtractor(sd_vit, sd_pm))
-    cpu_feats = cpu.fit(train)
+    cpu, cpu_feats, train = prefetched(oracle_fit)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         m = DoubleRGBPointFeatures(make_args())
@@ -68,6 +85,7 @@ def _rel(got, ref):
     return err.mean().item() / scale, err.max().item() / scale
 
 
+@pytest.mark.oracle_prefetch("oracle_fit")
 def test_fit_banks_and_statistics(fitted):
     cpu, cpu_feats, m, _ = fitted
     # F5 cross-wired scalar statistics

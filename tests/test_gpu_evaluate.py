@@ -19,7 +19,7 @@ from cmdiad_amd import evaluate as ev  # noqa: E402
 from cmdiad_amd.synth import SyntheticClass  # noqa: E402
 from cmdiad_amd.utils.au_pro_util import calculate_au_pro  # noqa: E402
 from oracle import nets, pipeline  # noqa: E402
-from conftest import pmap  # noqa: E402
+from conftest import pmap, prefetched  # noqa: E402
 
 
 def _oracle_class(cpu_ex, sd_h, data, lambdas, f_coreset, random_state):
@@ -47,6 +47,20 @@ def _oracle_class(cpu_ex, sd_h, data, lambdas, f_coreset, random_state):
                 picks=[cpu.main_coreset, cpu.fus_coreset])
 
 
+def oracle_class_loop():
+    """The CPU side of test_mtfi_class_loop_auroc_vs_oracle (no GPU call): weights, the two synthetic classes, the run's arguments
+    and the oracle's class loop over both classes."""
+    weights = (nets.synth_state_dict("vit", 31), nets.sharpen_pointmae(nets.synth_state_dict("pointmae", 21)),
+               nets.synth_state_dict("halluc", 51))
+    cpu_ex = pipeline.CpuExtractor(weights[0], weights[1])
+    data = {"bagel": SyntheticClass("bagel", 4, 20, index=0, severity=0.35), "rope": SyntheticClass("rope", 4, 20, index=8, severity=0.35)}
+    a = ev.mtfi_args(f_coreset=0.1, random_state=3)
+    lam = (a.xyz_s_lambda, a.xyz_smap_lambda, a.fusion_s_lambda, a.fusion_smap_lambda)
+    refs = dict(zip(data, pmap(lambda d: _oracle_class(cpu_ex, weights[2], d, lam, a.f_coreset, a.random_state), data.values(), 2, total=8)))
+    return weights, data, a, refs
+
+
+@pytest.mark.oracle_prefetch("oracle_class_loop")
 def test_mtfi_class_loop_auroc_vs_oracle(monkeypatch):
     """Two synthetic classes x (4 train, 20 test of which 6 anomalous) through cmdiad_amd.evaluate.evaluate_classes
     (drop-in RGBorXYZWithOneHallucination, main modality xyz, the whole five-call protocol on the GPU: memory bank, statistics,
@@ -64,14 +78,8 @@ def test_mtfi_class_loop_auroc_vs_oracle(monkeypatch):
     sample in tests/test_gpu_predictor.py) and swap: measured 3 pairs on bagel, 0 on rope -> 4e-2 (own picks: 5e-2).  A saturated
     metric agrees to 1e-2 and says nothing; this one moves when the scorer changes."""
     from cmdiad_amd.feature_extractors import multiple_features as mf
-    weights = (nets.synth_state_dict("vit", 31), nets.sharpen_pointmae(nets.synth_state_dict("pointmae", 21)),
-               nets.synth_state_dict("halluc", 51))
-    cpu_ex = pipeline.CpuExtractor(weights[0], weights[1])
-    data = {"bagel": SyntheticClass("bagel", 4, 20, index=0, severity=0.35), "rope": SyntheticClass("rope", 4, 20, index=8, severity=0.35)}
+    weights, data, a, refs = prefetched(oracle_class_loop)
     assert sum(int(l[0]) for _, _, l, _ in data["bagel"].test()) == 6
-    a = ev.mtfi_args(f_coreset=0.1, random_state=3)
-    lam = (a.xyz_s_lambda, a.xyz_smap_lambda, a.fusion_s_lambda, a.fusion_smap_lambda)
-    refs = dict(zip(data, pmap(lambda d: _oracle_class(cpu_ex, weights[2], d, lam, a.f_coreset, a.random_state), data.values(), 2, total=8)))
     queue = [pk for cls in ("bagel", "rope") for pk in refs[cls]["picks"]]      # run_coreset: main library, then fusion
     own = []
     inner = mf.RGBorXYZWithOneHallucination.get_coreset_idx_randomp
@@ -112,6 +120,15 @@ def test_mtfi_class_loop_auroc_vs_oracle(monkeypatch):
     # pass 2: nothing patched -- the drop-in selects its own coresets from its own bf16 features
     res_own = ev.evaluate_classes(a, data, weights=weights, log=print)
     check(res_own, 5e-2, 2e-2, 3e-2, "own coreset picks")
+    # pass 3: BASELINE configs[4] names fp16 -- the same loop with IEEE-half search operands (CMDIAD_SEARCH_DTYPE=fp16; the default
+    # is bf16 since round 5), the oracle's picks as in pass 1, the same tolerances
+    from cmdiad_amd import ops
+    own.clear()
+    with monkeypatch.context() as mp:
+        mp.setattr(ops, "SEARCH_DTYPE", torch.float16)
+        mp.setattr(mf.RGBorXYZWithOneHallucination, "get_coreset_idx_randomp", picker)
+        res_h = ev.evaluate_classes(a, data, weights=weights, log=print)
+    check(res_h, 4e-2, 1e-2, 2e-2, "fp16 search operands, oracle's coreset picks")
 
 
 def test_bench_evaluate_mode_through_rccl_world_of_one():

@@ -15,11 +15,14 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from cmdiad_amd import engine as eng  # noqa: E402
+from cmdiad_amd import ops  # noqa: E402
 from cmdiad_amd import runtime  # noqa: E402
 from cmdiad_amd.predictor import BatchPredictor  # noqa: E402
 from cmdiad_amd.synth import synth_cloud, synth_rgb  # noqa: E402
 from oracle import nets, pipeline  # noqa: E402
-from conftest import pmap  # noqa: E402
+import functools  # noqa: E402
+
+from conftest import pmap, prefetched  # noqa: E402
 
 DEV = "cuda"
 
@@ -50,15 +53,26 @@ def synth_sample(i, anomalous=False, frac=None):
     return rgb, pc, mask
 
 
-@pytest.fixture(scope="module")
-def weights():
+@functools.lru_cache(maxsize=None)
+def _weights():
     return (nets.synth_state_dict("vit", 31), nets.sharpen_pointmae(nets.synth_state_dict("pointmae", 21)),
             nets.synth_state_dict("halluc", 51))
 
 
+@functools.lru_cache(maxsize=None)
+def _cpu_ex():
+    w = _weights()
+    return pipeline.CpuExtractor(w[0], w[1])
+
+
 @pytest.fixture(scope="module")
-def cpu_ex(weights):
-    return pipeline.CpuExtractor(weights[0], weights[1])
+def weights():
+    return _weights()
+
+
+@pytest.fixture(scope="module")
+def cpu_ex():
+    return _cpu_ex()
 
 
 @pytest.fixture(scope="module")
@@ -99,11 +113,10 @@ def test_feature_error_is_far_below_the_patch_distances(weights, cpu_ex, gpu_eng
     assert err_x.mean() < 0.2 * nn_x.mean() and err_r.mean() < 0.05 * nn_r.mean()
 
 
-def test_predict_batch_b32_vs_oracle(weights, cpu_ex, gpu_engine, monkeypatch):
-    """B = 32 through BatchPredictor (HIP graphs, both buffer sets, and the eager path) against
-    oracle.pipeline.CpuDoubleRGBPoint.predict sample by sample: image score, blurred pixel map, and I-/P-AUROC over the 32
-    samples (10 anomalous)."""
-    cpu = pipeline.CpuDoubleRGBPoint(cpu_ex)
+def oracle_b32():
+    """The CPU side of test_predict_batch_b32_vs_oracle (no GPU call): oracle fit on 4 train samples, late-fusion models from 3
+    further normal samples, and the oracle's predict of the 32 test samples."""
+    cpu = pipeline.CpuDoubleRGBPoint(_cpu_ex())
     train = [synth_sample(100 + i)[:2] for i in range(4)]
     cpu.fit(train)
     # late-fusion models from the oracle's scores of 3 further normal samples (shared by both sides: only coef_/offset_ matter)
@@ -116,6 +129,16 @@ def test_predict_batch_b32_vs_oracle(weights, cpu_ex, gpu_engine, monkeypatch):
     ref = pmap(lambda smp: cpu.predict(smp[0], smp[1])[:2], samples, 8)       # the oracle, eight samples at a time on the host cores
     ref_img = np.array([float(det.score_samples(s.numpy())[0]) for s, _ in ref])
     ref_pix = np.stack([seg.score_samples(s_map.numpy()).reshape(224, 224) for _, s_map in ref])
+    return cpu, det, seg, samples, labels, ref_img, ref_pix
+
+
+@pytest.mark.oracle_prefetch("oracle_b32")
+def test_predict_batch_b32_vs_oracle(gpu_engine, monkeypatch):
+    """B = 32 through BatchPredictor (HIP graphs, both buffer sets, and the eager path) against
+    oracle.pipeline.CpuDoubleRGBPoint.predict sample by sample: image score, blurred pixel map, and I-/P-AUROC over the 32
+    samples (10 anomalous)."""
+    cpu, det, seg, samples, labels, ref_img, ref_pix = prefetched(oracle_b32)
+    B = len(samples)
 
     bank_xyz, bank_rgb = eng.Bank(cpu.xyz_lib.to(DEV)), eng.Bank(cpu.rgb_lib.to(DEV))
     stats = dict(xyz_mean=float(cpu.xyz_mean), xyz_std=float(cpu.xyz_std), rgb_mean=float(cpu.rgb_mean), rgb_std=float(cpu.rgb_std))
@@ -180,14 +203,10 @@ def test_predict_batch_b32_vs_oracle(weights, cpu_ex, gpu_engine, monkeypatch):
         assert np.abs(m1[0] - pix[b]).max() <= 2.5 * np.ptp(pix[b]) / 255.0 + 1e-9   # at most one 8-bit blur level per column
 
 
-def test_predict_batch_heavy_tailed_weights_vs_oracle():
-    """VERDICT round 4, item 4: test_predict_batch_b32_vs_oracle's protocol (fit, late-fusion models, batched predict against the
-    oracle sample by sample) on heavy-tailed weights -- oracle.nets.outlier_vit (three residual channels at ~100x from block 2 on,
-    one high-norm token) and outlier_pointmae (one 50x BatchNorm channel) on top of the sharpened Point-MAE -- at B = 8: the same
-    score / map bounds as on the O(1) weights."""
+def oracle_heavy_tailed():
+    """The CPU side of test_predict_batch_heavy_tailed_weights_vs_oracle (no GPU call)."""
     w_vit, w_pm = nets.outlier_vit(31), nets.sharpen_pointmae(nets.outlier_pointmae(21))
     cpu_ex = pipeline.CpuExtractor(w_vit, w_pm)
-    gpu_engine = eng.Engine(runtime.PackedViT(w_vit, device=DEV), runtime.PackedPointMAE(w_pm, device=DEV))
     cpu = pipeline.CpuDoubleRGBPoint(cpu_ex)
     cpu.fit(pmap(lambda i: synth_sample(100 + i)[:2], range(4), 1))
     rows = pmap(lambda i: cpu.predict(*synth_sample(200 + i)[:2])[:2], range(3), 3)
@@ -197,6 +216,18 @@ def test_predict_batch_heavy_tailed_weights_vs_oracle():
     ref = pmap(lambda smp: cpu.predict(smp[0], smp[1])[:2], samples, 8)
     ref_img = np.array([float(det.score_samples(s.numpy())[0]) for s, _ in ref])
     ref_pix = np.stack([seg.score_samples(s_map.numpy()).reshape(224, 224) for _, s_map in ref])
+    return w_vit, w_pm, cpu, det, seg, samples, ref_img, ref_pix
+
+
+@pytest.mark.oracle_prefetch("oracle_heavy_tailed")
+def test_predict_batch_heavy_tailed_weights_vs_oracle():
+    """VERDICT round 4, item 4: test_predict_batch_b32_vs_oracle's protocol (fit, late-fusion models, batched predict against the
+    oracle sample by sample) on heavy-tailed weights -- oracle.nets.outlier_vit (three residual channels at ~100x from block 2 on,
+    one high-norm token) and outlier_pointmae (one 50x BatchNorm channel) on top of the sharpened Point-MAE -- at B = 8: the same
+    score / map bounds as on the O(1) weights."""
+    w_vit, w_pm, cpu, det, seg, samples, ref_img, ref_pix = prefetched(oracle_heavy_tailed)
+    B = len(samples)
+    gpu_engine = eng.Engine(runtime.PackedViT(w_vit, device=DEV), runtime.PackedPointMAE(w_pm, device=DEV))
     bank_xyz, bank_rgb = eng.Bank(cpu.xyz_lib.to(DEV)), eng.Bank(cpu.rgb_lib.to(DEV))
     stats = dict(xyz_mean=float(cpu.xyz_mean), xyz_std=float(cpu.xyz_std), rgb_mean=float(cpu.rgb_mean), rgb_std=float(cpu.rgb_std))
     rgb = torch.cat([s[0] for s in samples]).to(DEV)
@@ -214,10 +245,9 @@ def test_predict_batch_heavy_tailed_weights_vs_oracle():
         assert np.corrcoef(pix[b].ravel(), ref_pix[b].ravel())[0, 1] > 0.995, b
 
 
-def test_mtfi_batch_vs_oracle(weights, cpu_ex, gpu_engine, monkeypatch):
-    """`--workload mtfi` (configs[4] per-GPU work): BatchPredictor with the hallucination network against
-    oracle.pipeline.CpuOneHallucination(main xyz).predict -- [xyz, hallucinated-rgb] columns, cross-wired statistics -- at
-    B = 24 (8 anomalous): image scores, pixel maps, and I-/P-AUROC over the batch."""
+def oracle_mtfi():
+    """The CPU oracle's side of the MTFI batch test (no GPU call), computed once for both operand types of the search."""
+    weights, cpu_ex = _weights(), _cpu_ex()
     cpu = pipeline.CpuOneHallucination(cpu_ex, weights[2], "xyz", lambdas=(1.0, 1.0, 1.0, 1.0))
     cpu.fit([synth_sample(100 + i)[:2] for i in range(4)])
     rows = [cpu.predict(*synth_sample(200 + i)[:2])[:2] for i in range(2)]
@@ -229,10 +259,24 @@ def test_mtfi_batch_vs_oracle(weights, cpu_ex, gpu_engine, monkeypatch):
     ref = pmap(lambda smp: cpu.predict(smp[0], smp[1])[:2], samples, 8)
     ref_img = np.array([float(det.score_samples(s.numpy())[0]) for s, _ in ref])
     ref_pix = np.stack([seg.score_samples(s_map.numpy()).reshape(224, 224) for _, s_map in ref])
+    return cpu, det, seg, samples, labels, ref_img, ref_pix
+
+
+@pytest.mark.oracle_prefetch("oracle_mtfi")
+@pytest.mark.parametrize("search_dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def test_mtfi_batch_vs_oracle(search_dtype, weights, gpu_engine, monkeypatch):
+    """`--workload mtfi` (configs[4] per-GPU work): BatchPredictor with the hallucination network against
+    oracle.pipeline.CpuOneHallucination(main xyz).predict -- [xyz, hallucinated-rgb] columns, cross-wired statistics -- at
+    B = 24 (8 anomalous): image scores, pixel maps, and I-/P-AUROC over the batch; on both operand types of the library search
+    (bf16: the default; fp16: what BASELINE configs[4] names, CMDIAD_SEARCH_DTYPE=fp16)."""
+    cpu, det, seg, samples, labels, ref_img, ref_pix = prefetched(oracle_mtfi)
+    B = len(samples)
+    monkeypatch.setattr(ops, "SEARCH_DTYPE", search_dtype)
     stats = dict(xyz_mean=float(cpu.mean), xyz_std=float(cpu.std), rgb_mean=float(cpu.mean), rgb_std=float(cpu.std))
     p = BatchPredictor(gpu_engine, eng.Bank(cpu.main_lib.to(DEV)), eng.Bank(cpu.fus_lib.to(DEV)), stats, det, seg,
                        lambdas=(1.0, 1.0, 1.0, 1.0), batch=B, workload="mtfi",
                        halluc=runtime.PackedHallucination(weights[2], device=DEV))
+    assert p.bank_xyz.bf16.dtype == search_dtype
     pcs = torch.cat([s[1] for s in samples]).to(DEV)
     img, pix = p.predict_batch(None, pcs)
     img2, pix2 = p.predict_batch(None, pcs)
@@ -249,7 +293,7 @@ def test_mtfi_batch_vs_oracle(weights, cpu_ex, gpu_engine, monkeypatch):
     assert np.array_equal(img_all, img) and np.array_equal(pix_all, pix)
     spread = float(ref_img.max() - ref_img.min())
     d_pix = np.abs(pix - ref_pix)
-    print(f"mtfi image score max |d| {np.abs(img - ref_img).max():.4f} of spread {spread:.4f}; pixel max |d| {d_pix.max():.5f} "
+    print(f"mtfi [{search_dtype}] image score max |d| {np.abs(img - ref_img).max():.4f} of spread {spread:.4f}; pixel max |d| {d_pix.max():.5f} "
           f"mean {d_pix.mean():.6f} of range {np.ptp(ref_pix):.4f}")
     # both columns inherit the bf16 xyz features (the hallucinated column through the distilled MLP as well)
     assert (np.abs(img - ref_img) / np.abs(ref_img)).max() <= 0.03 and np.abs(img - ref_img).mean() <= 0.08 * spread
@@ -258,7 +302,7 @@ def test_mtfi_batch_vs_oracle(weights, cpu_ex, gpu_engine, monkeypatch):
     i_got, i_ref = _auroc_pair(labels, img, ref_img)
     masks = np.stack([s[2].numpy().reshape(224, 224) for s in samples]).astype(int)
     p_got, p_ref = _auroc_pair(masks.ravel(), pix.ravel(), ref_pix.ravel())
-    print(f"mtfi I-AUROC {i_got:.4f} (oracle {i_ref:.4f}); P-AUROC {p_got:.4f} (oracle {p_ref:.4f})")
+    print(f"mtfi [{search_dtype}] I-AUROC {i_got:.4f} (oracle {i_ref:.4f}); P-AUROC {p_got:.4f} (oracle {p_ref:.4f})")
     assert abs(i_got - i_ref) <= 1e-2 and abs(p_got - p_ref) <= 1e-2
 
 

@@ -48,7 +48,8 @@ def _launch(nproc, script_args, extra_env, timeout=900):
 
 
 @pytest.mark.slow
-@pytest.mark.parametrize("world,bank", [(2, "replicated"), (2, "sharded"), (8, "sharded")])
+@pytest.mark.parametrize("world,bank", [pytest.param(2, "replicated", marks=pytest.mark.rehearsal), (2, "sharded"),
+                                        pytest.param(8, "sharded", marks=pytest.mark.rehearsal)])
 def test_bench_line_of_n_ranks_rehearsed_on_one_gpu(world, bank):
     """The driver's N > 1 command (`torch.distributed.run --nproc-per-node N bench.py --gpus N`) with every rank on device 0 and gloo
     in RCCL's place (CMDIAD_BENCH_ONE_DEVICE=1): the census, the max-over-ranks timing, every collective leg (sharded_search with its
