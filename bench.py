@@ -261,7 +261,11 @@ def main():
     legs = LegRunner(out, rank, store, emit_line)
     budget = float(os.environ.get("CMDIAD_BENCH_LEG_BUDGET", "0")) or None   # one budget for every leg (tests); default: per leg
 
+    only = [x for x in os.environ.get("CMDIAD_BENCH_LEGS", "").split(",") if x]   # A/B runs: only these secondary legs (default: all)
+
     def leg(name, fn, seconds, collective=False):
+        if only and name not in only and name != "teardown":
+            return None
         return legs.run(name, fn, budget or seconds, collective=collective)
 
     if not args.no_extras:
