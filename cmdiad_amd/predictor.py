@@ -116,8 +116,14 @@ class BatchPredictor:
         # CMDIAD_STREAM_PRIO="side,post" (A/B runs): stream priorities of the point-cloud branch and of the search / scoring stage
         # (0 = default, -1 = high; the ViT branch runs on the caller's stream)
         prio = [int(v) for v in os.environ.get("CMDIAD_STREAM_PRIO", "0,0").split(",")]
+        # The copy stream is a HIGH-priority stream: HIP multiplexes streams of one priority over a few hardware queues, and at the
+        # default priority the copy stream shared the main stream's -- the H2D copy of step i + 1 (issued under step i) then sat
+        # BEHIND step i's stage-1 graph in that queue and started only when it had finished, i.e. on the critical path (rocprofv3
+        # kernel + memory-copy trace, profiles/r6_notes.md: 0.7 ms of a 21.4 ms step, `h2d_inclusive` -4.5 %).  A priority of its
+        # own gives it its own queue.  CMDIAD_COPY_PRIO=0 restores the old mapping for A/B runs.
+        copy_prio = int(os.environ.get("CMDIAD_COPY_PRIO", "-1"))
         self.side, self.post, self.copy = (ops.shared_stream(dev, "predictor.side", prio[0]), ops.shared_stream(dev, "predictor.post", prio[1]),
-                                           ops.shared_stream(dev, "predictor.copy"))
+                                           ops.shared_stream(dev, "predictor.copy", copy_prio))
         # host ring: the step's FINAL outputs (image score, pixel map), f64 as sklearn's score_samples returns them
         self.ring = [(torch.empty((batch, 1), dtype=torch.float64, pin_memory=True),
                       torch.empty((batch, gt_size * gt_size), dtype=torch.float64, pin_memory=True)) for _ in range(ring)]
