@@ -96,7 +96,8 @@ def run_steps(pred, batches, n, first=None):
         if len(pending) >= depth:
             take(*pending.pop(0))
         j = i % len(batches)
-        pending.append((j, pred.submit(*batches[j])))
+        nxt = batches[(i + 1) % len(batches)] if i + 1 < n and os.environ.get("CMDIAD_BENCH_STAGE_NEXT", "1") != "0" else None
+        pending.append((j, pred.submit(*batches[j], next_batch=nxt)))    # the next batch's input copy is enqueued under this step
     for p in pending:
         take(*p)
     return first

@@ -116,12 +116,12 @@ class BatchPredictor:
         # CMDIAD_STREAM_PRIO="side,post" (A/B runs): stream priorities of the point-cloud branch and of the search / scoring stage
         # (0 = default, -1 = high; the ViT branch runs on the caller's stream)
         prio = [int(v) for v in os.environ.get("CMDIAD_STREAM_PRIO", "0,0").split(",")]
-        # The copy stream is a HIGH-priority stream: HIP multiplexes streams of one priority over a few hardware queues, and at the
-        # default priority the copy stream shared the main stream's -- the H2D copy of step i + 1 (issued under step i) then sat
-        # BEHIND step i's stage-1 graph in that queue and started only when it had finished, i.e. on the critical path (rocprofv3
-        # kernel + memory-copy trace, profiles/r6_notes.md: 0.7 ms of a 21.4 ms step, `h2d_inclusive` -4.5 %).  A priority of its
-        # own gives it its own queue.  CMDIAD_COPY_PRIO=0 restores the old mapping for A/B runs.
-        copy_prio = int(os.environ.get("CMDIAD_COPY_PRIO", "-1"))
+        # HIP multiplexes the streams over a few hardware queues, and the copy stream shares the main stream's: a copy is processed
+        # in the ORDER it was enqueued relative to the main stream's work (profiles/r6_notes.md, rocprofv3 kernel + memory-copy
+        # trace) -- which is why submit() enqueues the NEXT step's input copy before this step's stage-1 graph (`next_batch`).
+        # Giving the copy stream a priority (= a queue) of its own, or more hardware queues (GPU_MAX_HW_QUEUES=8), changes how ALL
+        # streams share the queues and costs 12-18 % of the step (measured, same notes): the default mapping stays.
+        copy_prio = int(os.environ.get("CMDIAD_COPY_PRIO", "0"))
         self.side, self.post, self.copy = (ops.shared_stream(dev, "predictor.side", prio[0]), ops.shared_stream(dev, "predictor.post", prio[1]),
                                            ops.shared_stream(dev, "predictor.copy", copy_prio))
         # host ring: the step's FINAL outputs (image score, pixel map), f64 as sklearn's score_samples returns them
@@ -159,7 +159,7 @@ class BatchPredictor:
         want_rgb = self.workload == "dino_pointmae"
         return dict(rgb=torch.zeros((self.B, 3, self.size, self.size), dtype=torch.float32, device=self.dev) if want_rgb else None,
                     pcs=torch.zeros((self.B, 3, self.size, self.size), dtype=torch.float32, device=self.dev),
-                    ready=None, free=None)
+                    ready=None, free=None, staged=None)
 
     # ---- stage 1: everything up to the 16-bit queries of both libraries
     def stage1(self, inp):
@@ -348,10 +348,10 @@ class BatchPredictor:
             except Exception:
                 pass
 
-    def _load_inputs(self, inp, rgb, pcs):
+    def _load_inputs(self, inp, rgb, pcs, wait=True):
         """Copies one batch into a set's static input buffers on the copy stream (H2D when the source is pinned host memory,
-        D2D when it is already resident); the compute stream waits for the copy, the copy waits until the previous user
-        of these buffers (stage 1 of two steps ago) has finished with them."""
+        D2D when it is already resident); the compute stream waits for the copy (wait=False: the caller does, later, on
+        inp["ready"]), the copy waits until the previous user of these buffers (stage 1 of two steps ago) has finished with them."""
         cur = torch.cuda.current_stream()
         if inp["free"] is not None:
             self.copy.wait_event(inp["free"])
@@ -366,12 +366,19 @@ class BatchPredictor:
         for t in (rgb, pcs):
             if t is not None and t.is_cuda:
                 t.record_stream(self.copy)
-        cur.wait_event(ev)
+        inp["ready"] = ev
+        inp["staged"] = (rgb, pcs)
+        if wait:
+            cur.wait_event(ev)
 
-    def submit(self, rgb, pcs):
+    def submit(self, rgb, pcs, next_batch=None):
         """rgb [B,3,S,S] f32 (None for 'mtfi'), pcs [B,3,S,S] f32 organised clouds; on the GPU or in (pinned) host memory.
         Returns a Ticket.  A ticket aliases one of the len(ring) pinned output slots until its wait() has copied the results
-        out: submitting into a slot whose ticket has not been waited for raises instead of overwriting that batch's results."""
+        out: submitting into a slot whose ticket has not been waited for raises instead of overwriting that batch's results.
+        next_batch = (rgb, pcs) of the FOLLOWING submit (optional, the very tensors it will pass): their copy into the other
+        buffer set is enqueued BEFORE this step's stage-1 graph, so it runs under this step instead of between the two steps --
+        the copy stream shares a hardware queue with the main stream and is served in enqueue order (features.py:127-128 start
+        from host tensors: this is what makes the PCIe-inclusive rate equal the resident one)."""
         if pcs.shape[0] != self.B:
             raise ValueError(f"batch of {pcs.shape[0]} given to a predictor built for {self.B}")
         if self._same_batch_check:
@@ -404,7 +411,16 @@ class BatchPredictor:
             which = self.step_no & 1
             st, inp = self.sets[which], self.inputs[which]
             self.step_no += 1
-            self._load_inputs(inp, rgb, pcs)
+            staged = inp.get("staged")
+            if not (staged is not None and staged[0] is rgb and staged[1] is pcs and inp.get("ready") is not None):
+                self._load_inputs(inp, rgb, pcs, wait=False)        # not staged by the previous submit: copy now
+            ready = inp["ready"]
+            inp["staged"] = inp["ready"] = None
+            if next_batch is not None:
+                # the other set's buffers were last read by stage 1 of the previous step (its `free` event is recorded): the copy
+                # waits for that on the device and is AHEAD of this step's graph in the queue
+                self._load_inputs(self.inputs[which ^ 1], next_batch[0], next_batch[1], wait=False)
+            cur.wait_event(ready)
             if st["done"] is not None:
                 cur.wait_event(st["done"])
             st["g1"].replay()
