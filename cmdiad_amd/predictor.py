@@ -416,9 +416,11 @@ class BatchPredictor:
                 self._load_inputs(inp, rgb, pcs, wait=False)        # not staged by the previous submit: copy now
             ready = inp["ready"]
             inp["staged"] = inp["ready"] = None
-            if next_batch is not None:
+            if next_batch is not None and not next_batch[1].is_cuda:
                 # the other set's buffers were last read by stage 1 of the previous step (its `free` event is recorded): the copy
-                # waits for that on the device and is AHEAD of this step's graph in the queue
+                # waits for that on the device and is AHEAD of this step's graph in the queue.  Host batches only: a resident
+                # batch's D2D copy takes 20 us at the step boundary, and moved under the step it cost 0-5 % of the step
+                # (three alternations, profiles/r6_notes.md: 21.3 / 22.3 / 22.5 ms against 21.3 ms every time)
                 self._load_inputs(self.inputs[which ^ 1], next_batch[0], next_batch[1], wait=False)
             cur.wait_event(ready)
             if st["done"] is not None:
