@@ -96,8 +96,9 @@ def run_steps(pred, batches, n, first=None):
         if len(pending) >= depth:
             take(*pending.pop(0))
         j = i % len(batches)
-        nxt = batches[(i + 1) % len(batches)] if i + 1 < n and os.environ.get("CMDIAD_BENCH_STAGE_NEXT", "1") != "0" else None
-        pending.append((j, pred.submit(*batches[j], next_batch=nxt)))    # the next batch's input copy is enqueued under this step
+        # host batches: the batch of the submit after the next is copied behind this step's tail (BatchPredictor.submit)
+        ahead = batches[(i + 2) % len(batches)] if i + 2 < n and os.environ.get("CMDIAD_BENCH_STAGE_AHEAD", "1") != "0" else None
+        pending.append((j, pred.submit(*batches[j], stage=ahead)))
     for p in pending:
         take(*p)
     return first

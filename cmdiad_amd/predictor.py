@@ -116,11 +116,11 @@ class BatchPredictor:
         # CMDIAD_STREAM_PRIO="side,post" (A/B runs): stream priorities of the point-cloud branch and of the search / scoring stage
         # (0 = default, -1 = high; the ViT branch runs on the caller's stream)
         prio = [int(v) for v in os.environ.get("CMDIAD_STREAM_PRIO", "0,0").split(",")]
-        # HIP multiplexes the streams over a few hardware queues, and the copy stream shares the main stream's: a copy is processed
-        # in the ORDER it was enqueued relative to the main stream's work (profiles/r6_notes.md, rocprofv3 kernel + memory-copy
-        # trace) -- which is why submit() enqueues the NEXT step's input copy before this step's stage-1 graph (`next_batch`).
-        # Giving the copy stream a priority (= a queue) of its own, or more hardware queues (GPU_MAX_HW_QUEUES=8), changes how ALL
-        # streams share the queues and costs 12-18 % of the step (measured, same notes): the default mapping stays.
+        # HIP multiplexes the streams over a few hardware queues, and the copy stream shares the main stream's: a copy there runs
+        # BETWEEN two steps, never under one (profiles/r6_notes.md, rocprofv3 kernel + memory-copy traces) -- which is why submit()
+        # can put a later batch's H2D copy on the post stream instead (`stage`).  Giving the copy stream a priority (= a queue)
+        # of its own, or more hardware queues (GPU_MAX_HW_QUEUES=8), changes how ALL streams share the queues and costs 12-18 %
+        # of the step (measured, same notes): the default mapping stays.
         copy_prio = int(os.environ.get("CMDIAD_COPY_PRIO", "0"))
         self.side, self.post, self.copy = (ops.shared_stream(dev, "predictor.side", prio[0]), ops.shared_stream(dev, "predictor.post", prio[1]),
                                            ops.shared_stream(dev, "predictor.copy", copy_prio))
@@ -371,14 +371,17 @@ class BatchPredictor:
         if wait:
             cur.wait_event(ev)
 
-    def submit(self, rgb, pcs, next_batch=None):
+    def submit(self, rgb, pcs, stage=None):
         """rgb [B,3,S,S] f32 (None for 'mtfi'), pcs [B,3,S,S] f32 organised clouds; on the GPU or in (pinned) host memory.
         Returns a Ticket.  A ticket aliases one of the len(ring) pinned output slots until its wait() has copied the results
         out: submitting into a slot whose ticket has not been waited for raises instead of overwriting that batch's results.
-        next_batch = (rgb, pcs) of the FOLLOWING submit (optional, the very tensors it will pass): their copy into the other
-        buffer set is enqueued BEFORE this step's stage-1 graph, so it runs under this step instead of between the two steps --
-        the copy stream shares a hardware queue with the main stream and is served in enqueue order (features.py:127-128 start
-        from host tensors: this is what makes the PCIe-inclusive rate equal the resident one)."""
+        stage = (rgb, pcs) of the submit AFTER THE NEXT (optional; host tensors, the very objects that submit will pass): their
+        H2D copy is enqueued on the post stream behind this step's search and scoring tail, into THIS step's input buffers (free
+        again: stage 1 has read them before the tail starts, and the step in between uses the other set).  The post stream has
+        ~10 ms of slack per step, so the copy costs nothing; on the copy stream it ran BETWEEN two steps whatever the order of
+        enqueueing, because that stream shares a hardware queue with the main stream and HIP serves a queue in order
+        (rocprofv3 kernel + memory-copy traces, profiles/r6_notes.md).  features.py:127-128 start from host tensors: this is what
+        brings the PCIe-inclusive rate to the resident one."""
         if pcs.shape[0] != self.B:
             raise ValueError(f"batch of {pcs.shape[0]} given to a predictor built for {self.B}")
         if self._same_batch_check:
@@ -413,15 +416,9 @@ class BatchPredictor:
             self.step_no += 1
             staged = inp.get("staged")
             if not (staged is not None and staged[0] is rgb and staged[1] is pcs and inp.get("ready") is not None):
-                self._load_inputs(inp, rgb, pcs, wait=False)        # not staged by the previous submit: copy now
+                self._load_inputs(inp, rgb, pcs, wait=False)        # not staged two submits ago: copy now, on the copy stream
             ready = inp["ready"]
             inp["staged"] = inp["ready"] = None
-            if next_batch is not None and not next_batch[1].is_cuda:
-                # the other set's buffers were last read by stage 1 of the previous step (its `free` event is recorded): the copy
-                # waits for that on the device and is AHEAD of this step's graph in the queue.  Host batches only: a resident
-                # batch's D2D copy takes 20 us at the step boundary, and moved under the step it cost 0-5 % of the step
-                # (three alternations, profiles/r6_notes.md: 21.3 / 22.3 / 22.5 ms against 21.3 ms every time)
-                self._load_inputs(self.inputs[which ^ 1], next_batch[0], next_batch[1], wait=False)
             cur.wait_event(ready)
             if st["done"] is not None:
                 cur.wait_event(st["done"])
@@ -456,6 +453,15 @@ class BatchPredictor:
                 flag = self._flag_to_host()
                 ev = torch.cuda.Event()
                 ev.record()
+                if stage is not None and not stage[1].is_cuda:
+                    # the batch of the submit after the next, into this step's input set, behind this step's tail (see the docstring).
+                    # Host batches only: a resident batch's D2D copy takes 20 us at the step boundary.
+                    if inp["rgb"] is not None:
+                        inp["rgb"].copy_(stage[0], non_blocking=True)
+                    inp["pcs"].copy_(stage[1], non_blocking=True)
+                    inp["ready"] = torch.cuda.Event()
+                    inp["ready"].record()
+                    inp["staged"] = stage
             st["done"] = ev
             return self._ticket(host_s, host_m, ev, flag, rgb, pcs)
         inp = self.inputs[0]
