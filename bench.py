@@ -64,6 +64,15 @@ from bench_legs.training import conv_head_train_leg, train_step_leg  # noqa: E40
 from bench_legs.workloads import mtfi_classes, mtfi_step_leg, var_n_leg  # noqa: E402
 
 
+def _traffic_with_ratio(t, bytes_alg):
+    """+ how many times the launch's algorithmic bytes (operands read once, keys written) crossed the fabric: the wasted-traffic
+    ratio of the decomposition (the library is re-streamed once per group of four query tiles; most of it is served by the L2 /
+    Infinity Cache side of the fabric counters, `l2_hit` in traffic_note)."""
+    if t.get("traffic"):
+        t["traffic_over_algorithmic"] = round(t["traffic"] / bytes_alg, 1)
+    return t
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -237,7 +246,7 @@ def main():
                          "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
                          "frac_in_pipeline": round(achieved_pipe / PEAK_BF16_TFLOPS, 4) if achieved_pipe else None,
-                         **profiled_traffic(),
+                         **_traffic_with_ratio(profiled_traffic(), bytes_alg),
                          "launch_ms": round(l2_ms, 3), "launch_ms_in_pipeline": round(l2_pipe_ms, 3),
                          "launch_ms_note": "launch_ms / frac: the step's launch repeated alone after the timed loop (HIP events, idle chip; median of ten) "
                                            "-- the regime of the stand-alone rocprofv3 row in profiles/r5_standalone.md; "

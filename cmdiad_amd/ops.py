@@ -43,12 +43,6 @@ def shared_stream(device, role, priority=0):
     key = (dev.index, role, int(priority))
     st = _SHARED_STREAMS.get(key)
     if st is None:
-        # CMDIAD_STREAM_PAD="role=n,role=n" (A/B runs): n streams are taken from torch's pool and dropped before this role's, which
-        # shifts the role onto another pool stream -- and so onto another of the few hardware queues HIP multiplexes streams over.
-        # Which streams share a queue moves the bench step by up to 18 % (profiles/r6_notes.md section 4).
-        pad = dict(kv.split("=") for kv in os.environ.get("CMDIAD_STREAM_PAD", "").split(",") if "=" in kv)
-        for _ in range(int(pad.get(role, 0))):
-            torch.cuda.Stream(dev, priority=int(priority))
         st = _SHARED_STREAMS[key] = torch.cuda.Stream(dev, priority=int(priority))
     return st
 
