@@ -172,6 +172,48 @@ def test_pipeline_repeats_a_step_whose_live_rows_exceed_the_sticky_cap():
         td.destroy_process_group()
 
 
+def test_host_batches_staged_two_submits_ahead_change_nothing():
+    """BatchPredictor.submit(stage=): a pinned host batch copied on the post stream behind the tail of the step two submits earlier
+    (what brings bench.py's `h2d_inclusive` towards the resident rate, profiles/r6_notes.md section 4) gives the outputs of the
+    plain submits, bit for bit -- with three tickets outstanding as bench.run_steps keeps them; a staged batch that is NOT the one
+    submitted later (the caller changed its mind) is simply copied again; resident batches ignore the hint."""
+    import importlib.util
+    import os
+    from cmdiad_amd.predictor import BatchPredictor
+    from cmdiad_amd.synth import synth_cloud, synth_rgb
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    st = bench.build_state(torch.device("cuda", 0))
+    B, n_max = 4, 34000
+    host = [(torch.cat([synth_rgb(900 + 10 * k + i) for i in range(B)]).pin_memory(),
+             torch.cat([synth_cloud(900 + 10 * k + i, 0.36 + 0.03 * k) for i in range(B)]).pin_memory()) for k in range(5)]
+    mk = lambda: BatchPredictor(st["engine"], st["bank_xyz"], st["bank_second"], st["stats"], st["det"], st["seg"], batch=B, n_max=n_max)   # noqa: E731
+    plain = mk()
+    want = [plain.predict_batch(*b) for b in host]
+    order = [0, 1, 2, 3, 4, 0, 2, 1]
+
+    def run(pred, hint):
+        pending, got = [], []
+        for n, k in enumerate(order):
+            if len(pending) == 3:
+                got.append(pending.pop(0).wait())
+            pending.append(pred.submit(*host[k], stage=hint(n)))
+        return got + [t.wait() for t in pending]
+
+    right = lambda n: host[order[n + 2]] if n + 2 < len(order) else None      # noqa: E731  the batch submitted two submits later
+    wrong = lambda n: host[(order[n] + 3) % 5]                                   # noqa: E731  some OTHER batch: must be ignored
+    for name, hint in (("staged", right), ("wrongly staged", wrong), ("no hint", lambda n: None)):
+        got = run(mk(), hint)
+        for (gs, gm), k in zip(got, order):
+            assert np.array_equal(gs, want[k][0]) and np.array_equal(gm, want[k][1]), (name, k)
+    dev = [(r.to(DEV), p.to(DEV)) for r, p in host]
+    pred = mk()
+    got = [pred.submit(*dev[k], stage=dev[(k + 2) % 5]).wait() for k in range(5)]
+    for (gs, gm), k in zip(got, range(5)):
+        assert np.array_equal(gs, want[k][0]) and np.array_equal(gm, want[k][1]), ("resident", k)
+
+
 def test_sharded_search_object_world_of_one_rccl_sticky_cap_and_overflow():
     """engine.ShardedSearch through RCCL with a world of one rank: the sticky cap ("auto") reads the counts on the host once,
     a later batch with MORE live rows than the cap raises the device flag, regrow() + the repeated step is exact again."""
