@@ -279,8 +279,8 @@ def score_patches(patch32, bank, dims, gt_size=224, group=None):
     Returns dict(min_val [B,Q], min_idx [B,Q] int64, s_idx [B], s_star [B], s [B], s_map_pre [B,gt,gt], ...).
 
     With `group` (torch.distributed over RCCL) the search is row-sharded: all-gather of the bf16 queries,
-    per-shard distance GEMM, ONE integer-MIN all-reduce of the packed keys; the exact fp32 re-score and
-    the re-weighting use the replicated fp32 library, so no further collectives are needed."""
+    per-shard distance GEMM, integer-MIN all-reduces of the packed keys (best plane, then runner-up plane); the exact fp32
+    decision between the two candidates and the re-weighting use the replicated fp32 library, so no further collectives are needed."""
     B, Q, D = patch32.shape
     dev = patch32.device
     flat = patch32.reshape(B * Q, D)
