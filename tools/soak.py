@@ -25,7 +25,11 @@ dev = torch.device("cuda", 0)
 st = bench.build_state(dev, workload)
 pred = BatchPredictor(st["engine"], st["bank_xyz"], st["bank_second"], st["stats"], st["det"], st["seg"], batch=bench.BATCH,
                       n_max=bench.N_POINTS, workload=workload, halluc=st["halluc"])
-batches = [(r.to(dev) if r is not None else None, p.to(dev)) for r, p in bench.make_batches(0, workload)]
+host_fed = len(sys.argv) > 3 and sys.argv[3] == "host"      # pinned host batches: H2D inside the loop, staged two submits ahead
+if host_fed:
+    batches = bench.make_batches(0, workload, pinned=True)
+else:
+    batches = [(r.to(dev) if r is not None else None, p.to(dev)) for r, p in bench.make_batches(0, workload)]
 first = bench.run_steps(pred, batches, 8)
 torch.cuda.synchronize()
 mem0, rss0 = torch.cuda.memory_allocated(), resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
@@ -38,4 +42,4 @@ while done < steps:
     print(f"{workload}: {done} steps, {1e3 * (time.time() - t0) / done:.2f} ms/step, device memory {torch.cuda.memory_allocated() - mem0:+d} B, "
           f"reserved {torch.cuda.memory_reserved() >> 20} MiB, host peak RSS {resource.getrusage(resource.RUSAGE_SELF).ru_maxrss - rss0:+d} KiB", flush=True)
 assert torch.cuda.memory_allocated() - mem0 < (64 << 20), "device memory grew during the soak"
-print("soak ok", workload, steps, flush=True)
+print("soak ok", workload, "host-fed" if host_fed else "resident", steps, flush=True)
