@@ -281,7 +281,7 @@ def main():
         n_h2d = max(8, min(args.steps, 12))
 
         # (with the row-sharded pipeline -- --bank sharded -- the H2D-fed steps are collective steps too)
-        leg("h2d_inclusive", lambda: h2d_leg(pred, host_batches, n_h2d, first), 120, collective=sharded)
+        leg("h2d_inclusive", lambda: h2d_leg(pred, host_batches, 2 * n_h2d, first), 120, collective=sharded)   # (its first two steps are not staged ahead)
         if group is None and pred.dedup:
             leg("every_row_searched", lambda: every_row_leg(st, pred, batches, n_h2d, first, args.workload), 180)
         if group is not None:
