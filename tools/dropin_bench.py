@@ -57,4 +57,4 @@ def main(n=40, warm=5):
 
 
 if __name__ == "__main__":
-    main()
+    main(*(int(x) for x in sys.argv[1:3]))      # [images] [warm-up images]; CMDIAD_PREDICT_BATCH selects the micro-batch size
