@@ -45,6 +45,7 @@ P, I, F, SZ, U32, D = c_void_p, c_int, c_float, c_size_t, c_uint32, c_double
 SIGNATURES = {
     "cmdiad_fps": [P, P, I, I, I, P, P, P, SZ, P],
     "cmdiad_knn_group": [P, P, P, I, I, I, I, P, P, P],
+    "cmdiad_knn_group_ws": [P, P, P, I, I, I, I, P, P, P, SZ, P],
     "cmdiad_unorganize": [P, I, I, I, P, P, P, P, P],
     "cmdiad_interp3nn": [P, P, P, I, I, I, P, P, P],
     "cmdiad_interp_gather": [P, P, P, P, I, I, I, I, P, P],
@@ -128,6 +129,7 @@ SIZE_QUERIES = {
     "cmdiad_blur8_lds_bytes": [I, I],
     "cmdiad_ocsvm_fit_workspace_bytes": [I, I],
     "cmdiad_rows_dedup_workspace_bytes": [I],
+    "cmdiad_knn_workspace_bytes": [I, I],
     "cmdiad_transformer_block_workspace_bytes": [I, I, I],
 }
 

@@ -44,6 +44,9 @@ constexpr unsigned long long kInf = ~0ull;
 // ascending order are those of the oracle bit for bit, whatever the visiting order.
 // ------------------------------------------------------------------------------------------------
 constexpr int kStepPts = 128;     // points per streaming step (two per lane)
+#ifndef CMDIAD_KNN_TRIG
+#define CMDIAD_KNN_TRIG 112       // candidates waiting for a prune (see knn_wave_kernel)
+#endif
 #ifdef CMDIAD_KNN_SCALAR
 constexpr bool kKnnScalar = true;    // timing-only build: one centre per arithmetic instruction (the form before round 4)
 #else
@@ -166,9 +169,6 @@ __global__ __launch_bounds__(kWaves * 64) void knn_wave_kernel(const float* __re
     // 64 entries: late in the stream, where a half step adds a few candidates, every prune then sorted ~65 keys in a 128-key
     // network, 12 prunes per centre instead of 9; the prunes are two thirds of this kernel.)  Measured, 32 x 24 576 points, same
     // box: 128 slots 0.795 ms; kTrig 80 / 96 / 112 / 128: 0.705 / 0.668 / 0.638 / 0.639 (the LDS of 128 costs a wave per SIMD).
-#ifndef CMDIAD_KNN_TRIG
-#define CMDIAD_KNN_TRIG 112
-#endif
     constexpr int kTrig = CMDIAD_KNN_TRIG, kCandCap = kTrig + 64;
     __shared__ unsigned long long s_cand[kWaves][kWaveCentres][kCandCap];
     const int b = blockIdx.y;
@@ -303,6 +303,234 @@ __global__ __launch_bounds__(kWaves * 64) void knn_wave_kernel(const float* __re
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Third formulation (round 6): the same selection on the points of a NEIGHBOURHOOD instead of the whole cloud -- exact.
+// The streaming kernel above evaluates every centre against every point (1 024 x 24 576 per cloud) although the 128 nearest
+// points of a centre are 0.5 % of an MVTec-3D cloud.  Here a cloud is first binned (knn_grid_build_kernel, one workgroup per
+// cloud): the bounding box, the TWO axes of largest extent (a depth-camera cloud is a 2.5-D sheet), a 64 x 64 grid of square
+// cells on them, a counting sort of the points by cell (x, y, z and the ORIGINAL index as 16 bytes; cells row-major, so a run
+// of cells of one grid row is one contiguous run of points).  A wave then owns ONE centre (knn_grid_query_kernel) and scans the
+// square rings of cells around it, innermost first, through the wave-level selection of the streaming kernel (same keys
+// (d2 bits << 32 | original index), same d2 = (dx*dx + dy*dy) + dz*dz single roundings, same sorted-128 state and prune):
+//   * every point NOT in a scanned cell differs from the centre by more than m cells along a grid axis (m = the scanned ring
+//     radius), i.e. lies farther than m * h -- so once the K-th best squared distance is below ((m - 0.01) h)^2 the K best
+//     of the scanned points are the K best of the cloud (0.01 cells of slack against the roundings of the cell index: 64 *
+//     2^-23 = 8e-6 cells);
+//   * otherwise the next radius is the one the current K-th best asks for (floor(sqrt(d2_K) / h) + 2), or twice the radius
+//     while fewer than K points have been met; radius 64 is the whole cloud.
+// Typically two rounds (radius 2, then 4): ~500 distance evaluations and 3-4 prunes per centre instead of 24 576 and 9.
+// The selected set and its order are those of the streaming kernel and of the oracle bit for bit: keys are unique, and the
+// final state is the K smallest keys of the cloud whatever the visiting order.
+// ------------------------------------------------------------------------------------------------
+constexpr int kGridSide = 64, kGridCells = kGridSide * kGridSide;
+constexpr int kGridHdr = 8;   // floats per cloud: min on axis A, min on axis B, 1 / h, h, axis A, axis B, n, unused
+
+__device__ __forceinline__ int grid_coord(float a, float mn, float inv_h)
+{
+    return (int)fminf(fmaxf((a - mn) * inv_h, 0.0f), (float)(kGridSide - 1));   // (NaN -> 0; monotone in a)
+}
+
+__device__ __forceinline__ float pick3(float x, float y, float z, int axis) { return axis == 0 ? x : (axis == 1 ? y : z); }
+
+__global__ __launch_bounds__(1024) void knn_grid_build_kernel(const float* __restrict__ xyz, const int32_t* __restrict__ n_valid, int N,
+                                                              float4* __restrict__ sorted, int* __restrict__ cell_start,
+                                                              float* __restrict__ hdr)
+{
+    __shared__ int s_cnt[kGridCells];
+    __shared__ float s_red[16][6];
+    __shared__ int s_wave[16];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = n_valid ? min(n_valid[b], N) : N;
+    const float* p = xyz + (size_t)b * N * 3;
+    float mn[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, mx[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    for (int k = tid; k < n; k += 1024) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float v = p[k * 3 + a];
+            mn[a] = fminf(mn[a], v);
+            mx[a] = fmaxf(mx[a], v);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            mn[a] = fminf(mn[a], __shfl_xor(mn[a], m, 64));
+            mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], m, 64));
+        }
+        if (lane == 0) { s_red[wave][a] = mn[a]; s_red[wave][3 + a] = mx[a]; }
+    }
+    for (int c = tid; c < kGridCells; c += 1024) s_cnt[c] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        mn[a] = s_red[0][a]; mx[a] = s_red[0][3 + a];
+        for (int w = 1; w < 16; ++w) { mn[a] = fminf(mn[a], s_red[w][a]); mx[a] = fmaxf(mx[a], s_red[w][3 + a]); }
+    }
+    // the two axes of largest extent (ties: the lower axis); h = the larger extent / 64
+    const float e0 = mx[0] - mn[0], e1 = mx[1] - mn[1], e2 = mx[2] - mn[2];
+    int A, Bx;
+    if (e0 >= e1 && e0 >= e2) { A = 0; Bx = e1 >= e2 ? 1 : 2; }
+    else if (e1 >= e2) { A = 1; Bx = e0 >= e2 ? 0 : 2; }
+    else { A = 2; Bx = e0 >= e1 ? 0 : 1; }
+    if (A > Bx) { const int t = A; A = Bx; Bx = t; }
+    const float ext = fmaxf(pick3(e0, e1, e2, A), pick3(e0, e1, e2, Bx));
+    const float h = ext > 0.0f && ext < __builtin_inff() ? ext * (1.0f / kGridSide) : 0.0f;
+    const float inv_h = h > 0.0f ? 1.0f / h : 0.0f;
+    const float mnA = pick3(mn[0], mn[1], mn[2], A), mnB = pick3(mn[0], mn[1], mn[2], Bx);
+    for (int k = tid; k < n; k += 1024) {
+        const float x = p[k * 3], y = p[k * 3 + 1], z = p[k * 3 + 2];
+        atomicAdd(&s_cnt[grid_coord(pick3(x, y, z, Bx), mnB, inv_h) * kGridSide + grid_coord(pick3(x, y, z, A), mnA, inv_h)], 1);
+    }
+    __syncthreads();
+    // exclusive scan of the 4 096 counts: four cells per thread, wave scan, 16 wave totals
+    int c4[4], sum = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { c4[i] = s_cnt[tid * 4 + i]; sum += c4[i]; }
+    int incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += s_wave[w];
+    int run = base + incl - sum;
+    int* cs = cell_start + (size_t)b * (kGridCells + 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        cs[tid * 4 + i] = run;
+        s_cnt[tid * 4 + i] = run;     // now the cell's write cursor
+        run += c4[i];
+    }
+    if (tid == 1023) cs[kGridCells] = run;
+    if (tid == 0) {
+        float* hd = hdr + (size_t)b * kGridHdr;
+        hd[0] = mnA; hd[1] = mnB; hd[2] = inv_h; hd[3] = h; hd[4] = (float)A; hd[5] = (float)Bx; hd[6] = (float)n; hd[7] = 0.0f;
+    }
+    __syncthreads();
+    float4* out = sorted + (size_t)b * N;
+    for (int k = tid; k < n; k += 1024) {
+        const float x = p[k * 3], y = p[k * 3 + 1], z = p[k * 3 + 2];
+        const int cell = grid_coord(pick3(x, y, z, Bx), mnB, inv_h) * kGridSide + grid_coord(pick3(x, y, z, A), mnA, inv_h);
+        const int pos = atomicAdd(&s_cnt[cell], 1);
+        out[pos] = float4{x, y, z, __int_as_float(k)};
+    }
+}
+
+template <int kWaves>
+__global__ __launch_bounds__(kWaves * 64) void knn_grid_query_kernel(const float* __restrict__ xyz, const int32_t* __restrict__ n_valid,
+                                                                    const float* __restrict__ center, const float4* __restrict__ sorted,
+                                                                    const int* __restrict__ cell_start, const float* __restrict__ hdr,
+                                                                    int N, int G, int K, int64_t* __restrict__ idx_out,
+                                                                    float* __restrict__ neigh_out)
+{
+    constexpr int kTrig = CMDIAD_KNN_TRIG, kCandCap = kTrig + 64;
+    __shared__ unsigned long long s_cand[kWaves][kCandCap];
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = blockIdx.x * kWaves + wave;
+    if (g >= G) return;
+    const float* p = xyz + (size_t)b * N * 3;
+    const float4* sp = sorted + (size_t)b * N;
+    const int* cs = cell_start + (size_t)b * (kGridCells + 1);
+    const float* hd = hdr + (size_t)b * kGridHdr;
+    const float mnA = hd[0], mnB = hd[1], inv_h = hd[2], h = hd[3];
+    const int A = (int)hd[4], Bx = (int)hd[5];
+    const float* cc = center + ((size_t)b * G + g) * 3;
+    const float cx = cc[0], cy = cc[1], cz = cc[2];
+    const int ia = __builtin_amdgcn_readfirstlane(grid_coord(pick3(cx, cy, cz, A), mnA, inv_h));
+    const int ib = __builtin_amdgcn_readfirstlane(grid_coord(pick3(cx, cy, cz, Bx), mnB, inv_h));
+
+    unsigned long long ta = kInf, tb = kInf, tau = kInf;
+    int cnt = 0;
+    unsigned long long* buf = s_cand[wave];
+    auto prune = [&]() {
+        const int take = min(cnt, 128), rest = cnt - take;   // rest <= 63
+        unsigned long long ca = lane < take ? buf[lane] : kInf;
+        unsigned long long cb = lane + 64 < take ? buf[lane + 64] : kInf;
+        sort128(ca, cb, lane);
+        merge128(ta, tb, ca, cb, lane);
+        const unsigned long long kth = K <= 64 ? ta : tb;
+        tau = shfl_u64(kth, (K - 1) & 63);
+        tau = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(tau >> 32)) << 32) | __builtin_amdgcn_readfirstlane((unsigned)tau);
+        cnt = 0;
+        if (rest > 0) {  // wave-uniform
+            const unsigned long long k2 = lane < rest ? buf[128 + lane] : kInf;
+            const bool keep = lane < rest && k2 < tau;
+            const unsigned long long mk = __ballot(keep);
+            if (keep) buf[__popcll(mk & ((1ull << lane) - 1ull))] = k2;
+            cnt = __popcll(mk);
+        }
+    };
+    // the points of the sorted array in [s, e): one contiguous run of cells of one grid row
+    auto scan = [&](int s, int e) {
+        for (int k0 = s; k0 < e; k0 += 64) {
+            const int k = k0 + lane;
+            const bool inb = k < e;
+            const float4 q = sp[min(k, e - 1)];
+            const float dx = q.x - cx, dy = q.y - cy, dz = q.z - cz;
+            const float d2 = (dx * dx + dy * dy) + dz * dz;
+            const unsigned long long key = pack_key(d2, (unsigned)__float_as_int(q.w));
+            const bool pass = inb && key < tau;
+            const unsigned long long m = __ballot(pass);
+            if (m) {  // wave-uniform
+                if (pass) buf[cnt + __popcll(m & ((1ull << lane) - 1ull))] = key;
+                cnt += __popcll(m);
+                if (cnt >= kTrig) prune();
+            }
+        }
+    };
+    auto row_run = [&](int j, int lo, int hi) {   // cells [lo, hi] of grid row j (already clipped, lo <= hi)
+        const int s = __builtin_amdgcn_readfirstlane(cs[j * kGridSide + lo]);
+        const int e = __builtin_amdgcn_readfirstlane(cs[j * kGridSide + hi + 1]);
+        if (e > s) scan(s, e);
+    };
+    int m_done = -1;          // rings 0 .. m_done have been scanned
+    int m = h > 0.0f ? 2 : kGridSide;   // (a degenerate grid -- all points in one cell -- is scanned whole)
+    for (;;) {
+        m = min(m, kGridSide);
+        for (int dj = -m; dj <= m; ++dj) {
+            const int j = ib + dj;
+            if (j < 0 || j >= kGridSide) continue;
+            const int lo = max(ia - m, 0), hi = min(ia + m, kGridSide - 1);
+            if (dj < -m_done || dj > m_done || m_done < 0) {
+                row_run(j, lo, hi);                       // a row outside the scanned square: all of it
+            } else {                                       // a row that crosses the scanned square: the two ends
+                if (ia - m_done - 1 >= lo) row_run(j, lo, ia - m_done - 1);
+                if (ia + m_done + 1 <= hi) row_run(j, ia + m_done + 1, hi);
+            }
+        }
+        if (cnt > 0) prune();
+        m_done = m;
+        if (m >= kGridSide) break;
+        const unsigned tau_bits = (unsigned)(tau >> 32);
+        if (tau != kInf && tau_bits < 0x7F800000u) {       // K points met, with a finite K-th distance
+            const float d2k = __uint_as_float(tau_bits);
+            const float r = ((float)m - 0.01f) * h;
+            if (d2k < r * r) break;                        // certified: nothing outside the scanned square can be nearer
+            m = max(m + 1, (int)(sqrtf(d2k) * inv_h) + 2);
+        } else m *= 2;
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int k = r * 64 + lane;
+        if (k >= K) continue;
+        const unsigned long long key = r == 0 ? ta : tb;
+        const int i = key == kInf ? 0 : (int)(key & 0xFFFFFFFFull);
+        const size_t o = ((size_t)b * G + g) * K + k;
+        if (idx_out) idx_out[o] = i;
+        if (neigh_out) {
+            neigh_out[o * 3 + 0] = p[i * 3 + 0] - cx;
+            neigh_out[o * 3 + 1] = p[i * 3 + 1] - cy;
+            neigh_out[o * 3 + 2] = p[i * 3 + 2] - cz;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int cmdiad_knn_group(const float* xyz, const int32_t* n_valid, const float* center, int B, int N,
@@ -339,6 +567,34 @@ extern "C" int cmdiad_knn_group(const float* xyz, const int32_t* n_valid, const 
                            K, idx_out, neigh_out);
     }
 #endif
+    CMDIAD_CHECK_LAUNCH();
+    return CMDIAD_OK;
+}
+
+// The same grouping through the neighbourhood search (knn_grid_*_kernel): needs a workspace for the binned cloud.  Falls back to
+// the streaming kernel for small clouds (binning does not pay) and when CMDIAD_KNN_GRID=0 (A/B runs, parity tests; read per call).
+extern "C" size_t cmdiad_knn_workspace_bytes(int B, int N)
+{
+    if (B <= 0 || N <= 0) return 0;
+    return (size_t)B * ((size_t)N * sizeof(float4) + (size_t)(kGridCells + 1) * sizeof(int) + (size_t)kGridHdr * sizeof(float)) + 64;
+}
+
+extern "C" int cmdiad_knn_group_ws(const float* xyz, const int32_t* n_valid, const float* center, int B, int N, int G, int K,
+                                   int64_t* idx_out, float* neigh_out, void* workspace, size_t workspace_bytes, cmdiad_stream_t stream)
+{
+    const char* e = getenv("CMDIAD_KNN_GRID");
+    const bool grid = !(e && e[0] == '0') && N >= 2048 && G > 0 && B > 0 && K > 0 && K <= 128 && K <= N;
+    if (!grid) return cmdiad_knn_group(xyz, n_valid, center, B, N, G, K, idx_out, neigh_out, stream);
+    CMDIAD_REQUIRE(xyz && center, CMDIAD_ERR_ARG, "cmdiad_knn_group_ws: null pointer");
+    CMDIAD_REQUIRE(workspace && workspace_bytes >= cmdiad_knn_workspace_bytes(B, N) && ((uintptr_t)workspace & 15) == 0, CMDIAD_ERR_WORKSPACE,
+                   "cmdiad_knn_group_ws: workspace too small or not 16-byte aligned");
+    float4* sorted = (float4*)workspace;
+    int* cell_start = (int*)(sorted + (size_t)B * N);
+    float* hdr = (float*)(cell_start + (size_t)B * (kGridCells + 1));
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(knn_grid_build_kernel, dim3(B), dim3(1024), 0, s, xyz, n_valid, N, sorted, cell_start, hdr);
+    hipLaunchKernelGGL((knn_grid_query_kernel<4>), dim3((G + 3) / 4, B), dim3(256), 0, s, xyz, n_valid, center, (const float4*)sorted,
+                       (const int*)cell_start, (const float*)hdr, N, G, K, idx_out, neigh_out);
     CMDIAD_CHECK_LAUNCH();
     return CMDIAD_OK;
 }

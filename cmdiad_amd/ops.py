@@ -86,7 +86,9 @@ def knn_group(xyz, center, K, n_valid=None, want_idx=True):
     G = center.shape[1]
     idx = torch.empty((B, G, K), dtype=torch.int64, device=xyz.device) if want_idx else None
     nb = torch.empty((B, G, K, 3), dtype=torch.float32, device=xyz.device)
-    _call("cmdiad_knn_group", _p(xyz), _p(n_valid), _p(center), B, N, G, K, _p(idx), _p(nb), _stream())
+    wsb = nat.lib().cmdiad_knn_workspace_bytes(B, N)     # the binned clouds of the neighbourhood search (clouds >= 2 048 points)
+    ws = torch.empty((max(wsb, 16),), dtype=torch.uint8, device=xyz.device)
+    _call("cmdiad_knn_group_ws", _p(xyz), _p(n_valid), _p(center), B, N, G, K, _p(idx), _p(nb), _p(ws), wsb, _stream())
     return idx, nb
 
 

@@ -69,6 +69,14 @@ int cmdiad_fps(const float* xyz, const int32_t* n_valid, int B, int N, int G, in
  * Bit-exact with oracle/cmdiad_oracle.c:orc_knn_group. */
 int cmdiad_knn_group(const float* xyz, const int32_t* n_valid, const float* center, int B, int N, int G,
                      int K, int64_t* idx_out, float* neigh_out, cmdiad_stream_t stream);
+/* The same result (bit for bit) by a NEIGHBOURHOOD search (ABI 6): the cloud is binned into a 64 x 64 grid on its two axes of
+ * largest extent (counting sort, one workgroup per cloud), a wave scans the rings of cells around its centre and stops when the
+ * K-th best distance is certified (no point outside the scanned square can be nearer) -- ~500 distance evaluations per centre
+ * instead of N.  workspace: cmdiad_knn_workspace_bytes(B, N), 16-byte aligned.  Clouds of fewer than 2 048 points (and
+ * CMDIAD_KNN_GRID=0) go through cmdiad_knn_group's streaming kernel. */
+size_t cmdiad_knn_workspace_bytes(int B, int N);
+int cmdiad_knn_group_ws(const float* xyz, const int32_t* n_valid, const float* center, int B, int N, int G, int K,
+                        int64_t* idx_out, float* neigh_out, void* workspace, size_t workspace_bytes, cmdiad_stream_t stream);
 
 /* 3-nearest-centre search + inverse-distance weights for every cloud point.
  * Replaces the selection half of models/pointnet2_utils.py:45-75 (interpolating_points):

@@ -152,6 +152,52 @@ def test_knn_group_bit_exact(frac, G, K, knn_variant):
     np.testing.assert_array_equal(nb.cpu().numpy(), nb_ref)
 
 
+def _knn_geometries():
+    rs = np.random.RandomState(4)
+    sheet = _cloud(31, 0.45)[0]                                                     # a depth-camera sheet (the production case)
+    wall = sheet[:, [0, 2, 1]].copy()                                               # the same sheet standing up: grid axes x and z
+    blob = rs.rand(6000, 3).astype(np.float32)                                      # a filled cube: the 2-D grid's worst case
+    two = np.concatenate([rs.randn(2500, 3) * 0.01, rs.randn(2500, 3) * 0.01 + 5.0]).astype(np.float32)   # two far clusters: empty cells between
+    line = np.stack([np.linspace(0, 1, 4000), np.zeros(4000), np.zeros(4000)], 1).astype(np.float32)       # one axis only (second extent 0)
+    same = np.tile(np.array([[0.3, -0.2, 0.9]], np.float32), (2100, 1))             # every point identical: h = 0, ties by index
+    dup = np.concatenate([sheet[:3000], sheet[:3000]])                              # every point twice
+    return dict(sheet=sheet, wall=wall, blob=blob, two_clusters=two, line=line, identical=same, duplicates=dup)
+
+
+@pytest.mark.parametrize("name", ["sheet", "wall", "blob", "two_clusters", "line", "identical", "duplicates"])
+def test_knn_neighbourhood_search_is_the_streaming_search(name, monkeypatch):
+    """cmdiad_knn_group_ws (round 6: the cloud binned into a 64 x 64 grid on its two widest axes, a wave scanning the rings of
+    cells around its centre until the K-th distance is certified) returns the streaming kernel's and the oracle's neighbours bit
+    for bit -- on geometries chosen against it: a standing sheet, a filled cube, two far clusters with empty cells between, points
+    on a line, all points identical (a degenerate grid), every point duplicated (ties by index), centres outside the cloud's
+    bounding box, K = 1 / 37 / 128, ragged n_valid."""
+    pts = _knn_geometries()[name]
+    rs = np.random.RandomState(5)
+    G = 96
+    cen = pts[rs.randint(0, len(pts), G)].copy()
+    cen[::7] += rs.randn(len(cen[::7]), 3).astype(np.float32) * 0.05               # off-surface centres
+    cen[::13] = pts.min(0) - 0.3                                                    # outside the bounding box
+    cen[5::13] = pts.max(0) + 2.0
+    N = len(pts) + 300
+    xyz = np.zeros((2, N, 3), np.float32)
+    xyz[0, :len(pts)] = pts
+    n1 = max(2048, len(pts) - 777) if len(pts) > 2900 else len(pts)
+    xyz[1, :n1] = pts[:n1]
+    xyz[:, len(pts):] = 1e6                                                         # garbage beyond n_valid must not be read as points
+    nv = torch.tensor([len(pts), n1], dtype=torch.int32, device=DEV)
+    x, c = torch.from_numpy(xyz).to(DEV), torch.from_numpy(np.stack([cen, cen])).to(DEV)
+    for K in (1, 37, 128):
+        monkeypatch.setenv("CMDIAD_KNN_GRID", "1")
+        idx, nb = ops.knn_group(x, c, K, n_valid=nv)
+        monkeypatch.setenv("CMDIAD_KNN_GRID", "0")
+        idx_s, nb_s = ops.knn_group(x, c, K, n_valid=nv)
+        assert torch.equal(idx, idx_s) and torch.equal(nb, nb_s), (name, K)
+        for i, n in enumerate((len(pts), n1)):
+            ir, nr = ok.knn_group(pts[None, :n], cen[None], K)
+            np.testing.assert_array_equal(idx[i].cpu().numpy(), ir[0], err_msg=f"{name} K={K} cloud {i}")
+            np.testing.assert_array_equal(nb[i].cpu().numpy(), nr[0], err_msg=f"{name} K={K} cloud {i}")
+
+
 def test_knn_group_production_instantiation_ragged():
     """The grid the pipeline runs (knn_wave_kernel<4, 4>: four waves per block, four centres per wave, chosen when
     B * ceil(G / 16) >= 512) on eight ragged clouds, bit for bit against the oracle and identical over repeated launches.  The
