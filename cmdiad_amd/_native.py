@@ -48,6 +48,7 @@ SIGNATURES = {
     "cmdiad_knn_group_ws": [P, P, P, I, I, I, I, P, P, P, SZ, P],
     "cmdiad_unorganize": [P, I, I, I, P, P, P, P, P],
     "cmdiad_interp3nn": [P, P, P, I, I, I, P, P, P],
+    "cmdiad_interp3nn_ws": [P, P, P, I, I, I, P, P, P, SZ, P],
     "cmdiad_interp_gather": [P, P, P, P, I, I, I, I, P, P],
     "cmdiad_xyz_patch_fused": [P, P, P, P, I, I, I, I, I, I, F, F, P, P, P],
     "cmdiad_gemm_bf16": [POINTER(GemmArgs), P],
@@ -130,6 +131,7 @@ SIZE_QUERIES = {
     "cmdiad_ocsvm_fit_workspace_bytes": [I, I],
     "cmdiad_rows_dedup_workspace_bytes": [I],
     "cmdiad_knn_workspace_bytes": [I, I],
+    "cmdiad_interp3nn_workspace_bytes": [I, I],
     "cmdiad_transformer_block_workspace_bytes": [I, I, I],
 }
 

@@ -151,6 +151,199 @@ __global__ __launch_bounds__(256) void interp3nn_kernel(const float* __restrict_
     w3[o] = r0 / norm; w3[o + 1] = r1 / norm; w3[o + 2] = r2 / norm;
 }
 
+// ---------------------------------------------------------------------------------------------
+// a7 (selection) as a NEIGHBOURHOOD search (round 6; the counterpart of knn_grid_*_kernel in knn_group.hip): the S centres of a
+// cloud are binned into a 16 x 16 grid on the two axes of their largest extent (interp3nn_bin_kernel, one workgroup per cloud:
+// counting sort, {x, y, z, |c|^2} + original index per centre), and a point looks at the rings of cells around it, innermost
+// first, until its three best are certified -- ~40 distance evaluations per point instead of S = 1 024.
+// Exactness.  The three "nearest" centres are the three smallest values of the reference's FORMULA d = -2 a.b + |a|^2 + |b|^2 in
+// fp32 (pointnet2_utils.py:19-22), ties to the lowest index; the same operation sequence as interp3nn_kernel gives the same d
+// for a (point, centre) pair whatever the visiting order, so the selection only has to see every centre that can matter:
+//   * a centre in an unscanned cell differs from the point by more than m cells along a grid axis, so its TRUE squared distance
+//     exceeds R^2 = ((m - 0.01) h)^2, and its formula value exceeds R^2 - E, E = 4e-6 (|a|^2 + max |c|^2) bounding the formula's
+//     rounding (<= ~10 roundings of magnitude (|a| + |c|)^2 <= 2 (|a|^2 + |c|^2): 1.2e-6 of that sum; E is 3 x the bound);
+//   * the search stops once the third best formula value is below R^2 - E (strictly); radius 16 is every centre.
+// Coordinates so large that E exceeds the centre spacing (the regime where the reference's own selection is rounding noise)
+// simply never certify early and scan everything: slower, still exact.
+// ---------------------------------------------------------------------------------------------
+constexpr int kCGrid = 16, kCCells = kCGrid * kCGrid, kCHdr = 8;
+
+__device__ __forceinline__ int cgrid_coord(float a, float mn, float inv_h)
+{
+    return (int)fminf(fmaxf((a - mn) * inv_h, 0.0f), (float)(kCGrid - 1));   // (NaN -> 0; monotone in a)
+}
+__device__ __forceinline__ float cpick3(float x, float y, float z, int axis) { return axis == 0 ? x : (axis == 1 ? y : z); }
+
+// workspace per cloud: float4 sorted[S] | int orig[S] | int cell_start[257] | float hdr[8]
+__device__ __forceinline__ size_t cgrid_stride(int S) { return (size_t)S * 20 + (size_t)(kCCells + 1) * 4 + kCHdr * 4; }
+
+__global__ __launch_bounds__(256) void interp3nn_bin_kernel(const float* __restrict__ center, int S, char* __restrict__ ws, size_t stride)
+{
+    __shared__ int s_cnt[kCCells];
+    __shared__ float s_red[4][7];
+    __shared__ int s_wave[4];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* cb = center + (size_t)b * S * 3;
+    char* w = ws + (size_t)b * stride;
+    float4* sorted = reinterpret_cast<float4*>(w);
+    int* orig = reinterpret_cast<int*>(w + (size_t)S * 16);
+    int* cs = orig + S;
+    float* hd = reinterpret_cast<float*>(cs + kCCells + 1);
+    float mn[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, mx[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    float cwmax = 0.0f;
+    for (int k = tid; k < S; k += 256) {
+        const float x = cb[k * 3], y = cb[k * 3 + 1], z = cb[k * 3 + 2];
+        mn[0] = fminf(mn[0], x); mx[0] = fmaxf(mx[0], x);
+        mn[1] = fminf(mn[1], y); mx[1] = fmaxf(mx[1], y);
+        mn[2] = fminf(mn[2], z); mx[2] = fmaxf(mx[2], z);
+        cwmax = fmaxf(cwmax, (x * x + y * y) + z * z);
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            mn[a] = fminf(mn[a], __shfl_xor(mn[a], m, 64));
+            mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], m, 64));
+        }
+        cwmax = fmaxf(cwmax, __shfl_xor(cwmax, m, 64));
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { s_red[wave][a] = mn[a]; s_red[wave][3 + a] = mx[a]; }
+        s_red[wave][6] = cwmax;
+    }
+    s_cnt[tid] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        mn[a] = fminf(fminf(s_red[0][a], s_red[1][a]), fminf(s_red[2][a], s_red[3][a]));
+        mx[a] = fmaxf(fmaxf(s_red[0][3 + a], s_red[1][3 + a]), fmaxf(s_red[2][3 + a], s_red[3][3 + a]));
+    }
+    cwmax = fmaxf(fmaxf(s_red[0][6], s_red[1][6]), fmaxf(s_red[2][6], s_red[3][6]));
+    const float e0 = mx[0] - mn[0], e1 = mx[1] - mn[1], e2 = mx[2] - mn[2];
+    int A, Bx;
+    if (e0 >= e1 && e0 >= e2) { A = 0; Bx = e1 >= e2 ? 1 : 2; }
+    else if (e1 >= e2) { A = 1; Bx = e0 >= e2 ? 0 : 2; }
+    else { A = 2; Bx = e0 >= e1 ? 0 : 1; }
+    if (A > Bx) { const int t = A; A = Bx; Bx = t; }
+    const float ext = fmaxf(cpick3(e0, e1, e2, A), cpick3(e0, e1, e2, Bx));
+    const float h = ext > 0.0f && ext < __builtin_inff() ? ext * (1.0f / kCGrid) : 0.0f;
+    const float inv_h = h > 0.0f ? 1.0f / h : 0.0f;
+    const float mnA = cpick3(mn[0], mn[1], mn[2], A), mnB = cpick3(mn[0], mn[1], mn[2], Bx);
+    for (int k = tid; k < S; k += 256) {
+        const float x = cb[k * 3], y = cb[k * 3 + 1], z = cb[k * 3 + 2];
+        atomicAdd(&s_cnt[cgrid_coord(cpick3(x, y, z, Bx), mnB, inv_h) * kCGrid + cgrid_coord(cpick3(x, y, z, A), mnA, inv_h)], 1);
+    }
+    __syncthreads();
+    const int mine = s_cnt[tid];
+    int incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int q = 0; q < wave; ++q) base += s_wave[q];
+    const int start = base + incl - mine;
+    cs[tid] = start;
+    if (tid == 255) cs[kCCells] = start + mine;
+    __syncthreads();          // (every thread has read its count)
+    s_cnt[tid] = start;       // now the cell's write cursor
+    if (tid == 0) { hd[0] = mnA; hd[1] = mnB; hd[2] = inv_h; hd[3] = h; hd[4] = (float)A; hd[5] = (float)Bx; hd[6] = cwmax; hd[7] = 0.0f; }
+    __syncthreads();
+    for (int k = tid; k < S; k += 256) {
+        const float x = cb[k * 3], y = cb[k * 3 + 1], z = cb[k * 3 + 2];
+        const int cell = cgrid_coord(cpick3(x, y, z, Bx), mnB, inv_h) * kCGrid + cgrid_coord(cpick3(x, y, z, A), mnA, inv_h);
+        const int pos = atomicAdd(&s_cnt[cell], 1);
+        sorted[pos] = float4{x, y, z, (x * x + y * y) + z * z};
+        orig[pos] = k;
+    }
+}
+
+__global__ __launch_bounds__(256) void interp3nn_grid_kernel(const float* __restrict__ xyz, const int32_t* __restrict__ n_valid,
+                                                             const char* __restrict__ ws, size_t stride, int N, int S,
+                                                             int32_t* __restrict__ idx3, float* __restrict__ w3)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4* s_c = reinterpret_cast<float4*>(smem);
+    int* s_i = reinterpret_cast<int*>(smem + (size_t)S * 16);
+    int* s_cs = s_i + S;
+    const int b = blockIdx.y;
+    const int n = n_valid ? n_valid[b] : N;
+    const char* w = ws + (size_t)b * stride;
+    {
+        const float4* g_c = reinterpret_cast<const float4*>(w);
+        const int* g_i = reinterpret_cast<const int*>(w + (size_t)S * 16);
+        for (int k = threadIdx.x; k < S; k += 256) { s_c[k] = g_c[k]; s_i[k] = g_i[k]; }
+        for (int k = threadIdx.x; k < kCCells + 1; k += 256) s_cs[k] = g_i[S + k];
+    }
+    const float* hd = reinterpret_cast<const float*>(w + (size_t)S * 20 + (size_t)(kCCells + 1) * 4);
+    const float mnA = hd[0], mnB = hd[1], inv_h = hd[2], h = hd[3], cwmax = hd[6];
+    const int A = (int)hd[4], Bx = (int)hd[5];
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float* p = xyz + ((size_t)b * N + i) * 3;
+    const float x = p[0], y = p[1], z = p[2];
+    const float n1 = (x * x + y * y) + z * z;
+    const int ia = cgrid_coord(cpick3(x, y, z, A), mnA, inv_h), ib = cgrid_coord(cpick3(x, y, z, Bx), mnB, inv_h);
+    float d0 = __builtin_inff(), d1 = __builtin_inff(), d2 = __builtin_inff();
+    int i0 = 0, i1 = 0, i2 = 0;
+    // (d, index) lexicographic order: the lowest index among equal distances, whatever the visiting order
+#define CMDIAD_TOP3_LEX(d, s)                                                                        \
+    {                                                                                                \
+        const bool l0 = (d) < d0 || ((d) == d0 && (s) < i0), l1 = (d) < d1 || ((d) == d1 && (s) < i1),      \
+                   l2 = (d) < d2 || ((d) == d2 && (s) < i2);                                          \
+        d2 = l1 ? d1 : (l2 ? (d) : d2); i2 = l1 ? i1 : (l2 ? (s) : i2);                              \
+        d1 = l0 ? d0 : (l1 ? (d) : d1); i1 = l0 ? i0 : (l1 ? (s) : i1);                              \
+        d0 = l0 ? (d) : d0;             i0 = l0 ? (s) : i0;                                          \
+    }
+    auto run = [&](int s, int e) {
+        for (int k = s; k < e; ++k) {
+            const float4 c = s_c[k];
+            const float dot = (x * c.x + y * c.y) + z * c.z;
+            float d = -2.0f * dot;
+            d = d + n1;
+            d = d + c.w;
+            if (d <= d2) {               // (NaN: never)
+                const int si = s_i[k];
+                CMDIAD_TOP3_LEX(d, si)
+            }
+        }
+    };
+    const float E = 4e-6f * (n1 + cwmax);
+    int m_done = -1, m = h > 0.0f ? 1 : kCGrid;
+    for (;;) {
+        m = min(m, kCGrid);
+        for (int dj = -m; dj <= m; ++dj) {
+            const int j = ib + dj;
+            if (j < 0 || j >= kCGrid) continue;
+            const int lo = max(ia - m, 0), hi = min(ia + m, kCGrid - 1);
+            if (dj < -m_done || dj > m_done || m_done < 0) {
+                run(s_cs[j * kCGrid + lo], s_cs[j * kCGrid + hi + 1]);
+            } else {
+                if (ia - m_done - 1 >= lo) run(s_cs[j * kCGrid + lo], s_cs[j * kCGrid + ia - m_done]);
+                if (ia + m_done + 1 <= hi) run(s_cs[j * kCGrid + ia + m_done + 1], s_cs[j * kCGrid + hi + 1]);
+            }
+        }
+        m_done = m;
+        if (m >= kCGrid) break;
+        const float r = ((float)m - 0.01f) * h;
+        if (d2 < r * r - E) break;      // three centres met (d2 finite) and nothing outside the scanned square can beat the third
+        m = d2 < __builtin_inff() ? max(m + 1, (int)(sqrtf(fmaxf(d2 + E, 0.0f)) * inv_h) + 2) : m * 2;
+    }
+#undef CMDIAD_TOP3_LEX
+    const float r0 = 1.0f / (d0 + 1e-8f);
+    const float r1 = S > 1 ? 1.0f / (d1 + 1e-8f) : 0.0f;
+    const float r2 = S > 2 ? 1.0f / (d2 + 1e-8f) : 0.0f;
+    const float norm = (r0 + r1) + r2;
+    const size_t o = ((size_t)b * N + i) * 3;
+    idx3[o] = i0; idx3[o + 1] = i1; idx3[o + 2] = i2;
+    w3[o] = r0 / norm; w3[o + 1] = r1 / norm; w3[o + 2] = r2 / norm;
+}
+
 // out[b][n][:] = (F[i0]*w0 + F[i1]*w1) + F[i2]*w2 ; one wave per point, 16-byte accesses.
 __global__ __launch_bounds__(256) void interp_gather_kernel(const float* __restrict__ feat, const int32_t* __restrict__ idx3,
                                                             const float* __restrict__ w3,
@@ -326,6 +519,33 @@ extern "C" int cmdiad_interp3nn(const float* xyz, const int32_t* n_valid, const 
     dim3 grid((N + 255) / 256, B);
     hipLaunchKernelGGL(interp3nn_kernel, grid, dim3(256), (size_t)((S + 1) / 2) * 2 * sizeof(float4), (hipStream_t)stream, xyz,
                        n_valid, center, N, S, idx3, w3);
+    CMDIAD_CHECK_LAUNCH();
+    return CMDIAD_OK;
+}
+
+// The same selection through the centre grid (interp3nn_bin_kernel + interp3nn_grid_kernel).  Falls back to interp3nn_kernel for
+// few centres (S < 64) and with CMDIAD_INTERP_GRID=0 (A/B runs, parity tests; read per call).
+extern "C" size_t cmdiad_interp3nn_workspace_bytes(int B, int S)
+{
+    if (B <= 0 || S <= 0) return 0;
+    return (size_t)B * (((size_t)S * 20 + (size_t)(kCCells + 1) * 4 + kCHdr * 4 + 15) / 16 * 16);
+}
+
+extern "C" int cmdiad_interp3nn_ws(const float* xyz, const int32_t* n_valid, const float* center, int B, int N, int S,
+                                   int32_t* idx3, float* w3, void* workspace, size_t workspace_bytes, cmdiad_stream_t stream)
+{
+    const char* e = getenv("CMDIAD_INTERP_GRID");
+    if ((e && e[0] == '0') || S < 64 || S > kMaxCentres || B <= 0 || N <= 0)
+        return cmdiad_interp3nn(xyz, n_valid, center, B, N, S, idx3, w3, stream);
+    CMDIAD_REQUIRE(xyz && center && idx3 && w3, CMDIAD_ERR_ARG, "cmdiad_interp3nn_ws: null pointer");
+    CMDIAD_REQUIRE(workspace && workspace_bytes >= cmdiad_interp3nn_workspace_bytes(B, S) && ((uintptr_t)workspace & 15) == 0,
+                   CMDIAD_ERR_WORKSPACE, "cmdiad_interp3nn_ws: workspace too small or not 16-byte aligned");
+    const size_t stride = ((size_t)S * 20 + (size_t)(kCCells + 1) * 4 + kCHdr * 4 + 15) / 16 * 16;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(interp3nn_bin_kernel, dim3(B), dim3(256), 0, s, center, S, (char*)workspace, stride);
+    const size_t lds = (size_t)S * 20 + (size_t)(kCCells + 1) * 4;
+    hipLaunchKernelGGL(interp3nn_grid_kernel, dim3((N + 255) / 256, B), dim3(256), lds, s, xyz, n_valid, (const char*)workspace, stride, N,
+                       S, idx3, w3);
     CMDIAD_CHECK_LAUNCH();
     return CMDIAD_OK;
 }

@@ -134,7 +134,10 @@ def interp3nn(xyz, center, n_valid=None):
     B, N, _ = xyz.shape
     idx3 = torch.zeros((B, N, 3), dtype=torch.int32, device=xyz.device)
     w3 = torch.zeros((B, N, 3), dtype=torch.float32, device=xyz.device)
-    _call("cmdiad_interp3nn", _p(xyz), _p(n_valid), _p(center), B, N, center.shape[1], _p(idx3), _p(w3), _stream())
+    S = center.shape[1]
+    wsb = nat.lib().cmdiad_interp3nn_workspace_bytes(B, S)      # the binned centres of the neighbourhood search (S >= 64)
+    ws = torch.empty((max(wsb, 16),), dtype=torch.uint8, device=xyz.device)
+    _call("cmdiad_interp3nn_ws", _p(xyz), _p(n_valid), _p(center), B, N, S, _p(idx3), _p(w3), _p(ws), wsb, _stream())
     return idx3, w3
 
 

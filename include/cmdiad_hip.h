@@ -84,6 +84,13 @@ int cmdiad_knn_group_ws(const float* xyz, const int32_t* n_valid, const float* c
  * xyz [B,N,3], center [B,S,3] -> idx3 [B,N,3] int32, w3 [B,N,3] f32.  S <= 4096. */
 int cmdiad_interp3nn(const float* xyz, const int32_t* n_valid, const float* center, int B, int N, int S,
                      int32_t* idx3, float* w3, cmdiad_stream_t stream);
+/* The same idx3 / w3 (bit for bit) by a NEIGHBOURHOOD search (ABI 6): the centres are binned into a 16 x 16 grid on their two axes
+ * of largest extent, a point scans the rings of cells around it until its third best formula value is certified against
+ * everything unscanned (with a bound on the formula's rounding) -- ~40 evaluations per point instead of S.
+ * workspace: cmdiad_interp3nn_workspace_bytes(B, S), 16-byte aligned.  S < 64 (and CMDIAD_INTERP_GRID=0) use cmdiad_interp3nn. */
+size_t cmdiad_interp3nn_workspace_bytes(int B, int S);
+int cmdiad_interp3nn_ws(const float* xyz, const int32_t* n_valid, const float* center, int B, int N, int S, int32_t* idx3, float* w3,
+                        void* workspace, size_t workspace_bytes, cmdiad_stream_t stream);
 
 /* Organised -> unorganised point cloud without zeros (feature_extractors/multiple_features.py:10-25):
  * keeps, in raster order, the pixels whose x, y and z are all non-zero.

@@ -198,6 +198,41 @@ def test_knn_neighbourhood_search_is_the_streaming_search(name, monkeypatch):
             np.testing.assert_array_equal(nb[i].cpu().numpy(), nr[0], err_msg=f"{name} K={K} cloud {i}")
 
 
+@pytest.mark.parametrize("name", ["sheet", "wall", "blob", "two_clusters", "line", "identical", "duplicates"])
+@pytest.mark.parametrize("scale", [1.0, 700.0], ids=["metres", "large_coordinates"])
+def test_interp3nn_neighbourhood_search_is_the_full_search(name, scale, monkeypatch):
+    """cmdiad_interp3nn_ws (round 6: the centres binned into a 16 x 16 grid, a point scanning the rings of cells around it until its
+    three best values of the reference's distance FORMULA are certified, rounding bound included) returns the full search's and
+    the oracle's idx3 / w3 bit for bit -- on the geometries of the kNN test, with centres that are cloud points, off-surface
+    points, duplicates of each other (ties by index) and far outliers; and with coordinates x 700 (millimetre-sized numbers: the
+    formula -2 a.b + |a|^2 + |b|^2 then carries rounding noise of the order of the centre spacing -- the search must fall back to
+    wider rings instead of certifying early)."""
+    pts = (_knn_geometries()[name] * scale + (0.0 if scale == 1.0 else 250.0)).astype(np.float32)
+    rs = np.random.RandomState(6)
+    S = 300
+    cen = pts[rs.randint(0, len(pts), S)].copy()
+    cen[::9] += (rs.randn(len(cen[::9]), 3) * 0.03 * scale).astype(np.float32)
+    cen[7] = cen[3]; cen[250] = cen[3]                                              # identical centres: ties by index
+    cen[11] = pts.max(0) + 5.0 * scale                                              # a far outlier stretches the grid
+    n = min(len(pts), 6000)
+    N = n + 100
+    xyz = np.zeros((2, N, 3), np.float32)
+    xyz[0, :n] = pts[:n]
+    xyz[1, :n - 500] = pts[500:n]
+    nv = torch.tensor([n, n - 500], dtype=torch.int32, device=DEV)
+    x, c = torch.from_numpy(xyz).to(DEV), torch.from_numpy(np.stack([cen, cen[::-1].copy()])).to(DEV)
+    monkeypatch.setenv("CMDIAD_INTERP_GRID", "1")
+    idx3, w3 = ops.interp3nn(x, c, n_valid=nv)
+    monkeypatch.setenv("CMDIAD_INTERP_GRID", "0")
+    idx_f, w_f = ops.interp3nn(x, c, n_valid=nv)
+    assert torch.equal(idx3, idx_f) and torch.equal(w3, w_f), name
+    feat = np.zeros((S, 4), np.float32)
+    for i, (m, cc) in enumerate(((n, cen), (n - 500, cen[::-1].copy()))):
+        _, ir, wr = ok.interp3nn(xyz[i, :m], cc, feat)
+        np.testing.assert_array_equal(idx3[i, :m].cpu().numpy(), ir, err_msg=f"{name} cloud {i}")
+        np.testing.assert_array_equal(w3[i, :m].cpu().numpy(), wr, err_msg=f"{name} cloud {i}")
+
+
 def test_knn_group_production_instantiation_ragged():
     """The grid the pipeline runs (knn_wave_kernel<4, 4>: four waves per block, four centres per wave, chosen when
     B * ceil(G / 16) >= 512) on eight ragged clouds, bit for bit against the oracle and identical over repeated launches.  The
