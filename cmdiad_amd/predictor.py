@@ -357,6 +357,10 @@ class BatchPredictor:
             self.copy.wait_event(inp["free"])
         else:
             self.copy.wait_stream(cur)
+        if inp.get("ready") is not None:
+            # a batch staged into these buffers (submit(stage=), on the post stream) that turned out not to be the one submitted:
+            # its copy may still be pending and must not land AFTER this one
+            self.copy.wait_event(inp["ready"])
         with torch.cuda.stream(self.copy):
             if inp["rgb"] is not None:
                 inp["rgb"].copy_(rgb, non_blocking=True)
