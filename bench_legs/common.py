@@ -71,38 +71,20 @@ def make_batches(rank, workload, pinned=False):
     return out
 
 
-_CHECKER = None
-
-
 def run_steps(pred, batches, n, first=None):
     """n pipelined steps over the rotating batches; returns the outputs and checks each against the first output seen for
-    the same batch index (`first`, filled on the way).  The check of a finished batch (finite everywhere, bit-identical to the first
-    outputs of its batch index: two passes over 12.8 MB of float64) runs on ONE helper thread -- numpy releases the interpreter
-    lock for them -- so the submitting thread is never late for the device because it was comparing arrays; every check has
-    finished (and any failure is raised) before run_steps returns, i.e. inside the timed region.  CMDIAD_BENCH_CHECK_THREAD=0 checks
-    in line (rounds 1-5), for A/B runs."""
+    the same batch index (`first`, filled on the way)."""
     import numpy as np
-    global _CHECKER
     first = {} if first is None else first
-    pending, checks = [], []
-    threaded = os.environ.get("CMDIAD_BENCH_CHECK_THREAD", "1") != "0"
-    if threaded and _CHECKER is None:
-        import concurrent.futures as cf
-        _CHECKER = cf.ThreadPoolExecutor(max_workers=1)
+    pending = []
 
-    def check(j, s, m):
+    def take(j, ticket):
+        s, m = ticket.wait()
         assert np.isfinite(s).all() and np.isfinite(m).all()
         if j not in first:
             first[j] = (s, m)
         else:
             assert np.array_equal(s, first[j][0]) and np.array_equal(m, first[j][1]), f"batch {j}: steps disagree"
-
-    def take(j, ticket):
-        s, m = ticket.wait()
-        if threaded:
-            checks.append(_CHECKER.submit(check, j, s, m))     # (one worker: the checks run in submission order, `first` has one writer)
-        else:
-            check(j, s, m)
 
     # Tickets outstanding on the host.  The predictor's pinned output ring has 3 slots, so the ticket of step i - 3 must have been
     # consumed before step i is submitted -- not the one of step i - 2: with three outstanding the host queues step i while the
@@ -119,6 +101,4 @@ def run_steps(pred, batches, n, first=None):
         pending.append((j, pred.submit(*batches[j], stage=ahead)))
     for p in pending:
         take(*p)
-    for c in checks:
-        c.result()          # raises what the check raised
     return first
