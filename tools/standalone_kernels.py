@@ -120,7 +120,13 @@ if not only_hbm and not only_l2:
     for _ in range(6):
         ops.knn_group(xyz, cen, K, nv)
     sync()
-    work["knn_wave_kernel"] = dict(evals=B * G * 24576, bytes=B * (24576 * 12 + G * 12 + G * K * 20), what="kNN grouping, 1024 centres x 128 neighbours per cloud")
+    work["knn_grid_query_kernel"] = dict(evals=B * G * 24576, bytes=B * (24576 * 12 + G * 12 + G * K * 20), what="kNN grouping, 1024 centres x 128 neighbours per cloud: the query half of the neighbourhood search (rate in brute-force-equivalent evaluations: 805 M would be evaluated by the streaming kernel, ~16 M are)")
+    work["knn_grid_build_kernel"] = dict(bytes=B * 24576 * (12 + 16), what="kNN grouping: the cloud binned into a 64 x 64 grid (counting sort, one workgroup per cloud)")
+    idx3, w3 = None, None
+    for _ in range(6):
+        idx3, w3 = ops.interp3nn(xyz, cen, nv)
+    sync()
+    work["interp3nn_grid_kernel"] = dict(evals=B * G * 24576, bytes=B * 24576 * (12 + 24), what="3-NN + weights, 24 576 points x 1024 centres per cloud, neighbourhood search on binned centres (brute-force-equivalent evaluations)")
     import numpy as np
     rs = np.random.RandomState(8)
     fr = (0.35 + 0.30 * rs.rand(B)) / 0.85

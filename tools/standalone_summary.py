@@ -78,7 +78,7 @@ for key, spec in work.items():
     if "flops" in spec:
         ach, frac, unit = spec["flops"] / us / 1e6, spec["flops"] / us / 1e6 / 2500.0, "TFLOP/s"
         algo = f"{spec['flops'] / 1e9:.1f} GFLOP"
-    elif "evals" in spec and "bytes" not in spec or kname.startswith("fps") or kname.startswith("knn"):
+    elif "evals" in spec and ("bytes" not in spec or kname.startswith(("fps", "knn", "interp3nn"))):
         ach, frac, unit = spec["evals"] / us / 1e3, None, "G distance evals/s"
         algo = f"{spec['evals'] / 1e6:.0f} M distance evaluations" + (f", {spec['bytes'] / 1e6:.1f} MB" if "bytes" in spec else "")
     else:
