@@ -493,7 +493,8 @@ class Engine:
         ctx = torch.cuda.stream(side_stream) if side_stream is not None else _Null()
         if side_stream is not None:
             side_stream.wait_stream(cur)
-        with ctx:
+
+        def cloud():
             if organized_pc is not None:
                 ex.xyz, ex.nz, ex.pix2pt, ex.n_valid = ops.unorganize(organized_pc.contiguous(), n_max)
             else:
@@ -501,10 +502,32 @@ class Engine:
                 ex.xyz, ex.nz, ex.n_valid = xyz.contiguous(), nz, None
                 ex.pix2pt = torch.full((B, self.size * self.size), -1, dtype=torch.int32, device=xyz.device)
                 ex.pix2pt.scatter_(1, nz.long(), torch.arange(N, dtype=torch.int32, device=xyz.device).expand(B, N))
-            ex.xyz_feats, ex.center, ex.ori_idx, ex.center_idx = self.pm.forward(ex.xyz, ex.n_valid)
+
+        def points(sampled=None):
+            ex.xyz_feats, ex.center, ex.ori_idx, ex.center_idx = self.pm.forward(ex.xyz, ex.n_valid, sampled=sampled)
             ex.idx3, ex.w3 = ops.interp3nn(ex.xyz, ex.center, ex.n_valid)
-            hooked = list(xyz_hook(ex) or ()) if xyz_hook is not None else []
-        ex.rgb_tokens = self.vit.forward_tokens(rgb) if want_rgb else None
+            return list(xyz_hook(ex) or ()) if xyz_hook is not None else []
+
+        # EAGER launches with both branches (the drop-in's micro-batches): the host queues one kernel at a time, so the order of
+        # queueing is the order of starting.  Farthest-point sampling goes first -- a chain of 1 023 dependent rounds on one CU per
+        # cloud that nothing can shorten -- then the ViT's ~90 launches (they fill the chip under it), then the rest of the
+        # point-cloud branch.  Queued branch after branch (rounds 1-5) the ViT's first kernel reached the device when FPS had
+        # finished: 83 % of a micro-batch ran with ONE kernel in flight (rocprofv3 trace, profiles/r6_notes.md section 11).
+        # Under stream capture the order of queueing is irrelevant (the graph holds the dependencies) and stays as it was.
+        fps_first = (side_stream is not None and want_rgb and not torch.cuda.is_current_stream_capturing()
+                     and os.environ.get("CMDIAD_FPS_FIRST", "1") != "0")      # (=0: branch after branch, for A/B runs)
+        if fps_first:
+            with ctx:
+                cloud()
+                sampled = self.pm.sample(ex.xyz, ex.n_valid)
+            ex.rgb_tokens = self.vit.forward_tokens(rgb)
+            with ctx:
+                hooked = points(sampled)
+        else:
+            with ctx:
+                cloud()
+                hooked = points()
+            ex.rgb_tokens = self.vit.forward_tokens(rgb) if want_rgb else None
         if rgb_hook is not None and want_rgb:
             rgb_hook(ex)
         if side_stream is not None:

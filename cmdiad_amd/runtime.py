@@ -293,10 +293,16 @@ class PackedPointMAE:
                 t += 1
         return feats.view(B, G, -1)
 
-    def forward(self, xyz, n_valid=None):
+    def sample(self, xyz, n_valid=None):
+        """Farthest-point sampling alone (models/models.py:70-78) -> (center_idx [B,G] int32, center [B,G,3]): a caller that
+        launches eagerly queues this first -- 1 023 dependent rounds on one CU per cloud -- and everything else under it."""
+        return ops.fps(xyz, self.num_group, n_valid)
+
+    def forward(self, xyz, n_valid=None, sampled=None):
         """xyz [B,N,3] f32 cuda (rows >= n_valid[b] are padding) ->
-        (feats [B,G,768] centre-major, center [B,G,3], ori_idx [B,G,Mg] int64, center_idx [B,G] int32)."""
-        center_idx, center = ops.fps(xyz, self.num_group, n_valid)
+        (feats [B,G,768] centre-major, center [B,G,3], ori_idx [B,G,Mg] int64, center_idx [B,G] int32).
+        sampled: the result of sample() on the same cloud, when it was queued earlier."""
+        center_idx, center = sampled if sampled is not None else ops.fps(xyz, self.num_group, n_valid)
         ori_idx, nb = ops.knn_group(xyz, center, self.group_size, n_valid)
         tok = self.encode(nb)
         feats = self.transform(tok, center)
