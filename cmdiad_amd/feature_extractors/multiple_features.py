@@ -276,19 +276,34 @@ class _MethodBase(Features):
         device->host copy: the return value is a _PendingScores (list-like; waits when first read)."""
         from .. import ops
         gt = self.gt_size
-        rs = []
-        for patch, mean, std, modal, _, _ in columns:
-            q = eng.normalize(patch.to(self.device).float().contiguous(), mean, std)        # a11: fused HIP kernel
-            side = int(math.sqrt(q.shape[1]))
-            rs.append(eng.score_patches(q, self._bank(getattr(self, f"patch_{modal}_lib")), (side, side), gt))
-        B, k = columns[0][0].shape[0], len(columns)
-        maps = ops.blur8_maps(torch.stack([r["s_map_pre"] for r in rs], 1).reshape(B * k, gt, gt).contiguous(),
-                              float(self.blur.radius))
-        dev_out = torch.cat([maps.reshape(-1), torch.stack([r["s"] for r in rs], 1).reshape(-1).float()])
-        host = torch.empty(dev_out.shape, dtype=dev_out.dtype, pin_memory=True)
-        host.copy_(dev_out, non_blocking=True)
-        event = torch.cuda.Event()
-        event.record()
+        # The scoring of a micro-batch (two library searches, exact re-score, re-weighting, maps, blur: ~3 ms of whole-chip work for
+        # 16 samples) runs on the post stream, BESIDE the extraction of the next micro-batch, whose launches the caller queues on the
+        # current stream as soon as this function returns -- what the batched predictor does with its HIP graphs, here with eager
+        # launches.  The patch tensors were produced on the current stream: the post stream waits for it, and the caching allocator
+        # is told that they are read there (record_stream).  CMDIAD_DROPIN_POST=0: everything on the current stream (rounds 1-5).
+        dev = torch.device(self.device)
+        cur = torch.cuda.current_stream(dev)
+        post = ops.shared_stream(dev, "predictor.post") if os.environ.get("CMDIAD_DROPIN_POST", "1") != "0" else cur
+        columns = [(c[0].to(dev), *c[1:]) for c in columns]
+        banks = [self._bank(getattr(self, f"patch_{c[3]}_lib")) for c in columns]   # (built on first use: on the CURRENT stream)
+        if post is not cur:
+            post.wait_stream(cur)
+            for c in columns:
+                c[0].record_stream(post)
+        with torch.cuda.stream(post):
+            rs = []
+            for (patch, mean, std, modal, _, _), bank in zip(columns, banks):
+                q = eng.normalize(patch.float().contiguous(), mean, std)        # a11: fused HIP kernel
+                side = int(math.sqrt(q.shape[1]))
+                rs.append(eng.score_patches(q, bank, (side, side), gt))
+            B, k = columns[0][0].shape[0], len(columns)
+            maps = ops.blur8_maps(torch.stack([r["s_map_pre"] for r in rs], 1).reshape(B * k, gt, gt).contiguous(),
+                                  float(self.blur.radius))
+            dev_out = torch.cat([maps.reshape(-1), torch.stack([r["s"] for r in rs], 1).reshape(-1).float()])
+            host = torch.empty(dev_out.shape, dtype=dev_out.dtype, pin_memory=True)
+            host.copy_(dev_out, non_blocking=True)
+            event = torch.cuda.Event()
+            event.record()
         return _PendingScores(host, event, dev_out, B, k, gt, [c[4] for c in columns], [c[5] for c in columns])
 
     def _record(self, s, s_map, mask, label, rgb_path):
