@@ -4,7 +4,7 @@ import time
 
 from .common import N_POINTS, RGB_ROWS, XYZ_ROWS
 
-def dropin_b1(n=64, warm=16):
+def dropin_b1(n=192, warm=32):
     """images/s of the B = 1 drop-in protocol (what the reference's main.py / cmdiad_runner.py drive):
     DoubleRGBPointFeatures.predict per image, host-resident samples (H2D of the sample and D2H of the maps included),
     bagel-sized libraries."""
