@@ -233,6 +233,24 @@ def test_interp3nn_neighbourhood_search_is_the_full_search(name, scale, monkeypa
         np.testing.assert_array_equal(w3[i, :m].cpu().numpy(), wr, err_msg=f"{name} cloud {i}")
 
 
+def test_interp3nn_far_from_the_origin_falls_back_to_the_whole_grid(monkeypatch):
+    """A unit sheet 3 000 units from the origin: the rounding of -2 a.b + |a|^2 + |b|^2 (~2) dwarfs the squared centre spacing, the
+    reference's own selection is rounding noise -- the neighbourhood search may not certify on geometry, widens to every centre and
+    returns the full search's / the oracle's idx3 and w3 bit for bit (tests/test_neighbourhood_model_cpu.py models the same case)."""
+    pts = (_knn_geometries()["sheet"][:5000] + 3000.0).astype(np.float32)
+    rs = np.random.RandomState(13)
+    cen = pts[rs.randint(0, len(pts), 256)].copy()
+    x, c = torch.from_numpy(pts[None]).to(DEV), torch.from_numpy(cen[None]).to(DEV)
+    monkeypatch.setenv("CMDIAD_INTERP_GRID", "1")
+    idx3, w3 = ops.interp3nn(x, c)
+    monkeypatch.setenv("CMDIAD_INTERP_GRID", "0")
+    idx_f, w_f = ops.interp3nn(x, c)
+    assert torch.equal(idx3, idx_f) and torch.equal(w3, w_f)
+    _, ir, wr = ok.interp3nn(pts, cen, np.zeros((256, 4), np.float32))
+    np.testing.assert_array_equal(idx3[0].cpu().numpy(), ir)
+    np.testing.assert_array_equal(w3[0].cpu().numpy(), wr)
+
+
 def test_knn_group_production_instantiation_ragged():
     """The grid the pipeline runs (knn_wave_kernel<4, 4>: four waves per block, four centres per wave, chosen when
     B * ceil(G / 16) >= 512) on eight ragged clouds, bit for bit against the oracle and identical over repeated launches.  The
